@@ -1,0 +1,142 @@
+/*
+ * vp8hip.h -- C ABI of the MI355X (gfx950) inter-frame path of vp8oclenc.
+ *
+ * Drop-in boundary: each entry point replaces a group of OpenCL calls that the reference host
+ * driver makes (citations are file:line under the reference's src/).  The library owns every
+ * device allocation; the host owns every host buffer; no host pointer is kept after a call
+ * returns.  All calls are made from one host thread per context.  Return value: 0 on success,
+ * negative vp8hip_status on failure (the reference stores cl_int errors in device.state_gpu,
+ * inter_part.h:380).  There is no CPU fallback: without a usable HIP device vp8hip_create fails.
+ *
+ * Plane convention at the boundary: tightly packed 8-bit planes of the padded ("wrk") size,
+ * width and height multiples of 16 (init.h:381-389), chroma planes (W/2)x(H/2) -- exactly
+ * hostFrameBuffers.current_Y/U/V and reconstructed_Y/U/V (vp8enc.h:364-372).
+ */
+#ifndef VP8HIP_H
+#define VP8HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp8hip_ctx vp8hip_ctx;
+
+typedef enum {
+    VP8HIP_OK = 0,
+    VP8HIP_ERR_ARG = -1,       /* bad size / NULL pointer */
+    VP8HIP_ERR_NO_DEVICE = -2, /* no HIP device, or device_ordinal out of range */
+    VP8HIP_ERR_HIP = -3,       /* a HIP runtime call failed (vp8hip_last_hip_error) */
+    VP8HIP_ERR_STATE = -4,     /* call out of order (e.g. loop filter before any transform) */
+    VP8HIP_ERR_ARCH = -5       /* device is not gfx950: the kernels are built for MI355X only */
+} vp8hip_status;
+
+/* segment_data[4], vp8enc.h:80-92: 11 ints per segment */
+#define VP8HIP_SD_INTS 44
+
+/* Host pointers filled by vp8hip_download_results; any member may be NULL (skipped).
+ * Layouts: vp8enc.h:105-120, 378-382. */
+typedef struct {
+    int32_t *MB_parts;           /* [MBs] 0=16x16 1=8x8                         inter_part.h:263 */
+    int32_t *MB_reference_frame; /* [MBs] 0 LAST 1 GOLDEN 2 ALTREF              inter_part.h:264 */
+    int16_t *MB_vectors;         /* [MBs][4]{x,y} qpel, TL TR BL BR             inter_part.h:265 */
+    int16_t *MB_coeffs;          /* [MBs][25][16] zig-zag order                 vp8enc.cpp:422   */
+    int32_t *MB_segment_id;      /* [MBs]                                        vp8enc.cpp:423   */
+    float *MB_SSIM;              /* [MBs]                                        vp8enc.cpp:424   */
+    uint8_t *recon_Y;            /* reconstruction BEFORE the loop filter        vp8enc.cpp:431   */
+    uint8_t *recon_U;            /*                                              vp8enc.cpp:432   */
+    uint8_t *recon_V;            /*                                              vp8enc.cpp:433   */
+} vp8hip_results;
+
+/* init_all() GPU half (init.h:133-312, 430-582, 595-1166) / finalize() (vp8enc.cpp:501-708).
+ * width,height: padded luma size.  ssim_target: video.SSIM_target (init.h:1512,1576). */
+int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, int device_ordinal);
+void vp8hip_destroy(vp8hip_ctx *ctx);
+
+/* clEnqueueWriteBuffer(current_frame_Y/U/V), vp8enc.cpp:386-388 */
+int vp8hip_upload_current(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* same, from planes already resident in this device's memory (tight stride); async on the ctx stream */
+int vp8hip_set_current_device(vp8hip_ctx *ctx, const void *d_y, const void *d_u, const void *d_v);
+
+/* LAST := these (already loop-filtered) planes: vp8enc.cpp:395-401, intra_part.h:1112-1125.
+ * Needed after a key frame and whenever the host changed the reconstruction. */
+int vp8hip_upload_last(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+int vp8hip_set_last_device(vp8hip_ctx *ctx, const void *d_y, const void *d_u, const void *d_v);
+
+/* clEnqueueWriteBuffer(segments_data_gpu), vp8enc.cpp:224 */
+int vp8hip_set_segments(vp8hip_ctx *ctx, const int32_t sd[VP8HIP_SD_INTS]);
+
+/* prepare_GPU_buffers() + inter_transform(), inter_part.h:1-94, 96-384.  Flags as computed at
+ * inter_part.h:103-104 and vp8enc.cpp:364-366.  Asynchronous; results via vp8hip_download_results. */
+int vp8hip_inter_transform(vp8hip_ctx *ctx, int prev_is_golden, int prev_is_altref, int use_golden,
+                           int use_altref);
+
+/* the clEnqueueReadBuffer group at inter_part.h:263-265 and vp8enc.cpp:422-433, followed by the
+ * clFinish at vp8enc.cpp:439-440: returns when the copies are complete */
+int vp8hip_download_results(vp8hip_ctx *ctx, const vp8hip_results *r);
+
+/* Host-side changes made between the transform and the loop filter (per-MB intra fallback,
+ * intra_part.h:1063-1084; key frames): any pointer may be NULL = keep the device copy.
+ * vp8enc.cpp:460-470, loop_filter.h:7, 63-65 */
+int vp8hip_upload_mb_data(vp8hip_ctx *ctx, const int16_t *MB_coeffs, const int32_t *MB_parts,
+                          const int32_t *MB_segment_id);
+int vp8hip_upload_recon(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+
+/* prepare_filter_mask_and_non_zero_coeffs(), loop_filter.h:25-55.  nz_out: [MBs] or NULL.
+ * (vp8hip_inter_transform already produced mask and counts for its own coefficients; this call
+ * recomputes them from the device copy, e.g. after vp8hip_upload_mb_data.) */
+int vp8hip_prepare_filter_mask(vp8hip_ctx *ctx, int32_t *nz_out);
+
+/* do_loop_filter(), loop_filter.h:185-190: normal loop filter on the reconstruction, in place,
+ * after which that reconstruction IS the LAST reference of the next vp8hip_inter_transform. */
+int vp8hip_loop_filter(vp8hip_ctx *ctx);
+
+/* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
+int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
+
+int vp8hip_synchronize(vp8hip_ctx *ctx);
+/* hipStream_t the context launches on (for event timing by the caller) */
+void *vp8hip_stream(vp8hip_ctx *ctx);
+int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
+const char *vp8hip_status_string(int status);
+
+/* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */
+typedef enum {
+    VP8HIP_K_PACK = 0,      /* tight planes -> padded surfaces */
+    VP8HIP_K_DOWNSAMPLE,    /* downsample_x2                     GPU_kernels.cl:429  */
+    VP8HIP_K_SEARCH1_L4,    /* luma_search_1step, 1/16           GPU_kernels.cl:459  */
+    VP8HIP_K_SEARCH1_L3,
+    VP8HIP_K_SEARCH1_L2,
+    VP8HIP_K_SEARCH1_L1,
+    VP8HIP_K_SEARCH1_L0,    /* full resolution: the kernel BASELINE.json's roofline target names */
+    VP8HIP_K_SEARCH2,       /* luma_search_2step                 GPU_kernels.cl:1068 */
+    VP8HIP_K_SELECT,        /* select_reference + pack_8x8_into_16x16 */
+    VP8HIP_K_MB,            /* predictors + dct/quant/wht/idct + SSIM + filter mask */
+    VP8HIP_K_FILTER_MASK,   /* prepare_filter_mask (recompute)   CPU_kernels.cl:782  */
+    VP8HIP_K_LOOP_FILTER,   /* loop_filter_frame_luma/_chroma    CPU_kernels.cl:970,1333 */
+    VP8HIP_K_BORDER,        /* edge replication of a new reference */
+    VP8HIP_K_COUNT
+} vp8hip_kernel_id;
+
+/* time the kernels whose bit is set in mask (1u << id) with hipEvents on the ctx stream */
+int vp8hip_profile_enable(vp8hip_ctx *ctx, uint32_t mask);
+/* blocks until the stream is idle; total_ms[id] / launches[id] since the last read (arrays of VP8HIP_K_COUNT) */
+int vp8hip_profile_read(vp8hip_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* stage outputs of the last vp8hip_inter_transform, for parity tests */
+typedef enum {
+    VP8HIP_DBG_NET1 = 0,   /* ref, -      : short2[b8]   (after the 2-step search: qpel vectors)   */
+    VP8HIP_DBG_NET2,       /* ref, -      : short2[b8]   (after the 1x 1-step search: full-pel)    */
+    VP8HIP_DBG_BDIFF,      /* ref, -      : int[b8]                                               */
+    VP8HIP_DBG_PYRAMID,    /* ref(3=cur), level 0..4 : tight (W>>l)x(H>>l) plane                   */
+    VP8HIP_DBG_MB_MASK,    /* -           : int[MBs]                                              */
+    VP8HIP_DBG_MB_NZ       /* -           : int[MBs]                                              */
+} vp8hip_debug_id;
+int vp8hip_debug_download(vp8hip_ctx *ctx, int what, int ref, int level, void *dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

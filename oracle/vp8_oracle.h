@@ -1,0 +1,131 @@
+/*
+ * vp8_oracle.h -- CPU restatement of the vp8oclenc inter-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file (and everything under oracle/) is the
+ * parity checker and the timed CPU baseline.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product path
+ * (vp8oclenc_amd/csrc, libvp8hip.so) never links or calls it.
+ *
+ * Parity pin: every function below is checked bit-for-bit (SSIM: 1e-4) against the
+ * reference's own kernels (src/GPU_kernels.cl, src/CPU_kernels.cl) compiled for
+ * x86 by oracle/build_ref.sh into oracle/_ref/libvp8ref.so (tests/test_oracle_vs_ref.py),
+ * and against the golden vectors that build produced (tests/golden/).  The reference
+ * ships no tests or golden vectors of its own.
+ *
+ * Each function cites the reference kernel it restates (paths relative to
+ * /root/reference).  All planes are tightly packed, row-major, stride == width.
+ */
+#ifndef VP8_ORACLE_H
+#define VP8_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/vp8enc.h:80-92 -- 11 ints per segment, 4 segments */
+enum {
+    SD_Y_AC_I = 0, SD_Y_DC_IDELTA, SD_Y2_DC_IDELTA, SD_Y2_AC_IDELTA, SD_UV_DC_IDELTA,
+    SD_UV_AC_IDELTA, SD_LOOP_FILTER_LEVEL, SD_MBEDGE_LIMIT, SD_SUB_BEDGE_LIMIT,
+    SD_INTERIOR_LIMIT, SD_HEV_THRESHOLD, SD_INTS = 11
+};
+
+enum { VP8O_LAST = 0, VP8O_GOLDEN = 1, VP8O_ALTREF = 2 };
+enum { VP8O_16x16 = 0, VP8O_8x8 = 1 };
+
+/* src/GPU_kernels.cl:85-190 (weight_opt): cost of one 4x4 difference block, d[16] row-major */
+int vp8o_weight(const int d[16]);
+
+/* src/GPU_kernels.cl:429-451 */
+void vp8o_downsample_x2(const uint8_t *src, uint8_t *dst, int src_w, int src_h);
+
+/* src/GPU_kernels.cl:459-560.  nets are short2 cells: net[2*cell+0]=x, [2*cell+1]=y */
+void vp8o_luma_search_1step(const uint8_t *cur, const uint8_t *ref, const int16_t *src_net,
+                            int16_t *dst_net, int net_width, int width, int height, int pixel_rate);
+
+/* src/GPU_kernels.cl:1068-1203 (+construct_opt1/2 :776-1066); ref addressed clamp-to-edge */
+void vp8o_luma_search_2step(const uint8_t *cur, const uint8_t *ref, const int16_t *net,
+                            int16_t *ref_net, int32_t *ref_Bdiff, int width, int height);
+
+/* src/GPU_kernels.cl:1205-1283 */
+void vp8o_select_reference(const int16_t *last_net, const int16_t *golden_net, const int16_t *altref_net,
+                           const int32_t *last_Bdiff, const int32_t *golden_Bdiff, const int32_t *altref_Bdiff,
+                           int32_t *MB_ref, int16_t *MB_vectors, int width, int height,
+                           int use_golden, int use_altref);
+
+/* src/GPU_kernels.cl:1346-1366 */
+void vp8o_pack_8x8_into_16x16(const int16_t *MB_vectors, int32_t *MB_parts, float *MB_SSIM, int mb_count);
+
+/* src/GPU_kernels.cl:1285-1344 (+construct :574-774).  plane: 0=Y 1=U 2=V; width/height of THAT plane */
+void vp8o_prepare_predictors_and_residual(const uint8_t *cur, const uint8_t *ref, uint8_t *predictor,
+                                          int16_t *residual, const int32_t *MB_ref, const int16_t *MB_vectors,
+                                          int width, int height, int plane, int ref_id);
+
+/* src/GPU_kernels.cl:1368-1496.  MB: short[mb_count][25][16] */
+void vp8o_dct4x4(const int16_t *residual, int16_t *MB, int32_t *MB_segment_id, const int32_t *MB_parts,
+                 const float *MB_SSIM, int width, int height, const int32_t *SD, int segment_id,
+                 float SSIM_target, int plane);
+
+/* src/GPU_kernels.cl:1498-1543 */
+void vp8o_wht4x4_iwht4x4(int16_t *MB, const int32_t *MB_segment_id, const int32_t *MB_parts,
+                         const int32_t *SD, int segment_id, int mb_count);
+
+/* src/GPU_kernels.cl:1545-1608 */
+void vp8o_idct4x4(uint8_t *recon, const uint8_t *predictor, const int16_t *MB, const int32_t *MB_segment_id,
+                  const int32_t *MB_parts, int width, int height, const int32_t *SD, int segment_id, int plane);
+
+/* src/GPU_kernels.cl:1610-1971 (luma, mb 16x16) and :1973-2095 (chroma, 8x8); float */
+void vp8o_count_SSIM(const uint8_t *f1, const uint8_t *f2, const int32_t *MB_segment_id, float *metric,
+                     int width, int height, int segment_id, int mb_size);
+/* src/GPU_kernels.cl:2097-2105 */
+void vp8o_gather_SSIM(const float *m1, const float *m2, const float *m3, float *MB_SSIM, int mb_count);
+
+/* src/CPU_kernels.cl:782-827 */
+void vp8o_prepare_filter_mask(const int16_t *MB, int32_t *MB_non_zero_coeffs, const int32_t *MB_parts,
+                              int32_t *mb_mask, int width, int height);
+
+/* src/CPU_kernels.cl:970-1075 (mb_size 16) and :1333-1439 (mb_size 8); width/height of the plane */
+void vp8o_loop_filter_frame(uint8_t *frame, const int32_t *MB_segment_ids, const int32_t *mb_mask,
+                            const int32_t *SD, int width, int height, int mb_size);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole inter frame, in the enqueue order of src/inter_part.h:96-384 followed by
+ * src/loop_filter.h:25-55,140-183.  One context keeps the three references and their pyramids
+ * the way prepare_GPU_buffers() (src/inter_part.h:1-94) rotates them.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vp8o_ctx vp8o_ctx;
+
+typedef struct {
+    int32_t *MB_parts;            /* [MBs] */
+    int32_t *MB_reference_frame;  /* [MBs] */
+    int16_t *MB_vectors;          /* [MBs][4][2] qpel */
+    int16_t *MB_coeffs;           /* [MBs][25][16] */
+    int32_t *MB_segment_id;       /* [MBs] */
+    float   *MB_SSIM;             /* [MBs] */
+    int32_t *MB_non_zero_coeffs;  /* [MBs] */
+    int32_t *mb_mask;             /* [MBs] */
+    uint8_t *recon_Y, *recon_U, *recon_V; /* loop-filtered reconstruction */
+    uint8_t *prefilter_Y, *prefilter_U, *prefilter_V; /* recon before the loop filter (may be NULL) */
+} vp8o_results;
+
+vp8o_ctx *vp8o_create(int width, int height, float ssim_target);
+void vp8o_destroy(vp8o_ctx *c);
+/* LAST := these planes (key-frame reconstruction or host-modified recon), src/vp8enc.cpp:395-401 */
+void vp8o_upload_last(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+void vp8o_set_segments(vp8o_ctx *c, const int32_t sd[44]);
+/* runs prepare_GPU_buffers + inter_transform + prepare_filter_mask + loop filter on cur;
+ * afterwards the filtered reconstruction is LAST.  Pointers in *out may be NULL to skip a copy. */
+void vp8o_inter_frame(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, const uint8_t *cur_v,
+                      int prev_is_golden, int prev_is_altref, int use_golden, int use_altref,
+                      vp8o_results *out);
+/* stage outputs of the last vp8o_inter_frame (for parity tests): level 0..4 = /16,/8,/4,/2,/1 */
+const int16_t *vp8o_debug_net(const vp8o_ctx *c, int ref, int which /*1 or 2*/);
+const int32_t *vp8o_debug_bdiff(const vp8o_ctx *c, int ref);
+const uint8_t *vp8o_debug_pyramid(const vp8o_ctx *c, int ref /*0..2, 3 = current*/, int level /*0..4 = 1x..1/16*/);
+int vp8o_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,171 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, where it was built, for the
+reference's own kernels compiled to x86 (oracle/_ref/libvp8ref.so).
+
+Test infrastructure: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+Both libraries export the same per-stage functions (prefix vp8o_ / ref_), so `Stages` wraps either.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8ref.so")
+
+SD_INTS = 11
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+ci = C.c_int
+
+_STAGES = {
+    "downsample_x2": [u8p, u8p, ci, ci],
+    "luma_search_1step": [u8p, u8p, i16p, i16p, ci, ci, ci, ci],
+    "luma_search_2step": [u8p, u8p, i16p, i16p, i32p, ci, ci],
+    "select_reference": [i16p, i16p, i16p, i32p, i32p, i32p, i32p, i16p, ci, ci, ci, ci],
+    "pack_8x8_into_16x16": [i16p, i32p, f32p, ci],
+    "prepare_predictors_and_residual": [u8p, u8p, u8p, i16p, i32p, i16p, ci, ci, ci, ci],
+    "dct4x4": [i16p, i16p, i32p, i32p, f32p, ci, ci, i32p, ci, C.c_float, ci],
+    "wht4x4_iwht4x4": [i16p, i32p, i32p, i32p, ci, ci],
+    "idct4x4": [u8p, u8p, i16p, i32p, i32p, ci, ci, i32p, ci, ci],
+    "count_SSIM": [u8p, u8p, i32p, f32p, ci, ci, ci, ci],
+    "gather_SSIM": [f32p, f32p, f32p, f32p, ci],
+    "prepare_filter_mask": [i16p, i32p, i32p, i32p, ci, ci],
+    "loop_filter_frame": [u8p, i32p, i32p, i32p, ci, ci, ci],
+}
+
+
+def build_oracle(force: bool = False) -> str:
+    """Compile oracle/liboracle.so (and oracle/_ref when /root/reference is present)."""
+    src = os.path.join(ORACLE_DIR, "vp8_oracle.c")
+    stale = (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+class Stages:
+    """Per-kernel entry points of one library (prefix 'vp8o_' = restatement, 'ref_' = reference kernels)."""
+
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.lib, self.prefix = lib, prefix
+        for name, argtypes in _STAGES.items():
+            fn = getattr(lib, prefix + name)
+            fn.argtypes = argtypes
+            fn.restype = None
+            setattr(self, name, fn)
+
+
+class Results(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs", "MB_segment_id", "MB_SSIM",
+        "MB_non_zero_coeffs", "mb_mask", "recon_Y", "recon_U", "recon_V",
+        "prefilter_Y", "prefilter_U", "prefilter_V")]
+
+
+def alloc_results(W: int, H: int) -> dict:
+    mbs = (W // 16) * (H // 16)
+    return {
+        "MB_parts": np.zeros(mbs, np.int32), "MB_reference_frame": np.zeros(mbs, np.int32),
+        "MB_vectors": np.zeros((mbs, 4, 2), np.int16), "MB_coeffs": np.zeros((mbs, 25, 16), np.int16),
+        "MB_segment_id": np.zeros(mbs, np.int32), "MB_SSIM": np.zeros(mbs, np.float32),
+        "MB_non_zero_coeffs": np.zeros(mbs, np.int32), "mb_mask": np.zeros(mbs, np.int32),
+        "recon_Y": np.zeros((H, W), np.uint8), "recon_U": np.zeros((H // 2, W // 2), np.uint8),
+        "recon_V": np.zeros((H // 2, W // 2), np.uint8),
+        "prefilter_Y": np.zeros((H, W), np.uint8), "prefilter_U": np.zeros((H // 2, W // 2), np.uint8),
+        "prefilter_V": np.zeros((H // 2, W // 2), np.uint8),
+    }
+
+
+class Oracle:
+    """Whole-frame driver of the restatement (vp8o_create / vp8o_inter_frame)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls) -> C.CDLL:
+        if cls._lib is None:
+            build_oracle()
+            lib = C.CDLL(ORACLE_SO)
+            lib.vp8o_create.restype = C.c_void_p
+            lib.vp8o_create.argtypes = [ci, ci, C.c_float]
+            lib.vp8o_destroy.argtypes = [C.c_void_p]
+            lib.vp8o_upload_last.argtypes = [C.c_void_p, u8p, u8p, u8p]
+            lib.vp8o_set_segments.argtypes = [C.c_void_p, i32p]
+            lib.vp8o_inter_frame.argtypes = [C.c_void_p, u8p, u8p, u8p, ci, ci, ci, ci, C.POINTER(Results)]
+            lib.vp8o_debug_net.restype = C.POINTER(C.c_int16)
+            lib.vp8o_debug_net.argtypes = [C.c_void_p, ci, ci]
+            lib.vp8o_debug_bdiff.restype = C.POINTER(C.c_int32)
+            lib.vp8o_debug_bdiff.argtypes = [C.c_void_p, ci]
+            lib.vp8o_debug_pyramid.restype = C.POINTER(C.c_uint8)
+            lib.vp8o_debug_pyramid.argtypes = [C.c_void_p, ci, ci]
+            lib.vp8o_num_threads.restype = ci
+            lib.vp8o_weight.argtypes = [i32p]
+            lib.vp8o_weight.restype = ci
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def stages(cls) -> Stages:
+        return Stages(cls.lib(), "vp8o_")
+
+    def __init__(self, W: int, H: int, ssim_target: float = -1.0):
+        self.W, self.H = W, H
+        self.mbs = (W // 16) * (H // 16)
+        self.h = self.lib().vp8o_create(W, H, ssim_target)
+        if not self.h:
+            raise ValueError("vp8o_create failed (size must be a multiple of 16)")
+
+    def close(self):
+        if self.h:
+            self.lib().vp8o_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_last(self, y, u, v):
+        self.lib().vp8o_upload_last(self.h, y, u, v)
+
+    def set_segments(self, sd):
+        self.lib().vp8o_set_segments(self.h, np.ascontiguousarray(sd, np.int32).reshape(-1))
+
+    def inter_frame(self, y, u, v, prev_is_golden, prev_is_altref, use_golden, use_altref) -> dict:
+        out = alloc_results(self.W, self.H)
+        r = Results(**{k: a.ctypes.data for k, a in out.items()})
+        self.lib().vp8o_inter_frame(self.h, y, u, v, int(prev_is_golden), int(prev_is_altref), int(use_golden),
+                                    int(use_altref), C.byref(r))
+        return out
+
+    def net(self, ref: int, which: int) -> np.ndarray:
+        p = self.lib().vp8o_debug_net(self.h, ref, which)
+        return np.ctypeslib.as_array(p, shape=(self.mbs * 4, 2)).copy()
+
+    def bdiff(self, ref: int) -> np.ndarray:
+        p = self.lib().vp8o_debug_bdiff(self.h, ref)
+        return np.ctypeslib.as_array(p, shape=(self.mbs * 4,)).copy()
+
+    def pyramid(self, ref: int, level: int) -> np.ndarray:
+        p = self.lib().vp8o_debug_pyramid(self.h, ref, level)
+        return np.ctypeslib.as_array(p, shape=(self.H >> level, self.W >> level)).copy()
+
+
+def ref_stages() -> Stages | None:
+    """The reference's own kernels (x86 build) or None when oracle/_ref was not built."""
+    if not os.path.exists(REF_SO):
+        try:
+            build_oracle()
+        except Exception:
+            return None
+    if not os.path.exists(REF_SO):
+        return None
+    return Stages(C.CDLL(REF_SO), "ref_")
