@@ -1,0 +1,53 @@
+/*
+ * vp8hip_host.h -- host-side mirror (C++ behind a C ABI, no GPU needed) of the reference host
+ * code that PRODUCES the parameters of the inter-frame path and sequences it.  The reference keeps
+ * this logic in vp8enc.cpp / init.h around its OpenCL calls; a maintainer who swaps the OpenCL calls
+ * for include/vp8hip.h keeps those functions as they are.  They are restated here so that the
+ * parity tests and bench.py drive the device path with the same numbers the reference would.
+ */
+#ifndef VP8HIP_HOST_H
+#define VP8HIP_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ParseArgs quantizer ladders, init.h:1585-1603.  Index 0..3 = UQ, HQ, AQ, LQ. */
+void vp8host_quantizer_ladders(int qi_min, int qi_max, int32_t lastqi[4], int32_t altrefqi[4]);
+
+/* get_loopfilter_strength(), vp8enc.cpp:96-127: brightness-based divisor and sharpness (0..7) */
+void vp8host_loopfilter_strength(const uint8_t *cur_y, int width, int height, int32_t *reductor, int32_t *sharpness);
+
+/* prepare_segments_data(), vp8enc.cpp:129-221.  refqi = lastqi or altrefqi (vp8enc.cpp:149-151);
+ * update_filter/shrpnss: the second call made from check_SSIM (vp8enc.cpp:260-261). */
+void vp8host_prepare_segments_data(int is_key_frame, const int32_t refqi[4], int qi_min, int reductor,
+                                   int sharpness, int update_filter, int shrpnss, int32_t sd[44]);
+
+/* frames.skip_prob, loop_filter.h:37-44 */
+int vp8host_skip_prob(const int32_t *MB_non_zero_coeffs, int mb_count);
+
+/* frame-type state machine, vp8enc.cpp:340-344, 364-374 and intra_part.h:1091-1098 */
+typedef struct {
+    int32_t gop_size, altref_range;
+    int32_t frame_number, frames_until_key, frames_until_altref;
+    int32_t golden_frame_number, altref_frame_number;
+    int32_t current_is_key, current_is_golden, current_is_altref;
+    int32_t prev_is_key, prev_is_golden, prev_is_altref;
+} vp8host_gop;
+
+void vp8host_gop_init(vp8host_gop *g, int gop_size, int altref_range);
+/* advance to the next input frame; fills the current_* / prev_* flags */
+void vp8host_gop_next(vp8host_gop *g);
+/* what intra_transform() does to the counters when the current frame is (or is forced to be) a key frame */
+void vp8host_gop_key_coded(vp8host_gop *g);
+/* flags of inter_transform(), inter_part.h:103-104 */
+void vp8host_gop_inter_flags(const vp8host_gop *g, int32_t *use_golden, int32_t *use_altref);
+/* ++frames.frame_number at the end of the loop body, vp8enc.cpp:487 */
+void vp8host_gop_frame_done(vp8host_gop *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -797,8 +797,8 @@ void vp8o_upload_last(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const uin
 
 void vp8o_set_segments(vp8o_ctx *c, const int32_t sd[44]) { memcpy(c->SD, sd, sizeof c->SD); }
 
-void vp8o_inter_frame(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, const uint8_t *cur_v,
-                      int prev_is_golden, int prev_is_altref, int use_golden, int use_altref, vp8o_results *out) {
+void vp8o_inter_transform(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, const uint8_t *cur_v,
+                          int prev_is_golden, int prev_is_altref, int use_golden, int use_altref, vp8o_results *out) {
     const int W = c->W, H = c->H, CW = W / 2, CH = H / 2;
     const int net_width = (W / 16) * 2;
     const int use[3] = {1, use_golden, use_altref};
@@ -858,11 +858,23 @@ void vp8o_inter_frame(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, c
         vp8o_gather_SSIM(c->metric[0], c->metric[1], c->metric[2], c->MB_SSIM, c->mbs);
     }
     if (out) {
+        const size_t n = c->mbs;
         if (out->prefilter_Y) memcpy(out->prefilter_Y, c->recon[0], (size_t)W * H);
         if (out->prefilter_U) memcpy(out->prefilter_U, c->recon[1], (size_t)CW * CH);
         if (out->prefilter_V) memcpy(out->prefilter_V, c->recon[2], (size_t)CW * CH);
+        if (out->MB_parts) memcpy(out->MB_parts, c->MB_parts, n * 4);
+        if (out->MB_reference_frame) memcpy(out->MB_reference_frame, c->MB_ref, n * 4);
+        if (out->MB_vectors) memcpy(out->MB_vectors, c->MB_vec, n * 16);
+        if (out->MB_coeffs) memcpy(out->MB_coeffs, c->MB_coeffs, n * 800);
+        if (out->MB_segment_id) memcpy(out->MB_segment_id, c->MB_seg, n * 4);
+        if (out->MB_SSIM) memcpy(out->MB_SSIM, c->MB_SSIM, n * 4);
     }
-    /* src/loop_filter.h:25-55 then :140-183 (three planes concurrently, one thread each) */
+}
+
+/* prepare_filter_mask_and_non_zero_coeffs() + do_loop_filter(): src/loop_filter.h:25-55 then :140-183
+ * (three planes concurrently, one thread each), after which the filtered reconstruction is LAST. */
+void vp8o_loop_filter(vp8o_ctx *c, vp8o_results *out) {
+    const int W = c->W, H = c->H, CW = W / 2, CH = H / 2;
     vp8o_prepare_filter_mask(c->MB_coeffs, c->MB_nz, c->MB_parts, c->mb_mask, W, H);
 #pragma omp parallel sections
     {
@@ -879,18 +891,24 @@ void vp8o_inter_frame(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, c
     memcpy(c->ref[0].V, c->recon[2], (size_t)CW * CH);
     if (out) {
         const size_t n = c->mbs;
-        if (out->MB_parts) memcpy(out->MB_parts, c->MB_parts, n * 4);
-        if (out->MB_reference_frame) memcpy(out->MB_reference_frame, c->MB_ref, n * 4);
-        if (out->MB_vectors) memcpy(out->MB_vectors, c->MB_vec, n * 16);
-        if (out->MB_coeffs) memcpy(out->MB_coeffs, c->MB_coeffs, n * 800);
-        if (out->MB_segment_id) memcpy(out->MB_segment_id, c->MB_seg, n * 4);
-        if (out->MB_SSIM) memcpy(out->MB_SSIM, c->MB_SSIM, n * 4);
         if (out->MB_non_zero_coeffs) memcpy(out->MB_non_zero_coeffs, c->MB_nz, n * 4);
         if (out->mb_mask) memcpy(out->mb_mask, c->mb_mask, n * 4);
         if (out->recon_Y) memcpy(out->recon_Y, c->recon[0], (size_t)W * H);
         if (out->recon_U) memcpy(out->recon_U, c->recon[1], (size_t)CW * CH);
         if (out->recon_V) memcpy(out->recon_V, c->recon[2], (size_t)CW * CH);
     }
+}
+
+/* host-side changes between transform and loop filter (vp8hip_upload_mb_data / vp8hip_upload_recon) */
+void vp8o_upload_mb_data(vp8o_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg) {
+    if (coeffs) memcpy(c->MB_coeffs, coeffs, (size_t)c->mbs * 800);
+    if (parts) memcpy(c->MB_parts, parts, (size_t)c->mbs * 4);
+    if (seg) memcpy(c->MB_seg, seg, (size_t)c->mbs * 4);
+}
+void vp8o_upload_recon(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    memcpy(c->recon[0], y, (size_t)c->W * c->H);
+    memcpy(c->recon[1], u, (size_t)c->W * c->H / 4);
+    memcpy(c->recon[2], v, (size_t)c->W * c->H / 4);
 }
 
 const int16_t *vp8o_debug_net(const vp8o_ctx *c, int ref, int which) { return c->net[ref][which - 1]; }

@@ -114,11 +114,16 @@ void vp8o_destroy(vp8o_ctx *c);
 /* LAST := these planes (key-frame reconstruction or host-modified recon), src/vp8enc.cpp:395-401 */
 void vp8o_upload_last(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 void vp8o_set_segments(vp8o_ctx *c, const int32_t sd[44]);
-/* runs prepare_GPU_buffers + inter_transform + prepare_filter_mask + loop filter on cur;
- * afterwards the filtered reconstruction is LAST.  Pointers in *out may be NULL to skip a copy. */
-void vp8o_inter_frame(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, const uint8_t *cur_v,
-                      int prev_is_golden, int prev_is_altref, int use_golden, int use_altref,
-                      vp8o_results *out);
+/* prepare_GPU_buffers + inter_transform on cur (src/inter_part.h:1-384).  Fills the MB_* members and
+ * prefilter_* of *out (NULL members are skipped). */
+void vp8o_inter_transform(vp8o_ctx *c, const uint8_t *cur_y, const uint8_t *cur_u, const uint8_t *cur_v,
+                          int prev_is_golden, int prev_is_altref, int use_golden, int use_altref,
+                          vp8o_results *out);
+/* prepare_filter_mask + loop filter (src/loop_filter.h); afterwards the filtered reconstruction is
+ * LAST.  Fills MB_non_zero_coeffs, mb_mask, recon_* of *out. */
+void vp8o_loop_filter(vp8o_ctx *c, vp8o_results *out);
+void vp8o_upload_mb_data(vp8o_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg);
+void vp8o_upload_recon(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 /* stage outputs of the last vp8o_inter_frame (for parity tests): level 0..4 = /16,/8,/4,/2,/1 */
 const int16_t *vp8o_debug_net(const vp8o_ctx *c, int ref, int which /*1 or 2*/);
 const int32_t *vp8o_debug_bdiff(const vp8o_ctx *c, int ref);

@@ -87,7 +87,7 @@ def alloc_results(W: int, H: int) -> dict:
 
 
 class Oracle:
-    """Whole-frame driver of the restatement (vp8o_create / vp8o_inter_frame)."""
+    """Whole-frame driver of the restatement, with the method names of vp8oclenc_amd.api.Vp8Hip."""
 
     _lib = None
 
@@ -101,7 +101,10 @@ class Oracle:
             lib.vp8o_destroy.argtypes = [C.c_void_p]
             lib.vp8o_upload_last.argtypes = [C.c_void_p, u8p, u8p, u8p]
             lib.vp8o_set_segments.argtypes = [C.c_void_p, i32p]
-            lib.vp8o_inter_frame.argtypes = [C.c_void_p, u8p, u8p, u8p, ci, ci, ci, ci, C.POINTER(Results)]
+            lib.vp8o_inter_transform.argtypes = [C.c_void_p, u8p, u8p, u8p, ci, ci, ci, ci, C.POINTER(Results)]
+            lib.vp8o_loop_filter.argtypes = [C.c_void_p, C.POINTER(Results)]
+            lib.vp8o_upload_mb_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.vp8o_upload_recon.argtypes = [C.c_void_p, u8p, u8p, u8p]
             lib.vp8o_debug_net.restype = C.POINTER(C.c_int16)
             lib.vp8o_debug_net.argtypes = [C.c_void_p, ci, ci]
             lib.vp8o_debug_bdiff.restype = C.POINTER(C.c_int32)
@@ -139,12 +142,49 @@ class Oracle:
     def set_segments(self, sd):
         self.lib().vp8o_set_segments(self.h, np.ascontiguousarray(sd, np.int32).reshape(-1))
 
-    def inter_frame(self, y, u, v, prev_is_golden, prev_is_altref, use_golden, use_altref) -> dict:
-        out = alloc_results(self.W, self.H)
-        r = Results(**{k: a.ctypes.data for k, a in out.items()})
-        self.lib().vp8o_inter_frame(self.h, y, u, v, int(prev_is_golden), int(prev_is_altref), int(use_golden),
-                                    int(use_altref), C.byref(r))
-        return out
+    # -- same call sequence as the C ABI (include/vp8hip.h) ------------------------------------
+    def upload_current(self, y, u, v):
+        self._cur = (np.ascontiguousarray(y), np.ascontiguousarray(u), np.ascontiguousarray(v))
+
+    def inter_transform(self, prev_is_golden, prev_is_altref, use_golden, use_altref):
+        self._out = alloc_results(self.W, self.H)
+        r = Results(**{k: a.ctypes.data for k, a in self._out.items()})
+        y, u, v = self._cur
+        self.lib().vp8o_inter_transform(self.h, y, u, v, int(prev_is_golden), int(prev_is_altref), int(use_golden),
+                                        int(use_altref), C.byref(r))
+
+    def download_results(self, recon: bool = True) -> dict:
+        keys = ["MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs", "MB_segment_id", "MB_SSIM"]
+        if recon:
+            keys += ["prefilter_Y", "prefilter_U", "prefilter_V"]
+        return {k: self._out[k].copy() for k in keys}
+
+    def upload_mb_data(self, coeffs=None, parts=None, seg=None):
+        p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data
+        self._keep = (coeffs, parts, seg)
+        self.lib().vp8o_upload_mb_data(self.h, p(coeffs), p(parts), p(seg))
+
+    def upload_recon(self, y, u, v):
+        self.lib().vp8o_upload_recon(self.h, np.ascontiguousarray(y), np.ascontiguousarray(u), np.ascontiguousarray(v))
+
+    def prepare_filter_mask(self, want_nz: bool = True):
+        # the restatement computes mask and counts inside vp8o_loop_filter (see filter_outputs)
+        return None
+
+    def loop_filter(self):
+        res = alloc_results(self.W, self.H)
+        r = Results(**{k: a.ctypes.data for k, a in res.items()})
+        self.lib().vp8o_loop_filter(self.h, C.byref(r))
+        self._lf = res
+
+    def filter_outputs(self) -> dict:
+        return {k: self._lf[k] for k in ("MB_non_zero_coeffs", "mb_mask", "recon_Y", "recon_U", "recon_V")}
+
+    def download_last(self):
+        return self._lf["recon_Y"], self._lf["recon_U"], self._lf["recon_V"]
+
+    def synchronize(self):
+        pass
 
     def net(self, ref: int, which: int) -> np.ndarray:
         p = self.lib().vp8o_debug_net(self.h, ref, which)

@@ -1,0 +1,219 @@
+"""Parity of the HIP path (through the C ABI, libvp8hip.so) against the CPU oracle on the same
+seeded inputs.  Bit-exact for every integer output; MB_SSIM within 1e-4 (the reference computes it
+in float: BASELINE.json north_star).  Run on the GPU box with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from pipeline import default_segments
+from vp8oclenc_amd import api
+from vp8oclenc_amd.driver import InterPathDriver
+from vp8oclenc_amd.synth import SynthSequence, noise_frames
+
+pytestmark = pytest.mark.gpu
+
+SSIM_TOL = 1e-4  # tolerance for the only floating-point output of the path
+
+
+def _compare(a: dict, b: dict, keys, tag=""):
+    bad = []
+    for k in keys:
+        if k == "MB_SSIM":
+            d = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
+            if not d <= SSIM_TOL:
+                bad.append((k, d))
+        elif not np.array_equal(a[k], b[k]):
+            bad.append((k, int((a[k] != b[k]).sum()), int(a[k].size)))
+    assert not bad, f"{tag}: HIP differs from oracle: {bad}"
+
+
+INTEGER_KEYS = ["MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs", "MB_segment_id", "MB_SSIM",
+                "prefilter_Y", "prefilter_U", "prefilter_V"]
+
+
+def _one_frame(W, H, frames, sd, flags, ssim_target=-1.0, saturate=False):
+    """LAST/GOLDEN/ALTREF = frames[0..2] (uploaded in the order that makes them so), current = frames[3]."""
+    hip = api.Vp8Hip(W, H, ssim_target)
+    ora = Oracle(W, H, ssim_target)
+    use_golden, use_altref = flags
+    out = []
+    for be in (hip, ora):
+        be.set_segments(sd)
+        # make frames[1] GOLDEN, frames[2] ALTREF, frames[0] LAST through the reference's own rotation rules
+        be.upload_last(*frames[1])
+        be.upload_current(*frames[3])
+        be.inter_transform(1, 0, 0, 0)      # golden := LAST(frames[1])
+        be.loop_filter()
+        be.upload_last(*frames[2])
+        be.upload_current(*frames[3])
+        be.inter_transform(0, 1, 0, 0)      # altref := LAST(frames[2])
+        be.loop_filter()
+        be.upload_last(*frames[0])
+        be.upload_current(*frames[3])
+        be.inter_transform(0, 0, use_golden, use_altref)
+        res = be.download_results(recon=True)
+        if be is hip:
+            for r in range(3):
+                if r == 0 or (use_golden, use_altref)[r - 1]:
+                    res[f"net2_r{r}"] = hip.debug(api.DBG_NET2, r)
+                    res[f"net1_r{r}"] = hip.debug(api.DBG_NET1, r)
+                    res[f"bdiff_r{r}"] = hip.debug(api.DBG_BDIFF, r)
+            for l in range(5):
+                res[f"cur_pyr{l}"] = hip.debug(api.DBG_PYRAMID, 3, l)
+                res[f"last_pyr{l}"] = hip.debug(api.DBG_PYRAMID, 0, l)
+        else:
+            for r in range(3):
+                if r == 0 or (use_golden, use_altref)[r - 1]:
+                    res[f"net2_r{r}"] = ora.net(r, 2)
+                    res[f"net1_r{r}"] = ora.net(r, 1)
+                    res[f"bdiff_r{r}"] = ora.bdiff(r)
+            for l in range(5):
+                res[f"cur_pyr{l}"] = ora.pyramid(3, l)
+                res[f"last_pyr{l}"] = ora.pyramid(0, l)
+        be.prepare_filter_mask(want_nz=False)
+        be.loop_filter()
+        if be is hip:
+            res["mb_mask"] = hip.debug(api.DBG_MB_MASK)
+            res["MB_non_zero_coeffs"] = hip.debug(api.DBG_MB_NZ)
+            res["recon_Y"], res["recon_U"], res["recon_V"] = hip.download_last()
+        else:
+            res.update(ora.filter_outputs())
+        out.append(res)
+    hip.close()
+    ora.close()
+    return out
+
+
+def _frames(W, H, seed, n=4, **kw):
+    s = SynthSequence(W, H, seed=seed, **kw)
+    return [s.frame(t) for t in range(n)]
+
+
+@pytest.mark.parametrize("W,H,seed,flags,ssim_target,kw", [
+    (64, 48, 1, (0, 0), -1.0, {}),
+    (64, 64, 2, (1, 1), -1.0, {}),
+    (256, 128, 5, (1, 1), 0.93, {}),
+    (256, 128, 7, (1, 0), 0.97, dict(noise=20, saturate=True)),
+    (352, 288, 3, (1, 1), 0.95, {}),
+    (16, 16, 4, (1, 1), -1.0, {}),        # a single macroblock
+    (1280, 720, 6, (0, 0), -1.0, {}),     # BASELINE configs[1] geometry (LAST only)
+])
+def test_single_frame_all_stages(W, H, seed, flags, ssim_target, kw):
+    f = _frames(W, H, seed, **kw)
+    # frames[0] is LAST: closest in time to the current frame
+    frames = [f[2], f[0], f[1], f[3]]
+    sd = default_segments()
+    h, o = _one_frame(f[0][0].shape[1], f[0][0].shape[0], frames, sd, flags, ssim_target)
+    keys = [k for k in o if k in h]
+    _compare(h, o, keys, f"{W}x{H} seed {seed}")
+
+
+def test_noise_frames_cost_wraparound():
+    """Nearly unrelated frames push the ushort cost of the 1-step search past 0x7fff / 0xffff."""
+    nf = noise_frames(128, 64, 9)
+    frames = [nf[0], nf[1], nf[0], nf[1]]
+    h, o = _one_frame(128, 64, frames, default_segments(), (1, 1))
+    _compare(h, o, [k for k in o if k in h], "noise")
+
+
+def test_loop_filter_level_zero_leaves_rest_of_plane():
+    """CPU_kernels.cl:990: the first macroblock whose segment has level 0 stops the whole plane."""
+    f = _frames(128, 96, 13)
+    sd = default_segments(lf_levels=(6, 10, 14, 0))   # LQ segment (the one every MB gets at target -1) has level 0
+    h, o = _one_frame(128, 96, [f[2], f[0], f[1], f[3]], sd, (1, 1))
+    _compare(h, o, ["recon_Y", "recon_U", "recon_V", "mb_mask"], "lf level 0")
+    assert np.array_equal(h["recon_Y"], h["prefilter_Y"])
+
+
+def test_sequence_through_driver_1080p_like_gop():
+    """30 frames through the reference's frame loop: key at 0, altref every 5, golden = key."""
+    W, H = 320, 192
+    s = SynthSequence(W, H, seed=21)
+    hip = api.Vp8Hip(s.W, s.H)
+    ora = Oracle(s.W, s.H)
+    dh = InterPathDriver(hip, s.W, s.H, gop_size=150, altref_range=5)
+    do = InterPathDriver(ora, s.W, s.H, gop_size=150, altref_range=5)
+    seen = set()
+    for t in range(30):
+        y, u, v = s.frame(t)
+        a, b = dh.encode_frame(y, u, v), do.encode_frame(y, u, v)
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        seen.add((a["use_golden"], a["use_altref"]))
+        _compare(a, b, INTEGER_KEYS, f"frame {t}")
+        ly, lu, lv = hip.download_last()
+        oy, ou, ov = ora.download_last()
+        assert np.array_equal(ly, oy) and np.array_equal(lu, ou) and np.array_equal(lv, ov), f"filtered recon, frame {t}"
+    assert (1, 1) in seen and (0, 0) in seen  # all three references were exercised
+    hip.close()
+    ora.close()
+
+
+def test_ssim_target_multi_pass_sequence():
+    """-SSIM-target 97: macroblocks take 1..4 segment passes (inter_part.h:329-378)."""
+    W, H = 192, 128
+    s = SynthSequence(W, H, seed=33, noise=12)
+    hip, ora = api.Vp8Hip(s.W, s.H, 0.97), Oracle(s.W, s.H, 0.97)
+    dh = InterPathDriver(hip, s.W, s.H, ssim_target=0.97)
+    do = InterPathDriver(ora, s.W, s.H, ssim_target=0.97)
+    segs = np.zeros(4, np.int64)
+    for t in range(8):
+        y, u, v = s.frame(t)
+        a, b = dh.encode_frame(y, u, v), do.encode_frame(y, u, v)
+        if a is None:
+            continue
+        _compare(a, b, INTEGER_KEYS, f"frame {t}")
+        segs += np.bincount(a["MB_segment_id"], minlength=4)
+        assert np.array_equal(hip.download_last()[0], ora.download_last()[0])
+    assert (segs > 0).sum() >= 3, f"expected several segments in use, got {segs}"
+    hip.close()
+    ora.close()
+
+
+def test_host_modified_mb_data_and_recon():
+    """vp8hip_upload_mb_data / vp8hip_upload_recon / vp8hip_prepare_filter_mask (host intra fallback path)."""
+    W, H = 128, 96
+    f = _frames(W, H, 17)
+    hip, ora = api.Vp8Hip(W, H), Oracle(W, H)
+    rng = np.random.default_rng(5)
+    for be in (hip, ora):
+        be.set_segments(default_segments())
+        be.upload_last(*f[0])
+        be.upload_current(*f[1])
+        be.inter_transform(1, 1, 0, 0)
+    rh = hip.download_results()
+    coeffs = rh["MB_coeffs"].copy()
+    coeffs[::3] = 0                                   # some MBs lose every coefficient
+    parts = rh["MB_parts"].copy()
+    parts[1::4] = 0
+    seg = rng.integers(0, 4, size=parts.shape).astype(np.int32)
+    ry = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    ru = rng.integers(0, 256, size=(H // 2, W // 2)).astype(np.uint8)
+    rv = rng.integers(0, 256, size=(H // 2, W // 2)).astype(np.uint8)
+    for be in (hip, ora):
+        be.upload_mb_data(coeffs, parts, seg)
+        be.upload_recon(ry, ru, rv)
+    nz = hip.prepare_filter_mask(want_nz=True)
+    hip.loop_filter()
+    ora.loop_filter()
+    fo = ora.filter_outputs()
+    assert np.array_equal(nz, fo["MB_non_zero_coeffs"])
+    assert np.array_equal(hip.debug(api.DBG_MB_MASK), fo["mb_mask"])
+    hy, hu, hv = hip.download_last()
+    assert np.array_equal(hy, fo["recon_Y"]) and np.array_equal(hu, fo["recon_U"]) and np.array_equal(hv, fo["recon_V"])
+    assert api.skip_prob(nz) == max(2, min(254, int((nz > 0).sum()) * 256 // nz.size))
+    hip.close()
+    ora.close()
+
+
+def test_error_behaviour():
+    with pytest.raises(api.Vp8HipError):
+        api.Vp8Hip(100, 64)          # not a multiple of 16
+    hip = api.Vp8Hip(64, 64)
+    with pytest.raises(api.Vp8HipError):
+        hip.inter_transform(0, 0, 0, 0)   # no LAST yet
+    with pytest.raises(api.Vp8HipError):
+        hip.loop_filter()                  # nothing to filter
+    hip.close()

@@ -1,0 +1,293 @@
+"""ctypes binding of libvp8hip.so: the C ABI of include/vp8hip.h and include/vp8hip_host.h.
+
+Python is plumbing here (tests, bench, multi-GPU launch); every computation of the hot path
+happens behind the C ABI in hand-written HIP.  There is NO fallback: if the library is missing
+or no gfx950 device is usable, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "search1_l1", "search1_l0", "search2",
+           "select", "mb", "filter_mask", "loop_filter", "border"]
+K_COUNT = len(K_NAMES)
+
+DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ = range(6)
+
+# every symbol include/vp8hip.h and include/vp8hip_host.h declare
+ABI_SYMBOLS = [
+    "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
+    "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
+    "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
+    "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download",
+    "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
+    "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
+    "vp8host_gop_frame_done",
+]
+
+
+class Vp8HipError(RuntimeError):
+    pass
+
+
+class _Results(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs",
+                                          "MB_segment_id", "MB_SSIM", "recon_Y", "recon_U", "recon_V")]
+
+
+class GopState(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "gop_size", "altref_range", "frame_number", "frames_until_key", "frames_until_altref",
+        "golden_frame_number", "altref_frame_number", "current_is_key", "current_is_golden", "current_is_altref",
+        "prev_is_key", "prev_is_golden", "prev_is_altref")]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libvp8hip.so (building it first if the sources are newer).  Raises if impossible."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _build.LIB
+    if path is None and _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this box: use the prebuilt file if there is one
+            if not os.path.exists(p):
+                raise Vp8HipError(f"libvp8hip.so is missing and cannot be built: {e}") from e
+    if not os.path.exists(p):
+        raise Vp8HipError(f"{p} not found: build it with `python -m vp8oclenc_amd.build`")
+    lib = C.CDLL(p)
+    u8 = C.c_void_p
+    vp = C.c_void_p
+    lib.vp8hip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.vp8hip_destroy.argtypes = [vp]
+    lib.vp8hip_destroy.restype = None
+    for n in ("vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last", "vp8hip_set_last_device",
+              "vp8hip_upload_recon", "vp8hip_download_last"):
+        getattr(lib, n).argtypes = [vp, u8, u8, u8]
+    lib.vp8hip_set_segments.argtypes = [vp, C.c_void_p]
+    lib.vp8hip_inter_transform.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.vp8hip_download_results.argtypes = [vp, C.POINTER(_Results)]
+    lib.vp8hip_upload_mb_data.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vp8hip_prepare_filter_mask.argtypes = [vp, C.c_void_p]
+    lib.vp8hip_loop_filter.argtypes = [vp]
+    lib.vp8hip_synchronize.argtypes = [vp]
+    lib.vp8hip_stream.argtypes = [vp]
+    lib.vp8hip_stream.restype = C.c_void_p
+    lib.vp8hip_last_hip_error.argtypes = [vp]
+    lib.vp8hip_status_string.argtypes = [C.c_int]
+    lib.vp8hip_status_string.restype = C.c_char_p
+    lib.vp8hip_profile_enable.argtypes = [vp, C.c_uint32]
+    lib.vp8hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.vp8hip_debug_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    i32p = C.POINTER(C.c_int32)
+    lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
+    lib.vp8host_quantizer_ladders.restype = None
+    lib.vp8host_loopfilter_strength.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p]
+    lib.vp8host_loopfilter_strength.restype = None
+    lib.vp8host_prepare_segments_data.argtypes = [C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+    lib.vp8host_prepare_segments_data.restype = None
+    lib.vp8host_skip_prob.argtypes = [C.c_void_p, C.c_int]
+    for n in ("vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_frame_done"):
+        getattr(lib, n).argtypes = [C.POINTER(GopState)]
+        getattr(lib, n).restype = None
+    lib.vp8host_gop_init.argtypes = [C.POINTER(GopState), C.c_int, C.c_int]
+    lib.vp8host_gop_init.restype = None
+    lib.vp8host_gop_inter_flags.argtypes = [C.POINTER(GopState), i32p, i32p]
+    lib.vp8host_gop_inter_flags.restype = None
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return int(a)  # raw device/host address (e.g. torch tensor.data_ptr())
+
+
+# ---- host-side mirror (no GPU needed) -----------------------------------------------------------
+def quantizer_ladders(qi_min: int = 0, qi_max: int = 48):
+    lib = load_library()
+    a, b = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+    lib.vp8host_quantizer_ladders(qi_min, qi_max, a, b)
+    return list(a), list(b)
+
+
+def loopfilter_strength(y: np.ndarray):
+    lib = load_library()
+    r, s = C.c_int32(), C.c_int32()
+    y = np.ascontiguousarray(y, np.uint8)
+    lib.vp8host_loopfilter_strength(y.ctypes.data, y.shape[1], y.shape[0], C.byref(r), C.byref(s))
+    return r.value, s.value
+
+
+def prepare_segments_data(is_key: bool, refqi, qi_min: int, reductor: int, sharpness: int, update_filter: bool = False,
+                          shrpnss: int = 0) -> np.ndarray:
+    lib = load_library()
+    q = (C.c_int32 * 4)(*[int(v) for v in refqi])
+    sd = (C.c_int32 * 44)()
+    lib.vp8host_prepare_segments_data(int(is_key), q, qi_min, reductor, sharpness, int(update_filter), shrpnss, sd)
+    return np.array(list(sd), np.int32).reshape(4, 11)
+
+
+def skip_prob(nz: np.ndarray) -> int:
+    nz = np.ascontiguousarray(nz, np.int32)
+    return load_library().vp8host_skip_prob(nz.ctypes.data, nz.size)
+
+
+class Gop:
+    """Frame-type state machine of the reference main loop (vp8enc.cpp:340-374)."""
+
+    def __init__(self, gop_size: int = 150, altref_range: int = 5):
+        self.lib = load_library()
+        self.s = GopState()
+        self.lib.vp8host_gop_init(C.byref(self.s), gop_size, altref_range)
+
+    def next(self):
+        self.lib.vp8host_gop_next(C.byref(self.s))
+        return self.s
+
+    def key_coded(self):
+        self.lib.vp8host_gop_key_coded(C.byref(self.s))
+
+    def inter_flags(self):
+        g, a = C.c_int32(), C.c_int32()
+        self.lib.vp8host_gop_inter_flags(C.byref(self.s), C.byref(g), C.byref(a))
+        return g.value, a.value
+
+    def frame_done(self):
+        self.lib.vp8host_gop_frame_done(C.byref(self.s))
+
+
+# ---- device path ------------------------------------------------------------------------------
+class Vp8Hip:
+    """One encoder context on one MI355X (vp8hip_create ... vp8hip_destroy)."""
+
+    def __init__(self, width: int, height: int, ssim_target: float = -1.0, device: int = 0):
+        self.lib = load_library()
+        self.W, self.H = width, height
+        self.mbs = (width // 16) * (height // 16)
+        self.b8 = self.mbs * 4
+        h = C.c_void_p()
+        rc = self.lib.vp8hip_create(C.byref(h), width, height, ssim_target, device)
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_create({width}x{height}, device {device}) failed: "
+                              f"{self.lib.vp8hip_status_string(rc).decode()} ({rc}); the HIP path has no CPU fallback")
+        self.h = h
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            raise Vp8HipError(f"{what}: {self.lib.vp8hip_status_string(rc).decode()} ({rc}), hipError "
+                              f"{self.lib.vp8hip_last_hip_error(self.h)}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vp8hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_current(self, y, u, v):
+        self._chk(self.lib.vp8hip_upload_current(self.h, _ptr(y), _ptr(u), _ptr(v)), "upload_current")
+
+    def set_current_device(self, y, u, v):
+        self._chk(self.lib.vp8hip_set_current_device(self.h, _ptr(y), _ptr(u), _ptr(v)), "set_current_device")
+
+    def upload_last(self, y, u, v):
+        self._chk(self.lib.vp8hip_upload_last(self.h, _ptr(y), _ptr(u), _ptr(v)), "upload_last")
+
+    def set_last_device(self, y, u, v):
+        self._chk(self.lib.vp8hip_set_last_device(self.h, _ptr(y), _ptr(u), _ptr(v)), "set_last_device")
+
+    def upload_recon(self, y, u, v):
+        self._chk(self.lib.vp8hip_upload_recon(self.h, _ptr(y), _ptr(u), _ptr(v)), "upload_recon")
+
+    def set_segments(self, sd):
+        sd = np.ascontiguousarray(sd, np.int32).reshape(-1)
+        assert sd.size == 44
+        self._chk(self.lib.vp8hip_set_segments(self.h, sd.ctypes.data), "set_segments")
+
+    def inter_transform(self, prev_is_golden, prev_is_altref, use_golden, use_altref):
+        self._chk(self.lib.vp8hip_inter_transform(self.h, int(prev_is_golden), int(prev_is_altref), int(use_golden),
+                                                  int(use_altref)), "inter_transform")
+
+    def download_results(self, recon: bool = True) -> dict:
+        W, H, n = self.W, self.H, self.mbs
+        out = {
+            "MB_parts": np.zeros(n, np.int32), "MB_reference_frame": np.zeros(n, np.int32),
+            "MB_vectors": np.zeros((n, 4, 2), np.int16), "MB_coeffs": np.zeros((n, 25, 16), np.int16),
+            "MB_segment_id": np.zeros(n, np.int32), "MB_SSIM": np.zeros(n, np.float32),
+        }
+        if recon:
+            out.update(recon_Y=np.zeros((H, W), np.uint8), recon_U=np.zeros((H // 2, W // 2), np.uint8),
+                       recon_V=np.zeros((H // 2, W // 2), np.uint8))
+        r = _Results(**{k: a.ctypes.data for k, a in out.items()})
+        self._chk(self.lib.vp8hip_download_results(self.h, C.byref(r)), "download_results")
+        if recon:  # before the loop filter these are the unfiltered planes
+            out["prefilter_Y"], out["prefilter_U"], out["prefilter_V"] = out.pop("recon_Y"), out.pop("recon_U"), out.pop("recon_V")
+        return out
+
+    def upload_mb_data(self, coeffs=None, parts=None, seg=None):
+        self._chk(self.lib.vp8hip_upload_mb_data(self.h, _ptr(coeffs), _ptr(parts), _ptr(seg)), "upload_mb_data")
+
+    def prepare_filter_mask(self, want_nz: bool = True):
+        nz = np.zeros(self.mbs, np.int32) if want_nz else None
+        self._chk(self.lib.vp8hip_prepare_filter_mask(self.h, _ptr(nz)), "prepare_filter_mask")
+        return nz
+
+    def loop_filter(self):
+        self._chk(self.lib.vp8hip_loop_filter(self.h), "loop_filter")
+
+    def download_last(self):
+        W, H = self.W, self.H
+        y, u, v = np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)
+        self._chk(self.lib.vp8hip_download_last(self.h, y.ctypes.data, u.ctypes.data, v.ctypes.data), "download_last")
+        return y, u, v
+
+    def synchronize(self):
+        self._chk(self.lib.vp8hip_synchronize(self.h), "synchronize")
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.vp8hip_stream(self.h) or 0)
+
+    def profile_enable(self, kernels):
+        mask = 0
+        for k in kernels:
+            mask |= 1 << (K_NAMES.index(k) if isinstance(k, str) else int(k))
+        self._chk(self.lib.vp8hip_profile_enable(self.h, mask), "profile_enable")
+
+    def profile_read(self) -> dict:
+        ms = (C.c_double * K_COUNT)()
+        n = (C.c_int64 * K_COUNT)()
+        self._chk(self.lib.vp8hip_profile_read(self.h, ms, n), "profile_read")
+        return {K_NAMES[i]: (ms[i], n[i]) for i in range(K_COUNT) if n[i]}
+
+    def debug(self, what: int, ref: int = 0, level: int = 0) -> np.ndarray:
+        if what in (DBG_NET1, DBG_NET2):
+            a = np.zeros((self.b8, 2), np.int16)
+        elif what == DBG_BDIFF:
+            a = np.zeros(self.b8, np.int32)
+        elif what == DBG_PYRAMID:
+            a = np.zeros((self.H >> level, self.W >> level), np.uint8)
+        else:
+            a = np.zeros(self.mbs, np.int32)
+        self._chk(self.lib.vp8hip_debug_download(self.h, what, ref, level, a.ctypes.data, a.nbytes), "debug_download")
+        return a

@@ -1,0 +1,453 @@
+// kernels_mb.hip -- per-macroblock reconstruction loop of the inter-frame path for gfx950.
+//
+// One fused kernel replaces the reference's per-frame sequence (inter_part.h:268-378)
+//   prepare_predictors_and_residual x9, then for each segment LQ..UQ:
+//   dct4x4 x3, wht4x4_iwht4x4, idct4x4 x3, count_SSIM x3, gather_SSIM
+// and prepare_filter_mask (loop_filter.h:25-46).  Every step is local to a macroblock (the SSIM
+// that gates the next segment pass is the macroblock's own), so the whole segment loop runs inside
+// the kernel with predictor, residual and coefficients in registers: the predictor/residual planes
+// of the reference never exist in HBM.  Mapping: 32 lanes per macroblock, lane b < 24 owns 4x4
+// block b (0-15 Y raster, 16-19 U, 20-23 V) -- the block index of macroblock_coeffs_t.
+#include "vp8hip_dev.h"
+
+namespace vp8 {
+
+static __device__ __constant__ const int k_dc_q[128] = {  // GPU_kernels.cl:58-68
+    4,   5,   6,   7,   8,   9,   10,  10,  11,  12,  13,  14,  15,  16,  17,  17,  18,  19,  20,  20,  21,  21,
+    22,  22,  23,  23,  24,  25,  25,  26,  27,  28,  29,  30,  31,  32,  33,  34,  35,  36,  37,  37,  38,  39,
+    40,  41,  42,  43,  44,  45,  46,  46,  47,  48,  49,  50,  51,  52,  53,  54,  55,  56,  57,  58,  59,  60,
+    61,  62,  63,  64,  65,  66,  67,  68,  69,  70,  71,  72,  73,  74,  75,  76,  76,  77,  78,  79,  80,  81,
+    82,  83,  84,  85,  86,  87,  88,  89,  91,  93,  95,  96,  98,  100, 101, 102, 104, 106, 108, 110, 112, 114,
+    116, 118, 122, 124, 126, 128, 130, 132, 134, 136, 138, 140, 143, 145, 148, 151, 154, 157};
+static __device__ __constant__ const int k_ac_q[128] = {  // GPU_kernels.cl:70-80
+    4,   5,   6,   7,   8,   9,   10,  11,  12,  13,  14,  15,  16,  17,  18,  19,  20,  21,  22,  23,  24,  25,
+    26,  27,  28,  29,  30,  31,  32,  33,  34,  35,  36,  37,  38,  39,  40,  41,  42,  43,  44,  45,  46,  47,
+    48,  49,  50,  51,  52,  53,  54,  55,  56,  57,  58,  60,  62,  64,  66,  68,  70,  72,  74,  76,  78,  80,
+    82,  84,  86,  88,  90,  92,  94,  96,  98,  100, 102, 104, 106, 108, 110, 112, 114, 116, 119, 122, 125, 128,
+    131, 134, 137, 140, 143, 146, 149, 152, 155, 158, 161, 164, 167, 170, 173, 177, 181, 185, 189, 193, 197, 201,
+    205, 209, 213, 217, 221, 225, 229, 234, 239, 245, 249, 254, 259, 264, 269, 274, 279, 284};
+
+__device__ __forceinline__ int qi(int v) { return iclamp(v, 0, 127); }
+
+// `construct`, GPU_kernels.cl:574-774: separable six-tap on a 4x4 block at integer position (ix,iy)
+// with 1/8-pel phases (fx,fy).  Of the nine horizontally filtered lines the first six are saturated
+// to u8, the last three are narrowed with a plain (uchar) cast (wrap mod 256) -- :702-708,727-733,752-758.
+__device__ __forceinline__ void predict4x4(const Plane &rf, int ix, int iy, int fx, int fy, int out[16]) {
+    int H[9][4];
+    int f[6];
+    load_taps(fx, f);
+#pragma unroll
+    for (int L = 0; L < 9; ++L) {
+        const uint8_t *p = rf.p + (ptrdiff_t)(iy - 2 + L) * rf.stride + (ix - 2);
+        const uint32_t w0 = ld_u32(p), w1 = ld_u32(p + 4), w2 = ld_u32(p + 8);
+        int bb[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bb[i] = byte_of(i < 4 ? w0 : (i < 8 ? w1 : w2), i & 3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int s = 64;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s += bb[c + t] * f[t];
+            const int v = div128(s);
+            H[L][c] = (L < 6) ? sat8(v) : (v & 0xff);
+        }
+    }
+    load_taps(fy, f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int s = 64;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s += H[i + t][c] * f[t];
+            out[4 * i + c] = sat8_shr7(s);
+        }
+}
+
+// dct4x4, GPU_kernels.cl:1417-1476: libvpx fdct constants, vertical pass first
+__device__ __forceinline__ void fdct4x4(const int in[16], int out[16]) {
+    int L[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r0 = in[c], r1 = in[4 + c], r2 = in[8 + c], r3 = in[12 + c];
+        const int a1 = (r0 + r3) * 8, d1 = (r0 - r3) * 8, b1 = (r1 + r2) * 8, c1 = (r1 - r2) * 8;
+        L[c] = a1 + b1;
+        L[8 + c] = a1 - b1;
+        L[4 + c] = (c1 * 2217 + d1 * 5352 + 14500) >> 12;
+        L[12 + c] = (d1 * 2217 - c1 * 5352 + 7500) >> 12;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e0 = L[4 * i], e1 = L[4 * i + 1], e2 = L[4 * i + 2], e3 = L[4 * i + 3];
+        const int a1 = e0 + e3, d1 = e0 - e3, b1 = e1 + e2, c1 = e1 - e2;
+        out[4 * i] = (a1 + b1 + 7) >> 4;
+        out[4 * i + 2] = (a1 - b1 + 7) >> 4;
+        out[4 * i + 1] = ((c1 * 2217 + d1 * 5352 + 12000) >> 16) + (d1 != 0);
+        out[4 * i + 3] = (d1 * 2217 - c1 * 5352 + 51000) >> 16;
+    }
+}
+
+// dequant_and_iDCT, GPU_kernels.cl:192-255 (inputs already dequantised)
+__device__ __forceinline__ void idct4x4(int L[16]) {
+    int T[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i0 = L[c], i1 = L[4 + c], i2 = L[8 + c], i3 = L[12 + c];
+        const int a1 = i0 + i2, b1 = i0 - i2;
+        const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
+        const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+        T[c] = a1 + d1;
+        T[12 + c] = a1 - d1;
+        T[4 + c] = b1 + c1;
+        T[8 + c] = b1 - c1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i0 = T[4 * r], i1 = T[4 * r + 1], i2 = T[4 * r + 2], i3 = T[4 * r + 3];
+        const int a1 = i0 + i2, b1 = i0 - i2;
+        const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
+        const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+        L[4 * r] = (a1 + d1 + 4) >> 3;
+        L[4 * r + 3] = (a1 - d1 + 4) >> 3;
+        L[4 * r + 1] = (b1 + c1 + 4) >> 3;
+        L[4 * r + 2] = (b1 - c1 + 4) >> 3;
+    }
+}
+
+// WHT_and_quant + dequant_and_iWHT, GPU_kernels.cl:257-401.  X: the 16 luma DCs (raster) in, the
+// reconstructed DCs out; Q: the quantised second-order block (raster).
+__device__ __forceinline__ void wht_roundtrip(int X[16], int Q[16], int dc_q, int ac_q) {
+    int T[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int a = X[c] + X[12 + c], b = X[4 + c] + X[8 + c], cc = X[4 + c] - X[8 + c], d = X[c] - X[12 + c];
+        T[c] = a + b;
+        T[4 + c] = cc + d;
+        T[8 + c] = a - b;
+        T[12 + c] = d - cc;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = T[4 * r], y = T[4 * r + 1], z = T[4 * r + 2], w = T[4 * r + 3];
+        const int a1 = x + w, b1 = y + z, c1 = y - z, d1 = x - w;
+        int o[4] = {a1 + b1, c1 + d1, a1 - b1, d1 - c1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] += (o[k] > 0);
+            o[k] >>= 1;
+            Q[4 * r + k] = o[k] / ((r == 0 && k == 0) ? dc_q : ac_q);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) X[k] = Q[k] * (k == 0 ? dc_q : ac_q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = X[4 * r], y = X[4 * r + 1], z = X[4 * r + 2], w = X[4 * r + 3];
+        const int a1 = x + w, b1 = y + z, c1 = y - z, d1 = x - w;
+        T[4 * r] = a1 + b1;
+        T[4 * r + 1] = c1 + d1;
+        T[4 * r + 2] = a1 - b1;
+        T[4 * r + 3] = d1 - c1;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int a = T[c] + T[12 + c], b = T[4 + c] + T[8 + c], cc = T[4 + c] - T[8 + c], d = T[c] - T[12 + c];
+        X[c] = (a + b + 3) >> 3;
+        X[4 + c] = (cc + d + 3) >> 3;
+        X[8 + c] = (a - b + 3) >> 3;
+        X[12 + c] = (d - cc + 3) >> 3;
+    }
+}
+
+// zig-zag position of raster coefficient k: coeff[inv_zigzag[k]] = L[k], GPU_kernels.cl:1489
+__device__ __forceinline__ constexpr int inv_zigzag(int k) {
+    constexpr int t[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
+    return t[k];
+}
+__device__ __forceinline__ void store_zigzag(int16_t *dst, const int L[16]) {
+    int z[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[inv_zigzag(k)] = L[k];
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = (uint32_t)(uint16_t)z[2 * k] | ((uint32_t)(uint16_t)z[2 * k + 1] << 16);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    d4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    d4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+struct MBArgs {
+    Frame cur;
+    Frame ref[3];
+    Frame recon;
+    MBOut o;
+    const SegData *sd;
+    float ssim_target;
+    int mbw, mbs;
+};
+
+// LDS per macroblock: current and reconstructed pixels, plane-major (Y 16x16, U 8x8, V 8x8)
+struct MBTile { uint8_t cur[384]; uint8_t rec[384]; };
+
+// one SSIM term chain in the reference's float4 order (count_SSIM_luma/_chroma, :1610-2095): lane-component
+// `comp` accumulates pixels (r, 4j+comp), r outer, j inner; n = 16 (luma) or 8 (chroma).
+// All float ops are written so that nothing can be contracted (the reference's mad is a*b+c, unfused).
+__global__ __launch_bounds__(256) void k_mb(MBArgs a) {
+    __shared__ MBTile s_t[8];
+    const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int mb_raw = blockIdx.x * 8 + g;
+    const bool live = mb_raw < a.mbs;
+    const int mb = live ? mb_raw : a.mbs - 1;
+    const int mbx = mb % a.mbw, mby = mb / a.mbw;
+    const int32_t *SD = a.sd->v;
+
+    const bool blk = lane < 24;
+    const int plane = lane < 16 ? 0 : (lane < 20 ? 1 : 2);
+    const int bi = lane < 16 ? lane : (lane - 16) & 3;       // block index inside its plane
+    const int bw = plane == 0 ? 4 : 2;                        // blocks per MB row of the plane
+    const int bx = blk ? bi % bw : 0, by = blk ? bi / bw : 0;
+    const int msz = plane == 0 ? 16 : 8;
+    const int posx = mbx * msz + bx * 4, posy = mby * msz + by * 4;
+    const int ref = a.o.ref[mb];
+    const int parts = a.o.parts[mb];
+    const Plane &cp = plane == 0 ? a.cur.Y[0] : (plane == 1 ? a.cur.U : a.cur.V);
+    const Plane &rc = plane == 0 ? a.recon.Y[0] : (plane == 1 ? a.recon.U : a.recon.V);
+    const Frame &rfm = ref == 0 ? a.ref[0] : (ref == 1 ? a.ref[1] : a.ref[2]);
+    const Plane &rp = plane == 0 ? rfm.Y[0] : (plane == 1 ? rfm.U : rfm.V);
+    const int tile_off = plane == 0 ? 0 : (plane == 1 ? 256 : 320);
+
+    int pred[16], res[16], curp[16];
+    if (blk) {
+        // prepare_predictors_and_residual, :1285-1344: vector of the block's 8x8 quadrant
+        const int quad = plane == 0 ? (by >> 1) * 2 + (bx >> 1) : by * 2 + bx;
+        const uint32_t vv = reinterpret_cast<const uint32_t *>(a.o.vec)[mb * 4 + quad];
+        const int vx = (int16_t)(vv & 0xffffu), vy = (int16_t)(vv >> 16);
+        const int gsh = plane == 0 ? 2 : 3, gm = plane == 0 ? 3 : 7;
+        const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;  // >= 0 for every in-frame vector
+        const int dx = (fxp & gm) * (plane == 0 ? 2 : 1), dy = (fyp & gm) * (plane == 0 ? 2 : 1);
+        const int ix = iclamp(fxp >> gsh, 2 - EXT, rp.w + EXT - 7), iy = iclamp(fyp >> gsh, 2 - EXT, rp.h + EXT - 7);
+        predict4x4(rp, ix, iy, dx, dy, pred);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t cw = *reinterpret_cast<const uint32_t *>(cp.p + (ptrdiff_t)(posy + r) * cp.stride + posx);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                curp[4 * r + c] = byte_of(cw, c);
+                res[4 * r + c] = curp[4 * r + c] - pred[4 * r + c];
+            }
+            *reinterpret_cast<uint32_t *>(&s_t[g].cur[tile_off + (by * 4 + r) * msz + bx * 4]) = cw;
+        }
+    }
+    __syncthreads();
+
+    // ---- SSIM terms of the current frame: mean (exact in float) and variance chain ---------------
+    // lanes 0..11: plane sp = lane>>2, float4 component comp = lane&3
+    const int sp = (lane >> 2) < 3 ? (lane >> 2) : 2, comp = lane & 3;
+    const int sn = sp == 0 ? 16 : 8;
+    const uint8_t *tc = &s_t[g].cur[sp == 0 ? 0 : (sp == 1 ? 256 : 320)];
+    const uint8_t *tr = &s_t[g].rec[sp == 0 ? 0 : (sp == 1 ? 256 : 320)];
+    const float area = (float)(sn * sn);
+    float M1, D1;
+    {
+        float acc = 0.0f;
+        for (int r = 0; r < sn; ++r)
+            for (int j = 0; j < sn / 4; ++j) acc = __fadd_rn(acc, (float)tc[r * sn + 4 * j + comp]);
+        const float s0 = __shfl(acc, (lane & ~3) + 0, 32), s1 = __shfl(acc, (lane & ~3) + 1, 32);
+        const float s2 = __shfl(acc, (lane & ~3) + 2, 32), s3 = __shfl(acc, (lane & ~3) + 3, 32);
+        M1 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3), area);
+        acc = 0.0f;
+        for (int r = 0; r < sn; ++r)
+            for (int j = 0; j < sn / 4; ++j) {
+                const float t = __fsub_rn((float)tc[r * sn + 4 * j + comp], M1);
+                const float tt = __fmul_rn(t, t);
+                acc = (r == 0 && j == 0) ? tt : __fadd_rn(tt, acc);
+            }
+        const float d0 = __shfl(acc, (lane & ~3) + 0, 32), d1 = __shfl(acc, (lane & ~3) + 1, 32);
+        const float d2 = __shfl(acc, (lane & ~3) + 2, 32), d3 = __shfl(acc, (lane & ~3) + 3, 32);
+        D1 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(d0, d1), d2), d3), area);
+    }
+
+    float ssim = -2.0f;  // pack_8x8_into_16x16, :1352
+    int seg_final = a.o.seg[mb];
+    int coef[16];
+    int q24[16];
+    int recp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { coef[k] = 0; q24[k] = 0; recp[k] = 0; }
+    bool any_pass = false;
+
+    for (int seg = 3; seg >= 0; --seg) {        // inter_part.h:329
+        // dct4x4 gate, :1391 (same value in all 32 lanes of a macroblock).  The eight macroblocks of
+        // the workgroup may need different numbers of passes: barriers stay workgroup-uniform.
+        const bool do_pass = !(ssim > a.ssim_target);
+        if (!__syncthreads_or(do_pass)) break;
+        if (do_pass) {
+        any_pass = true;
+        seg_final = seg;
+        const int i = SD[seg * SD_INTS + SD_Y_AC_I];
+        int dc_q, ac_q;
+        if (plane == 0) {                        // :1394-1408
+            ac_q = k_ac_q[i];
+            dc_q = parts == 0 ? 1 : k_dc_q[qi(SD[SD_Y_DC_IDELTA] + i)];
+        } else {
+            dc_q = imin(k_dc_q[qi(SD[SD_UV_DC_IDELTA] + i)], 132);
+            ac_q = k_ac_q[qi(SD[SD_UV_AC_IDELTA] + i)];
+        }
+        if (blk) {
+            fdct4x4(res, coef);
+            coef[0] /= dc_q;                     // truncating, :1478-1481
+#pragma unroll
+            for (int k = 1; k < 16; ++k) coef[k] /= ac_q;
+        }
+        if (parts == 0) {                        // wht4x4_iwht4x4, :1498-1543 (all lanes: shuffles)
+            int X[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) X[k] = (int16_t)__shfl(coef[0], k, 32);
+            const int y2dc = k_dc_q[qi(SD[SD_Y2_DC_IDELTA] + i)] * 2;
+            const int y2ac = imax(31 * k_ac_q[qi(SD[SD_Y2_AC_IDELTA] + i)] / 20, 8);
+            wht_roundtrip(X, q24, y2dc, y2ac);
+            if (lane < 16) {
+                int nd = X[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) nd = (lane == k) ? X[k] : nd;
+                coef[0] = (int16_t)nd;           // stored as short, :1537
+            }
+        }
+        if (blk) {                               // idct4x4, :1545-1608
+            int L[16];
+            L[0] = (int16_t)coef[0] * dc_q;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) L[k] = (int16_t)coef[k] * ac_q;
+            idct4x4(L);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    recp[4 * r + c] = sat8(L[4 * r + c] + pred[4 * r + c]);
+                    w |= (uint32_t)recp[4 * r + c] << (8 * c);
+                }
+                *reinterpret_cast<uint32_t *>(&s_t[g].rec[tile_off + (by * 4 + r) * msz + bx * 4]) = w;
+            }
+        }
+        }
+        __syncthreads();
+        if (do_pass) {
+        // count_SSIM_*, gather_SSIM
+        float M2, D, C;
+        {
+            float acc = 0.0f;
+            for (int r = 0; r < sn; ++r)
+                for (int j = 0; j < sn / 4; ++j) acc = __fadd_rn(acc, (float)tr[r * sn + 4 * j + comp]);
+            const float s0 = __shfl(acc, (lane & ~3) + 0, 32), s1 = __shfl(acc, (lane & ~3) + 1, 32);
+            const float s2 = __shfl(acc, (lane & ~3) + 2, 32), s3 = __shfl(acc, (lane & ~3) + 3, 32);
+            M2 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3), area);
+            float acc2 = 0.0f, acc3 = 0.0f;
+            for (int r = 0; r < sn; ++r)
+                for (int j = 0; j < sn / 4; ++j) {
+                    const float t1 = __fsub_rn((float)tc[r * sn + 4 * j + comp], M1);
+                    const float t2 = __fsub_rn((float)tr[r * sn + 4 * j + comp], M2);
+                    const float tt = __fmul_rn(t2, t2);
+                    const float tc12 = __fmul_rn(t1, t2);
+                    acc2 = (r == 0 && j == 0) ? tt : __fadd_rn(tt, acc2);
+                    acc3 = (r == 0 && j == 0) ? tc12 : __fadd_rn(acc3, tc12);
+                }
+            const float d0 = __shfl(acc2, (lane & ~3) + 0, 32), d1 = __shfl(acc2, (lane & ~3) + 1, 32);
+            const float d2 = __shfl(acc2, (lane & ~3) + 2, 32), d3 = __shfl(acc2, (lane & ~3) + 3, 32);
+            D = __fadd_rn(D1, __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(d0, d1), d2), d3), area));
+            const float c0 = __shfl(acc3, (lane & ~3) + 0, 32), c1_ = __shfl(acc3, (lane & ~3) + 1, 32);
+            const float c2_ = __shfl(acc3, (lane & ~3) + 2, 32), c3 = __shfl(acc3, (lane & ~3) + 3, 32);
+            C = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(c0, c1_), c2_), c3), area);
+        }
+        const float k1 = 0.01f * 0.01f * 255 * 255, k2 = 0.03f * 0.03f * 255 * 255;
+        const float num = __fmul_rn(__fadd_rn(__fmul_rn(M1, __fmul_rn(M2, 2.0f)), k1), __fadd_rn(__fmul_rn(C, 2.0f), k2));
+        const float den = __fmul_rn(__fadd_rn(__fmul_rn(M1, M1), __fadd_rn(__fmul_rn(M2, M2), k1)), __fadd_rn(D, k2));
+        float metric = __fdiv_rn(num, den);
+        float dm = __fsub_rn(M1, M2);
+        dm = dm < 0 ? -dm : dm;
+        dm = dm > 4 ? __fmul_rn(0.02f, dm) : 0.0f;
+        metric = __fsub_rn(metric, dm);
+        const float m1 = __shfl(metric, 0, 32), m2 = __shfl(metric, 4, 32), m3 = __shfl(metric, 8, 32);
+        ssim = __fdiv_rn(__fadd_rn(__fadd_rn(m1, m2), m3), 3.0f);
+        }
+    }
+
+    // ---- results -------------------------------------------------------------------------------
+    int nz = 0;
+    if (blk && any_pass) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t w = (uint32_t)recp[4 * r] | ((uint32_t)recp[4 * r + 1] << 8) | ((uint32_t)recp[4 * r + 2] << 16) |
+                               ((uint32_t)recp[4 * r + 3] << 24);
+            if (live) *reinterpret_cast<uint32_t *>(rc.p + (ptrdiff_t)(posy + r) * rc.stride + posx) = w;
+        }
+        if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + lane) * 16, coef);
+        // prepare_filter_mask, CPU_kernels.cl:800-819
+#pragma unroll
+        for (int k = 1; k < 16; ++k) nz += iabs((int16_t)coef[k]);
+        if (plane != 0 || parts != 0) nz += iabs((int16_t)coef[0]);
+    }
+    if (any_pass && parts == 0 && lane == 24) {
+        if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + 24) * 16, q24);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nz += iabs((int16_t)q24[k]);
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) nz += __shfl_xor(nz, m, 32);
+    if (lane == 0 && live) {
+        if (any_pass) {
+            a.o.seg[mb] = seg_final;
+            a.o.nz[mb] = nz;
+            a.o.mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
+        }
+        a.o.ssim[mb] = ssim;
+    }
+}
+
+void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const Frame &recon, const MBOut &o,
+               const SegData *d_sd, float ssim_target, int mbw, int mbh) {
+    MBArgs a;
+    a.cur = cur;
+    for (int r = 0; r < 3; ++r) a.ref[r] = refs.ref[r];
+    a.recon = recon;
+    a.o = o;
+    a.sd = d_sd;
+    a.ssim_target = ssim_target;
+    a.mbw = mbw;
+    a.mbs = mbw * mbh;
+    hipLaunchKernelGGL(k_mb, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepare_filter_mask, CPU_kernels.cl:782-827, recomputed from the device copy of the coefficients
+// (after the host changed them: vp8hip_upload_mb_data).  32 lanes per macroblock.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_filter_mask(MBOut o, const SegData *sd, int mbs) {
+    const int lane = threadIdx.x & 31;
+    const int mb_raw = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = mb_raw < mbs;
+    const int mb = live ? mb_raw : mbs - 1;
+    const int parts = o.parts[mb];
+    int nz = 0;
+    if (lane < 25) {
+        const int16_t *c = o.coeffs + ((size_t)mb * 25 + lane) * 16;
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += iabs(c[k]);
+        if (lane < 16) nz = s + (parts != 0 ? iabs(c[0]) : 0);
+        else if (lane < 24) nz = s + iabs(c[0]);
+        else nz = parts == 0 ? s + iabs(c[0]) : 0;
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) nz += __shfl_xor(nz, m, 32);
+    if (lane == 0 && live) {
+        o.nz[mb] = nz;
+        o.mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
+    }
+}
+
+void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs) {
+    hipLaunchKernelGGL(k_filter_mask, dim3((mbs + 7) / 8), dim3(256), 0, s, o, d_sd, mbs);
+}
+
+}  // namespace vp8

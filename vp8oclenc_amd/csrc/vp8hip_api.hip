@@ -1,0 +1,565 @@
+// vp8hip_api.hip -- context, HBM surfaces and the C ABI (include/vp8hip.h) of the inter-frame path.
+//
+// What the reference keeps as ~70 cl_mem objects and 60 pre-bound cl_kernel instances
+// (init.h:430-593, 595-1271) is one context here: a pool of padded frame surfaces (a reference
+// "slot" is an index into the pool, so golden := last is a pointer copy, not the five
+// clEnqueueCopyBuffer + three clEnqueueCopyImage of inter_part.h:35-50,72-83), the vector nets,
+// the per-macroblock outputs, and one in-order HIP stream.
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/vp8hip.h"
+#include "vp8hip_dev.h"
+
+using namespace vp8;
+
+namespace {
+
+constexpr int NFRAMES = 5;  // LAST, GOLDEN, ALTREF may all differ, + the reconstruction in flight, + 1 spare
+constexpr int MAX_EVENTS = 4096;
+
+struct FrameSurf {
+    Frame f;
+    bool pyramid_valid = false;
+};
+
+}  // namespace
+
+struct vp8hip_ctx {
+    int W = 0, H = 0, mbw = 0, mbh = 0, mbs = 0, b8 = 0;
+    float ssim_target = -1.0f;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int last_hip_error = 0;
+
+    uint8_t *pixel_pool = nullptr;  // one allocation for every surface
+    FrameSurf frames[NFRAMES];
+    Frame cur;
+    int slot[3] = {-1, -1, -1};     // pool index of LAST / GOLDEN / ALTREF
+    int recon = -1;                 // pool index of the reconstruction being produced
+    bool recon_ready = false;       // holds an unfiltered reconstruction
+    bool cur_pyramid_valid = false;
+
+    NetSet nets{};
+    MBOut out{};
+    SegData *d_sd = nullptr;
+    int32_t *d_progress = nullptr;
+    void *scratch = nullptr;        // device staging for debug pyramid downloads
+
+    uint32_t prof_mask = 0;
+    hipEvent_t ev[MAX_EVENTS];
+    int ev_kernel[MAX_EVENTS / 2];
+    int ev_used = 0;
+    bool ev_created = false;
+    double prof_ms[VP8HIP_K_COUNT] = {0};
+    int64_t prof_n[VP8HIP_K_COUNT] = {0};
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                  \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) {                          \
+            (c)->last_hip_error = (int)e_;               \
+            return VP8HIP_ERR_HIP;                       \
+        }                                                \
+    } while (0)
+
+size_t plane_bytes(int w, int h, int *stride) {
+    *stride = (w + 2 * PAD + 63) / 64 * 64;
+    return (size_t)(*stride) * (h + 2 * PAD);
+}
+
+// carve one plane out of the pool; returns the advanced cursor
+uint8_t *carve(uint8_t *cursor, int w, int h, Plane *pl) {
+    int stride;
+    const size_t bytes = plane_bytes(w, h, &stride);
+    pl->p = cursor + (size_t)PAD * stride + PAD;
+    pl->stride = stride;
+    pl->w = w;
+    pl->h = h;
+    return cursor + (bytes + 255) / 256 * 256;
+}
+
+size_t frame_bytes(int W, int H) {
+    size_t n = 0;
+    int s;
+    for (int l = 0; l < 5; ++l) n += (plane_bytes(W >> l, H >> l, &s) + 255) / 256 * 256;
+    n += 2 * ((plane_bytes(W / 2, H / 2, &s) + 255) / 256 * 256);
+    return n;
+}
+
+uint8_t *carve_frame(uint8_t *cursor, int W, int H, Frame *f) {
+    for (int l = 0; l < 5; ++l) cursor = carve(cursor, W >> l, H >> l, &f->Y[l]);
+    cursor = carve(cursor, W / 2, H / 2, &f->U);
+    cursor = carve(cursor, W / 2, H / 2, &f->V);
+    return cursor;
+}
+
+// ---- per-kernel event timing --------------------------------------------------------------------
+struct Timed {
+    vp8hip_ctx *c;
+    int slot = -1;
+    Timed(vp8hip_ctx *ctx, int kernel) : c(ctx) {
+        if (!(c->prof_mask & (1u << kernel)) || c->ev_used + 2 > MAX_EVENTS) return;
+        slot = c->ev_used;
+        c->ev_kernel[slot / 2] = kernel;
+        c->ev_used += 2;
+        hipEventRecord(c->ev[slot], c->stream);
+    }
+    ~Timed() {
+        if (slot >= 0) hipEventRecord(c->ev[slot + 1], c->stream);
+    }
+};
+
+int prof_collect(vp8hip_ctx *c) {
+    if (c->ev_used == 0) return VP8HIP_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->ev_used; i += 2) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->prof_ms[c->ev_kernel[i / 2]] += ms;
+        c->prof_n[c->ev_kernel[i / 2]] += 1;
+    }
+    c->ev_used = 0;
+    return VP8HIP_OK;
+}
+
+int pick_free_frame(const vp8hip_ctx *c) {
+    for (int i = 0; i < NFRAMES; ++i) {
+        if (i == c->slot[0] || i == c->slot[1] || i == c->slot[2] || i == c->recon) continue;
+        return i;
+    }
+    return -1;
+}
+
+// tight host/device planes -> padded surface
+int copy_in(vp8hip_ctx *c, const Plane &dst, const void *src, hipMemcpyKind kind) {
+    HIPCHK(c, hipMemcpy2DAsync(dst.p, dst.stride, src, dst.w, dst.w, dst.h, kind, c->stream));
+    return VP8HIP_OK;
+}
+int copy_out(vp8hip_ctx *c, void *dst, const Plane &src) {
+    HIPCHK(c, hipMemcpy2DAsync(dst, src.w, src.p, src.stride, src.w, src.h, hipMemcpyDeviceToHost, c->stream));
+    return VP8HIP_OK;
+}
+
+int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
+    Timed t(c, VP8HIP_K_PACK);
+    int rc;
+    if ((rc = copy_in(c, f.Y[0], y, kind))) return rc;
+    if ((rc = copy_in(c, f.U, u, kind))) return rc;
+    return copy_in(c, f.V, v, kind);
+}
+
+void build_pyramid(vp8hip_ctx *c, Frame *a, Frame *b) {
+    // cascade: every level from the rounded previous level (inter_part.h:11-33)
+    for (int l = 1; l < 5; ++l) {
+        Timed t(c, VP8HIP_K_DOWNSAMPLE);
+        Plane src[2] = {a->Y[l - 1], b ? b->Y[l - 1] : a->Y[l - 1]};
+        Plane dst[2] = {a->Y[l], b ? b->Y[l] : a->Y[l]};
+        launch_downsample(c->stream, src, dst, b ? 2 : 1);
+    }
+}
+
+int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
+    const int idx = pick_free_frame(c);
+    if (idx < 0) return VP8HIP_ERR_STATE;
+    int rc = set_frame_planes(c, c->frames[idx].f, y, u, v, kind);
+    if (rc) return rc;
+    {
+        Timed t(c, VP8HIP_K_BORDER);
+        launch_border(c->stream, c->frames[idx].f);
+    }
+    c->frames[idx].pyramid_valid = false;
+    c->slot[0] = idx;
+    return VP8HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, int device_ordinal) {
+    if (!out || width < 16 || height < 16 || (width % 16) || (height % 16) || width > 8192 || height > 8192)
+        return VP8HIP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev)
+        return VP8HIP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return VP8HIP_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VP8HIP_ERR_ARCH;
+    vp8hip_ctx *c = new (std::nothrow) vp8hip_ctx();
+    if (!c) return VP8HIP_ERR_ARG;
+    c->W = width;
+    c->H = height;
+    c->mbw = width / 16;
+    c->mbh = height / 16;
+    c->mbs = c->mbw * c->mbh;
+    c->b8 = c->mbs * 4;
+    c->ssim_target = ssim_target;
+    c->device = device_ordinal;
+#define CR(call)                                   \
+    do {                                           \
+        hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) {                    \
+            c->last_hip_error = (int)e_;           \
+            vp8hip_destroy(c);                     \
+            return VP8HIP_ERR_HIP;                 \
+        }                                          \
+    } while (0)
+    CR(hipSetDevice(device_ordinal));
+    CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t fb = frame_bytes(width, height);
+    CR(hipMalloc(&c->pixel_pool, fb * (NFRAMES + 1)));
+    CR(hipMemsetAsync(c->pixel_pool, 0, fb * (NFRAMES + 1), c->stream));
+    uint8_t *cur = c->pixel_pool;
+    for (int i = 0; i < NFRAMES; ++i) cur = carve_frame(cur, width, height, &c->frames[i].f);
+    carve_frame(cur, width, height, &c->cur);
+    for (int r = 0; r < 3; ++r) {
+        CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
+        CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
+        CR(hipMalloc(&c->nets.bdiff[r], (size_t)c->b8 * 4));
+    }
+    CR(hipMalloc(&c->out.parts, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.ref, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.seg, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.nz, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.mask, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.ssim, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->out.vec, (size_t)c->mbs * 16));
+    CR(hipMalloc(&c->out.coeffs, (size_t)c->mbs * 800));
+    CR(hipMalloc(&c->out.first_lf0, 64));
+    CR(hipMalloc(&c->d_sd, sizeof(SegData)));
+    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 64));
+    CR(hipMalloc(&c->scratch, (size_t)width * height));
+    CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.seg, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.nz, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.mask, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.ssim, 0, (size_t)c->mbs * 4, c->stream));
+    CR(hipMemsetAsync(c->out.vec, 0, (size_t)c->mbs * 16, c->stream));
+    CR(hipMemsetAsync(c->out.coeffs, 0, (size_t)c->mbs * 800, c->stream));
+    CR(hipMemsetAsync(c->d_sd, 0, sizeof(SegData), c->stream));
+    for (int i = 0; i < MAX_EVENTS; ++i) CR(hipEventCreate(&c->ev[i]));
+    c->ev_created = true;
+    c->recon = 0;
+    CR(hipStreamSynchronize(c->stream));
+#undef CR
+    *out = c;
+    return VP8HIP_OK;
+}
+
+void vp8hip_destroy(vp8hip_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ev_created)
+        for (int i = 0; i < MAX_EVENTS; ++i) hipEventDestroy(c->ev[i]);
+    hipFree(c->pixel_pool);
+    for (int r = 0; r < 3; ++r) {
+        hipFree(c->nets.net[r][0]);
+        hipFree(c->nets.net[r][1]);
+        hipFree(c->nets.bdiff[r]);
+    }
+    hipFree(c->out.parts);
+    hipFree(c->out.ref);
+    hipFree(c->out.seg);
+    hipFree(c->out.nz);
+    hipFree(c->out.mask);
+    hipFree(c->out.ssim);
+    hipFree(c->out.vec);
+    hipFree(c->out.coeffs);
+    hipFree(c->out.first_lf0);
+    hipFree(c->d_sd);
+    hipFree(c->d_progress);
+    hipFree(c->scratch);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    c->cur_pyramid_valid = false;
+    int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    // pageable host memory: the call must not return while the copy still reads the host buffer
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    c->cur_pyramid_valid = false;
+    return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice);
+}
+
+int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    int rc = make_last(c, y, u, v, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_set_last_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    return make_last(c, y, u, v, hipMemcpyDeviceToDevice);
+}
+
+int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
+    if (!c || !sd) return VP8HIP_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->d_sd, sd, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
+    hipStream_t s = c->stream;
+    // reference rotation, inter_part.h:35-50,72-83: golden/altref := the frame that is LAST now
+    if (prev_is_golden) c->slot[1] = c->slot[0];
+    if (prev_is_altref) c->slot[2] = c->slot[0];
+    if ((use_golden && c->slot[1] < 0) || (use_altref && c->slot[2] < 0)) return VP8HIP_ERR_STATE;
+    if (c->recon < 0 || c->recon == c->slot[0] || c->recon == c->slot[1] || c->recon == c->slot[2]) {
+        c->recon = -1;
+        c->recon = pick_free_frame(c);
+        if (c->recon < 0) return VP8HIP_ERR_STATE;
+    }
+    // prepare_GPU_buffers, inter_part.h:1-33
+    {
+        Timed t(c, VP8HIP_K_DOWNSAMPLE);
+        launch_reset_nets(s, c->nets, c->b8);
+    }
+    FrameSurf &last = c->frames[c->slot[0]];
+    if (!last.pyramid_valid && !c->cur_pyramid_valid) {
+        build_pyramid(c, &c->cur, &last.f);
+    } else {
+        if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
+        if (!last.pyramid_valid) build_pyramid(c, &last.f, nullptr);
+    }
+    last.pyramid_valid = true;
+    c->cur_pyramid_valid = true;
+
+    RefSet refs;
+    refs.use[0] = 1;
+    refs.use[1] = use_golden ? 1 : 0;
+    refs.use[2] = use_altref ? 1 : 0;
+    for (int r = 0; r < 3; ++r) refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
+    const int net_width = c->mbw * 2;
+    // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854
+    int src = 0;
+    for (int l = 4; l >= 0; --l) {
+        Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
+        launch_search1(s, c->cur, refs, c->nets, l, src, net_width);
+        src ^= 1;
+    }
+    {
+        Timed t(c, VP8HIP_K_SEARCH2);
+        launch_search2(s, c->cur, refs, c->nets);
+    }
+    {
+        Timed t(c, VP8HIP_K_SELECT);
+        launch_select(s, c->nets, c->out, c->mbw, c->mbh, use_golden ? 1 : 0, use_altref ? 1 : 0);
+    }
+    {
+        Timed t(c, VP8HIP_K_MB);
+        launch_mb(s, c->cur, refs, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
+    }
+    c->recon_ready = true;
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_download_results(vp8hip_ctx *c, const vp8hip_results *r) {
+    if (!c || !r) return VP8HIP_ERR_ARG;
+    if (!c->recon_ready && (r->recon_Y || r->recon_U || r->recon_V)) return VP8HIP_ERR_STATE;
+    hipStream_t s = c->stream;
+    const size_t n = c->mbs;
+    if (r->MB_parts) HIPCHK(c, hipMemcpyAsync(r->MB_parts, c->out.parts, n * 4, hipMemcpyDeviceToHost, s));
+    if (r->MB_reference_frame) HIPCHK(c, hipMemcpyAsync(r->MB_reference_frame, c->out.ref, n * 4, hipMemcpyDeviceToHost, s));
+    if (r->MB_vectors) HIPCHK(c, hipMemcpyAsync(r->MB_vectors, c->out.vec, n * 16, hipMemcpyDeviceToHost, s));
+    if (r->MB_coeffs) HIPCHK(c, hipMemcpyAsync(r->MB_coeffs, c->out.coeffs, n * 800, hipMemcpyDeviceToHost, s));
+    if (r->MB_segment_id) HIPCHK(c, hipMemcpyAsync(r->MB_segment_id, c->out.seg, n * 4, hipMemcpyDeviceToHost, s));
+    if (r->MB_SSIM) HIPCHK(c, hipMemcpyAsync(r->MB_SSIM, c->out.ssim, n * 4, hipMemcpyDeviceToHost, s));
+    const Frame &f = c->frames[c->recon].f;
+    int rc;
+    if (r->recon_Y && (rc = copy_out(c, r->recon_Y, f.Y[0]))) return rc;
+    if (r->recon_U && (rc = copy_out(c, r->recon_U, f.U))) return rc;
+    if (r->recon_V && (rc = copy_out(c, r->recon_V, f.V))) return rc;
+    HIPCHK(c, hipStreamSynchronize(s));
+    return VP8HIP_OK;
+}
+
+int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg) {
+    if (!c) return VP8HIP_ERR_ARG;
+    hipStream_t s = c->stream;
+    const size_t n = c->mbs;
+    if (coeffs) HIPCHK(c, hipMemcpyAsync(c->out.coeffs, coeffs, n * 800, hipMemcpyHostToDevice, s));
+    if (parts) HIPCHK(c, hipMemcpyAsync(c->out.parts, parts, n * 4, hipMemcpyHostToDevice, s));
+    if (seg) HIPCHK(c, hipMemcpyAsync(c->out.seg, seg, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return VP8HIP_OK;
+}
+
+int vp8hip_upload_recon(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    if (c->recon < 0 || c->recon == c->slot[0] || c->recon == c->slot[1] || c->recon == c->slot[2]) {
+        c->recon = -1;
+        c->recon = pick_free_frame(c);
+        if (c->recon < 0) return VP8HIP_ERR_STATE;
+    }
+    int rc = set_frame_planes(c, c->frames[c->recon].f, y, u, v, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->recon_ready = true;
+    return VP8HIP_OK;
+}
+
+int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
+    if (!c) return VP8HIP_ERR_ARG;
+    hipStream_t s = c->stream;
+    {
+        Timed t(c, VP8HIP_K_FILTER_MASK);
+        launch_filter_mask(s, c->out, c->d_sd, c->mbs);
+    }
+    if (nz_out) {
+        HIPCHK(c, hipMemcpyAsync(nz_out, c->out.nz, (size_t)c->mbs * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return VP8HIP_OK;
+}
+
+int vp8hip_loop_filter(vp8hip_ctx *c) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
+    Frame &f = c->frames[c->recon].f;
+    {
+        Timed t(c, VP8HIP_K_LOOP_FILTER);
+        launch_loop_filter(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
+    }
+    {
+        Timed t(c, VP8HIP_K_BORDER);
+        launch_border(c->stream, f);
+    }
+    // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
+    c->frames[c->recon].pyramid_valid = false;
+    c->slot[0] = c->recon;
+    c->recon = -1;
+    c->recon_ready = false;
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
+    const Frame &f = c->frames[c->slot[0]].f;
+    int rc;
+    if (y && (rc = copy_out(c, y, f.Y[0]))) return rc;
+    if (u && (rc = copy_out(c, u, f.U))) return rc;
+    if (v && (rc = copy_out(c, v, f.V))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_synchronize(vp8hip_ctx *c) {
+    if (!c) return VP8HIP_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+void *vp8hip_stream(vp8hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int vp8hip_last_hip_error(const vp8hip_ctx *c) { return c ? c->last_hip_error : 0; }
+
+const char *vp8hip_status_string(int status) {
+    switch (status) {
+        case VP8HIP_OK: return "ok";
+        case VP8HIP_ERR_ARG: return "bad argument";
+        case VP8HIP_ERR_NO_DEVICE: return "no HIP device";
+        case VP8HIP_ERR_HIP: return "HIP runtime error";
+        case VP8HIP_ERR_STATE: return "call out of order";
+        case VP8HIP_ERR_ARCH: return "device is not gfx950";
+        default: return "unknown";
+    }
+}
+
+int vp8hip_profile_enable(vp8hip_ctx *c, uint32_t mask) {
+    if (!c) return VP8HIP_ERR_ARG;
+    int rc = prof_collect(c);
+    c->prof_mask = mask;
+    return rc;
+}
+
+int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
+    if (!c) return VP8HIP_ERR_ARG;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    for (int k = 0; k < VP8HIP_K_COUNT; ++k) {
+        if (total_ms) total_ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_n[k];
+        c->prof_ms[k] = 0;
+        c->prof_n[k] = 0;
+    }
+    return VP8HIP_OK;
+}
+
+int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst, size_t bytes) {
+    if (!c || !dst) return VP8HIP_ERR_ARG;
+    hipStream_t s = c->stream;
+    switch (what) {
+        case VP8HIP_DBG_NET1:
+        case VP8HIP_DBG_NET2: {
+            if (ref < 0 || ref > 2 || bytes != (size_t)c->b8 * 4) return VP8HIP_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(dst, c->nets.net[ref][what == VP8HIP_DBG_NET1 ? 0 : 1], bytes, hipMemcpyDeviceToHost, s));
+            break;
+        }
+        case VP8HIP_DBG_BDIFF:
+            if (ref < 0 || ref > 2 || bytes != (size_t)c->b8 * 4) return VP8HIP_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(dst, c->nets.bdiff[ref], bytes, hipMemcpyDeviceToHost, s));
+            break;
+        case VP8HIP_DBG_PYRAMID: {
+            if (ref < 0 || ref > 3 || level < 0 || level > 4) return VP8HIP_ERR_ARG;
+            if (ref < 3 && c->slot[ref] < 0) return VP8HIP_ERR_STATE;
+            const Frame &f = ref == 3 ? c->cur : c->frames[c->slot[ref]].f;
+            const Plane &p = f.Y[level];
+            if (bytes != (size_t)p.w * p.h) return VP8HIP_ERR_ARG;
+            int rc = copy_out(c, dst, p);
+            if (rc) return rc;
+            break;
+        }
+        case VP8HIP_DBG_MB_MASK:
+        case VP8HIP_DBG_MB_NZ:
+            if (bytes != (size_t)c->mbs * 4) return VP8HIP_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(dst, what == VP8HIP_DBG_MB_MASK ? c->out.mask : c->out.nz, bytes, hipMemcpyDeviceToHost, s));
+            break;
+        default:
+            return VP8HIP_ERR_ARG;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return VP8HIP_OK;
+}
+
+// test tap (not in the public header): re-run the quarter-pel search of one reference and return, for
+// block `block`, 26 x {8 rows x 8 predicted pixels, cost, valid} as 26 x 18 dwords
+int vp8hip_debug_search2_block(vp8hip_ctx *c, int ref, int block, void *out) {
+    if (!c || !out || ref < 0 || ref > 2 || c->slot[ref] < 0) return VP8HIP_ERR_ARG;
+    RefSet refs;
+    for (int r = 0; r < 3; ++r) {
+        refs.use[r] = r == ref;
+        refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
+    }
+    HIPCHK(c, hipMemsetAsync(c->scratch, 0, 4096, c->stream));
+    launch_search2(c->stream, c->cur, refs, c->nets, (uint32_t *)c->scratch, block);
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch, 4096, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+}  // extern "C"
