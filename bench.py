@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- macroblocks/s of the inter-frame path (ME + DCT + loop filter) on N MI355X.
+
+One "step" = one inter frame through the whole hot path behind the C ABI (vp8hip_set_current_device,
+vp8hip_set_segments, vp8hip_inter_transform, vp8hip_loop_filter) on synthetic 1080p YUV420 that is
+already resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL for the barrier and
+the max-over-ranks time only); every rank encodes its own GOP chunk -- GOPs are independent units
+(SURVEY.md section 8e), so there is no data-path collective and scaling is weak.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time
+  cpu_baseline -- the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+# ALGORITHMIC bytes per launch of each kernel, as a function of the frame
+# geometry: mbs macroblocks, b8 = 4*mbs 8x8 blocks, nrefs enabled references.
+def algorithmic_bytes(kernel: str, W: int, H: int, nrefs: float) -> float:
+    mbs = (W // 16) * (H // 16)
+    b8 = 4 * mbs
+    if kernel.startswith("search1_l"):
+        lvl = int(kernel[-1])
+        blocks = ((W >> lvl) // 8) * ((H >> lvl) // 8)
+        return 133.0 * blocks * nrefs          # 64 B cur + 64 B ref + 1 B parent MV + 4 B MV out
+    if kernel == "search2":
+        return (64 + 64 + 4 + 4 + 4) * b8 * nrefs  # cur + ref + MV in + MV out + cost out
+    if kernel == "mb":
+        return (384 + 384 + 16 + 8 + 800 + 384 + 20) * mbs  # cur + ref + MVs/ref/parts in; coeffs + recon + ids out
+    if kernel == "loop_filter":
+        return (384 * 2 + 8) * mbs             # recon read + written in place, mask + segment id
+    if kernel == "downsample":
+        return 0.0
+    return 0.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--distinct-frames", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from vp8oclenc_amd import api
+    from vp8oclenc_amd.synth import SynthSequence
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    # ---- workload: BASELINE.json configs[2] geometry, each rank its own GOP (different seed) -------
+    seq = SynthSequence(args.width, args.height, seed=1 + rank)
+    W, H = seq.W, seq.H
+    mbs = (W // 16) * (H // 16)
+    nd = max(2, args.distinct_frames)
+    host_frames = [seq.frame(t) for t in range(nd)]
+    dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in host_frames]
+    enc = api.Vp8Hip(W, H, -1.0, device=local)
+    lastqi, altrefqi = api.quantizer_ladders(0, 48)        # reference defaults, init.h:1548-1603
+    seg_last, seg_alt = [], []
+    for y, _, _ in host_frames:                             # host parameter producers, outside the timed path
+        red, sharp = api.loopfilter_strength(y)
+        seg_last.append(api.prepare_segments_data(False, lastqi, 0, red, sharp))
+        seg_alt.append(api.prepare_segments_data(False, altrefqi, 0, red, sharp))
+    gop = api.Gop(gop_size=1 << 30, altref_range=5)        # one long GOP per rank: key frame only at t = 0
+    ref_hist = {"frames": 0, "refs": 0}
+
+    def key_frame():
+        gop.next()
+        gop.key_coded()
+        y, u, v = dev_frames[0]
+        enc.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+        gop.frame_done()
+
+    def step(t: int):
+        g = gop.next()
+        y, u, v = dev_frames[t % nd]
+        enc.set_current_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+        enc.set_segments(seg_alt[t % nd] if g.current_is_altref else seg_last[t % nd])
+        ug, ua = gop.inter_flags()
+        enc.inter_transform(g.prev_is_golden, g.prev_is_altref, ug, ua)
+        enc.loop_filter()
+        gop.frame_done()
+        ref_hist["frames"] += 1
+        ref_hist["refs"] += 1 + ug + ua
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    key_frame()
+    t = 1
+    # ---- warmup, with every kernel timed once to find the dominant one -----------------------------
+    enc.profile_enable(api.K_NAMES)
+    for _ in range(max(args.warmup, 1)):
+        step(t)
+        t += 1
+    enc.synchronize()
+    warm = enc.profile_read()
+    per_frame = {k: ms / max(args.warmup, 1) for k, (ms, n) in warm.items()}
+    dominant = max((k for k in per_frame if algorithmic_bytes(k, W, H, 1) > 0), key=lambda k: per_frame[k])
+    timed_kernels = api.K_NAMES if args.profile_all else sorted({dominant, "search1_l0"})
+    enc.profile_enable(timed_kernels)
+    ref_hist.update(frames=0, refs=0)
+
+    # ---- timed region --------------------------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(t)
+        t += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = enc.profile_read()
+    nrefs_avg = ref_hist["refs"] / max(ref_hist["frames"], 1)
+
+    out = None
+    if rank == 0:
+        value = mbs * args.steps * world / elapsed
+        ms_k, n_k = prof[dominant]
+        avg_ms = ms_k / max(n_k, 1)
+        abytes = algorithmic_bytes(dominant, W, H, nrefs_avg)
+        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k)}
+        extra = {}
+        for k, (ms, n) in prof.items():
+            if k == dominant or n == 0:
+                continue
+            b = algorithmic_bytes(k, W, H, nrefs_avg)
+            a = b / (ms / n * 1e-3) / 1e9 if b else None
+            extra[k] = {"avg_launch_ms": round(ms / n, 5), "achieved_GBs": None if a is None else round(a, 3),
+                        "frac": None if a is None else round(a / HBM_PEAK_GBS, 6)}
+        out = {
+            "metric": "macroblocks/sec inter-frame (ME+DCT+loopfilter), 1080p", "value": round(value, 1),
+            "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, LAST+GOLDEN+ALTREF "
+                                   f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, one GOP per GPU",
+                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": -1, "qi_ladder": lastqi,
+                       "altref_range": 5, "frames_per_gpu": args.steps},
+            "roofline": roof,
+            "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
+            "other_kernels": extra,
+            "fps": round(args.steps * world / elapsed, 2),
+        }
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(args, host_frames, seg_last, W, H, mbs)
+    if rank == 0:
+        print(json.dumps(out))
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, host_frames, seg_last, W, H, mbs):
+    """Times oracle/vp8_oracle.c (the checker; OpenMP over blocks/MBs) on the host cores: kind 'port'."""
+    # all host cores this process may run on (libgomp reads the variable when liboracle.so is loaded)
+    os.environ["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    from oracle_lib import Oracle
+    ora = Oracle(W, H, -1.0)
+    threads = int(Oracle.lib().vp8o_num_threads())
+    ora.upload_last(*host_frames[0])
+    ora.set_segments(seg_last[1])
+    # warm once with LAST only (sets golden = altref = LAST like the frame after a key frame), then time
+    ora.upload_current(*host_frames[1])
+    ora.inter_transform(1, 1, 0, 0)
+    ora.loop_filter()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        f = host_frames[(2 + n) % len(host_frames)]
+        ora.set_segments(seg_last[(2 + n) % len(host_frames)])
+        ora.upload_current(*f)
+        ora.inter_transform(0, 0, 1, 1)
+        ora.loop_filter()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n >= 8:
+            break
+    ora.close()
+    return {"value": round(mbs * n / el, 1), "unit": "macroblocks/s", "cores": threads, "kind": "port",
+            "sample": f"{n} inter frames {W}x{H}, 3 references, oracle/vp8_oracle.c with OpenMP on {threads} threads, "
+                      f"{el:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

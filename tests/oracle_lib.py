@@ -95,6 +95,11 @@ class Oracle:
     def lib(cls) -> C.CDLL:
         if cls._lib is None:
             build_oracle()
+            # libgomp reads these once, when the library is loaded.  Tests use a modest team (the many
+            # small parallel regions of the restatement crawl when 128 spinning threads share a box);
+            # bench.py's cpu_baseline leg sets OMP_NUM_THREADS itself before calling in here.
+            os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+            os.environ.setdefault("OMP_NUM_THREADS", str(min(8, len(os.sched_getaffinity(0)))))
             lib = C.CDLL(ORACLE_SO)
             lib.vp8o_create.restype = C.c_void_p
             lib.vp8o_create.argtypes = [ci, ci, C.c_float]

@@ -46,6 +46,8 @@ struct vp8hip_ctx {
     NetSet nets{};
     MBOut out{};
     SegData *d_sd = nullptr;
+    SegData *h_sd_ring = nullptr;   // pinned staging for vp8hip_set_segments
+    unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
     void *scratch = nullptr;        // device staging for debug pyramid downloads
 
@@ -235,6 +237,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->out.coeffs, (size_t)c->mbs * 800));
     CR(hipMalloc(&c->out.first_lf0, 64));
     CR(hipMalloc(&c->d_sd, sizeof(SegData)));
+    CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
     CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 64));
     CR(hipMalloc(&c->scratch, (size_t)width * height));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
@@ -277,6 +280,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->out.coeffs);
     hipFree(c->out.first_lf0);
     hipFree(c->d_sd);
+    if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
     hipFree(c->d_progress);
     hipFree(c->scratch);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -314,8 +318,11 @@ int vp8hip_set_last_device(vp8hip_ctx *c, const void *y, const void *u, const vo
 
 int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
     if (!c || !sd) return VP8HIP_ERR_ARG;
-    HIPCHK(c, hipMemcpyAsync(c->d_sd, sd, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // staged through a ring of pinned slots so the call neither keeps the caller's pointer nor stalls
+    // the stream (176 bytes per frame; 16 slots cover any realistic number of frames in flight)
+    SegData *slot = c->h_sd_ring + (c->sd_ring_pos++ & 15);
+    memcpy(slot, sd, sizeof(SegData));
+    HIPCHK(c, hipMemcpyAsync(c->d_sd, slot, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
     return VP8HIP_OK;
 }
 
@@ -442,7 +449,9 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     Frame &f = c->frames[c->recon].f;
     {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
+        static const bool use_v1 = getenv("VP8HIP_LF_V1") != nullptr;  // A/B switch for measurements only
+        if (use_v1) launch_loop_filter(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
+        else launch_loop_filter2(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
     }
     {
         Timed t(c, VP8HIP_K_BORDER);

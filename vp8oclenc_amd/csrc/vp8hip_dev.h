@@ -63,7 +63,9 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const Frame 
                const SegData *d_sd, float ssim_target, int mbw, int mbh);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
 void launch_loop_filter(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                        int mbw, int mbh);
+                        int mbw, int mbh);   // first version: one wave per MB row, hand-off through HBM (kept for A/B)
+void launch_loop_filter2(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh);  // banded wavefront in LDS (the one the library uses)
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
