@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: two gloo ranks encode alternate GOP chunks (through the same driver and the CPU
+oracle backend) and together reproduce, frame for frame, what one process produces for the whole
+sequence.  No data-path collective: only all_gather of the per-frame digests and a MAX all_reduce."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from oracle_lib import Oracle
+from vp8oclenc_amd import gop_shard
+from vp8oclenc_amd.synth import SynthSequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, FRAMES, GOP = 64, 48, 12, 3
+
+
+def test_gop_chunks_cover_sequence_once():
+    ch = gop_shard.gop_chunks(10, 4)
+    assert ch == [(0, 4), (4, 4), (8, 2)]
+    assert gop_shard.chunks_of_rank(10, 4, 1, 2) == [(4, 4)]
+    got = sorted(sum((gop_shard.chunks_of_rank(37, 5, r, 4) for r in range(4)), []))
+    assert got == gop_shard.gop_chunks(37, 5)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from oracle_lib import Oracle
+    from vp8oclenc_amd import gop_shard
+    from vp8oclenc_amd.synth import SynthSequence
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    seq = SynthSequence({W}, {H}, seed=5)
+    dist.barrier(); t0 = time.perf_counter()
+    mine = gop_shard.encode_chunks(lambda: Oracle(seq.W, seq.H), seq,
+                                   gop_shard.chunks_of_rank({FRAMES}, {GOP}, rank, world), seq.W, seq.H)
+    dist.barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    allv = gop_shard.gather_digests(mine, {FRAMES}, dist)
+    if rank == 0:
+        np.save({out!r}, allv)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_gloo_ranks_reproduce_single_process(tmp_path):
+    seq = SynthSequence(W, H, seed=5)
+    serial = gop_shard.encode_chunks(lambda: Oracle(seq.W, seq.H), seq, gop_shard.gop_chunks(FRAMES, GOP), seq.W, seq.H)
+    serial_vec = gop_shard.gather_digests(serial, FRAMES)
+    assert (serial_vec >= 0).all()
+    out = str(tmp_path / "digests.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, W=W, H=H, FRAMES=FRAMES, GOP=GOP, out=out))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    sharded = np.load(out)
+    assert np.array_equal(sharded, serial_vec)

@@ -217,3 +217,43 @@ def test_error_behaviour():
     with pytest.raises(api.Vp8HipError):
         hip.loop_filter()                  # nothing to filter
     hip.close()
+
+
+# ---- the committed golden vectors (outputs of the reference's own kernels, scripts/gen_golden.py) ----
+import glob as _glob
+import os as _os
+
+_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[_os.path.basename(p)[:-4] for p in _GOLDEN])
+def test_golden_vectors(path):
+    z = np.load(path)
+    meta = eval(str(z["meta"]))
+    cur = tuple(np.ascontiguousarray(z[f"in_cur_{p}"]) for p in "YUV")
+    refs = [tuple(np.ascontiguousarray(z[f"in_ref{r}_{p}"]) for p in "YUV") for r in range(3)]
+    flags = (meta["use_golden"], meta["use_altref"])
+    h, _ = _one_frame(meta["W"], meta["H"], [refs[0], refs[1], refs[2], cur], z["segments"], flags, meta["ssim_target"])
+    bad = []
+    for k in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_segment_id", "prefilter_Y", "prefilter_U",
+              "prefilter_V", "MB_non_zero_coeffs", "mb_mask", "recon_Y", "recon_U", "recon_V"):
+        if not np.array_equal(h[k], z[k]):
+            bad.append((k, int((h[k] != z[k]).sum())))
+    if float(np.abs(h["MB_SSIM"].astype(np.float64) - z["MB_SSIM"]).max()) > SSIM_TOL:
+        bad.append(("MB_SSIM", float(np.abs(h["MB_SSIM"] - z["MB_SSIM"]).max())))
+    c, g = h["MB_coeffs"].copy(), z["MB_coeffs"].copy()
+    c[h["MB_parts"] != 0, 24] = 0       # block 24 exists only for 16x16 macroblocks
+    g[z["MB_parts"] != 0, 24] = 0
+    if not np.array_equal(c, g):
+        bad.append(("MB_coeffs", int((c != g).sum())))
+    for r in range(3):
+        if r == 0 or flags[r - 1]:
+            for hk, zk in ((f"net1_r{r}", f"net1_r{r}"), (f"bdiff_r{r}", f"bdiff_r{r}"), (f"net2_r{r}", f"net_r{r}_l0")):
+                if not np.array_equal(h[hk], z[zk]):
+                    bad.append((hk, int((h[hk] != z[zk]).sum())))
+    for l in range(5):
+        if not np.array_equal(h[f"cur_pyr{l}"], z[f"cur_pyr_{l}"]):
+            bad.append((f"cur_pyr{l}",))
+        if not np.array_equal(h[f"last_pyr{l}"], z[f"ref0_pyr_{l}"]):
+            bad.append((f"last_pyr{l}",))
+    assert not bad, f"{_os.path.basename(path)}: HIP differs from the reference kernels' outputs: {bad}"

@@ -1,0 +1,66 @@
+"""Closed-GOP sharding of a sequence over ranks (one process per GPU) -- SURVEY.md section 8e.
+
+A key frame resets every reference (intra_part.h:1091-1098, inter_part.h:35-50), so GOPs are independent
+units: rank r encodes chunks r, r+world, ... with the ordinary single-GPU pipeline and the outputs are
+concatenated in frame order.  No collective sits on the data path; torch.distributed (RCCL on the GPUs,
+gloo in the CPU tests) carries only the barrier, the max-over-ranks time and the gathering of results.
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+
+def gop_chunks(total_frames: int, gop_size: int) -> list[tuple[int, int]]:
+    """(first frame, length) of every closed GOP when a key frame is forced every gop_size frames."""
+    return [(s, min(gop_size, total_frames - s)) for s in range(0, total_frames, gop_size)]
+
+
+def chunks_of_rank(total_frames: int, gop_size: int, rank: int, world: int) -> list[tuple[int, int]]:
+    return gop_chunks(total_frames, gop_size)[rank::world]
+
+
+def frame_digest(out: dict | None, last_planes) -> int:
+    """CRC of everything the entropy coder and the next frame consume from one frame of the path."""
+    crc = 0
+    if out is not None:
+        for k in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_segment_id"):
+            crc = zlib.crc32(np.ascontiguousarray(out[k]).tobytes(), crc)
+        c = out["MB_coeffs"].copy()
+        c[out["MB_parts"] != 0, 24] = 0      # block 24 only exists for 16x16 macroblocks
+        crc = zlib.crc32(c.tobytes(), crc)
+    for p in last_planes:
+        crc = zlib.crc32(np.ascontiguousarray(p).tobytes(), crc)
+    return crc
+
+
+def encode_chunks(make_backend, sequence, chunks, width, height, **driver_kw) -> dict[int, int]:
+    """Run the inter-path driver over the given GOP chunks; returns {frame number: digest}."""
+    from .driver import InterPathDriver
+    digests = {}
+    for start, length in chunks:
+        be = make_backend()
+        drv = InterPathDriver(be, width, height, gop_size=1 << 30, **driver_kw)
+        for t in range(start, start + length):
+            y, u, v = sequence.frame(t)
+            out = drv.encode_frame(y, u, v)
+            digests[t] = frame_digest(out, be.download_last() if out is not None else (y, u, v))
+        be.close()
+    return digests
+
+
+def gather_digests(local: dict[int, int], total_frames: int, dist=None) -> np.ndarray:
+    """All ranks' digests in frame order (all_gather of a dense int64 vector; -1 = not mine)."""
+    vec = np.full(total_frames, -1, np.int64)
+    for t, d in local.items():
+        vec[t] = d
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return vec
+    import torch
+    mine = torch.from_numpy(vec)
+    bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, mine)
+    allv = torch.stack(bufs).numpy()
+    assert ((allv >= 0).sum(axis=0) == 1).all(), "every frame must be encoded by exactly one rank"
+    return allv.max(axis=0)
