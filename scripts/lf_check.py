@@ -36,6 +36,12 @@ def run(W, H, seed, levels=(6, 10, 14, 20), reps=1):
         ok = [ok[0] and np.array_equal(ry, fo["recon_Y"]), ok[1] and np.array_equal(ru, fo["recon_U"]), ok[2] and np.array_equal(rv, fo["recon_V"])]
         if not all(ok): hy, hu, hv = ry, ru, rv
     pr = hip.profile_read()["loop_filter"]
+    if os.environ.get("LF_STAMPS"):
+        import ctypes as C
+        st = np.zeros(64, np.uint64)
+        hip.lib.vp8hip_debug_download(hip.h, 100, 0, 0, C.c_void_p(st.ctypes.data), 512)
+        steps = W // 16 + 1 + 14
+        print("   stamps (cycles/step: wait p1 p2 wb) per band,wave:", (st.reshape(16, 4)[:8] / steps).astype(int).tolist())
     bad = ""
     if not all(ok):
         d = np.argwhere(hy != fo["recon_Y"])

@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     odir = os.path.join(PKG, "build")
     os.makedirs(odir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-unused-value",
-             "-I", os.path.join(PKG, "..", "include")]
+             "-I", os.path.join(PKG, "..", "include")] + os.environ.get("VP8HIP_EXTRA_FLAGS", "").split()
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):

@@ -33,68 +33,88 @@ constexpr int TILE_YS = 24, TILE_CS = 12;              // work-tile row strides
 constexpr int TILE_BYTES = 16 * TILE_YS + 2 * 8 * TILE_CS;
 constexpr int TILE_SLOTS = 4;           // steps a finished tile stays in LDS for the writer wave
 
+// ---- edge filters -------------------------------------------------------------------------------
+// The reference works on u = pixel - 128 (CPU_kernels.cl:928-956); every quantity it forms is a
+// difference of two samples or sample +- correction, so the same arithmetic runs on the pixel values
+// themselves.  Here samples carry a +BIAS so that they stay positive even when an unsaturated
+// register (reference quirk, :1024/:1062) dips below 0, which lets |a-b| be one v_sad_u16.
+// Clamps that cannot trigger are dropped: (27w+63)>>7 etc. lie in [-27,27] for w in [-128,127], and
+// a+3 / a+4 can only exceed the upper bound.
+constexpr int BIAS = 64;
 __device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
+__device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_sad_u16((uint32_t)a, (uint32_t)b, 0u); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return imax(imax(a, b), c); }
 struct EdgeRegs { int p3, p2, p1, p0, q0, q1, q2, q3; };
 
-__device__ __forceinline__ bool lf_mask(const EdgeRegs &e, int int_lim, int edge_lim) {
-    const bool over = (iabs(e.p3 - e.p2) > int_lim) | (iabs(e.p2 - e.p1) > int_lim) | (iabs(e.p1 - e.p0) > int_lim) |
-                      (iabs(e.q1 - e.q0) > int_lim) | (iabs(e.q2 - e.q1) > int_lim) | (iabs(e.q3 - e.q2) > int_lim) |
-                      ((iabs(e.p0 - e.q0) * 2 + iabs(e.p1 - e.q1) / 2) > edge_lim);
-    return !over;
+__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_lim, int hev_thr, bool &mask,
+                                           bool &hev) {
+    const int d10 = ad(e.p1, e.p0), dq10 = ad(e.q1, e.q0);
+    const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
+    const int m2 = max3i(dq10, ad(e.q2, e.q1), ad(e.q3, e.q2));
+    const int edge = ad(e.p0, e.q0) * 2 + (ad(e.p1, e.q1) >> 1);
+    mask = (imax(m1, m2) <= int_lim) & (edge <= edge_lim);
+    hev = imax(d10, dq10) > hev_thr;
 }
 __device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, int mb_lim, int int_lim, int hev_thr) {  // :829-883
-    const bool mask = lf_mask(e, int_lim, mb_lim);
-    const bool hev = (iabs(e.p1 - e.p0) > hev_thr) | (iabs(e.q1 - e.q0) > hev_thr);
+    bool mask, hev;
+    edge_masks(e, int_lim, mb_lim, hev_thr, mask, hev);
     int w = c128(e.p1 - e.q1);
     w = c128(w + (e.q0 - e.p0) * 3);
     w = mask ? w : 0;
     int a = hev ? w : 0;
-    const int b = c128(a + 3) >> 3;
-    a = c128(a + 4) >> 3;
+    const int b = imin(a + 3, 127) >> 3;
+    a = imin(a + 4, 127) >> 3;
     e.q0 -= a; e.p0 += b;
     w = hev ? 0 : w;
-    a = c128((w * 27 + 63) >> 7); e.q0 -= a; e.p0 += a;
-    a = c128((w * 18 + 63) >> 7); e.q1 -= a; e.p1 += a;
-    a = c128((w * 9 + 63) >> 7);  e.q2 -= a; e.p2 += a;
+    a = (w * 27 + 63) >> 7; e.q0 -= a; e.p0 += a;
+    a = (w * 18 + 63) >> 7; e.q1 -= a; e.p1 += a;
+    a = (w * 9 + 63) >> 7;  e.q2 -= a; e.p2 += a;
 }
 __device__ __forceinline__ void filter_b_edge(EdgeRegs &e, int b_lim, int int_lim, int hev_thr) {  // :885-926
-    const bool mask = lf_mask(e, int_lim, b_lim);
-    const bool hev = (iabs(e.p1 - e.p0) > hev_thr) | (iabs(e.q1 - e.q0) > hev_thr);
+    bool mask, hev;
+    edge_masks(e, int_lim, b_lim, hev_thr, mask, hev);
     int a = c128(e.p1 - e.q1);
     a = hev ? a : 0;
     a = c128(a + (e.q0 - e.p0) * 3);
     a = mask ? a : 0;
-    const int b = c128(a + 3) >> 3;
-    a = c128(a + 4) >> 3;
+    const int b = imin(a + 3, 127) >> 3;
+    a = imin(a + 4, 127) >> 3;
     e.q0 -= a; e.p0 += b;
     a = (a + 1) >> 1;
     a = hev ? 0 : a;
     e.q1 -= a; e.p1 += a;
 }
-__device__ __forceinline__ int px(int u) { return sat8(u + 128); }
 
-// One line of pixel values t[0..msz+3] (t[0..3] precede the macroblock edge) through the MB edge and
-// the inner edges; stored values are saturated, the p/q registers handed from edge to edge are not.
+// One line of biased samples t[0..msz+3] (t[0..3] precede the macroblock edge) through the MB edge and
+// the inner edges.  t[] receives the UNSATURATED results (saturation = the reference's store happens
+// when the line is packed, pack4); the p/q registers handed from edge to edge stay unsaturated too.
 __device__ __forceinline__ void filter_line(int (&t)[20], int msz, bool has_mb_edge, bool inner, int mb_lim,
                                             int b_lim, int int_lim, int hev_thr) {
     EdgeRegs e;
-    e.q0 = t[4] - 128; e.q1 = t[5] - 128; e.q2 = t[6] - 128; e.q3 = t[7] - 128;
+    e.q0 = t[4]; e.q1 = t[5]; e.q2 = t[6]; e.q3 = t[7];
     if (has_mb_edge) {
-        e.p3 = t[0] - 128; e.p2 = t[1] - 128; e.p1 = t[2] - 128; e.p0 = t[3] - 128;
+        e.p3 = t[0]; e.p2 = t[1]; e.p1 = t[2]; e.p0 = t[3];
         filter_mb_edge(e, mb_lim, int_lim, hev_thr);
-        t[1] = px(e.p2); t[2] = px(e.p1); t[3] = px(e.p0);
-        t[4] = px(e.q0); t[5] = px(e.q1); t[6] = px(e.q2);
+        t[1] = e.p2; t[2] = e.p1; t[3] = e.p0;
+        t[4] = e.q0; t[5] = e.q1; t[6] = e.q2;
     }
 #pragma unroll
     for (int k = 4; k < 16; k += 4) {
         if (inner && k < msz) {
             e.p3 = e.q0; e.p2 = e.q1; e.p1 = e.q2; e.p0 = e.q3;
-            e.q0 = t[4 + k] - 128; e.q1 = t[5 + k] - 128; e.q2 = t[6 + k] - 128; e.q3 = t[7 + k] - 128;
+            e.q0 = t[4 + k]; e.q1 = t[5 + k]; e.q2 = t[6 + k]; e.q3 = t[7 + k];
             filter_b_edge(e, b_lim, int_lim, hev_thr);
-            t[2 + k] = px(e.p1); t[3 + k] = px(e.p0); t[4 + k] = px(e.q0); t[5 + k] = px(e.q1);
+            t[2 + k] = e.p1; t[3 + k] = e.p0; t[4 + k] = e.q0; t[5 + k] = e.q1;
         }
     }
 }
+
+// four biased samples -> four saturated bytes (the reference's convert_uchar_sat on store)
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    return (uint32_t)sat8(a - BIAS) | ((uint32_t)sat8(b - BIAS) << 8) | ((uint32_t)sat8(c - BIAS) << 16) |
+           ((uint32_t)sat8(d - BIAS) << 24);
+}
+__device__ __forceinline__ int ub(uint32_t w, int k) { return byte_of(w, k) + BIAS; }
 
 __device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -292,7 +312,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
     }
     uint32_t left4 = 0;
     const int steps = mbw + 1 + 2 * (ROWS - 1);
+#ifdef LF2_STAMPS
+    unsigned long long st_wait = 0, st_p1 = 0, st_p2 = 0, st_wb = 0, st_t0, st_t1;
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#else
+#define STAMP(v)
+#endif
     for (int S = 0; S < steps; ++S) {
+        STAMP(st_t0);
         // ---- dependencies --------------------------------------------------------------------
         if (wave > 0) while (sh.prog[wave - 1] < S) __builtin_amdgcn_s_sleep(1);                  // data from above
         // ring space below: our second row may not lap the row under it, nor the writer wave that still
@@ -309,6 +336,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
             const int need = imin(x + 1, mbw);
             while (sh.top_ready < need) __builtin_amdgcn_s_sleep(1);
         }
+#ifdef LF2_STAMPS
+        STAMP(st_t1); st_wait += st_t1 - st_t0; st_t0 = st_t1;
+#endif
         const int x0 = x * msz;
         const uint4 own = nxt;
         const int seg = nxt_seg, maskv = nxt_mask;
@@ -328,34 +358,40 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
         if (mbstep) {
             int t[20];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = byte_of(left4, k);
+            for (int k = 0; k < 4; ++k) t[k] = ub(left4, k);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[4 + k] = byte_of(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
+            for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
             if (do_filter) filter_line(t, msz, x > 0, inner, mb_lim, b_lim, int_lim, hev_thr);
 #pragma unroll
             for (int j = 0; j < 5; ++j)
-                if (j <= nd) trow[j] = (uint32_t)t[4 * j] | ((uint32_t)t[4 * j + 1] << 8) | ((uint32_t)t[4 * j + 2] << 16) | ((uint32_t)t[4 * j + 3] << 24);
+                if (j <= nd) trow[j] = pack4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
         } else if (act && row_real) {
             trow[0] = left4;   // flush column: only the carried four columns are meaningful
         }
         lds_fence();
+#ifdef LF2_STAMPS
+        STAMP(st_t1); st_p1 += st_t1 - st_t0; st_t0 = st_t1;
+#endif
         // ---- phase 2: horizontal edges, lane = pixel column -------------------------------------
         if (mbstep && do_filter) {
             int t[20];
             const int rc = (x0 + li) & (rw - 1);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = top[k * rw + rc];
+            for (int k = 0; k < 4; ++k) t[k] = (int)top[k * rw + rc] + BIAS;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[4 + k] = k < msz ? tile[k * tstride + 4 + li] : 0;
+            for (int k = 0; k < 16; ++k) t[4 + k] = k < msz ? (int)tile[k * tstride + 4 + li] + BIAS : BIAS;
             filter_line(t, msz, has_top, inner, mb_lim, b_lim, int_lim, hev_thr);
             if (has_top) {
-                top[1 * rw + rc] = (uint8_t)t[1]; top[2 * rw + rc] = (uint8_t)t[2]; top[3 * rw + rc] = (uint8_t)t[3];
+                top[1 * rw + rc] = (uint8_t)sat8(t[1] - BIAS); top[2 * rw + rc] = (uint8_t)sat8(t[2] - BIAS); top[3 * rw + rc] = (uint8_t)sat8(t[3] - BIAS);
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k)
-                if (k < msz) tile[k * tstride + 4 + li] = (uint8_t)t[4 + k];
+                if (k < msz) tile[k * tstride + 4 + li] = (uint8_t)sat8(t[4 + k] - BIAS);
         }
         lds_fence();
+#ifdef LF2_STAMPS
+        STAMP(st_t1); st_p2 += st_t1 - st_t0; st_t0 = st_t1;
+#endif
         // ---- write-back -----------------------------------------------------------------------
         if (act) {
             if (row_real) {
@@ -374,7 +410,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
         }
         lds_fence();
         if (lane == 0) sh.prog[wave] = S + 1;
+#ifdef LF2_STAMPS
+        STAMP(st_t1); st_wb += st_t1 - st_t0;
+#endif
     }
+#ifdef LF2_STAMPS
+    if (lane == 0 && band < 4) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.gprog + 1024) + (band * WORKERS + wave) * 4;
+        o[0] = st_wait; o[1] = st_p1; o[2] = st_p2; o[3] = st_wb;
+    }
+#endif
 }
 
 }  // namespace lf2

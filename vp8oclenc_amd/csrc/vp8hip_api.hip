@@ -238,7 +238,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->out.first_lf0, 64));
     CR(hipMalloc(&c->d_sd, sizeof(SegData)));
     CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
-    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 64));
+    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096)
     CR(hipMalloc(&c->scratch, (size_t)width * height));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
@@ -547,6 +547,10 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
         case VP8HIP_DBG_MB_NZ:
             if (bytes != (size_t)c->mbs * 4) return VP8HIP_ERR_ARG;
             HIPCHK(c, hipMemcpyAsync(dst, what == VP8HIP_DBG_MB_MASK ? c->out.mask : c->out.nz, bytes, hipMemcpyDeviceToHost, s));
+            break;
+        case 100:  // diagnostic build only (-DLF2_STAMPS): cycle sums written by the loop filter
+            if (bytes != 512) return VP8HIP_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(dst, (const char *)c->d_progress + 4096, 512, hipMemcpyDeviceToHost, s));
             break;
         default:
             return VP8HIP_ERR_ARG;
