@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct-frames", type=int, default=8)
+    ap.add_argument("--gops-per-gpu", type=int, default=4, help="independent GOP chunks in flight per GPU (1 = one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
     return ap.parse_args()
@@ -81,75 +82,92 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    # ---- workload: BASELINE.json configs[2] geometry, each rank its own GOP (different seed) -------
+    # ---- workload: BASELINE.json configs[2] geometry.  Every rank encodes `gops_per_gpu` independent GOP
+    # chunks concurrently, one C-ABI context (= one HIP stream) each: closed GOPs are the unit the path
+    # shards by, across GPUs and, on a 256-CU part whose loop filter is a latency-bound
+    # wavefront on a handful of CUs, also inside one GPU.
     seq = SynthSequence(args.width, args.height, seed=1 + rank)
     W, H = seq.W, seq.H
     mbs = (W // 16) * (H // 16)
     nd = max(2, args.distinct_frames)
+    G = max(1, args.gops_per_gpu)
     host_frames = [seq.frame(t) for t in range(nd)]
     dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in host_frames]
-    enc = api.Vp8Hip(W, H, -1.0, device=local)
     lastqi, altrefqi = api.quantizer_ladders(0, 48)        # reference defaults, init.h:1548-1603
     seg_last, seg_alt = [], []
     for y, _, _ in host_frames:                             # host parameter producers, outside the timed path
         red, sharp = api.loopfilter_strength(y)
         seg_last.append(api.prepare_segments_data(False, lastqi, 0, red, sharp))
         seg_alt.append(api.prepare_segments_data(False, altrefqi, 0, red, sharp))
-    gop = api.Gop(gop_size=1 << 30, altref_range=5)        # one long GOP per rank: key frame only at t = 0
     ref_hist = {"frames": 0, "refs": 0}
 
-    def key_frame():
-        gop.next()
-        gop.key_coded()
-        y, u, v = dev_frames[0]
-        enc.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-        gop.frame_done()
+    class GopStream:
+        """One closed GOP: its own context/stream, frame-type state machine and position in the sequence."""
 
-    def step(t: int):
-        g = gop.next()
-        y, u, v = dev_frames[t % nd]
-        enc.set_current_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-        enc.set_segments(seg_alt[t % nd] if g.current_is_altref else seg_last[t % nd])
-        ug, ua = gop.inter_flags()
-        enc.inter_transform(g.prev_is_golden, g.prev_is_altref, ug, ua)
-        enc.loop_filter()
-        gop.frame_done()
-        ref_hist["frames"] += 1
-        ref_hist["refs"] += 1 + ug + ua
+        def __init__(self, k: int):
+            self.enc = api.Vp8Hip(W, H, -1.0, device=local)
+            self.gop = api.Gop(gop_size=1 << 30, altref_range=5)   # key frame only at the start of the chunk
+            self.t = (k * 3) % nd                                   # chunks start at different frames
+            self.gop.next()
+            self.gop.key_coded()                                    # key frame: coded by the host (out of scope)
+            y, u, v = dev_frames[self.t % nd]
+            self.enc.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+            self.gop.frame_done()
+            self.t += 1
+
+        def step(self):
+            g = self.gop.next()
+            i = self.t % nd
+            y, u, v = dev_frames[i]
+            self.enc.set_current_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+            self.enc.set_segments(seg_alt[i] if g.current_is_altref else seg_last[i])
+            ug, ua = self.gop.inter_flags()
+            self.enc.inter_transform(g.prev_is_golden, g.prev_is_altref, ug, ua)
+            self.enc.loop_filter()
+            self.gop.frame_done()
+            self.t += 1
+            ref_hist["frames"] += 1
+            ref_hist["refs"] += 1 + ug + ua
+
+    streams = [GopStream(k) for k in range(G)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    key_frame()
-    t = 1
     # ---- warmup, with every kernel timed once to find the dominant one -----------------------------
-    enc.profile_enable(api.K_NAMES)
-    for _ in range(max(args.warmup, 1)):
-        step(t)
-        t += 1
-    enc.synchronize()
-    warm = enc.profile_read()
-    per_frame = {k: ms / max(args.warmup, 1) for k, (ms, n) in warm.items()}
+    nwarm = max(args.warmup, 1)
+    streams[0].enc.profile_enable(api.K_NAMES)
+    for i in range(nwarm):
+        streams[i % G].step()
+    torch.cuda.synchronize()
+    warm = streams[0].enc.profile_read()
+    n0 = len(range(0, nwarm, G))
+    per_frame = {k: ms / max(n0, 1) for k, (ms, n) in warm.items()}
     dominant = max((k for k in per_frame if algorithmic_bytes(k, W, H, 1) > 0), key=lambda k: per_frame[k])
     timed_kernels = api.K_NAMES if args.profile_all else sorted({dominant, "search1_l0"})
-    enc.profile_enable(timed_kernels)
+    for st in streams:
+        st.enc.profile_enable(timed_kernels)
     ref_hist.update(frames=0, refs=0)
 
     # ---- timed region --------------------------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(t)
-        t += 1
+    for i in range(args.steps):
+        streams[i % G].step()
+    enqueue_s = time.perf_counter() - t0      # host time to issue everything (diagnostic: host- vs GPU-bound)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    prof = enc.profile_read()
+    prof = {}
+    for st in streams:
+        for k, (ms, n) in st.enc.profile_read().items():
+            pm, pn = prof.get(k, (0.0, 0))
+            prof[k] = (pm + ms, pn + n)
     nrefs_avg = ref_hist["refs"] / max(ref_hist["frames"], 1)
 
     out = None
@@ -176,20 +194,22 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, LAST+GOLDEN+ALTREF "
-                                   f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, one GOP per GPU",
+                                   f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
                        "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": -1, "qi_ladder": lastqi,
-                       "altref_range": 5, "frames_per_gpu": args.steps},
+                       "altref_range": 5, "frames_per_gpu": args.steps, "gops_per_gpu": G},
             "roofline": roof,
             "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
             "other_kernels": extra,
             "fps": round(args.steps * world / elapsed, 2),
+            "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
         }
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, host_frames, seg_last, W, H, mbs)
     if rank == 0:
         print(json.dumps(out))
-    enc.close()
+    for st in streams:
+        st.enc.close()
     if dist is not None:
         dist.destroy_process_group()
 

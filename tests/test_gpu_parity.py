@@ -208,6 +208,41 @@ def test_host_modified_mb_data_and_recon():
     ora.close()
 
 
+def test_device_resident_inputs_match_host_upload():
+    """vp8hip_set_current_device / vp8hip_set_last_device (planes already in HBM, what bench.py uses)."""
+    import torch
+    W, H = 208, 112
+    f = _frames(W, H, 19)
+    sd = default_segments()
+    res = []
+    for dev in (False, True):
+        hip = api.Vp8Hip(W, H)
+        hip.set_segments(sd)
+        keep = []
+        for t in range(1, 4):
+            if dev:
+                last = [torch.from_numpy(p).cuda() for p in f[t - 1]] if t == 1 else None
+                cur = [torch.from_numpy(p).cuda() for p in f[t]]
+                keep += [last, cur]
+                if last:
+                    hip.set_last_device(*[x.data_ptr() for x in last])
+                hip.set_current_device(*[x.data_ptr() for x in cur])
+            else:
+                if t == 1:
+                    hip.upload_last(*f[0])
+                hip.upload_current(*f[t])
+            hip.inter_transform(t == 1, t == 1, t > 1, t > 1)
+            r = hip.download_results()
+            hip.loop_filter()
+        r["last"] = hip.download_last()
+        res.append(r)
+        hip.close()
+    for k in INTEGER_KEYS:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    for a, b in zip(res[0]["last"], res[1]["last"]):
+        assert np.array_equal(a, b)
+
+
 def test_error_behaviour():
     with pytest.raises(api.Vp8HipError):
         api.Vp8Hip(100, 64)          # not a multiple of 16

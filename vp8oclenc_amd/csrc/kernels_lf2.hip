@@ -128,7 +128,8 @@ struct Args {
     Plane Y, U, V;
     MBOut o;
     const SegData *sd;
-    int32_t *gprog;   // [bands] macroblock steps finished by the LAST row of each band (zeroed per launch)
+    int32_t *gprog;   // [bands] gbase + macroblock steps finished by the LAST row of each band
+    int gbase;        // counters only grow: launch n uses the range (n*(mbw+2), (n+1)*(mbw+2)], so no memset
     int mbw, mbh, nbands;
 };
 
@@ -139,6 +140,7 @@ struct Shared {
     volatile int top_ready;                 // macroblocks of strip[0] delivered by the loader
     volatile int pub_done;                  // macroblocks of strip[ROWS] handed to the next band
     volatile int wr_done;                   // steps whose finished blocks the writer has read out of LDS
+    int first_lf0;                          // first macroblock whose segment has loop_filter_level 0 (:990)
 };
 
 constexpr int NWAVES = WORKERS + 3;         // workers + loader + publisher + writer
@@ -148,10 +150,24 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
     const int band = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < WORKERS) sh.prog[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { sh.top_ready = 0; sh.pub_done = 0; sh.wr_done = 0; }
+    if (threadIdx.x == 0) { sh.top_ready = 0; sh.pub_done = 0; sh.wr_done = 0; sh.first_lf0 = 0x7fffffff; }
     __syncthreads();
     const int mbw = a.mbw, mbh = a.mbh;
     const int band_row0 = band * ROWS;
+    {
+        // CPU_kernels.cl:990: a macroblock whose segment has level 0 ends the plane.  Levels are >= 1 for
+        // every quantizer the host produces, so the scan over segment ids runs only if one IS zero.
+        const int32_t *sdv = a.sd->v;
+        const bool any0 = sdv[SD_LOOP_FILTER_LEVEL] == 0 || sdv[SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 ||
+                          sdv[2 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 || sdv[3 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0;
+        if (any0) {
+            int first = 0x7fffffff;
+            for (int mb = threadIdx.x; mb < mbw * mbh; mb += NWAVES * 64)
+                if (sdv[a.o.seg[mb] * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0) { first = mb; break; }
+            if (first != 0x7fffffff) atomicMin(&sh.first_lf0, first);
+            __syncthreads();
+        }
+    }
 
     // ---------------------------------------------------------------------------------------------
     // publisher wave: bottom strip of the band's last row (strip[ROWS]) -> the frame (sc1, write-
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 sh.pub_done = x + 1;
-                __hip_atomic_store(&a.gprog[band], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.gprog[band], a.gbase + x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
         uint8_t *sp = sh.strip[0] + (pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC)) + r * rw;
         for (int x = 0; x < mbw; ++x) {
             const int need = imin(x + 2, mbw + 1);
-            while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+            while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need)
                 __builtin_amdgcn_s_sleep(2);
             // ring space: the WRITER still reads strip[0] for row 0's finished blocks (row 0: step == x),
             // and it may trail the workers by TILE_SLOTS-1 steps
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
     const int y0 = gr * msz;
     const bool has_top = gr > 0;
     const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
-    const int first_lf0 = *a.o.first_lf0;
+    const int first_lf0 = sh.first_lf0;
     // segment parameters packed per segment: int_lim | mb_lim<<8 | b_lim<<16 | hev<<24 (all < 256)
     uint32_t sdp[4];
 #pragma unroll
@@ -424,13 +440,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter2(Args a) {
 
 }  // namespace lf2
 
-__global__ __launch_bounds__(256) void k_first_lf0_v2(MBOut o, const SegData *sd, int mbs) {
-    const int mb = blockIdx.x * 256 + threadIdx.x;
-    if (mb < mbs && sd->v[o.seg[mb] * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0) atomicMin(o.first_lf0, mb);
-}
-
 void launch_loop_filter2(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh) {
+                         int mbw, int mbh, unsigned launch_no) {
     lf2::Args a;
     a.Y = recon.Y[0];
     a.U = recon.U;
@@ -441,9 +452,12 @@ void launch_loop_filter2(hipStream_t s, const Frame &recon, const MBOut &o, cons
     a.mbw = mbw;
     a.mbh = mbh;
     a.nbands = (mbh + 1 + lf2::ROWS - 1) / lf2::ROWS;   // + the virtual flush row
-    hipMemsetAsync(progress, 0, sizeof(int32_t) * (a.nbands + 1), s);
-    hipMemsetAsync(o.first_lf0, 0x7f, 4, s);
-    hipLaunchKernelGGL(k_first_lf0_v2, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, o, d_sd, mbw * mbh);
+    // band counters are never reset: every launch counts inside its own window (wraps after ~2^31/(mbw+2)
+    // launches; the host zeroes the buffer when the window index wraps)
+    const unsigned window = 0x7fffffffu / (unsigned)(mbw + 2) - 1;
+    const unsigned n = launch_no % window;
+    if (n == 0) hipMemsetAsync(progress, 0, sizeof(int32_t) * (a.nbands + 1), s);
+    a.gbase = (int)(n * (unsigned)(mbw + 2));
     hipLaunchKernelGGL(lf2::k_loop_filter2, dim3(a.nbands), dim3(lf2::NWAVES * 64), 0, s, a);
 }
 

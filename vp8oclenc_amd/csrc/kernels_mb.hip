@@ -184,6 +184,8 @@ struct MBArgs {
     const SegData *sd;
     float ssim_target;
     int mbw, mbs;
+    NetSet nets;
+    int use_golden, use_altref;
 };
 
 // LDS per macroblock: current and reconstructed pixels, plane-major (Y 16x16, U 8x8, V 8x8)
@@ -208,8 +210,33 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
     const int bx = blk ? bi % bw : 0, by = blk ? bi / bw : 0;
     const int msz = plane == 0 ? 16 : 8;
     const int posx = mbx * msz + bx * 4, posy = mby * msz + by * 4;
-    const int ref = a.o.ref[mb];
-    const int parts = a.o.parts[mb];
+    // select_reference (GPU_kernels.cl:1205-1283) + pack_8x8_into_16x16 (:1346-1366), per macroblock:
+    // cheapest of the three references by the sum of its four block costs (ties: LAST over ALTREF, then
+    // that over GOLDEN), its four vectors, 16x16 iff they are equal.  Every lane evaluates it (same
+    // addresses across the 32 lanes: one broadcast load each), lane 0 stores the outputs.
+    const int b8w = a.mbw * 2;
+    const int cell0 = (mby * 2) * b8w + mbx * 2;
+    const int cidx[4] = {cell0, cell0 + 1, cell0 + b8w, cell0 + b8w + 1};
+    int diff1 = a.nets.bdiff[0][cidx[0]] + a.nets.bdiff[0][cidx[1]] + a.nets.bdiff[0][cidx[2]] + a.nets.bdiff[0][cidx[3]];
+    int diff2 = 0x7fffffff;
+    if (a.use_altref == 1)
+        diff2 = a.nets.bdiff[2][cidx[0]] + a.nets.bdiff[2][cidx[1]] + a.nets.bdiff[2][cidx[2]] + a.nets.bdiff[2][cidx[3]];
+    int ref = diff1 <= diff2 ? 0 : 2;
+    diff1 = diff1 <= diff2 ? diff1 : diff2;
+    diff2 = 0x7fffffff;
+    if (a.use_golden == 1)
+        diff2 = a.nets.bdiff[1][cidx[0]] + a.nets.bdiff[1][cidx[1]] + a.nets.bdiff[1][cidx[2]] + a.nets.bdiff[1][cidx[3]];
+    ref = diff1 <= diff2 ? ref : 1;
+    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.nets.net[0][0] : (ref == 1 ? a.nets.net[1][0] : a.nets.net[2][0]));
+    uint32_t mbv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mbv[k] = vnet[cidx[k]];
+    const int parts = (mbv[1] == mbv[0] && mbv[2] == mbv[0] && mbv[3] == mbv[0]) ? 0 : 1;
+    if (lane == 0 && live) {
+        a.o.ref[mb] = ref;
+        a.o.parts[mb] = parts;
+        *reinterpret_cast<uint4 *>(a.o.vec + 8 * mb) = make_uint4(mbv[0], mbv[1], mbv[2], mbv[3]);
+    }
     const Plane &cp = plane == 0 ? a.cur.Y[0] : (plane == 1 ? a.cur.U : a.cur.V);
     const Plane &rc = plane == 0 ? a.recon.Y[0] : (plane == 1 ? a.recon.U : a.recon.V);
     const Frame &rfm = ref == 0 ? a.ref[0] : (ref == 1 ? a.ref[1] : a.ref[2]);
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
     if (blk) {
         // prepare_predictors_and_residual, :1285-1344: vector of the block's 8x8 quadrant
         const int quad = plane == 0 ? (by >> 1) * 2 + (bx >> 1) : by * 2 + bx;
-        const uint32_t vv = reinterpret_cast<const uint32_t *>(a.o.vec)[mb * 4 + quad];
+        const uint32_t vv = quad == 0 ? mbv[0] : (quad == 1 ? mbv[1] : (quad == 2 ? mbv[2] : mbv[3]));
         const int vx = (int16_t)(vv & 0xffffu), vy = (int16_t)(vv >> 16);
         const int gsh = plane == 0 ? 2 : 3, gm = plane == 0 ? 3 : 7;
         const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;  // >= 0 for every in-frame vector
@@ -404,8 +431,8 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
     }
 }
 
-void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const Frame &recon, const MBOut &o,
-               const SegData *d_sd, float ssim_target, int mbw, int mbh) {
+void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
+               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
     MBArgs a;
     a.cur = cur;
     for (int r = 0; r < 3; ++r) a.ref[r] = refs.ref[r];
@@ -415,6 +442,9 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const Frame 
     a.ssim_target = ssim_target;
     a.mbw = mbw;
     a.mbs = mbw * mbh;
+    a.nets = nets;
+    a.use_golden = refs.use[1];
+    a.use_altref = refs.use[2];
     hipLaunchKernelGGL(k_mb, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
 }
 

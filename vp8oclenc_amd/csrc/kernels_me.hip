@@ -60,6 +60,99 @@ void launch_downsample(hipStream_t s, const Plane *src, const Plane *dst, int ns
 }
 
 // ------------------------------------------------------------------------------------------------
+// The whole pyramid in one launch (replaces 4 x downsample_x2 per surface, inter_part.h:11-33).
+// A workgroup takes a 64x64 tile of the full-resolution plane and produces the 32x32, 16x16, 8x8 and
+// 4x4 tiles below it; every level is computed from the ROUNDED level above it, exactly like the
+// reference's cascade of launches.  grid = (ceil(W/64), ceil(H/64), surfaces), block = 256.
+// ------------------------------------------------------------------------------------------------
+struct PyrArgs { Frame f[2]; };
+
+__global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
+    __shared__ uint8_t s2[16][16];
+    __shared__ uint8_t s3[8][8];
+    const Frame &f = a.f[blockIdx.z];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const Plane &P0 = f.Y[0];
+    // 4x4 source pixels -> 2x2 of level 1 -> 1 of level 2
+    const int sx = imin(blockIdx.x * 64 + 4 * tx, P0.w - 4), sy0 = blockIdx.y * 64 + 4 * ty;
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = *reinterpret_cast<const uint32_t *>(P0.p + (ptrdiff_t)imin(sy0 + k, P0.h - 1) * P0.stride + sx);
+    int l1[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            l1[j][i] = (byte_of(r[2 * j], 2 * i) + byte_of(r[2 * j], 2 * i + 1) + byte_of(r[2 * j + 1], 2 * i) +
+                        byte_of(r[2 * j + 1], 2 * i + 1) + 2) >> 2;
+    const Plane &P1 = f.Y[1];
+    const int x1 = blockIdx.x * 32 + 2 * tx, y1 = blockIdx.y * 32 + 2 * ty;
+    if (x1 < P1.w) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (y1 + j < P1.h)
+                *reinterpret_cast<uint16_t *>(P1.p + (ptrdiff_t)(y1 + j) * P1.stride + x1) = (uint16_t)(l1[j][0] | (l1[j][1] << 8));
+    }
+    const int l2 = (l1[0][0] + l1[0][1] + l1[1][0] + l1[1][1] + 2) >> 2;
+    const Plane &P2 = f.Y[2];
+    const int x2 = blockIdx.x * 16 + tx, y2 = blockIdx.y * 16 + ty;
+    if (x2 < P2.w && y2 < P2.h) P2.p[(ptrdiff_t)y2 * P2.stride + x2] = (uint8_t)l2;
+    s2[ty][tx] = (uint8_t)l2;
+    __syncthreads();
+    if (t < 64) {
+        const int ux = t & 7, uy = t >> 3;
+        const int l3 = (s2[2 * uy][2 * ux] + s2[2 * uy][2 * ux + 1] + s2[2 * uy + 1][2 * ux] + s2[2 * uy + 1][2 * ux + 1] + 2) >> 2;
+        const Plane &P3 = f.Y[3];
+        const int x3 = blockIdx.x * 8 + ux, y3 = blockIdx.y * 8 + uy;
+        if (x3 < P3.w && y3 < P3.h) P3.p[(ptrdiff_t)y3 * P3.stride + x3] = (uint8_t)l3;
+        s3[uy][ux] = (uint8_t)l3;
+    }
+    __syncthreads();
+    if (t < 16) {
+        const int ux = t & 3, uy = t >> 2;
+        const int l4 = (s3[2 * uy][2 * ux] + s3[2 * uy][2 * ux + 1] + s3[2 * uy + 1][2 * ux] + s3[2 * uy + 1][2 * ux + 1] + 2) >> 2;
+        const Plane &P4 = f.Y[4];
+        const int x4 = blockIdx.x * 4 + ux, y4 = blockIdx.y * 4 + uy;
+        if (x4 < P4.w && y4 < P4.h) P4.p[(ptrdiff_t)y4 * P4.stride + x4] = (uint8_t)l4;
+    }
+}
+
+void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b) {
+    PyrArgs p;
+    p.f[0] = *a;
+    p.f[1] = b ? *b : *a;
+    hipLaunchKernelGGL(k_pyramid, dim3((a->Y[0].w + 63) / 64, (a->Y[0].h + 63) / 64, b ? 2 : 1), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch (8 bytes per thread).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(Plane py, Plane pu, Plane pv, const uint8_t *sy, const uint8_t *su,
+                                              const uint8_t *sv) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    const int ny = (py.w >> 3) * py.h, nc = (pu.w >> 3) * pu.h;
+    const Plane *pl = &py;
+    const uint8_t *src = sy;
+    if (i >= ny) {
+        i -= ny;
+        pl = &pu;
+        src = su;
+        if (i >= nc) { i -= nc; pl = &pv; src = sv; }
+        if (i >= nc) return;
+    }
+    const int upr = pl->w >> 3;     // 8-byte units per row
+    const int y = i / upr, x = (i % upr) * 8;
+    *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
+}
+
+void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
+    const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
+    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, f.Y[0], f.U, f.V, (const uint8_t *)y,
+                       (const uint8_t *)u, (const uint8_t *)v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // reset_vectors, GPU_kernels.cl:404-427
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reset_nets(NetSet n, int b8) {
@@ -101,6 +194,7 @@ struct Search1Args {
     int16_t *dst[3];
     int refmap[3];
     int net_width, w, h, pixel_rate, rate_shift, nblk, bw;
+    int pbw, pbh;   // block grid of the coarser level (whose cells of src[] were written this frame)
 };
 
 __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
@@ -110,8 +204,12 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
     if (b >= a.nblk) return;
     const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
     // parent cell of the coarser level (:495-500); vector / pixel_rate truncates toward zero
+    // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
+    // coarser level's block grid are read but never written; reading them as 0 here is the same thing
+    // without the extra kernel.
     const int parent = (cy >> 4) * a.net_width + (cx >> 4);
-    const uint32_t pv = reinterpret_cast<const uint32_t *>(a.src[r])[parent];
+    const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
+    const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
     int v0x = (int16_t)(pv & 0xffffu), v0y = (int16_t)(pv >> 16);
     const int rmask = a.pixel_rate - 1;
     v0x = (v0x + ((v0x >> 31) & rmask)) >> a.rate_shift;
@@ -175,6 +273,8 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.rate_shift = level;
     a.bw = a.w / 8;
     a.nblk = (a.w / 8) * (a.h / 8);
+    a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
+    a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
     if (a.nblk <= 0 || n == 0) return;
     hipLaunchKernelGGL(k_search1, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
 }

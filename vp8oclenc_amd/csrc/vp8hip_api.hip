@@ -49,6 +49,7 @@ struct vp8hip_ctx {
     SegData *h_sd_ring = nullptr;   // pinned staging for vp8hip_set_segments
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
+    unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
     void *scratch = nullptr;        // device staging for debug pyramid downloads
 
     uint32_t prof_mask = 0;
@@ -151,6 +152,10 @@ int copy_out(vp8hip_ctx *c, void *dst, const Plane &src) {
 
 int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
     Timed t(c, VP8HIP_K_PACK);
+    if (kind == hipMemcpyDeviceToDevice) {
+        launch_pack(c->stream, f, y, u, v);
+        return VP8HIP_OK;
+    }
     int rc;
     if ((rc = copy_in(c, f.Y[0], y, kind))) return rc;
     if ((rc = copy_in(c, f.U, u, kind))) return rc;
@@ -158,13 +163,9 @@ int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, cons
 }
 
 void build_pyramid(vp8hip_ctx *c, Frame *a, Frame *b) {
-    // cascade: every level from the rounded previous level (inter_part.h:11-33)
-    for (int l = 1; l < 5; ++l) {
-        Timed t(c, VP8HIP_K_DOWNSAMPLE);
-        Plane src[2] = {a->Y[l - 1], b ? b->Y[l - 1] : a->Y[l - 1]};
-        Plane dst[2] = {a->Y[l], b ? b->Y[l] : a->Y[l]};
-        launch_downsample(c->stream, src, dst, b ? 2 : 1);
-    }
+    // cascade: every level from the rounded previous level (inter_part.h:11-33), one launch
+    Timed t(c, VP8HIP_K_DOWNSAMPLE);
+    launch_pyramid(c->stream, a, b);
 }
 
 int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
@@ -339,11 +340,7 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         c->recon = pick_free_frame(c);
         if (c->recon < 0) return VP8HIP_ERR_STATE;
     }
-    // prepare_GPU_buffers, inter_part.h:1-33
-    {
-        Timed t(c, VP8HIP_K_DOWNSAMPLE);
-        launch_reset_nets(s, c->nets, c->b8);
-    }
+    // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
     FrameSurf &last = c->frames[c->slot[0]];
     if (!last.pyramid_valid && !c->cur_pyramid_valid) {
         build_pyramid(c, &c->cur, &last.f);
@@ -372,12 +369,8 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         launch_search2(s, c->cur, refs, c->nets);
     }
     {
-        Timed t(c, VP8HIP_K_SELECT);
-        launch_select(s, c->nets, c->out, c->mbw, c->mbh, use_golden ? 1 : 0, use_altref ? 1 : 0);
-    }
-    {
-        Timed t(c, VP8HIP_K_MB);
-        launch_mb(s, c->cur, refs, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
+        Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
+        launch_mb(s, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
@@ -451,7 +444,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
         static const bool use_v1 = getenv("VP8HIP_LF_V1") != nullptr;  // A/B switch for measurements only
         if (use_v1) launch_loop_filter(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
-        else launch_loop_filter2(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
+        else launch_loop_filter2(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++);
     }
     {
         Timed t(c, VP8HIP_K_BORDER);
