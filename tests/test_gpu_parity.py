@@ -208,6 +208,30 @@ def test_host_modified_mb_data_and_recon():
     ora.close()
 
 
+def test_block_match_metric_device_vs_oracle():
+    """weight_opt (GPU_kernels.cl:85-190): the packed-16-bit / dot2 device form against the restatement on
+    200k random difference blocks of every amplitude, plus the extreme blocks that bound its int16 ranges."""
+    import ctypes as C
+    hip = api.Vp8Hip(16, 16)
+    rng = np.random.default_rng(11)
+    blocks = [rng.integers(-a, a + 1, size=(40000, 16)) for a in (1, 4, 32, 128, 255)]
+    ext = []
+    for s0 in (-255, 255):
+        for pat in range(64):      # sign patterns over rows/columns drive every butterfly to its extreme
+            rows = [(1 if (pat >> r) & 1 else -1) for r in range(4)]
+            cols = [(1 if (pat >> (4 + c % 2)) & 1 else -1) for c in range(4)]
+            ext.append([s0 * rows[r] * cols[c] for r in range(4) for c in range(4)])
+    d = np.ascontiguousarray(np.concatenate(blocks + [np.array(ext)]), np.int32)
+    out = np.zeros(len(d), np.int32)
+    rc = hip.lib.vp8hip_debug_weight(hip.h, C.c_void_p(d.ctypes.data), len(d), C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    lib = Oracle.lib()
+    exp = np.array([lib.vp8o_weight(row) for row in d], np.int32)
+    bad = np.nonzero(out != exp)[0]
+    assert bad.size == 0, (bad[:5], d[bad[:2]], out[bad[:5]], exp[bad[:5]])
+    hip.close()
+
+
 def test_device_resident_inputs_match_host_upload():
     """vp8hip_set_current_device / vp8hip_set_last_device (planes already in HBM, what bench.py uses)."""
     import torch

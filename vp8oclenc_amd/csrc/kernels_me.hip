@@ -197,16 +197,23 @@ struct Search1Args {
     int pbw, pbh;   // block grid of the coarser level (whose cells of src[] were written this frame)
 };
 
+// Mapping: five lanes per 8x8 block, lane j = candidate row dy = j-2; the lane loads its eight
+// 12-byte reference rows once and walks the five dx candidates over them in registers (the window
+// bytes are shared by the five candidates of a row).  12 blocks per wave (60 of 64 lanes busy).
+constexpr int S1_BLOCKS_PER_WAVE = 12;
+constexpr int S1_BLOCKS_PER_WG = 4 * S1_BLOCKS_PER_WAVE;
+
 __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
     const int r = a.refmap[blockIdx.y];
-    const int cand = threadIdx.x & 31;
-    const int b = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (b >= a.nblk) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / 5, j = lane - 5 * grp;
+    const int b_raw = (blockIdx.x * 4 + wave) * S1_BLOCKS_PER_WAVE + grp;
+    const bool live = grp < S1_BLOCKS_PER_WAVE && b_raw < a.nblk;
+    const int b = live ? b_raw : a.nblk - 1;
     const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
-    // parent cell of the coarser level (:495-500); vector / pixel_rate truncates toward zero
     // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
     // coarser level's block grid are read but never written; reading them as 0 here is the same thing
-    // without the extra kernel.
+    // without the extra kernel.  vector / pixel_rate truncates toward zero (:495-500).
     const int parent = (cy >> 4) * a.net_width + (cx >> 4);
     const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
     const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
@@ -216,31 +223,61 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
     v0y = (v0y + ((v0y >> 31) & rmask)) >> a.rate_shift;
     if (a.pixel_rate > 8) v0x = v0y = 0;
 
-    const int ox = cand % 5 - 2, oy = cand / 5 - 2;
-    const int px = (int16_t)(cx + v0x + ox), py = (int16_t)(cy + v0y + oy);
-    const bool valid = cand < 25 && px >= 0 && px <= a.w - 8 && py >= 0 && py <= a.h - 8;
-    const int lx = valid ? px : cx, ly = valid ? py : cy;  // masked lanes read the block itself
+    const int py = (int16_t)(cy + v0y + (j - 2));
+    const bool row_valid = live && py >= 0 && py <= a.h - 8;
+    const int xb = cx + v0x - 2;                       // x of candidate dx = -2
+    // rows that cannot hold a valid candidate are read at a harmless in-frame position
+    const bool loadable = row_valid && xb >= -8 && xb <= a.w - 4;
+    const int lx = loadable ? xb : cx, ly = loadable ? py : cy;
 
     const uint8_t *cp = a.cur.p + (ptrdiff_t)cy * a.cur.stride + cx;
     const uint8_t *rp = a.ref[r].p + (ptrdiff_t)ly * a.ref[r].stride + lx;
-    uint32_t c_lo[8], c_hi[8], r_lo[8], r_hi[8];
+    // One 4x4 sub-block at a time (loop NOT unrolled): 4 current dwords + 4 x 8 reference bytes feed
+    // the five dx candidates, whose costs accumulate in acc[].  Measured on MI355X
+    // (scripts/ubench/valu_rates.hip): one wave issues a VALU instruction every ~5.5 cycles whatever
+    // the instruction, and throughput scales linearly to >= 4 waves per SIMD -- so the register
+    // footprint (waves per SIMD), not the instruction mix, decides the speed of this kernel.
+    int acc[5] = {0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int sb = 0; sb < 4; ++sb) {
+        const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
+        uint32_t c[4], q0[4], q1[4];
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        const uint2 c = *reinterpret_cast<const uint2 *>(cp + (ptrdiff_t)y * a.cur.stride);
-        const uint2 q = ld_u64(rp + (ptrdiff_t)y * a.ref[r].stride);
-        c_lo[y] = c.x; c_hi[y] = c.y; r_lo[y] = q.x; r_hi[y] = q.y;
+        for (int y = 0; y < 4; ++y) {
+            c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)(sy + y) * a.cur.stride + sx);
+            const uint2 q = ld_u64(rp + (ptrdiff_t)(sy + y) * a.ref[r].stride + sx);
+            q0[y] = q.x; q1[y] = q.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            uint32_t p[4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) p[y] = i == 0 ? q0[y] : (i == 4 ? q1[y] : __builtin_amdgcn_alignbyte(q1[y], q0[y], i));
+            acc[i] += weight_quads(c, p);
+        }
     }
-    int diff = weight_quads(c_lo, r_lo) + weight_quads(c_lo + 4, r_lo + 4) + weight_quads(c_hi, r_hi) +
-               weight_quads(c_hi + 4, r_hi + 4);
-    // :542-543 (sic): |displacement| minus the signed parent vector, only on the two finest levels
-    const int pen = (iabs(iabs(px - cx) - v0x) + iabs(iabs(py - cy) - v0y)) * (a.pixel_rate < 4 ? 32 : 0);
-    diff = (diff + pen) & 0xffff;  // ushort accumulator
-    uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)cand : 0xffffffffu;
-    key = halfwave_min(key);
-    if (cand == 0) {
+    const int pen_scale = a.pixel_rate < 4 ? 32 : 0;
+    const int pen_y = iabs(iabs(py - cy) - v0y);
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int px = (int16_t)(xb + i);
+        const bool valid = loadable && px >= 0 && px <= a.w - 8;
+        // :542-543 (sic): |displacement| minus the signed parent vector, only on the two finest levels
+        const int diff = (acc[i] + (iabs(iabs(px - cx) - v0x) + pen_y) * pen_scale) & 0xffff;   // ushort accumulator
+        const uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)(j * 5 + i) : 0xffffffffu;
+        best = key < best ? key : best;
+    }
+    // minimum over the five lanes of the block: (cost << 8 | dxy) = the reference's first strict minimum
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl((int)best, lane + off, 64);
+        if (j + off < 5 && o < best) best = o;
+    }
+    if (j == 0 && live) {
         int bx, by;  // best position minus block position
-        if (key != 0xffffffffu) {
-            const int k = key & 0xff;
+        if (best != 0xffffffffu) {
+            const int k = best & 0xff;
             bx = v0x + (k % 5 - 2);
             by = v0y + (k / 5 - 2);
         } else {  // nothing accepted: "vector" still holds the scaled parent, :501,:551-556
@@ -276,7 +313,7 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
     a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
     if (a.nblk <= 0 || n == 0) return;
-    hipLaunchKernelGGL(k_search1, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_search1, dim3((a.nblk + S1_BLOCKS_PER_WG - 1) / S1_BLOCKS_PER_WG, n), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,6 +524,19 @@ __global__ __launch_bounds__(256) void k_select(NetSet n, MBOut o, int mbw, int 
     o.ref[mb] = ref;
     *reinterpret_cast<uint4 *>(o.vec + 8 * mb) = make_uint4(v[0], v[1], v[2], v[3]);
     o.parts[mb] = (v[1] == v[0] && v[2] == v[0] && v[3] == v[0]) ? 0 : 1;
+}
+
+// test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)
+__global__ __launch_bounds__(256) void k_weight_tap(const int32_t *d, int n, int32_t *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = d[i * 16 + k];
+    out[i] = weight4x4(v);
+}
+void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out) {
+    hipLaunchKernelGGL(k_weight_tap, dim3((n + 255) / 256), dim3(256), 0, s, d, n, out);
 }
 
 void launch_select(hipStream_t s, const NetSet &nets, const MBOut &o, int mbw, int mbh, int use_golden, int use_altref) {

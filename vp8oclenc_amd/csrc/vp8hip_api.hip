@@ -554,6 +554,21 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
 
 // test tap (not in the public header): re-run the quarter-pel search of one reference and return, for
 // block `block`, 26 x {8 rows x 8 predicted pixels, cost, valid} as 26 x 18 dwords
+// test tap (not in the public header): weight_opt of n caller-supplied 4x4 difference blocks
+int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
+    if (!c || !d || !out || n <= 0) return VP8HIP_ERR_ARG;
+    int32_t *dd = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&dd, (size_t)n * 64));
+    HIPCHK(c, hipMalloc(&dout, (size_t)n * 4));
+    HIPCHK(c, hipMemcpyAsync(dd, d, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+    launch_weight_tap(c->stream, dd, n, dout);
+    HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(dd);
+    hipFree(dout);
+    return VP8HIP_OK;
+}
+
 int vp8hip_debug_search2_block(vp8hip_ctx *c, int ref, int block, void *out) {
     if (!c || !out || ref < 0 || ref > 2 || c->slot[ref] < 0) return VP8HIP_ERR_ARG;
     RefSet refs;

@@ -59,6 +59,7 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
                     int src_idx, int net_width);
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
                     int dbg_block = -1);
+void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_select(hipStream_t s, const NetSet &nets, const MBOut &o, int mbw, int mbh, int use_golden,
                    int use_altref);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
@@ -92,31 +93,69 @@ __device__ __forceinline__ uint2 ld_u64(const uint8_t *p) {     // byte-aligned 
 // The block-match metric (src/GPU_kernels.cl:85-190, weight_opt): sum of |coefficients| of a 4x4
 // forward transform of the difference block, DC/4.  Column pass keeps the reference's quirk (its b1
 // is overwritten; rows 1 and 3 use the raw r2).  d = 4 rows x 4 columns, row-major.
+// The two rotations x*2217 + y*5352 + k and y*2217 - x*5352 + k are one v_dot2_i32_i16 each on the
+// packed pair (x,y): every operand fits int16 (|x|,|y| <= 16320 in the row pass, <= 4080 in the
+// column pass for 8-bit pixel differences).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+__device__ __forceinline__ int dot2(uint32_t xy, uint32_t k, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, xy), __builtin_bit_cast(s16x2, k), c, false);
+}
+constexpr uint32_t K_ROT_A = 2217u | (5352u << 16);              // (x, y) . ( 2217, 5352)
+constexpr uint32_t K_ROT_B = (uint32_t)(-5352 & 0xffff) | (2217u << 16);  // (x, y) . (-5352, 2217)
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// sum of |lo| + |hi| of a packed pair of int16, added to acc: one xor + one v_sad_u16
+__device__ __forceinline__ uint32_t abs_acc(s16x2 v, uint32_t acc) {
+    return __builtin_amdgcn_sad_u16(as_u32(v) ^ 0x80008000u, 0x80008000u, acc);
+}
+
+// Column pass in 32-bit, row pass on PAIRS of rows in packed 16-bit (v_pk_*): every intermediate fits
+// int16 for 8-bit pixel differences (|R| <= 8160, |a1|,|b1| <= 16320, |a1 +- b1 + 7| <= 32647), so
+// the arithmetic is the same integers as the 32-bit form.  The kernels that use this are bound by
+// VALU issue (measured), so fewer instructions per 4x4 block is the whole game.
 __device__ __forceinline__ int weight4x4(const int d[16]) {
-    int R[16];
+    s16x2 A[4], B[4];   // A[c] = (R0[c], R1[c]) = rows 0,1 of the column-pass output, B[c] = rows 2,3
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int r0 = d[c], r1 = d[4 + c], r2 = d[8 + c], r3 = d[12 + c];
-        const int a = (r0 + r3) * 8;
-        const int dd = (r0 - r3) * 8;
-        const int cc = (r1 - r2) * 8;
-        R[c] = a + cc;
-        R[8 + c] = a - cc;
-        R[4 + c] = (r2 * 2217 + dd * 5352 + 14500) >> 12;
-        R[12 + c] = (dd * 2217 - r2 * 5352 + 7500) >> 12;
+        const int s03 = r0 + r3, d12 = r1 - r2;
+        const int R0 = (s03 + d12) * 8;        // a + c1 with a = (r0+r3)<<3, c1 = (r1-r2)<<3
+        const int R2 = (s03 - d12) * 8;
+        const uint32_t xy = pk16(r2, (r0 - r3) * 8);   // (raw r2, d): the reference's quirk
+        const int R1 = dot2(xy, K_ROT_A, 14500) >> 12;
+        const int R3 = dot2(xy, K_ROT_B, 7500) >> 12;
+        A[c] = as_s16x2(pk16(R0, R1));
+        B[c] = as_s16x2(pk16(R2, R3));
     }
-    int sum = 0;
+    uint32_t acc = 0;
+    int o00 = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e0 = R[4 * i], e1 = R[4 * i + 1], e2 = R[4 * i + 2], e3 = R[4 * i + 3];
-        const int a1 = e0 + e3, d1 = e0 - e3, b1 = e1 + e2, c1 = e1 - e2;
-        const int o0 = (a1 + b1 + 7) >> 4;
-        const int o2 = (a1 - b1 + 7) >> 4;
-        const int o1 = ((c1 * 2217 + d1 * 5352 + 12000) >> 16) + (d1 != 0);
-        const int o3 = (d1 * 2217 - c1 * 5352 + 51000) >> 16;
-        sum += (i == 0 ? (iabs(o0) >> 2) : iabs(o0)) + iabs(o1) + iabs(o2) + iabs(o3);
+    for (int h = 0; h < 2; ++h) {
+        const s16x2 *X = h == 0 ? A : B;
+        const s16x2 a1 = X[0] + X[3], d1 = X[0] - X[3], b1 = X[1] + X[2], c1 = X[1] - X[2];
+        const s16x2 a7 = a1 + s16x2{7, 7};
+        const s16x2 o0 = (a7 + b1) >> s16x2{4, 4};
+        const s16x2 o2 = (a7 - b1) >> s16x2{4, 4};
+        const uint32_t xy_lo = __builtin_amdgcn_perm(as_u32(d1), as_u32(c1), 0x05040100u);   // (c1, d1) of the first row
+        const uint32_t xy_hi = __builtin_amdgcn_perm(as_u32(d1), as_u32(c1), 0x07060302u);   // ... of the second row
+        const int t1l = dot2(xy_lo, K_ROT_A, 12000), t1h = dot2(xy_hi, K_ROT_A, 12000);
+        const int t3l = dot2(xy_lo, K_ROT_B, 51000), t3h = dot2(xy_hi, K_ROT_B, 51000);
+        // (x >> 16) of both rows = the high halves, packed
+        s16x2 o1 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1h, (uint32_t)t1l, 0x07060302u));
+        const s16x2 o3 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3h, (uint32_t)t3l, 0x07060302u));
+        const u16x2 nz = __builtin_bit_cast(u16x2, d1 | (s16x2{0, 0} - d1)) >> u16x2{15, 15};   // d1 != 0
+        o1 = o1 + __builtin_bit_cast(s16x2, nz);
+        acc = abs_acc(o0, acc);
+        acc = abs_acc(o1, acc);
+        acc = abs_acc(o2, acc);
+        acc = abs_acc(o3, acc);
+        if (h == 0) o00 = o0.x;
     }
-    return sum;
+    const int a00 = iabs(o00);
+    return (int)acc - (a00 - (a00 >> 2));   // DC counts a quarter (DC_UNSIGNIFICANCE, :83,:183)
 }
 
 // weight of the 4x4 block whose rows are the byte quads c[r] (current) and p[r] (candidate)
