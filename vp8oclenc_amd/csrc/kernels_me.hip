@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_search2(Search2Args a) {
     }
 }
 
-void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
+void launch_search2_v1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
     Search2Args a;
     a.cur = cur.Y[0];
     int n = 0;

@@ -1,0 +1,271 @@
+// kernels_s2.hip -- quarter-pel refinement (luma_search_2step, src/GPU_kernels.cl:1094-1203) on dot4.
+//
+// The search kernels are VALU-issue bound on gfx950 (scripts/ubench/valu_rates.hip), so this version is
+// built around instruction count.  Pixels are kept as signed bytes (p-128) so that both six-tap passes run
+// on v_dot4_i32_i8: sum(p*f) = sum((p-128)*f) + 128*128 because every tap set sums to 128.
+//   * 32 lanes per 8x8 block (2 blocks per wave, 8 per workgroup), one reference per blockIdx.y.
+//   * The 14x20-byte window around the 1x winner is staged in LDS once (biased).
+//   * Horizontal pass: 28 lanes = (4 fractional x cases) x (7 row pairs); 8 columns x 2 rows each, 2.25
+//     dot4 per sample (the taps are pre-shifted into the 4 possible byte alignments, K_H6), the saturated
+//     pair goes to LDS TRANSPOSED (column-major, 16 B per column) with one ds_write_b16.  The whole-pel x
+//     case is a transposing byte copy done by all 32 lanes.
+//   * Vertical pass: lane k = candidate (dx,dy); a column is one ds_read_b128 and the six taps run down its
+//     bytes: 2.5 dot4 per sample with 7-tap pre-shifted constants (K_V7; the 7th slot absorbs the one-row
+//     offset between dy<0 and dy>=0), v_ashr_pk_u8_i32 saturates two samples at a time.
+//   * The current block and the zero-MV block are transposed through LDS so the metric sees columns too.
+// Results are bit-identical to the first version (kernels_me.hip, launch_search2_v1; VP8HIP_S2_V1=1 selects it
+// for A/B timing).
+#include <stdlib.h>
+
+#include "vp8hip_dev.h"
+
+namespace vp8 {
+
+void launch_search2_v1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg,
+                       int dbg_block);
+
+namespace {
+
+constexpr uint32_t pk8(int a, int b, int c, int d) {
+    return (uint32_t)(a & 255) | ((uint32_t)(b & 255) << 8) | ((uint32_t)(c & 255) << 16) | ((uint32_t)(d & 255) << 24);
+}
+// six taps placed at byte offset s = 0..3 of a dword stream: entries [2s], [2s+1] and, for s = 3, [8]
+#define H6(f0, f1, f2, f3, f4, f5)                                                                               \
+    {pk8(f0, f1, f2, f3), pk8(f4, f5, 0, 0), pk8(0, f0, f1, f2), pk8(f3, f4, f5, 0), pk8(0, 0, f0, f1),           \
+     pk8(f2, f3, f4, f5), pk8(0, 0, 0, f0),  pk8(f1, f2, f3, f4), pk8(f5, 0, 0, 0),  0, 0, 0}
+// seven taps at byte offset s: s=0 -> [0],[1]; s=1 -> [2],[3]; s=2 -> [4],[5],[6]; s=3 -> [7],[8],[9]
+#define V7(t0, t1, t2, t3, t4, t5, t6)                                                                           \
+    {pk8(t0, t1, t2, t3), pk8(t4, t5, t6, 0), pk8(0, t0, t1, t2), pk8(t3, t4, t5, t6), pk8(0, 0, t0, t1),         \
+     pk8(t2, t3, t4, t5), pk8(t6, 0, 0, 0),   pk8(0, 0, 0, t0),   pk8(t1, t2, t3, t4), pk8(t5, t6, 0, 0), 0, 0}
+
+// x case 0..4 = dx -2..2 quarter pels: phases 4,6,(0),2,4 of the 1/8-pel table (GPU_kernels.cl:563-572)
+static __device__ __constant__ const uint32_t K_H6[5][12] = {
+    H6(3, -16, 77, 77, -16, 3), H6(1, -8, 36, 108, -11, 2), H6(0, 0, 0, 0, 0, 0), H6(2, -11, 108, 36, -8, 1),
+    H6(3, -16, 77, 77, -16, 3)};
+// y case 0..4; dy < 0 starts one row higher (leading six taps), dy > 0 one row lower (trailing six)
+static __device__ __constant__ const uint32_t K_V7[5][12] = {
+    V7(3, -16, 77, 77, -16, 3, 0), V7(1, -8, 36, 108, -11, 2, 0), V7(0, 0, 0, 0, 0, 0, 0),
+    V7(0, 2, -11, 108, 36, -8, 1), V7(0, 3, -16, 77, 77, -16, 3)};
+
+constexpr int HT_XC = 36;            // dwords per x case in the transposed H array: 8 columns x 16 B + 16 B bank skew
+constexpr int KBIAS = 128 * 128 + 64;  // undo the -128 pixel bias (taps sum to 128) + rounding
+
+struct S2Args {
+    Plane cur;
+    Plane ref[3];
+    const int16_t *net_in[3];
+    int16_t *net_out[3];
+    int32_t *bdiff[3];
+    int refmap[3];
+    int w, h, nblk, bw;
+    uint32_t *dbg;   // test tap: per-candidate prediction (column-major) and cost of block dbg_block, or nullptr
+    int dbg_block;
+};
+
+__device__ __forceinline__ uint32_t halfwave_min(uint32_t key) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)key, m, 32);
+        key = o < key ? o : key;
+    }
+    return key;
+}
+
+// sat_u8(a >> 7) in byte 0, sat_u8(b >> 7) in byte 1 (v_ashr_pk_u8_i32).  The builtin, not inline asm: a
+// VALU read of a dot4 result needs wait states on gfx950 that the compiler only inserts for instructions it
+// can see (an asm version read stale sums), and as a 16-bit value the undefined bits 31:16 stay explicit.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short ashr7_pk_u8(int a, int b) { return __builtin_amdgcn_ashr_pk_u8_i32(a, b, 7); }
+__device__ __forceinline__ uint32_t pack4(unsigned short lo, unsigned short hi) {
+    const us2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+
+// weight of the 4x4 block whose COLUMNS are the byte quads c[k] (current) and p[k] (candidate)
+__device__ __forceinline__ int weight_cols(const uint32_t c[4], const uint32_t p[4]) {
+    int d[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[4 * r + k] = byte_of(c[k], r) - byte_of(p[k], r);
+    return weight4x4(d);
+}
+
+__global__ __launch_bounds__(256) void k_search2(S2Args a) {
+    __shared__ uint32_t s_win[8][72];
+    __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
+    __shared__ uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half]
+    const int r = a.refmap[blockIdx.y];
+    const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int b = imin(blockIdx.x * 8 + g, a.nblk - 1);
+    const bool live = blockIdx.x * 8 + g < a.nblk;
+    const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
+    const uint32_t nv = reinterpret_cast<const uint32_t *>(a.net_in[r])[b];
+    const int nx = (int16_t)(nv & 0xffffu), ny = (int16_t)(nv >> 16);
+    const int v0x = (int16_t)(nx * 4), v0y = (int16_t)(ny * 4);
+    // window origin; a garbage vector (possible only when every candidate is out of frame) is clamped
+    // so that the loads stay inside the allocated margin
+    const int Lx = iclamp(cx + nx, 3 - EXT, a.w + EXT - 11), Ly = iclamp(cy + ny, 3 - EXT, a.h + EXT - 11);
+    const Plane rf = a.ref[r];
+    const int ax = (Lx - 3) & ~3, o = (Lx - 3) & 3;
+    for (int idx = lane; idx < 70; idx += 32) {
+        const int row = idx / 5, j = idx % 5;
+        s_win[g][idx] =
+            *reinterpret_cast<const uint32_t *>(rf.p + (ptrdiff_t)(Ly - 3 + row) * rf.stride + ax + 4 * j) ^ 0x80808080u;
+    }
+    {   // current block (lanes 0-15) and zero-MV block (16-31): one dword each, scattered as column bytes
+        const int sel = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+        const uint8_t *base = sel ? rf.p : a.cur.p;
+        const int stride = sel ? rf.stride : a.cur.stride;
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)(cy + row) * stride + cx + 4 * half);
+        uint8_t *cz = reinterpret_cast<uint8_t *>(s_cz[g]) + sel * 64 + half * 32 + row;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cz[j * 8] = (uint8_t)(v >> (8 * j));
+    }
+    __syncthreads();
+
+    // ---- horizontal pass -------------------------------------------------------------------------
+    if (lane < 28) {
+        const int xi = lane / 7, rp = lane - xi * 7;
+        const int xc = xi + (xi >> 1);           // 0, 1, 3, 4
+        const int s0 = o + (xc >= 2);           // byte of the row holding tap 0 of column 0: o + xo + 1
+        const int j0 = s0 >> 2, sh = s0 & 3;
+        uint32_t t[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t[i] = K_H6[xc][i];
+        int sum[2][8];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint32_t *wr = &s_win[g][(2 * rp + rr) * 5 + j0];
+            uint32_t w[5], q[4];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) w[j] = wr[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int m = c >> 2, s = c & 3;
+                int acc = dot4(q[m], t[2 * s], KBIAS);
+                acc = dot4(q[m + 1], t[2 * s + 1], acc);
+                if (s == 3) acc = dot4(q[m + 2], t[8], acc);
+                sum[rr][c] = acc;
+            }
+        }
+        uint16_t *ht = reinterpret_cast<uint16_t *>(s_HT[g] + xc * HT_XC) + rp;   // byte c*16 + 2*rp
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ht[c * 8] = ashr7_pk_u8(sum[0][c], sum[1][c]) ^ 0x8080u;
+    }
+    {   // whole-pel x case: column c of the window, rows 4*rg..4*rg+3 (rows 14,15 only ever meet zero taps)
+        const int c = lane & 7, rg = lane >> 3;
+        const uint8_t *wb = reinterpret_cast<const uint8_t *>(s_win[g]) + o + 3 + c;
+        uint32_t v = 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * 20] << (8 * rr);
+        s_HT[g][2 * HT_XC + c * 4 + rg] = v;
+    }
+    __syncthreads();
+
+    // ---- vertical pass + cost ----------------------------------------------------------------------
+    const int k = lane;
+    const int dx = k % 5 - 2, dy = k / 5 - 2;
+    int qx = (int16_t)(cx * 4 + v0x + dx), qy = (int16_t)(cy * 4 + v0y + dy);
+    if (k == 25) { qx = cx * 4; qy = cy * 4; }
+    const bool valid = live && k < 26 && qx >= 0 && qx <= a.w * 4 - 32 && qy >= 0 && qy <= a.h * 4 - 32;
+    uint32_t P[8][2];
+    if (k < 25) {
+        const int xc = k % 5, yc = k / 5;
+        uint32_t t[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) t[i] = K_V7[yc][i];
+        const uint4 *H = reinterpret_cast<const uint4 *>(s_HT[g] + xc * HT_XC);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 hv = H[c];
+            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w};
+            int s[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = i >> 2, si = i & 3;
+                const int tb = si == 0 ? 0 : (si == 1 ? 2 : (si == 2 ? 4 : 7));
+                int acc = dot4(h[m], t[tb], KBIAS);
+                acc = dot4(h[m + 1], t[tb + 1], acc);
+                if (si >= 2) acc = dot4(h[m + 2], t[tb + 2], acc);
+                s[i] = acc;
+            }
+            P[c][0] = pack4(ashr7_pk_u8(s[0], s[1]), ashr7_pk_u8(s[2], s[3]));
+            P[c][1] = pack4(ashr7_pk_u8(s[4], s[5]), ashr7_pk_u8(s[6], s[7]));
+            if (yc == 2) {   // whole-pel dy: rows 3..10 of the column, un-biased
+                P[c][0] = __builtin_amdgcn_alignbyte(h[1], h[0], 3) ^ 0x80808080u;
+                P[c][1] = __builtin_amdgcn_alignbyte(h[2], h[1], 3) ^ 0x80808080u;
+            }
+        }
+    } else {  // zero MV: whole-pel, both passes are the identity
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { P[c][0] = s_cz[g][16 + 2 * c]; P[c][1] = s_cz[g][17 + 2 * c]; }
+    }
+    int diff = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            uint32_t cc[4], pp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cc[j] = s_cz[g][(4 * n + j) * 2 + m]; pp[j] = P[4 * n + j][m]; }
+            diff += weight_cols(cc, pp);
+        }
+    if (k < 25) diff += (iabs(dx) + iabs(dy)) * 32;  // :1176-1178
+    if (a.dbg && live && b == a.dbg_block) {
+        if (k < 26) {
+            uint32_t *d = a.dbg + k * 18;
+            for (int c = 0; c < 8; ++c) { d[2 * c] = P[c][0]; d[2 * c + 1] = P[c][1]; }
+            d[16] = (uint32_t)diff;
+            d[17] = valid;
+        }
+        for (int i = lane; i < 5 * HT_XC; i += 32) a.dbg[468 + i] = s_HT[g][i];
+        for (int i = lane; i < 72; i += 32) a.dbg[648 + i] = s_win[g][i];
+        if (lane == 0) { a.dbg[730] = (uint32_t)Lx; a.dbg[731] = (uint32_t)Ly; a.dbg[732] = (uint32_t)o; }
+    }
+    uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
+    key = halfwave_min(key);
+    if (lane == 0 && live) {
+        int bqx = (int16_t)(a.w * 4 - 32), bqy = (int16_t)(a.h * 4 - 32), md = 0x7fff;  // :1136-1137
+        if (key != 0xffffffffu) {
+            const int kk = key & 0xff;
+            md = (int)(key >> 8);
+            bqx = kk == 25 ? cx * 4 : (int16_t)(cx * 4 + v0x + (kk % 5 - 2));
+            bqy = kk == 25 ? cy * 4 : (int16_t)(cy * 4 + v0y + (kk / 5 - 2));
+        }
+        const int vx = (int16_t)(bqx - cx * 4), vy = (int16_t)(bqy - cy * 4);
+        if ((vx != 0) | (vy != 0)) md -= (iabs(vx - v0x) + iabs(vy - v0y)) * 32;  // :1195-1197
+        reinterpret_cast<uint32_t *>(a.net_out[r])[b] = (uint32_t)(uint16_t)vx | ((uint32_t)(uint16_t)vy << 16);
+        a.bdiff[r][b] = md;
+    }
+}
+
+}  // namespace
+
+void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
+    static const bool use_v1 = getenv("VP8HIP_S2_V1") != nullptr;   // A/B switch for measurements only
+    if (use_v1) return launch_search2_v1(s, cur, refs, nets, dbg, dbg_block);
+    S2Args a;
+    a.cur = cur.Y[0];
+    int n = 0;
+    for (int r = 0; r < 3; ++r) {
+        a.ref[r] = refs.ref[r].Y[0];
+        a.net_in[r] = nets.net[r][1];   // vnet2 holds the 1x result, init.h:832-854
+        a.net_out[r] = nets.net[r][0];
+        a.bdiff[r] = nets.bdiff[r];
+        if (refs.use[r]) a.refmap[n++] = r;
+    }
+    for (int i = n; i < 3; ++i) a.refmap[i] = 0;
+    a.w = a.cur.w;
+    a.h = a.cur.h;
+    a.bw = a.w / 8;
+    a.nblk = a.w * a.h / 64;
+    a.dbg = dbg;
+    a.dbg_block = dbg_block;
+    hipLaunchKernelGGL(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
+}
+
+}  // namespace vp8
