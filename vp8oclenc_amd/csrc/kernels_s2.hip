@@ -81,6 +81,9 @@ __device__ __forceinline__ uint32_t pack4(unsigned short lo, unsigned short hi) 
     return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+// first link of a chain: the clamp bit (int32 saturation, never reached) selects the three-address VOP3P
+// form with the bias in an SGPR instead of v_mov + v_dot4c
+__device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
 
 // weight of the 4x4 block whose COLUMNS are the byte quads c[k] (current) and p[k] (candidate)
 __device__ __forceinline__ int weight_cols(const uint32_t c[4], const uint32_t p[4]) {
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int m = c >> 2, s = c & 3;
-                int acc = dot4(q[m], t[2 * s], KBIAS);
+                int acc = dot4k(q[m], t[2 * s], KBIAS);
                 acc = dot4(q[m + 1], t[2 * s + 1], acc);
                 if (s == 3) acc = dot4(q[m + 2], t[8], acc);
                 sum[rr][c] = acc;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
             for (int i = 0; i < 8; ++i) {
                 const int m = i >> 2, si = i & 3;
                 const int tb = si == 0 ? 0 : (si == 1 ? 2 : (si == 2 ? 4 : 7));
-                int acc = dot4(h[m], t[tb], KBIAS);
+                int acc = dot4k(h[m], t[tb], KBIAS);
                 acc = dot4(h[m + 1], t[tb + 1], acc);
                 if (si >= 2) acc = dot4(h[m + 2], t[tb + 2], acc);
                 s[i] = acc;

@@ -99,7 +99,9 @@ __device__ __forceinline__ uint2 ld_u64(const uint8_t *p) {     // byte-aligned 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 __device__ __forceinline__ int dot2(uint32_t xy, uint32_t k, int c) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, xy), __builtin_bit_cast(s16x2, k), c, false);
+    // clamp (int32 saturation, never reached here) selects the three-address VOP3P form that takes the
+    // rounding constant straight from an SGPR; without it hipcc emits v_dot2c + a v_mov per use
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, xy), __builtin_bit_cast(s16x2, k), c, true);
 }
 constexpr uint32_t K_ROT_A = 2217u | (5352u << 16);              // (x, y) . ( 2217, 5352)
 constexpr uint32_t K_ROT_B = (uint32_t)(-5352 & 0xffff) | (2217u << 16);  // (x, y) . (-5352, 2217)
