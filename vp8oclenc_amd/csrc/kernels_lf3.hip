@@ -1,0 +1,462 @@
+// kernels_lf3.hip -- VP8 normal loop filter, banded wavefront in LDS, one-step row lag (gfx950).
+//
+// Same arithmetic and ordering semantics as loop_filter_frame_luma/_chroma (CPU_kernels.cl:970-1075,
+// :1333-1439; edge filters :829-926).  The filter is a chain of dependent edge filters: MB(x,y) needs
+// MB(x-1,y) complete and, for its horizontal edges only, the vertical MB edge of MB(x+1,y-1).  A single wave
+// issues one VALU instruction every ~5.5 cycles no matter what (scripts/ubench/valu_rates.hip), so the frame
+// time is (steps on the critical path) x (instructions per step); both are what this version cuts:
+//
+//   * Each macroblock step has two phases: P1 = vertical edges (lane = pixel row, registers), P2 = horizontal
+//     edges (lane = pixel column, through an LDS tile).  P2 of MB(x,y) needs only P1 of MB(x+1,y-1), so row y
+//     runs ONE macroblock behind row y-1 (x = S - r at step S) with a hand-off in the middle of the step:
+//     mb_w + mb_h steps per frame instead of mb_w + 2*mb_h.
+//   * A workgroup owns a band of ROWS MB rows; a wave runs two rows (32 lanes each: 0-15 luma, 16-23 U,
+//     24-31 V), so every second hand-off is inside a wave and costs nothing.
+//   * Branch-free edge filters: edges that do not apply (frame border, chroma lanes, skipped inner edges,
+//     the level-0 exit) run with their mask forced off instead of being jumped over, which removes the
+//     divergent control flow (and its register shuffling) from the instruction stream.
+//   * Samples carry +256 in registers: |a-b| is one v_sad_u16 even when an unsaturated carry (reference
+//     quirk, :1024/:1062) dips below zero, and the saturated byte is just the low byte of a clamp.
+//   * Bottom strips of each row live in an LDS ring; finished 16x16 blocks (shifted by (-4,-4)) are drained
+//     to HBM by a writer wave; the strip between bands goes through the frame (sc1) with a loader and a
+//     publisher wave, so workers never issue or wait for a global store.
+//   * One LDS poll per step (middle of the step) covers every dependency.
+#include "vp8hip_dev.h"
+
+namespace vp8 {
+
+namespace lf3 {
+
+constexpr int WORKERS = 4;             // worker waves per band (one per SIMD)
+constexpr int ROWS = 2 * WORKERS;      // MB rows per band
+constexpr int RING_MB = 16;            // strip ring length in macroblocks
+constexpr int RWY = RING_MB * 16, RWC = RING_MB * 8;   // ring widths in pixels
+constexpr int STRIP_BYTES = 4 * RWY + 2 * 4 * RWC;     // Y, U, V bottom strips of one MB row
+constexpr int TILE_YS = 24, TILE_CS = 12;              // work-tile row strides
+constexpr int TILE_BYTES = 16 * TILE_YS + 2 * 8 * TILE_CS;
+constexpr int TILE_SLOTS = 8;          // steps a finished tile stays in LDS for the writer wave
+constexpr int BIAS = 256;
+
+enum { F_TOP = WORKERS, F_PUB, F_WR, F_COUNT };   // flag[0..WORKERS-1] = 2*step + phase of each worker
+
+__device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_sad_u16((uint32_t)a, (uint32_t)b, 0u); }
+__device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return imax(imax(a, b), c); }
+struct EdgeRegs { int p3, p2, p1, p0, q0, q1, q2, q3; };
+struct Limits { int int_lim, mb_lim2, b_lim2, hev_thr; };   // *_lim2 = 2*limit + 1, see edge_masks
+
+// 2|p0-q0| + (|p1-q1| >> 1) <= L  <=>  |p1-q1| + 4|p0-q0| <= 2L + 1
+__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_lim2, int hev_thr, bool en,
+                                           bool &mask, bool &hev) {
+    const int d10 = ad(e.p1, e.p0), dq10 = ad(e.q1, e.q0);
+    const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
+    const int m2 = max3i(dq10, ad(e.q2, e.q1), ad(e.q3, e.q2));
+    const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)(ad(e.p0, e.q0) << 2));
+    mask = en & (m1 <= int_lim) & (m2 <= int_lim) & (edge <= edge_lim2);
+    hev = imax(d10, dq10) > hev_thr;
+}
+__device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, bool en) {  // :829-883
+    bool mask, hev;
+    edge_masks(e, L.int_lim, L.mb_lim2, L.hev_thr, en, mask, hev);
+    int w = c128(e.p1 - e.q1);
+    w = c128(w + (e.q0 - e.p0) * 3);
+    w = mask ? w : 0;
+    int a = hev ? w : 0;
+    const int b = imin(a + 3, 127) >> 3;
+    a = imin(a + 4, 127) >> 3;
+    e.q0 -= a; e.p0 += b;
+    w = hev ? 0 : w;
+    a = (w * 27 + 63) >> 7; e.q0 -= a; e.p0 += a;
+    a = (w * 18 + 63) >> 7; e.q1 -= a; e.p1 += a;
+    a = (w * 9 + 63) >> 7;  e.q2 -= a; e.p2 += a;
+}
+__device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, bool en) {  // :885-926
+    bool mask, hev;
+    edge_masks(e, L.int_lim, L.b_lim2, L.hev_thr, en, mask, hev);
+    int a = c128(e.p1 - e.q1);
+    a = hev ? a : 0;
+    a = c128(a + (e.q0 - e.p0) * 3);
+    a = mask ? a : 0;
+    const int b = imin(a + 3, 127) >> 3;
+    a = imin(a + 4, 127) >> 3;
+    e.q0 -= a; e.p0 += b;
+    a = (a + 1) >> 1;
+    a = hev ? 0 : a;
+    e.q1 -= a; e.p1 += a;
+}
+
+// One line of biased samples t[0..19] (t[0..3] precede the macroblock edge) through the MB edge and the three
+// inner edges, each under its enable.  t[] receives the UNSATURATED results (the reference saturates when it
+// stores); the p/q registers handed from edge to edge stay unsaturated too (:1024, :1062).
+__device__ __forceinline__ void filter_line(int (&t)[20], const Limits &L, bool en_mb, bool en4, bool en8, bool en12) {
+    EdgeRegs e;
+    e.p3 = t[0]; e.p2 = t[1]; e.p1 = t[2]; e.p0 = t[3];
+    e.q0 = t[4]; e.q1 = t[5]; e.q2 = t[6]; e.q3 = t[7];
+    filter_mb_edge(e, L, en_mb);
+    t[1] = e.p2; t[2] = e.p1; t[3] = e.p0;
+    t[4] = e.q0; t[5] = e.q1; t[6] = e.q2;
+#pragma unroll
+    for (int k = 4; k < 16; k += 4) {
+        e.p3 = e.q0; e.p2 = e.q1; e.p1 = e.q2; e.p0 = e.q3;
+        e.q0 = t[4 + k]; e.q1 = t[5 + k]; e.q2 = t[6 + k]; e.q3 = t[7 + k];
+        filter_b_edge(e, L, k == 4 ? en4 : (k == 8 ? en8 : en12));
+        t[2 + k] = e.p1; t[3 + k] = e.p0; t[4 + k] = e.q0; t[5 + k] = e.q1;
+    }
+}
+
+// biased sample -> biased saturated sample; its low byte is the pixel (BIAS = 256)
+__device__ __forceinline__ int satb(int v) { return iclamp(v, BIAS, BIAS + 255); }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)satb(b), (uint32_t)satb(a), 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)satb(d), (uint32_t)satb(c), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+__device__ __forceinline__ int ub(uint32_t w, int k) { return byte_of(w, k) | BIAS; }
+
+__device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct Args {
+    Plane Y, U, V;
+    MBOut o;
+    const SegData *sd;
+    int32_t *gprog;   // [bands] gbase + macroblocks of the band's bottom strip published so far
+    int gbase;        // counters only grow: launch n uses the range (n*(mbw+2), (n+1)*(mbw+2)], so no memset
+    int mbw, mbh, nbands;
+};
+
+struct Shared {
+    uint8_t strip[ROWS + 1][STRIP_BYTES];         // strip[r] = bottom rows of the MB row ABOVE local row r
+    uint8_t tile[ROWS][TILE_SLOTS][TILE_BYTES];   // work tiles, one slot per step in flight (writer drains)
+    volatile int flag[8];                         // worker progress, F_TOP, F_PUB, F_WR
+    int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
+};
+
+constexpr int NWAVES = WORKERS + 3;         // workers + loader + publisher + writer
+
+__global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
+    __shared__ __attribute__((aligned(16))) Shared sh;
+    const int band = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 8) sh.flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
+    __syncthreads();
+    const int mbw = a.mbw, mbh = a.mbh;
+    const int band_row0 = band * ROWS;
+    {
+        // CPU_kernels.cl:990: a macroblock whose segment has level 0 ends the plane.  Levels are >= 1 for
+        // every quantizer the host produces, so the scan over segment ids runs only if one IS zero.
+        const int32_t *sdv = a.sd->v;
+        const bool any0 = sdv[SD_LOOP_FILTER_LEVEL] == 0 || sdv[SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 ||
+                          sdv[2 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 || sdv[3 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0;
+        if (any0) {
+            int first = 0x7fffffff;
+            for (int mb = threadIdx.x; mb < mbw * mbh; mb += NWAVES * 64)
+                if (sdv[a.o.seg[mb] * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0) { first = mb; break; }
+            if (first != 0x7fffffff) atomicMin(&sh.first_lf0, first);
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // publisher wave: bottom strip of the band's last row (strip[ROWS]) -> the frame (sc1, write-
+    // through) -> HBM counter.  Keeps the store drain (s_waitcnt vmcnt(0)) off the workers' path.
+    // ---------------------------------------------------------------------------------------------
+    if (wave == WORKERS + 1) {
+        if (band + 1 >= a.nbands) return;
+        // lane < 44: one dword of 4 rows x (5 + 3 + 3) dwords = columns x0-4 .. x0+msz-1 of Y, U, V
+        const int pl = lane < 20 ? 0 : (lane < 32 ? 1 : 2);
+        const int k = pl == 0 ? lane : (pl == 1 ? lane - 20 : lane - 32);
+        const int ndw = pl == 0 ? 5 : 3;
+        const int rr = k / ndw, j = k % ndw;
+        const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
+        const int msz = pl == 0 ? 16 : 8, rw = pl == 0 ? RWY : RWC;
+        const int y = (band_row0 + ROWS - 1) * msz + (msz - 4) + rr;
+        const uint8_t *sp = sh.strip[ROWS] + (pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC)) + rr * rw;
+        for (int x = 0; x <= mbw; ++x) {
+            const int done = 2 * (x + ROWS - 1) + 2;   // the last row has finished macroblock x
+            while (sh.flag[WORKERS - 1] < done) __builtin_amdgcn_s_sleep(1);
+            if (lane < 44) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & (rw - 1)));
+                st_sc1(reinterpret_cast<uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz - 4) + j, v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                sh.flag[F_PUB] = x + 1;
+                __hip_atomic_store(&a.gprog[band], a.gbase + x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // loader wave: previous band's bottom strip (in the frame, written with sc1) -> strip[0]
+    // ---------------------------------------------------------------------------------------------
+    if (wave == WORKERS) {
+        if (band == 0) return;
+        const int l = lane & 31;
+        // lane l < 32: one dword of the 4 x (16 + 8 + 8) pixels above macroblock x
+        const int pl = l < 16 ? 0 : (l < 24 ? 1 : 2);
+        const int k = pl == 0 ? l : (pl == 1 ? l - 16 : l - 24);     // dword index inside the plane's 4 rows
+        const int nd = pl == 0 ? 4 : 2;                               // dwords per row
+        const int r = k / nd, j = k % nd;
+        const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
+        const int msz = pl == 0 ? 16 : 8, rw = pl == 0 ? RWY : RWC;
+        const int y = band_row0 * msz - 4 + r;
+        uint8_t *sp = sh.strip[0] + (pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC)) + r * rw;
+        for (int x = 0; x < mbw; ++x) {
+            // columns x0+13..15 are final once the previous band's last row has run P1 of macroblock x+1
+            const int need = imin(x + 2, mbw + 1);
+            while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need)
+                __builtin_amdgcn_s_sleep(2);
+            // ring space: the slot still holds macroblock x-RING_MB, whose last four columns the writer reads
+            // together with macroblock x-RING_MB+1 (row 0: step == macroblock)
+            while (sh.flag[F_WR] < x - (RING_MB - 2)) __builtin_amdgcn_s_sleep(1);
+            if (lane < 32) {
+                const uint32_t v = ld_sc1(reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz) + j);
+                *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & (rw - 1))) = v;
+            }
+            lds_fence();
+            if (lane == 0) sh.flag[F_TOP] = x + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // writer wave: after every step, the blocks that became final -- 16x16 (8x8) shifted by (-4,-4):
+    // four pixel rows from the strip above + msz-4 rows of the row's tile slot -- go LDS -> HBM.
+    // ---------------------------------------------------------------------------------------------
+    if (wave == WORKERS + 2) {
+        const int half = lane >> 5, l32 = lane & 31;
+        const int pl = l32 < 16 ? 0 : (l32 < 24 ? 1 : 2);
+        const int li = pl == 0 ? l32 : (pl == 1 ? l32 - 16 : l32 - 24);
+        const int msz = pl == 0 ? 16 : 8, nd = msz / 4;
+        const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
+        const int rw = pl == 0 ? RWY : RWC;
+        const int tstride = pl == 0 ? TILE_YS : TILE_CS;
+        const int strip_off = pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC);
+        const int tile_off = pl == 0 ? 0 : (pl == 1 ? 16 * TILE_YS : 16 * TILE_YS + 8 * TILE_CS);
+        const int steps = mbw + ROWS;
+        for (int S = 0; S < steps; ++S) {
+            for (int w = 0; w < WORKERS; ++w)
+                while (sh.flag[w] < 2 * S + 2) __builtin_amdgcn_s_sleep(1);
+            for (int rp = 0; rp < ROWS; rp += 2) {
+                const int r = rp + half, gr = band_row0 + r;
+                const int x = S - r;
+                const bool row_real = gr < mbh;
+                if (gr > mbh || x < 0 || x > mbw) continue;
+                const int x0 = x * msz, yy = gr * msz - 4 + li;
+                const bool from_top = li < 4;
+                if (!(from_top ? gr > 0 : row_real) || yy < 0) continue;
+                const uint8_t *top = sh.strip[r] + strip_off;
+                const uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)] + tile_off;
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nd)
+                        v[j] = from_top ? *reinterpret_cast<const uint32_t *>(top + li * rw + ((x0 - 4 + 4 * j) & (rw - 1)))
+                                        : reinterpret_cast<const uint32_t *>(tile + (li - 4) * tstride)[j];
+                uint8_t *g = P.p + (ptrdiff_t)yy * P.stride + x0 - 4;
+                if (from_top && r == 0 && band > 0) {
+                    // these four pixel rows share cache lines with the previous band's strip hand-off:
+                    // every access to them inside this launch is sc1
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < nd) st_sc1(reinterpret_cast<uint32_t *>(g) + j, v[j]);
+                } else if (pl == 0) {
+                    __builtin_memcpy(g, v, 16);
+                } else {
+                    __builtin_memcpy(g, v, 8);
+                }
+            }
+            lds_fence();   // our LDS reads of this step are complete before the slot is released
+            if (lane == 0) sh.flag[F_WR] = S + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // worker waves
+    // ---------------------------------------------------------------------------------------------
+    const int half = lane >> 5, l32 = lane & 31;
+    const int r = 2 * wave + half;              // local MB row
+    const int gr = band_row0 + r;               // global MB row (gr == mbh: virtual row that only flushes)
+    const bool row_real = gr < mbh, row_any = gr <= mbh;
+    const int pl = l32 < 16 ? 0 : (l32 < 24 ? 1 : 2);
+    const int li = pl == 0 ? l32 : (pl == 1 ? l32 - 16 : l32 - 24);
+    const int msz = pl == 0 ? 16 : 8, nd = msz / 4;
+    const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
+    const int rw = pl == 0 ? RWY : RWC;
+    const int tstride = pl == 0 ? TILE_YS : TILE_CS;
+    const int strip_off = pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC);
+    const int tile_off = pl == 0 ? 0 : (pl == 1 ? 16 * TILE_YS : 16 * TILE_YS + 8 * TILE_CS);
+    uint8_t *top = sh.strip[r] + strip_off;         // 4 rows x rw: bottom of the row above
+    uint8_t *bot = sh.strip[r + 1] + strip_off;     // 4 rows x rw: our own bottom rows
+    const int y0 = gr * msz;
+    const bool has_top = gr > 0;
+    const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
+    const int first_lf0 = sh.first_lf0;
+    // segment parameters packed per segment: int_lim | mb_lim<<8 | b_lim<<16 | hev<<24 (all < 256)
+    uint32_t sdp[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int32_t *sd = a.sd->v + s * SD_INTS;
+        sdp[s] = (uint32_t)(sd[SD_INTERIOR_LIMIT] & 0xff) | ((uint32_t)(sd[SD_MBEDGE_LIMIT] & 0xff) << 8) |
+                 ((uint32_t)(sd[SD_SUB_BEDGE_LIMIT] & 0xff) << 16) | ((uint32_t)(sd[SD_HEV_THRESHOLD] & 0xff) << 24);
+    }
+
+    // prefetch of macroblock 0
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    int nxt_seg = 0, nxt_mask = 0;
+    if (row_real) {
+        const uint8_t *g = P.p + (ptrdiff_t)(y0 + li) * P.stride;
+        if (pl == 0) nxt = *reinterpret_cast<const uint4 *>(g);
+        else { const uint2 t2 = *reinterpret_cast<const uint2 *>(g); nxt.x = t2.x; nxt.y = t2.y; }
+        nxt_seg = a.o.seg[gr * mbw];
+        nxt_mask = a.o.mask[gr * mbw];
+    }
+    uint32_t left4 = 0;
+    const int steps = mbw + ROWS;
+#ifdef LF_STAMPS
+    unsigned long long st_p1 = 0, st_wait = 0, st_p2 = 0, st_wb = 0, st_t0, st_t1;
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#else
+#define STAMP(v)
+#endif
+    for (int S = 0; S < steps; ++S) {
+        STAMP(st_t0);
+        uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)] + tile_off;
+        const int x = S - r;
+        const bool act = row_any && x >= 0 && x <= mbw;
+        const bool mbstep = act && row_real && x < mbw;    // a real macroblock (else: flush column / flush row)
+        const int x0 = x * msz;
+        const uint4 own = nxt;
+        const int seg = nxt_seg, maskv = nxt_mask;
+        if (mbstep && x + 1 < mbw) {   // prefetch the next macroblock of this row
+            const uint8_t *g = P.p + (ptrdiff_t)(y0 + li) * P.stride + x0 + msz;
+            if (pl == 0) nxt = *reinterpret_cast<const uint4 *>(g);
+            else { const uint2 t2 = *reinterpret_cast<const uint2 *>(g); nxt.x = t2.x; nxt.y = t2.y; }
+            nxt_seg = a.o.seg[gr * mbw + x + 1];
+            nxt_mask = a.o.mask[gr * mbw + x + 1];
+        }
+        const uint32_t sp = seg == 0 ? sdp[0] : (seg == 1 ? sdp[1] : (seg == 2 ? sdp[2] : sdp[3]));
+        Limits L;
+        L.int_lim = sp & 0xff;
+        L.mb_lim2 = ((sp >> 8) & 0xff) * 2 + 1;
+        L.b_lim2 = ((sp >> 16) & 0xff) * 2 + 1;
+        L.hev_thr = sp >> 24;
+        const bool do_filter = mbstep && (gr * mbw + x) < first_lf0;
+        const bool en_in = do_filter && maskv != 0;
+        const bool en8 = en_in && pl == 0;
+        uint32_t *trow = reinterpret_cast<uint32_t *>(tile + li * tstride);
+        // ---- P1: vertical edges, lane = pixel row, in registers ---------------------------------
+        if (mbstep) {
+            int t[20];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = ub(left4, k);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
+            filter_line(t, L, do_filter && x > 0, en_in, en8, en8);
+            const uint32_t d0 = pack4(t[0], t[1], t[2], t[3]);
+            trow[0] = d0;
+#pragma unroll
+            for (int j = 1; j < 5; ++j)
+                if (j <= nd) trow[j] = pack4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+            // the row below reads columns x0-4..x0-1 of our bottom rows in P2 of this very step
+            if (li >= msz - 4) *reinterpret_cast<uint32_t *>(bot + (li - (msz - 4)) * rw + ((x0 - 4) & (rw - 1))) = d0;
+        } else if (act && row_real) {
+            trow[0] = left4;   // flush column: only the carried four columns are meaningful
+        }
+        lds_fence();
+        if (lane == 0) sh.flag[wave] = 2 * S + 1;
+        STAMP(st_t1);
+#ifdef LF_STAMPS
+        st_p1 += st_t1 - st_t0; st_t0 = st_t1;
+#endif
+        // ---- the one poll of the step ------------------------------------------------------------
+        {
+            const int need_up = 2 * S + 1;                       // P1 of the rows above (their macroblock x+1)
+            const int need_wr = S + 1 - (TILE_SLOTS - 1);         // tile slot of the NEXT step has been drained
+            const int x_r0 = S - 2 * wave;                        // macroblock of this wave's first row
+            const bool top_dep = wave == 0 && band > 0 && x_r0 >= 0 && x_r0 <= mbw && band_row0 <= mbh;
+            const int need_top = imin(x_r0 + 1, mbw);
+            // last wave: the publisher must have drained what the second row is about to overwrite in strip[ROWS]
+            const int need_pub = (wave + 1 == WORKERS && publishes) ? S - (ROWS - 1) - (RING_MB - 2) : 0;
+            for (;;) {
+                const int f_up = wave > 0 ? sh.flag[wave - 1] : need_up;
+                const int f_wr = sh.flag[F_WR];
+                const int f_top = top_dep ? sh.flag[F_TOP] : need_top;
+                const int f_pub = sh.flag[F_PUB];
+                if (f_up >= need_up && f_wr >= need_wr && f_top >= need_top && f_pub >= need_pub) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        STAMP(st_t1);
+#ifdef LF_STAMPS
+        st_wait += st_t1 - st_t0; st_t0 = st_t1;
+#endif
+        // ---- P2: horizontal edges, lane = pixel column ---------------------------------------------
+        if (mbstep) {
+            int t[20];
+            const int rc = (x0 + li) & (rw - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = (int)top[k * rw + rc] | BIAS;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[4 + k] = k < msz ? ((int)tile[k * tstride + 4 + li] | BIAS) : BIAS;
+            filter_line(t, L, do_filter && has_top, en_in, en8, en8);
+            if (has_top) {
+                top[1 * rw + rc] = (uint8_t)satb(t[1]); top[2 * rw + rc] = (uint8_t)satb(t[2]); top[3 * rw + rc] = (uint8_t)satb(t[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < msz) {
+                    const uint8_t v = (uint8_t)satb(t[4 + k]);
+                    tile[k * tstride + 4 + li] = v;
+                    if (k >= msz - 4) bot[(k - (msz - 4)) * rw + rc] = v;   // our bottom rows -> strip of the row below
+                }
+            left4 = trow[nd];   // columns msz-4 .. msz-1 of this macroblock after both phases (next P1's left side)
+        }
+        lds_fence();
+        if (lane == 0) sh.flag[wave] = 2 * S + 2;
+        STAMP(st_t1);
+#ifdef LF_STAMPS
+        st_p2 += st_t1 - st_t0;
+#endif
+    }
+#ifdef LF_STAMPS
+    if (lane == 0 && band < 4) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.gprog + 1024) + (band * WORKERS + wave) * 4;
+        o[0] = st_wait; o[1] = st_p1; o[2] = st_p2; o[3] = st_wb;
+    }
+#endif
+}
+
+}  // namespace lf3
+
+void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh, unsigned launch_no) {
+    lf3::Args a;
+    a.Y = recon.Y[0];
+    a.U = recon.U;
+    a.V = recon.V;
+    a.o = o;
+    a.sd = d_sd;
+    a.gprog = progress;
+    a.mbw = mbw;
+    a.mbh = mbh;
+    a.nbands = (mbh + 1 + lf3::ROWS - 1) / lf3::ROWS;   // + the virtual flush row
+    // band counters are never reset: every launch counts inside its own window (wraps after ~2^31/(mbw+2)
+    // launches; the host zeroes the buffer when the window index wraps)
+    const unsigned window = 0x7fffffffu / (unsigned)(mbw + 2) - 1;
+    const unsigned n = launch_no % window;
+    if (n == 0) hipMemsetAsync(progress, 0, sizeof(int32_t) * (a.nbands + 1), s);
+    a.gbase = (int)(n * (unsigned)(mbw + 2));
+    hipLaunchKernelGGL(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
+}
+
+}  // namespace vp8

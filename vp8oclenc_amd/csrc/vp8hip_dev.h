@@ -68,7 +68,9 @@ void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int 
 void launch_loop_filter(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
                         int mbw, int mbh);   // first version: one wave per MB row, hand-off through HBM (kept for A/B)
 void launch_loop_filter2(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no);  // banded wavefront in LDS (the one the library uses)
+                         int mbw, int mbh, unsigned launch_no);  // banded wavefront in LDS, two-step row lag (A/B)
+void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh, unsigned launch_no);  // one-step row lag, branch-free filters (the one used)
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
