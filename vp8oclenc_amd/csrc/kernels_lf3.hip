@@ -30,10 +30,14 @@ namespace lf3 {
 constexpr int WORKERS = 4;             // worker waves per band (one per SIMD)
 constexpr int ROWS = 2 * WORKERS;      // MB rows per band
 constexpr int RING_MB = 16;            // strip ring length in macroblocks
-constexpr int RWY = RING_MB * 16, RWC = RING_MB * 8;   // ring widths in pixels
-constexpr int STRIP_BYTES = 4 * RWY + 2 * 4 * RWC;     // Y, U, V bottom strips of one MB row
-constexpr int TILE_YS = 24, TILE_CS = 12;              // work-tile row strides
-constexpr int TILE_BYTES = 16 * TILE_YS + 2 * 8 * TILE_CS;
+// One layout for all three planes (chroma simply uses half of it), so that every LDS access of the worker
+// loop is base + immediate offset and nothing in it depends on the plane of the lane:
+constexpr int SROW = RING_MB * 16;                     // strip row stride; ring width = RING_MB * msz pixels
+constexpr int STRIP_PLANE = 4 * SROW;                  // four pixel rows per plane
+constexpr int STRIP_BYTES = 3 * STRIP_PLANE;           // Y, U, V bottom strips of one MB row
+constexpr int TILE_S = 24;                             // work-tile row stride: 4 carried columns + 16 + pad
+constexpr int TILE_PLANE = 16 * TILE_S;
+constexpr int TILE_BYTES = 3 * TILE_PLANE;
 constexpr int TILE_SLOTS = 8;          // steps a finished tile stays in LDS for the writer wave
 constexpr int BIAS = 256;
 
@@ -43,21 +47,21 @@ __device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_s
 __device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return imax(imax(a, b), c); }
 struct EdgeRegs { int p3, p2, p1, p0, q0, q1, q2, q3; };
-struct Limits { int int_lim, mb_lim2, b_lim2, hev_thr; };   // *_lim2 = 2*limit + 1, see edge_masks
+struct Limits { int mb_lim2, b_lim2, hev_thr; };   // *_lim2 = 2*limit + 1, see edge_masks
 
 // 2|p0-q0| + (|p1-q1| >> 1) <= L  <=>  |p1-q1| + 4|p0-q0| <= 2L + 1
-__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_lim2, int hev_thr, bool en,
-                                           bool &mask, bool &hev) {
+__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_lim2, int hev_thr, bool &mask,
+                                           bool &hev) {
     const int d10 = ad(e.p1, e.p0), dq10 = ad(e.q1, e.q0);
     const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
     const int m2 = max3i(dq10, ad(e.q2, e.q1), ad(e.q3, e.q2));
     const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)(ad(e.p0, e.q0) << 2));
-    mask = en & (m1 <= int_lim) & (m2 <= int_lim) & (edge <= edge_lim2);
+    mask = (imax(m1, m2) <= int_lim) & (edge <= edge_lim2);   // int_lim == -1: edge switched off
     hev = imax(d10, dq10) > hev_thr;
 }
-__device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, bool en) {  // :829-883
+__device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, int int_lim) {  // :829-883
     bool mask, hev;
-    edge_masks(e, L.int_lim, L.mb_lim2, L.hev_thr, en, mask, hev);
+    edge_masks(e, int_lim, L.mb_lim2, L.hev_thr, mask, hev);
     int w = c128(e.p1 - e.q1);
     w = c128(w + (e.q0 - e.p0) * 3);
     w = mask ? w : 0;
@@ -70,9 +74,9 @@ __device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, boo
     a = (w * 18 + 63) >> 7; e.q1 -= a; e.p1 += a;
     a = (w * 9 + 63) >> 7;  e.q2 -= a; e.p2 += a;
 }
-__device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, bool en) {  // :885-926
+__device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, int int_lim) {  // :885-926
     bool mask, hev;
-    edge_masks(e, L.int_lim, L.b_lim2, L.hev_thr, en, mask, hev);
+    edge_masks(e, int_lim, L.b_lim2, L.hev_thr, mask, hev);
     int a = c128(e.p1 - e.q1);
     a = hev ? a : 0;
     a = c128(a + (e.q0 - e.p0) * 3);
@@ -86,20 +90,20 @@ __device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, bool
 }
 
 // One line of biased samples t[0..19] (t[0..3] precede the macroblock edge) through the MB edge and the three
-// inner edges, each under its enable.  t[] receives the UNSATURATED results (the reference saturates when it
+// inner edges, each under its own interior limit (-1 = edge switched off).  t[] receives the UNSATURATED results (the reference saturates when it
 // stores); the p/q registers handed from edge to edge stay unsaturated too (:1024, :1062).
-__device__ __forceinline__ void filter_line(int (&t)[20], const Limits &L, bool en_mb, bool en4, bool en8, bool en12) {
+__device__ __forceinline__ void filter_line(int (&t)[20], const Limits &L, int il_mb, int il4, int il8) {
     EdgeRegs e;
     e.p3 = t[0]; e.p2 = t[1]; e.p1 = t[2]; e.p0 = t[3];
     e.q0 = t[4]; e.q1 = t[5]; e.q2 = t[6]; e.q3 = t[7];
-    filter_mb_edge(e, L, en_mb);
+    filter_mb_edge(e, L, il_mb);
     t[1] = e.p2; t[2] = e.p1; t[3] = e.p0;
     t[4] = e.q0; t[5] = e.q1; t[6] = e.q2;
 #pragma unroll
     for (int k = 4; k < 16; k += 4) {
         e.p3 = e.q0; e.p2 = e.q1; e.p1 = e.q2; e.p0 = e.q3;
         e.q0 = t[4 + k]; e.q1 = t[5 + k]; e.q2 = t[6 + k]; e.q3 = t[7 + k];
-        filter_b_edge(e, L, k == 4 ? en4 : (k == 8 ? en8 : en12));
+        filter_b_edge(e, L, k == 4 ? il4 : il8);
         t[2 + k] = e.p1; t[3 + k] = e.p0; t[4 + k] = e.q0; t[5 + k] = e.q1;
     }
 }
@@ -119,6 +123,7 @@ __device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) {
 __device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+constexpr int WAIT_LGKM0 = 0xc07f;   // s_waitcnt lgkmcnt(0) as the builtin's immediate: the compiler's own waitcnt pass sees it
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 struct Args {
@@ -134,6 +139,7 @@ struct Shared {
     uint8_t strip[ROWS + 1][STRIP_BYTES];         // strip[r] = bottom rows of the MB row ABOVE local row r
     uint8_t tile[ROWS][TILE_SLOTS][TILE_BYTES];   // work tiles, one slot per step in flight (writer drains)
     volatile int flag[8];                         // worker progress, F_TOP, F_PUB, F_WR
+    uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
 };
 
@@ -175,14 +181,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const int ndw = pl == 0 ? 5 : 3;
         const int rr = k / ndw, j = k % ndw;
         const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
-        const int msz = pl == 0 ? 16 : 8, rw = pl == 0 ? RWY : RWC;
+        const int msz = pl == 0 ? 16 : 8, rmask = RING_MB * msz - 1;
         const int y = (band_row0 + ROWS - 1) * msz + (msz - 4) + rr;
-        const uint8_t *sp = sh.strip[ROWS] + (pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC)) + rr * rw;
+        const uint8_t *sp = sh.strip[ROWS] + pl * STRIP_PLANE + rr * SROW;
         for (int x = 0; x <= mbw; ++x) {
             const int done = 2 * (x + ROWS - 1) + 2;   // the last row has finished macroblock x
             while (sh.flag[WORKERS - 1] < done) __builtin_amdgcn_s_sleep(1);
             if (lane < 44) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & (rw - 1)));
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & rmask));
                 st_sc1(reinterpret_cast<uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz - 4) + j, v);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -206,9 +212,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const int nd = pl == 0 ? 4 : 2;                               // dwords per row
         const int r = k / nd, j = k % nd;
         const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
-        const int msz = pl == 0 ? 16 : 8, rw = pl == 0 ? RWY : RWC;
+        const int msz = pl == 0 ? 16 : 8, rmask = RING_MB * msz - 1;
         const int y = band_row0 * msz - 4 + r;
-        uint8_t *sp = sh.strip[0] + (pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC)) + r * rw;
+        uint8_t *sp = sh.strip[0] + pl * STRIP_PLANE + r * SROW;
         for (int x = 0; x < mbw; ++x) {
             // columns x0+13..15 are final once the previous band's last row has run P1 of macroblock x+1
             const int need = imin(x + 2, mbw + 1);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             while (sh.flag[F_WR] < x - (RING_MB - 2)) __builtin_amdgcn_s_sleep(1);
             if (lane < 32) {
                 const uint32_t v = ld_sc1(reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz) + j);
-                *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & (rw - 1))) = v;
+                *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = v;
             }
             lds_fence();
             if (lane == 0) sh.flag[F_TOP] = x + 1;
@@ -237,10 +243,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const int li = pl == 0 ? l32 : (pl == 1 ? l32 - 16 : l32 - 24);
         const int msz = pl == 0 ? 16 : 8, nd = msz / 4;
         const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
-        const int rw = pl == 0 ? RWY : RWC;
-        const int tstride = pl == 0 ? TILE_YS : TILE_CS;
-        const int strip_off = pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC);
-        const int tile_off = pl == 0 ? 0 : (pl == 1 ? 16 * TILE_YS : 16 * TILE_YS + 8 * TILE_CS);
+        const int rmask = RING_MB * msz - 1;
+        const int strip_off = pl * STRIP_PLANE, tile_off = pl * TILE_PLANE;
         const int steps = mbw + ROWS;
         for (int S = 0; S < steps; ++S) {
             for (int w = 0; w < WORKERS; ++w)
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < nd)
-                        v[j] = from_top ? *reinterpret_cast<const uint32_t *>(top + li * rw + ((x0 - 4 + 4 * j) & (rw - 1)))
-                                        : reinterpret_cast<const uint32_t *>(tile + (li - 4) * tstride)[j];
+                        v[j] = from_top ? *reinterpret_cast<const uint32_t *>(top + li * SROW + ((x0 - 4 + 4 * j) & rmask))
+                                        : reinterpret_cast<const uint32_t *>(tile + (li - 4) * TILE_S)[j];
                 uint8_t *g = P.p + (ptrdiff_t)yy * P.stride + x0 - 4;
                 if (from_top && r == 0 && band > 0) {
                     // these four pixel rows share cache lines with the previous band's strip hand-off:
@@ -291,12 +295,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     const int li = pl == 0 ? l32 : (pl == 1 ? l32 - 16 : l32 - 24);
     const int msz = pl == 0 ? 16 : 8, nd = msz / 4;
     const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
-    const int rw = pl == 0 ? RWY : RWC;
-    const int tstride = pl == 0 ? TILE_YS : TILE_CS;
-    const int strip_off = pl == 0 ? 0 : (pl == 1 ? 4 * RWY : 4 * RWY + 4 * RWC);
-    const int tile_off = pl == 0 ? 0 : (pl == 1 ? 16 * TILE_YS : 16 * TILE_YS + 8 * TILE_CS);
-    uint8_t *top = sh.strip[r] + strip_off;         // 4 rows x rw: bottom of the row above
-    uint8_t *bot = sh.strip[r + 1] + strip_off;     // 4 rows x rw: our own bottom rows
+    const int rmask = RING_MB * msz - 1;
+    uint8_t *top = sh.strip[r] + pl * STRIP_PLANE;       // 4 rows: bottom of the row above
+    uint8_t *bot = sh.strip[r + 1] + pl * STRIP_PLANE;   // 4 rows: our own bottom rows
+    // P1 hands columns x0-4..x0-1 of the bottom four pixel rows to the row below; the other lanes aim the
+    // same store at a private dummy word instead of branching around it
+    const bool bottom_lane = li >= msz - 4;
+    uint8_t *botw = bottom_lane ? bot + (li - (msz - 4)) * SROW : reinterpret_cast<uint8_t *>(&sh.dummy[lane]);
+    const int botw_mask = bottom_lane ? rmask : 0;
+    const int tile_lane = pl * TILE_PLANE + li * TILE_S;    // this lane's row of the tile (P1)
+    const int tile_col = pl * TILE_PLANE + 4 + li;          // this lane's column of the tile (P2)
     const int y0 = gr * msz;
     const bool has_top = gr > 0;
     const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 #endif
     for (int S = 0; S < steps; ++S) {
         STAMP(st_t0);
-        uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)] + tile_off;
+        uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)];
         const int x = S - r;
         const bool act = row_any && x >= 0 && x <= mbw;
         const bool mbstep = act && row_real && x < mbw;    // a real macroblock (else: flush column / flush row)
@@ -346,14 +354,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         }
         const uint32_t sp = seg == 0 ? sdp[0] : (seg == 1 ? sdp[1] : (seg == 2 ? sdp[2] : sdp[3]));
         Limits L;
-        L.int_lim = sp & 0xff;
         L.mb_lim2 = ((sp >> 8) & 0xff) * 2 + 1;
         L.b_lim2 = ((sp >> 16) & 0xff) * 2 + 1;
         L.hev_thr = sp >> 24;
+        // an edge that does not apply gets interior limit -1: its mask can never be true
+        const int int_lim = sp & 0xff;
         const bool do_filter = mbstep && (gr * mbw + x) < first_lf0;
         const bool en_in = do_filter && maskv != 0;
-        const bool en8 = en_in && pl == 0;
-        uint32_t *trow = reinterpret_cast<uint32_t *>(tile + li * tstride);
+        const int il4 = en_in ? int_lim : -1;
+        const int il8 = en_in && pl == 0 ? int_lim : -1;
+        uint32_t *trow = reinterpret_cast<uint32_t *>(tile + tile_lane);
         // ---- P1: vertical edges, lane = pixel row, in registers ---------------------------------
         if (mbstep) {
             int t[20];
@@ -361,18 +371,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             for (int k = 0; k < 4; ++k) t[k] = ub(left4, k);
 #pragma unroll
             for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
-            filter_line(t, L, do_filter && x > 0, en_in, en8, en8);
+            filter_line(t, L, do_filter && x > 0 ? int_lim : -1, il4, il8);
             const uint32_t d0 = pack4(t[0], t[1], t[2], t[3]);
             trow[0] = d0;
 #pragma unroll
-            for (int j = 1; j < 5; ++j)
-                if (j <= nd) trow[j] = pack4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+            for (int j = 1; j < 5; ++j) trow[j] = pack4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
             // the row below reads columns x0-4..x0-1 of our bottom rows in P2 of this very step
-            if (li >= msz - 4) *reinterpret_cast<uint32_t *>(bot + (li - (msz - 4)) * rw + ((x0 - 4) & (rw - 1))) = d0;
+            *reinterpret_cast<uint32_t *>(botw + ((x0 - 4) & botw_mask)) = d0;
         } else if (act && row_real) {
             trow[0] = left4;   // flush column: only the carried four columns are meaningful
         }
-        lds_fence();
+        __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
         if (lane == 0) sh.flag[wave] = 2 * S + 1;
         STAMP(st_t1);
 #ifdef LF_STAMPS
@@ -403,25 +412,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         // ---- P2: horizontal edges, lane = pixel column ---------------------------------------------
         if (mbstep) {
             int t[20];
-            const int rc = (x0 + li) & (rw - 1);
+            const int rc = (x0 + li) & rmask;
+            uint8_t *tp = top + rc, *bp = bot + rc, *tc = tile + tile_col;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = (int)top[k * rw + rc] | BIAS;
+            for (int k = 0; k < 4; ++k) t[k] = (int)tp[k * SROW];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[4 + k] = k < msz ? ((int)tile[k * tstride + 4 + li] | BIAS) : BIAS;
-            filter_line(t, L, do_filter && has_top, en_in, en8, en8);
-            if (has_top) {
-                top[1 * rw + rc] = (uint8_t)satb(t[1]); top[2 * rw + rc] = (uint8_t)satb(t[2]); top[3 * rw + rc] = (uint8_t)satb(t[3]);
-            }
+            for (int k = 0; k < 16; ++k) t[4 + k] = (int)tc[k * TILE_S];   // chroma lanes: rows 8-15 are don't-care
+            __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);   // one wait for the twenty loads instead of one per use
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < msz) {
-                    const uint8_t v = (uint8_t)satb(t[4 + k]);
-                    tile[k * tstride + 4 + li] = v;
-                    if (k >= msz - 4) bot[(k - (msz - 4)) * rw + rc] = v;   // our bottom rows -> strip of the row below
-                }
+            for (int k = 0; k < 20; ++k) t[k] |= BIAS;
+            filter_line(t, L, do_filter && has_top ? int_lim : -1, il4, il8);
+            // rows 1-3 of the strip above (row 0 of the frame: a scratch strip nobody reads)
+            tp[1 * SROW] = (uint8_t)satb(t[1]); tp[2 * SROW] = (uint8_t)satb(t[2]); tp[3 * SROW] = (uint8_t)satb(t[3]);
+            int s[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { s[k] = satb(t[4 + k]); tc[k * TILE_S] = (uint8_t)s[k]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bp[j * SROW] = (uint8_t)(pl == 0 ? s[12 + j] : s[4 + j]);   // our bottom rows -> row below
             left4 = trow[nd];   // columns msz-4 .. msz-1 of this macroblock after both phases (next P1's left side)
         }
-        lds_fence();
+        __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
         if (lane == 0) sh.flag[wave] = 2 * S + 2;
         STAMP(st_t1);
 #ifdef LF_STAMPS
