@@ -38,10 +38,10 @@ constexpr int STRIP_BYTES = 3 * STRIP_PLANE;           // Y, U, V bottom strips 
 constexpr int TILE_S = 24;                             // work-tile row stride: 4 carried columns + 16 + pad
 constexpr int TILE_PLANE = 16 * TILE_S;
 constexpr int TILE_BYTES = 3 * TILE_PLANE;
-constexpr int TILE_SLOTS = 8;          // steps a finished tile stays in LDS for the writer wave
+constexpr int TILE_SLOTS = 2;          // a finished tile is drained to HBM at the top of the next step
 constexpr int BIAS = 256;
 
-enum { F_TOP = WORKERS, F_PUB, F_WR, F_COUNT };   // flag[0..WORKERS-1] = 2*step + phase of each worker
+enum { F_TOP = WORKERS, F_PUB, F_COUNT };   // flag[0..WORKERS-1] = 2*step + phase of each worker
 
 __device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_sad_u16((uint32_t)a, (uint32_t)b, 0u); }
 __device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
@@ -137,13 +137,13 @@ struct Args {
 
 struct Shared {
     uint8_t strip[ROWS + 1][STRIP_BYTES];         // strip[r] = bottom rows of the MB row ABOVE local row r
-    uint8_t tile[ROWS][TILE_SLOTS][TILE_BYTES];   // work tiles, one slot per step in flight (writer drains)
-    volatile int flag[8];                         // worker progress, F_TOP, F_PUB, F_WR
+    uint8_t tile[ROWS][TILE_SLOTS][TILE_BYTES];   // work tiles: this step's and the previous one's (being drained)
+    volatile int flag[8];                         // worker progress, F_TOP, F_PUB
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
 };
 
-constexpr int NWAVES = WORKERS + 3;         // workers + loader + publisher + writer
+constexpr int NWAVES = WORKERS + 2;         // workers + loader + publisher
 
 __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
@@ -220,66 +220,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             const int need = imin(x + 2, mbw + 1);
             while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need)
                 __builtin_amdgcn_s_sleep(2);
-            // ring space: the slot still holds macroblock x-RING_MB, whose last four columns the writer reads
-            // together with macroblock x-RING_MB+1 (row 0: step == macroblock)
-            while (sh.flag[F_WR] < x - (RING_MB - 2)) __builtin_amdgcn_s_sleep(1);
+            // ring space: the slot still holds macroblock x-RING_MB, whose last four columns row 0 stores
+            // together with macroblock x-RING_MB+1, at the top of step x-RING_MB+2 (row 0: step == macroblock)
+            while (sh.flag[0] < 2 * (x - (RING_MB - 2)) + 1) __builtin_amdgcn_s_sleep(1);
             if (lane < 32) {
                 const uint32_t v = ld_sc1(reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz) + j);
                 *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = v;
             }
             lds_fence();
             if (lane == 0) sh.flag[F_TOP] = x + 1;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------
-    // writer wave: after every step, the blocks that became final -- 16x16 (8x8) shifted by (-4,-4):
-    // four pixel rows from the strip above + msz-4 rows of the row's tile slot -- go LDS -> HBM.
-    // ---------------------------------------------------------------------------------------------
-    if (wave == WORKERS + 2) {
-        const int half = lane >> 5, l32 = lane & 31;
-        const int pl = l32 < 16 ? 0 : (l32 < 24 ? 1 : 2);
-        const int li = pl == 0 ? l32 : (pl == 1 ? l32 - 16 : l32 - 24);
-        const int msz = pl == 0 ? 16 : 8, nd = msz / 4;
-        const Plane &P = pl == 0 ? a.Y : (pl == 1 ? a.U : a.V);
-        const int rmask = RING_MB * msz - 1;
-        const int strip_off = pl * STRIP_PLANE, tile_off = pl * TILE_PLANE;
-        const int steps = mbw + ROWS;
-        for (int S = 0; S < steps; ++S) {
-            for (int w = 0; w < WORKERS; ++w)
-                while (sh.flag[w] < 2 * S + 2) __builtin_amdgcn_s_sleep(1);
-            for (int rp = 0; rp < ROWS; rp += 2) {
-                const int r = rp + half, gr = band_row0 + r;
-                const int x = S - r;
-                const bool row_real = gr < mbh;
-                if (gr > mbh || x < 0 || x > mbw) continue;
-                const int x0 = x * msz, yy = gr * msz - 4 + li;
-                const bool from_top = li < 4;
-                if (!(from_top ? gr > 0 : row_real) || yy < 0) continue;
-                const uint8_t *top = sh.strip[r] + strip_off;
-                const uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)] + tile_off;
-                uint32_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nd)
-                        v[j] = from_top ? *reinterpret_cast<const uint32_t *>(top + li * SROW + ((x0 - 4 + 4 * j) & rmask))
-                                        : reinterpret_cast<const uint32_t *>(tile + (li - 4) * TILE_S)[j];
-                uint8_t *g = P.p + (ptrdiff_t)yy * P.stride + x0 - 4;
-                if (from_top && r == 0 && band > 0) {
-                    // these four pixel rows share cache lines with the previous band's strip hand-off:
-                    // every access to them inside this launch is sc1
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nd) st_sc1(reinterpret_cast<uint32_t *>(g) + j, v[j]);
-                } else if (pl == 0) {
-                    __builtin_memcpy(g, v, 16);
-                } else {
-                    __builtin_memcpy(g, v, 8);
-                }
-            }
-            lds_fence();   // our LDS reads of this step are complete before the slot is released
-            if (lane == 0) sh.flag[F_WR] = S + 1;
         }
         return;
     }
@@ -305,6 +254,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     const int botw_mask = bottom_lane ? rmask : 0;
     const int tile_lane = pl * TILE_PLANE + li * TILE_S;    // this lane's row of the tile (P1)
     const int tile_col = pl * TILE_PLANE + 4 + li;          // this lane's column of the tile (P2)
+    // Drain: the block that became final in a step -- 16x16 (8x8) shifted by (-4,-4) = four pixel rows of the
+    // strip above (lanes li < 4) + msz-4 rows of the tile (lanes li >= 4) -- is stored at the top of the NEXT
+    // step, right behind the prefetch, so the stores have a whole step to retire before anything waits on vmcnt.
+    const bool from_top = li < 4;
+    const bool drain_lane = row_any && (from_top ? gr > 0 : row_real);
+    const uint8_t *dr_src = from_top ? top + li * SROW : sh.tile[r][0] + pl * TILE_PLANE + (li - 4) * TILE_S;
+    const int dr_slot = from_top ? 0 : TILE_BYTES;          // tile lanes alternate between the two slots
+    const int dr_and = from_top ? rmask : 0xffff;            // strip lanes wrap around the ring
+    const int dr_col = from_top ? -1 : 0;                    // ... and start at column x0-4
+    uint8_t *dr_g = P.p + (ptrdiff_t)(gr * msz - 4 + li) * P.stride - 4;
+    const bool dr_sc1 = from_top && r == 0 && band > 0;      // rows shared with the previous band's hand-off: sc1 only
     const int y0 = gr * msz;
     const bool has_top = gr > 0;
     const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
@@ -329,7 +289,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         nxt_mask = a.o.mask[gr * mbw];
     }
     uint32_t left4 = 0;
-    const int steps = mbw + ROWS;
+    const int steps = mbw + ROWS + 1;   // + one step that only drains
 #ifdef LF_STAMPS
     unsigned long long st_p1 = 0, st_wait = 0, st_p2 = 0, st_wb = 0, st_t0, st_t1;
 #define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
@@ -338,7 +298,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 #endif
     for (int S = 0; S < steps; ++S) {
         STAMP(st_t0);
-        uint8_t *tile = sh.tile[r][S & (TILE_SLOTS - 1)];
+        uint8_t *tile = sh.tile[r][S & 1];
         const int x = S - r;
         const bool act = row_any && x >= 0 && x <= mbw;
         const bool mbstep = act && row_real && x < mbw;    // a real macroblock (else: flush column / flush row)
@@ -351,6 +311,22 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             else { const uint2 t2 = *reinterpret_cast<const uint2 *>(g); nxt.x = t2.x; nxt.y = t2.y; }
             nxt_seg = a.o.seg[gr * mbw + x + 1];
             nxt_mask = a.o.mask[gr * mbw + x + 1];
+        }
+        if (drain_lane && x >= 1 && x <= mbw + 1) {   // the block of macroblock x-1 (or the flush column)
+            const int c0 = ((x - 1) * msz - 4) & dr_col;
+            const uint8_t *src = dr_src + ((S - 1) & 1) * dr_slot;
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint32_t *>(src + ((c0 + 4 * j) & dr_and));
+            uint32_t *g = reinterpret_cast<uint32_t *>(dr_g + (x - 1) * msz);
+            if (dr_sc1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nd) st_sc1(g + j, v[j]);
+            } else {
+                *reinterpret_cast<uint2 *>(g) = make_uint2(v[0], v[1]);
+                if (pl == 0) *reinterpret_cast<uint2 *>(g + 2) = make_uint2(v[2], v[3]);
+            }
         }
         const uint32_t sp = seg == 0 ? sdp[0] : (seg == 1 ? sdp[1] : (seg == 2 ? sdp[2] : sdp[3]));
         Limits L;
@@ -390,7 +366,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         // ---- the one poll of the step ------------------------------------------------------------
         {
             const int need_up = 2 * S + 1;                       // P1 of the rows above (their macroblock x+1)
-            const int need_wr = S + 1 - (TILE_SLOTS - 1);         // tile slot of the NEXT step has been drained
+            // ring space below: our second row is about to overwrite, in its bottom strip, the slot of macroblock
+            // x-RING_MB, whose last columns the wave below stores at the top of its step S-(RING_MB-3)
+            const int need_dn = wave + 1 < WORKERS ? 2 * (S - (RING_MB - 3)) + 1 : 0;
             const int x_r0 = S - 2 * wave;                        // macroblock of this wave's first row
             const bool top_dep = wave == 0 && band > 0 && x_r0 >= 0 && x_r0 <= mbw && band_row0 <= mbh;
             const int need_top = imin(x_r0 + 1, mbw);
@@ -398,10 +376,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             const int need_pub = (wave + 1 == WORKERS && publishes) ? S - (ROWS - 1) - (RING_MB - 2) : 0;
             for (;;) {
                 const int f_up = wave > 0 ? sh.flag[wave - 1] : need_up;
-                const int f_wr = sh.flag[F_WR];
+                const int f_dn = wave + 1 < WORKERS ? sh.flag[wave + 1] : need_dn;
                 const int f_top = top_dep ? sh.flag[F_TOP] : need_top;
                 const int f_pub = sh.flag[F_PUB];
-                if (f_up >= need_up && f_wr >= need_wr && f_top >= need_top && f_pub >= need_pub) break;
+                if (f_up >= need_up && f_dn >= need_dn && f_top >= need_top && f_pub >= need_pub) break;
                 __builtin_amdgcn_s_sleep(1);
             }
         }
