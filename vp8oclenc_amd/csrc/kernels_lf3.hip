@@ -17,10 +17,15 @@
 //     divergent control flow (and its register shuffling) from the instruction stream.
 //   * Samples carry +256 in registers: |a-b| is one v_sad_u16 even when an unsaturated carry (reference
 //     quirk, :1024/:1062) dips below zero, and the saturated byte is just the low byte of a clamp.
-//   * Bottom strips of each row live in an LDS ring; finished 16x16 blocks (shifted by (-4,-4)) are drained
-//     to HBM by a writer wave; the strip between bands goes through the frame (sc1) with a loader and a
-//     publisher wave, so workers never issue or wait for a global store.
+//   * Bottom strips of each row live in an LDS ring.  A finished 16x16 block (shifted by (-4,-4)) is stored to
+//     HBM by its own row at the top of the NEXT step, right behind the prefetch of the next macroblock, so the
+//     stores have a full step to retire before the wave waits on vmcnt again (gfx9 counts loads and stores in
+//     one counter).  The strip between bands goes through the frame (sc1 = write-through) with a loader and a
+//     publisher wave per band; the loader also stores the rows it loaded once row 0 has filtered across them,
+//     because a write-through store takes longer than a step to retire.
 //   * One LDS poll per step (middle of the step) covers every dependency.
+// History (1080p, one frame): v1 one wave per row through HBM 1.9 ms; v2 (kernels_lf2.hip) banded, two-step lag,
+// writer wave 0.71 ms; this file 0.36 ms.
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -47,21 +52,23 @@ __device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_s
 __device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return imax(imax(a, b), c); }
 struct EdgeRegs { int p3, p2, p1, p0, q0, q1, q2, q3; };
-struct Limits { int mb_lim2, b_lim2, hev_thr; };   // *_lim2 = 2*limit + 1, see edge_masks
+struct Limits { int mb_delta, b_delta, hev_thr; };   // *_delta = interior limit - 2*edge limit - 1, see edge_masks
 
-// 2|p0-q0| + (|p1-q1| >> 1) <= L  <=>  |p1-q1| + 4|p0-q0| <= 2L + 1
-__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_lim2, int hev_thr, bool &mask,
+// 2|p0-q0| + (|p1-q1| >> 1) <= E  <=>  |p1-q1| + 4|p0-q0| <= 2E + 1  <=>  that sum + (I - 2E - 1) <= I, so the
+// edge test joins the six interior tests (each |a-b| <= I) in one max3 and one compare.  edge_delta = I-2E-1.
+// I == -1 switches the edge off: the interior differences are >= 0, so the mask can never be true.
+__device__ __forceinline__ void edge_masks(const EdgeRegs &e, int int_lim, int edge_delta, int hev_thr, bool &mask,
                                            bool &hev) {
     const int d10 = ad(e.p1, e.p0), dq10 = ad(e.q1, e.q0);
     const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
     const int m2 = max3i(dq10, ad(e.q2, e.q1), ad(e.q3, e.q2));
-    const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)(ad(e.p0, e.q0) << 2));
-    mask = (imax(m1, m2) <= int_lim) & (edge <= edge_lim2);   // int_lim == -1: edge switched off
+    const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)((ad(e.p0, e.q0) << 2) + edge_delta));
+    mask = max3i(m1, m2, edge) <= int_lim;
     hev = imax(d10, dq10) > hev_thr;
 }
 __device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, int int_lim) {  // :829-883
     bool mask, hev;
-    edge_masks(e, int_lim, L.mb_lim2, L.hev_thr, mask, hev);
+    edge_masks(e, int_lim, L.mb_delta, L.hev_thr, mask, hev);
     int w = c128(e.p1 - e.q1);
     w = c128(w + (e.q0 - e.p0) * 3);
     w = mask ? w : 0;
@@ -76,7 +83,7 @@ __device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, int
 }
 __device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, int int_lim) {  // :885-926
     bool mask, hev;
-    edge_masks(e, int_lim, L.b_lim2, L.hev_thr, mask, hev);
+    edge_masks(e, int_lim, L.b_delta, L.hev_thr, mask, hev);
     int a = c128(e.p1 - e.q1);
     a = hev ? a : 0;
     a = c128(a + (e.q0 - e.p0) * 3);
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const uint8_t *sp = sh.strip[ROWS] + pl * STRIP_PLANE + rr * SROW;
         for (int x = 0; x <= mbw; ++x) {
             const int done = 2 * (x + ROWS - 1) + 2;   // the last row has finished macroblock x
-            while (sh.flag[WORKERS - 1] < done) __builtin_amdgcn_s_sleep(1);
+            while (sh.flag[WORKERS - 1] < done) __builtin_amdgcn_s_sleep(3);
             if (lane < 44) {
                 const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & rmask));
                 st_sc1(reinterpret_cast<uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz - 4) + j, v);
@@ -215,27 +222,37 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const int msz = pl == 0 ? 16 : 8, rmask = RING_MB * msz - 1;
         const int y = band_row0 * msz - 4 + r;
         uint8_t *sp = sh.strip[0] + pl * STRIP_PLANE + r * SROW;
+        uint8_t *gp = P.p + (ptrdiff_t)y * P.stride + 4 * j;
+        // The four pixel rows above this band share cache lines with the previous band's hand-off, so every access
+        // to them inside the launch is sc1 -- including their final store once row 0 has filtered across them.
+        // That store is done here, not by worker 0: a write-through store takes longer than a step to retire and
+        // would sit in front of every vmcnt wait of the worker.  Block m = columns m0-4 .. m0+msz-5, final when
+        // row 0 has finished macroblock m (row 0: step == macroblock).
+        auto drain_top = [&](int m) {
+            while (sh.flag[0] < 2 * m + 2) __builtin_amdgcn_s_sleep(8);
+            if (lane < 32) st_sc1(reinterpret_cast<uint32_t *>(gp + m * msz - 4), *reinterpret_cast<const uint32_t *>(sp + ((m * msz - 4 + 4 * j) & rmask)));
+        };
         for (int x = 0; x < mbw; ++x) {
             // columns x0+13..15 are final once the previous band's last row has run P1 of macroblock x+1
             const int need = imin(x + 2, mbw + 1);
             while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need)
                 __builtin_amdgcn_s_sleep(2);
-            // ring space: the slot still holds macroblock x-RING_MB, whose last four columns row 0 stores
-            // together with macroblock x-RING_MB+1, at the top of step x-RING_MB+2 (row 0: step == macroblock)
-            while (sh.flag[0] < 2 * (x - (RING_MB - 2)) + 1) __builtin_amdgcn_s_sleep(1);
-            if (lane < 32) {
-                const uint32_t v = ld_sc1(reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz) + j);
-                *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = v;
-            }
+            // ring space: the slot still holds macroblock x-RING_MB, whose last four columns belong to the block
+            // of macroblock x-RING_MB+1
+            if (x >= RING_MB - 1) drain_top(x - (RING_MB - 1));
+            if (lane < 32) *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = ld_sc1(reinterpret_cast<const uint32_t *>(gp + x * msz));
             lds_fence();
             if (lane == 0) sh.flag[F_TOP] = x + 1;
         }
+        for (int m = imax(mbw - (RING_MB - 1), 0); m <= mbw; ++m) drain_top(m);
         return;
     }
 
     // ---------------------------------------------------------------------------------------------
     // worker waves
     // ---------------------------------------------------------------------------------------------
+    // the loader and publisher waves share SIMDs with workers 0 and 1: let them issue only in idle slots
+    __builtin_amdgcn_s_setprio(3);
     const int half = lane >> 5, l32 = lane & 31;
     const int r = 2 * wave + half;              // local MB row
     const int gr = band_row0 + r;               // global MB row (gr == mbh: virtual row that only flushes)
@@ -258,14 +275,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     // strip above (lanes li < 4) + msz-4 rows of the tile (lanes li >= 4) -- is stored at the top of the NEXT
     // step, right behind the prefetch, so the stores have a whole step to retire before anything waits on vmcnt.
     const bool from_top = li < 4;
-    const bool drain_lane = row_any && (from_top ? gr > 0 : row_real);
+    const bool drain_lane = row_any && (from_top ? gr > 0 && !(r == 0 && band > 0) : row_real);   // (the loader stores those)
     const uint8_t *dr_src = from_top ? top + li * SROW : sh.tile[r][0] + pl * TILE_PLANE + (li - 4) * TILE_S;
     const int dr_slot = from_top ? 0 : TILE_BYTES;          // tile lanes alternate between the two slots
     const int dr_and = from_top ? rmask : 0xffff;            // strip lanes wrap around the ring
     const int dr_col = from_top ? -1 : 0;                    // ... and start at column x0-4
     uint8_t *dr_g = P.p + (ptrdiff_t)(gr * msz - 4 + li) * P.stride - 4;
-    const bool dr_sc1 = from_top && r == 0 && band > 0;      // rows shared with the previous band's hand-off: sc1 only
-    const int y0 = gr * msz;
     const bool has_top = gr > 0;
     const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
     const int first_lf0 = sh.first_lf0;
@@ -278,15 +293,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
                  ((uint32_t)(sd[SD_SUB_BEDGE_LIMIT] & 0xff) << 16) | ((uint32_t)(sd[SD_HEV_THRESHOLD] & 0xff) << 24);
     }
 
-    // prefetch of macroblock 0
+    // Prefetch of macroblock 0.  Every lane loads 16 bytes (chroma lanes use 8 of them; at the right frame edge
+    // the rest is margin).  The loads stay inside a branch on purpose: hoisted to the top of the loop body, hipcc
+    // parks an s_waitcnt vmcnt(0) right behind them (measured: +700 cycles per step).
+    const uint8_t *pf_p = P.p + (ptrdiff_t)(imin(gr, mbh - 1) * msz + li) * P.stride;
+    const int32_t *pf_seg = a.o.seg + imin(gr, mbh - 1) * mbw, *pf_mask = a.o.mask + imin(gr, mbh - 1) * mbw;
     uint4 nxt = make_uint4(0, 0, 0, 0);
     int nxt_seg = 0, nxt_mask = 0;
     if (row_real) {
-        const uint8_t *g = P.p + (ptrdiff_t)(y0 + li) * P.stride;
-        if (pl == 0) nxt = *reinterpret_cast<const uint4 *>(g);
-        else { const uint2 t2 = *reinterpret_cast<const uint2 *>(g); nxt.x = t2.x; nxt.y = t2.y; }
-        nxt_seg = a.o.seg[gr * mbw];
-        nxt_mask = a.o.mask[gr * mbw];
+        nxt = *reinterpret_cast<const uint4 *>(pf_p);
+        nxt_seg = pf_seg[0];
+        nxt_mask = pf_mask[0];
     }
     uint32_t left4 = 0;
     const int steps = mbw + ROWS + 1;   // + one step that only drains
@@ -306,11 +323,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const uint4 own = nxt;
         const int seg = nxt_seg, maskv = nxt_mask;
         if (mbstep && x + 1 < mbw) {   // prefetch the next macroblock of this row
-            const uint8_t *g = P.p + (ptrdiff_t)(y0 + li) * P.stride + x0 + msz;
-            if (pl == 0) nxt = *reinterpret_cast<const uint4 *>(g);
-            else { const uint2 t2 = *reinterpret_cast<const uint2 *>(g); nxt.x = t2.x; nxt.y = t2.y; }
-            nxt_seg = a.o.seg[gr * mbw + x + 1];
-            nxt_mask = a.o.mask[gr * mbw + x + 1];
+            nxt = *reinterpret_cast<const uint4 *>(pf_p + x0 + msz);
+            nxt_seg = pf_seg[x + 1];
+            nxt_mask = pf_mask[x + 1];
         }
         if (drain_lane && x >= 1 && x <= mbw + 1) {   // the block of macroblock x-1 (or the flush column)
             const int c0 = ((x - 1) * msz - 4) & dr_col;
@@ -319,22 +334,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint32_t *>(src + ((c0 + 4 * j) & dr_and));
             uint32_t *g = reinterpret_cast<uint32_t *>(dr_g + (x - 1) * msz);
-            if (dr_sc1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nd) st_sc1(g + j, v[j]);
-            } else {
-                *reinterpret_cast<uint2 *>(g) = make_uint2(v[0], v[1]);
-                if (pl == 0) *reinterpret_cast<uint2 *>(g + 2) = make_uint2(v[2], v[3]);
-            }
+            *reinterpret_cast<uint2 *>(g) = make_uint2(v[0], v[1]);
+            if (pl == 0) *reinterpret_cast<uint2 *>(g + 2) = make_uint2(v[2], v[3]);
         }
         const uint32_t sp = seg == 0 ? sdp[0] : (seg == 1 ? sdp[1] : (seg == 2 ? sdp[2] : sdp[3]));
         Limits L;
-        L.mb_lim2 = ((sp >> 8) & 0xff) * 2 + 1;
-        L.b_lim2 = ((sp >> 16) & 0xff) * 2 + 1;
-        L.hev_thr = sp >> 24;
         // an edge that does not apply gets interior limit -1: its mask can never be true
         const int int_lim = sp & 0xff;
+        L.mb_delta = int_lim - ((sp >> 8) & 0xff) * 2 - 1;
+        L.b_delta = int_lim - ((sp >> 16) & 0xff) * 2 - 1;
+        L.hev_thr = sp >> 24;
         const bool do_filter = mbstep && (gr * mbw + x) < first_lf0;
         const bool en_in = do_filter && maskv != 0;
         const int il4 = en_in ? int_lim : -1;
