@@ -47,15 +47,30 @@ def algorithmic_bytes(kernel: str, W: int, H: int, nrefs: float) -> float:
     return 0.0
 
 
+def pmc_traffic(kernel: str, W: int, H: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; FETCH_SIZE and
+    WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot
+    run the profiler on itself, so this is the last measured value for the same geometry, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(f"{W}x{H}", {}).get(kernel)
+        if e:
+            return int(e["hbm_bytes_per_launch"]), t.get("source", "profiles/pmc_traffic.json")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct-frames", type=int, default=8)
-    ap.add_argument("--gops-per-gpu", type=int, default=4, help="independent GOP chunks in flight per GPU (1 = one stream)")
+    ap.add_argument("--gops-per-gpu", type=int, default=16, help="independent GOP chunks in flight per GPU (1 = one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
     return ap.parse_args()
@@ -146,7 +161,7 @@ def main():
     n0 = len(range(0, nwarm, G))
     per_frame = {k: ms / max(n0, 1) for k, (ms, n) in warm.items()}
     dominant = max((k for k in per_frame if algorithmic_bytes(k, W, H, 1) > 0), key=lambda k: per_frame[k])
-    timed_kernels = api.K_NAMES if args.profile_all else sorted({dominant, "search1_l0"})
+    timed_kernels = api.K_NAMES if args.profile_all else sorted({dominant, "search1_l0", "search2", "mb"})
     for st in streams:
         st.enc.profile_enable(timed_kernels)
     ref_hist.update(frames=0, refs=0)
@@ -177,8 +192,9 @@ def main():
         avg_ms = ms_k / max(n_k, 1)
         abytes = algorithmic_bytes(dominant, W, H, nrefs_avg)
         achieved = abytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dominant, W, H)
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k)}
         extra = {}
         for k, (ms, n) in prof.items():
