@@ -24,7 +24,7 @@
 //     publisher wave per band; the loader also stores the rows it loaded once row 0 has filtered across them,
 //     because a write-through store takes longer than a step to retire.
 //   * One LDS poll per step (middle of the step) covers every dependency.
-// History (1080p, one frame): v1 one wave per row through HBM 1.9 ms; v2 (kernels_lf2.hip) banded, two-step lag,
+// History (1080p, one frame): v1 one wave per row through HBM 1.9 ms; v2 (git history) banded, two-step lag,
 // writer wave 0.71 ms; this file 0.36 ms.
 #include "vp8hip_dev.h"
 

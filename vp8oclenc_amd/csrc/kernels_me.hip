@@ -33,33 +33,7 @@ void launch_border(hipStream_t s, const Frame &f) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// downsample_x2, GPU_kernels.cl:429-451: dst = (a+b+c+d+2)/4 of each 2x2.  One thread per output
-// pixel pair-of-rows column; blockIdx.y selects the surface (current / LAST are done together).
-// ------------------------------------------------------------------------------------------------
-struct DownArgs { Plane src[2], dst[2]; };
-
-__global__ __launch_bounds__(256) void k_downsample(DownArgs a) {
-    const Plane s = a.src[blockIdx.y], d = a.dst[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.w * d.h) return;
-    const int x = i % d.w, y = i / d.w;
-    const uint8_t *p = s.p + (ptrdiff_t)(2 * y) * s.stride + 2 * x;
-    const int v = p[0] + p[1] + p[s.stride] + p[s.stride + 1] + 2;
-    d.p[(ptrdiff_t)y * d.stride + x] = (uint8_t)(v >> 2);
-}
-
-void launch_downsample(hipStream_t s, const Plane *src, const Plane *dst, int nsurf) {
-    DownArgs a;
-    for (int i = 0; i < 2; ++i) {
-        a.src[i] = src[i < nsurf ? i : 0];
-        a.dst[i] = dst[i < nsurf ? i : 0];
-    }
-    const int n = dst[0].w * dst[0].h;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_downsample, dim3((n + 255) / 256, nsurf), dim3(256), 0, s, a);
-}
-
-// ------------------------------------------------------------------------------------------------
+// downsample_x2, GPU_kernels.cl:429-451: dst = (a+b+c+d+2)/4 of each 2x2.
 // The whole pyramid in one launch (replaces 4 x downsample_x2 per surface, inter_part.h:11-33).
 // A workgroup takes a 64x64 tile of the full-resolution plane and produces the 32x32, 16x16, 8x8 and
 // 4x4 tiles below it; every level is computed from the ROUNDED level above it, exactly like the
@@ -150,24 +124,6 @@ void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, co
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, f.Y[0], f.U, f.V, (const uint8_t *)y,
                        (const uint8_t *)u, (const uint8_t *)v);
-}
-
-// ------------------------------------------------------------------------------------------------
-// reset_vectors, GPU_kernels.cl:404-427
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reset_nets(NetSet n, int b8) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= b8) return;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        reinterpret_cast<uint32_t *>(n.net[r][0])[i] = 0;
-        reinterpret_cast<uint32_t *>(n.net[r][1])[i] = 0;
-        n.bdiff[r][i] = 0x7fffffff;
-    }
-}
-
-void launch_reset_nets(hipStream_t s, const NetSet &n, int b8) {
-    hipLaunchKernelGGL(k_reset_nets, dim3((b8 + 255) / 256), dim3(256), 0, s, n, b8);
 }
 
 // minimum of a packed key over the 32 lanes of a half-wave
@@ -316,216 +272,6 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     hipLaunchKernelGGL(k_search1, dim3((a.nblk + S1_BLOCKS_PER_WG - 1) / S1_BLOCKS_PER_WG, n), dim3(256), 0, s, a);
 }
 
-// ------------------------------------------------------------------------------------------------
-// luma_search_2step, GPU_kernels.cl:1068-1203 (+construct_opt1/2 :776-1066).
-// v0 = 4*net is a whole-pel vector, so the 25 candidates q = 4c+v0+(dx,dy), dx,dy in -2..2 use only
-// five x cases and five y cases: (integer offset, 1/8-pel phase) = (-1,4) (-1,6) (0,0) (0,2) (0,4).
-// Per block (32 lanes): stage the 14x14 reference window in LDS, filter the 14 rows once for each of
-// the five x cases (saturated to u8, exactly what every construct_opt call would recompute), then
-// lane k applies only its vertical taps, takes the 4 sub-block costs and the winner is a packed min.
-// Lane 25 is the explicit zero-MV candidate (changelog.txt:93).  grid = (ceil(b8/8), refs), block 256.
-// ------------------------------------------------------------------------------------------------
-struct Search2Args {
-    Plane cur;
-    Plane ref[3];
-    const int16_t *net_in[3];
-    int16_t *net_out[3];
-    int32_t *bdiff[3];
-    int refmap[3];
-    int w, h, nblk, bw;
-    uint32_t *dbg;   // test tap: per-candidate prediction and cost of block dbg_block (or nullptr)
-    int dbg_block;
-};
-
-__device__ __forceinline__ int case_phase(int c) { return c == 0 ? 4 : (c == 1 ? 6 : (c == 2 ? 0 : (c == 3 ? 2 : 4))); }
-
-__global__ __launch_bounds__(256) void k_search2(Search2Args a) {
-    __shared__ uint32_t s_win[8][14 * 5];
-    __shared__ uint32_t s_H[8][5 * 14 * 2];
-    const int r = a.refmap[blockIdx.y];
-    const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const int b = imin(blockIdx.x * 8 + g, a.nblk - 1);
-    const bool live = blockIdx.x * 8 + g < a.nblk;
-    const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
-    const uint32_t nv = reinterpret_cast<const uint32_t *>(a.net_in[r])[b];
-    const int nx = (int16_t)(nv & 0xffffu), ny = (int16_t)(nv >> 16);
-    const int v0x = (int16_t)(nx * 4), v0y = (int16_t)(ny * 4);
-    // window origin; a garbage vector (possible only when every candidate is out of frame) is clamped
-    // so that the loads stay inside the allocated margin
-    const int Lx = iclamp(cx + nx, 3 - EXT, a.w + EXT - 11), Ly = iclamp(cy + ny, 3 - EXT, a.h + EXT - 11);
-    const Plane rf = a.ref[r];
-    const int ax = (Lx - 3) & ~3, o = (Lx - 3) & 3;
-    for (int idx = lane; idx < 70; idx += 32) {
-        const int row = idx / 5, j = idx % 5;
-        s_win[g][idx] = *reinterpret_cast<const uint32_t *>(rf.p + (ptrdiff_t)(Ly - 3 + row) * rf.stride + ax + 4 * j);
-    }
-    __syncthreads();
-    // horizontal pass: (x case, window row) pairs
-    for (int pi = lane; pi < 70; pi += 32) {
-        const int xc = pi / 14, row = pi % 14;
-        const int xo = xc < 2 ? -1 : 0, phx = case_phase(xc);
-        const int s0 = o + xo + 1;  // byte of the row that holds tap 0 of output column 0
-        uint32_t w[6];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) w[j] = s_win[g][row * 5 + j];
-        w[5] = 0;
-        const bool j0 = (s0 >> 2) != 0;
-        const int sh = s0 & 3;
-        uint32_t q[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = __builtin_amdgcn_alignbyte(j0 ? w[j + 2] : w[j + 1], j0 ? w[j + 1] : w[j], sh);
-        int bb[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) bb[i] = byte_of(q[i >> 2], i & 3);
-        uint32_t out[2] = {0, 0};
-        if (phx == 0) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) out[c >> 2] |= (uint32_t)bb[c + 2] << (8 * (c & 3));
-        } else {
-            int f[6];
-            load_taps(phx, f);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                int sum = 64;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) sum += bb[c + t] * f[t];
-                out[c >> 2] |= (uint32_t)sat8_shr7(sum) << (8 * (c & 3));  // negative sums saturate to 0 either way
-            }
-        }
-        s_H[g][pi * 2] = out[0];
-        s_H[g][pi * 2 + 1] = out[1];
-    }
-    __syncthreads();
-
-    const int k = lane;
-    const int dx = k % 5 - 2, dy = k / 5 - 2;
-    int qx = (int16_t)(cx * 4 + v0x + dx), qy = (int16_t)(cy * 4 + v0y + dy);
-    if (k == 25) { qx = cx * 4; qy = cy * 4; }
-    const bool valid = live && k < 26 && qx >= 0 && qx <= a.w * 4 - 32 && qy >= 0 && qy <= a.h * 4 - 32;
-    uint32_t p_lo[8], p_hi[8];
-    if (k < 25) {
-        const int xc = k % 5, yc = k / 5;
-        const int rb = (yc < 2 ? -1 : 0) + 1, phy = case_phase(yc);
-        const uint32_t *H = &s_H[g][xc * 28];
-        if (phy == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { p_lo[i] = H[(rb + i + 2) * 2]; p_hi[i] = H[(rb + i + 2) * 2 + 1]; }
-        } else {
-            int f[6];
-            load_taps(phy, f);
-            uint32_t hl[13], hh[13];
-#pragma unroll
-            for (int i = 0; i < 13; ++i) { hl[i] = H[(rb + i) * 2]; hh[i] = H[(rb + i) * 2 + 1]; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    int s1 = 64, s2 = 64;
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) {
-                        s1 += byte_of(hl[i + t], c) * f[t];
-                        s2 += byte_of(hh[i + t], c) * f[t];
-                    }
-                    lo |= (uint32_t)sat8_shr7(s1) << (8 * c);
-                    hi |= (uint32_t)sat8_shr7(s2) << (8 * c);
-                }
-                p_lo[i] = lo; p_hi[i] = hi;
-            }
-        }
-    } else {  // zero MV: whole-pel, both passes are the identity
-        const uint8_t *zp = rf.p + (ptrdiff_t)cy * rf.stride + cx;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint2 z = *reinterpret_cast<const uint2 *>(zp + (ptrdiff_t)i * rf.stride);
-            p_lo[i] = z.x; p_hi[i] = z.y;
-        }
-    }
-    const uint8_t *cp = a.cur.p + (ptrdiff_t)cy * a.cur.stride + cx;
-    uint32_t c_lo[8], c_hi[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint2 c = *reinterpret_cast<const uint2 *>(cp + (ptrdiff_t)i * a.cur.stride);
-        c_lo[i] = c.x; c_hi[i] = c.y;
-    }
-    int diff = weight_quads(c_lo, p_lo) + weight_quads(c_lo + 4, p_lo + 4) + weight_quads(c_hi, p_hi) +
-               weight_quads(c_hi + 4, p_hi + 4);
-    if (k < 25) diff += (iabs(dx) + iabs(dy)) * 32;  // :1176-1178
-    if (a.dbg && live && b == a.dbg_block && k < 26) {
-        uint32_t *d = a.dbg + k * 18;
-        for (int i = 0; i < 8; ++i) { d[2 * i] = p_lo[i]; d[2 * i + 1] = p_hi[i]; }
-        d[16] = (uint32_t)diff;
-        d[17] = valid;
-    }
-    if (a.dbg && live && b == a.dbg_block) {
-        for (int i = lane; i < 70; i += 32) a.dbg[26 * 18 + i] = s_win[g][i];
-        for (int i = lane; i < 140; i += 32) a.dbg[26 * 18 + 70 + i] = s_H[g][i];
-        if (lane == 0) { a.dbg[26 * 18 + 210] = (uint32_t)Lx; a.dbg[26 * 18 + 211] = (uint32_t)Ly; a.dbg[26 * 18 + 212] = (uint32_t)o; }
-    }
-    uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
-    key = halfwave_min(key);
-    if (lane == 0 && live) {
-        int bqx = (int16_t)(a.w * 4 - 32), bqy = (int16_t)(a.h * 4 - 32), md = 0x7fff;  // :1136-1137
-        if (key != 0xffffffffu) {
-            const int kk = key & 0xff;
-            md = (int)(key >> 8);
-            bqx = kk == 25 ? cx * 4 : (int16_t)(cx * 4 + v0x + (kk % 5 - 2));
-            bqy = kk == 25 ? cy * 4 : (int16_t)(cy * 4 + v0y + (kk / 5 - 2));
-        }
-        const int vx = (int16_t)(bqx - cx * 4), vy = (int16_t)(bqy - cy * 4);
-        if ((vx != 0) | (vy != 0)) md -= (iabs(vx - v0x) + iabs(vy - v0y)) * 32;  // :1195-1197
-        reinterpret_cast<uint32_t *>(a.net_out[r])[b] = (uint32_t)(uint16_t)vx | ((uint32_t)(uint16_t)vy << 16);
-        a.bdiff[r][b] = md;
-    }
-}
-
-void launch_search2_v1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
-    Search2Args a;
-    a.cur = cur.Y[0];
-    int n = 0;
-    for (int r = 0; r < 3; ++r) {
-        a.ref[r] = refs.ref[r].Y[0];
-        a.net_in[r] = nets.net[r][1];   // vnet2 holds the 1x result, init.h:832-854
-        a.net_out[r] = nets.net[r][0];
-        a.bdiff[r] = nets.bdiff[r];
-        if (refs.use[r]) a.refmap[n++] = r;
-    }
-    for (int i = n; i < 3; ++i) a.refmap[i] = 0;
-    a.w = a.cur.w;
-    a.h = a.cur.h;
-    a.bw = a.w / 8;
-    a.nblk = a.w * a.h / 64;
-    a.dbg = dbg;
-    a.dbg_block = dbg_block;
-    hipLaunchKernelGGL(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
-}
-
-// ------------------------------------------------------------------------------------------------
-// select_reference (GPU_kernels.cl:1205-1283) + pack_8x8_into_16x16 (:1346-1366), one thread per MB
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_select(NetSet n, MBOut o, int mbw, int mbs, int use_golden, int use_altref) {
-    const int mb = blockIdx.x * 256 + threadIdx.x;
-    if (mb >= mbs) return;
-    const int b8w = mbw * 2;
-    const int b = ((mb / mbw) * 2) * b8w + (mb % mbw) * 2;
-    const int idx[4] = {b, b + 1, b + b8w, b + b8w + 1};
-    int diff1 = n.bdiff[0][idx[0]] + n.bdiff[0][idx[1]] + n.bdiff[0][idx[2]] + n.bdiff[0][idx[3]];
-    int diff2 = 0x7fffffff;
-    if (use_altref == 1) diff2 = n.bdiff[2][idx[0]] + n.bdiff[2][idx[1]] + n.bdiff[2][idx[2]] + n.bdiff[2][idx[3]];
-    int ref = diff1 <= diff2 ? 0 : 2;
-    diff1 = diff1 <= diff2 ? diff1 : diff2;
-    diff2 = 0x7fffffff;
-    if (use_golden == 1) diff2 = n.bdiff[1][idx[0]] + n.bdiff[1][idx[1]] + n.bdiff[1][idx[2]] + n.bdiff[1][idx[3]];
-    ref = diff1 <= diff2 ? ref : 1;
-    const uint32_t *net = reinterpret_cast<const uint32_t *>(n.net[ref][0]);
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = net[idx[k]];
-    o.ref[mb] = ref;
-    *reinterpret_cast<uint4 *>(o.vec + 8 * mb) = make_uint4(v[0], v[1], v[2], v[3]);
-    o.parts[mb] = (v[1] == v[0] && v[2] == v[0] && v[3] == v[0]) ? 0 : 1;
-}
-
 // test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)
 __global__ __launch_bounds__(256) void k_weight_tap(const int32_t *d, int n, int32_t *out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -537,11 +283,6 @@ __global__ __launch_bounds__(256) void k_weight_tap(const int32_t *d, int n, int
 }
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out) {
     hipLaunchKernelGGL(k_weight_tap, dim3((n + 255) / 256), dim3(256), 0, s, d, n, out);
-}
-
-void launch_select(hipStream_t s, const NetSet &nets, const MBOut &o, int mbw, int mbh, int use_golden, int use_altref) {
-    const int mbs = mbw * mbh;
-    hipLaunchKernelGGL(k_select, dim3((mbs + 255) / 256), dim3(256), 0, s, nets, o, mbw, mbs, use_golden, use_altref);
 }
 
 }  // namespace vp8

@@ -13,16 +13,10 @@
 //     bytes: 2.5 dot4 per sample with 7-tap pre-shifted constants (K_V7; the 7th slot absorbs the one-row
 //     offset between dy<0 and dy>=0), v_ashr_pk_u8_i32 saturates two samples at a time.
 //   * The current block and the zero-MV block are transposed through LDS so the metric sees columns too.
-// Results are bit-identical to the first version (kernels_me.hip, launch_search2_v1; VP8HIP_S2_V1=1 selects it
-// for A/B timing).
-#include <stdlib.h>
-
+// First version (32-bit multiply-adds, row-major H array; git history): 0.156 ms per 1080p frame, this one 0.091.
 #include "vp8hip_dev.h"
 
 namespace vp8 {
-
-void launch_search2_v1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg,
-                       int dbg_block);
 
 namespace {
 
@@ -249,8 +243,6 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
 }  // namespace
 
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
-    static const bool use_v1 = getenv("VP8HIP_S2_V1") != nullptr;   // A/B switch for measurements only
-    if (use_v1) return launch_search2_v1(s, cur, refs, nets, dbg, dbg_block);
     S2Args a;
     a.cur = cur.Y[0];
     int n = 0;

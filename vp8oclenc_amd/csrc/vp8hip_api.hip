@@ -442,13 +442,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     Frame &f = c->frames[c->recon].f;
     {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
-        static const bool use_v1 = getenv("VP8HIP_LF_V1") != nullptr;  // A/B switch for measurements only
-        if (use_v1) launch_loop_filter(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh);
-        else {
-            static const bool use_v2 = getenv("VP8HIP_LF_V2") != nullptr;
-            if (use_v2) launch_loop_filter2(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++);
-            else launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++);
-        }
+        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++);
     }
     {
         Timed t(c, VP8HIP_K_BORDER);

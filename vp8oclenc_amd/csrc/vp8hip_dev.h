@@ -51,8 +51,6 @@ struct SegData { int32_t v[4 * SD_INTS]; };
 
 // ---- launchers (kernels_*.hip) ---------------------------------------------------------------
 void launch_border(hipStream_t s, const Frame &f);
-void launch_downsample(hipStream_t s, const Plane *src, const Plane *dst, int nsurf);
-void launch_reset_nets(hipStream_t s, const NetSet &n, int b8);
 void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b);   // all four levels of one or two frames
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
@@ -60,17 +58,11 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
                     int dbg_block = -1);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
-void launch_select(hipStream_t s, const NetSet &nets, const MBOut &o, int mbw, int mbh, int use_golden,
-                   int use_altref);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
-void launch_loop_filter(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                        int mbw, int mbh);   // first version: one wave per MB row, hand-off through HBM (kept for A/B)
-void launch_loop_filter2(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no);  // banded wavefront in LDS, two-step row lag (A/B)
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no);  // one-step row lag, branch-free filters (the one used)
+                         int mbw, int mbh, unsigned launch_no);  // banded wavefront in LDS, one-step row lag
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
