@@ -29,6 +29,22 @@ static __device__ __constant__ const int k_ac_q[128] = {  // GPU_kernels.cl:70-8
 
 __device__ __forceinline__ int qi(int v) { return iclamp(v, 0, 127); }
 
+// C division x / q (truncating toward zero, GPU_kernels.cl:1478-1481) by a quantiser that is the same for a
+// whole pass: floor(n/q) = (n*M) >> 24 with M = floor(2^24/q) + 1 is exact for n < 2^15 and 2 <= q < 512
+// (error term n*(M*q - 2^24)/(q*2^24) < 2^-9 < 1/q).  Every |coefficient| here is below 2^15 (fdct <= 2040,
+// WHT <= 16320) and every quantiser below 512 (y2ac <= 440).  n*M needs 39 bits: the two full-rate 24-bit
+// multiplies give its low 32 and high 16 bits.  q == 1 (the DC of a 16x16 macroblock) is passed through.
+struct TDiv { uint32_t M; bool one; };
+__device__ __forceinline__ TDiv tdiv_make(int q) { return TDiv{(1u << 24) / (uint32_t)q + 1u, q == 1}; }
+__device__ __forceinline__ int tdiv(int x, const TDiv &d) {
+    const int s = x >> 31;
+    const uint32_t n = (uint32_t)((x ^ s) - s);
+    // both factors provably below 2^24: hipcc selects v_mul_u32_u24 + v_mul_hi_u32_u24 + v_alignbit
+    const uint64_t p = (uint64_t)(n & 0xffffffu) * (uint64_t)(d.M & 0xffffffu);
+    const uint32_t r = d.one ? n : (uint32_t)(p >> 24);
+    return ((int)r ^ s) - s;
+}
+
 // `construct`, GPU_kernels.cl:574-774: separable six-tap on a 4x4 block at integer position (ix,iy)
 // with 1/8-pel phases (fx,fy).  Of the nine horizontally filtered lines the first six are saturated
 // to u8, the last three are narrowed with a plain (uchar) cast (wrap mod 256) -- :702-708,727-733,752-758.
@@ -73,8 +89,10 @@ __device__ __forceinline__ void fdct4x4(const int in[16], int out[16]) {
         const int a1 = (r0 + r3) * 8, d1 = (r0 - r3) * 8, b1 = (r1 + r2) * 8, c1 = (r1 - r2) * 8;
         L[c] = a1 + b1;
         L[8 + c] = a1 - b1;
-        L[4 + c] = (c1 * 2217 + d1 * 5352 + 14500) >> 12;
-        L[12 + c] = (d1 * 2217 - c1 * 5352 + 7500) >> 12;
+        // |c1|,|d1| <= 4080 here and <= 16320 in the row pass: both rotations are one v_dot2_i32_i16 each
+        const uint32_t xy = pk16(c1, d1);
+        L[4 + c] = dot2(xy, K_ROT_A, 14500) >> 12;     // c1*2217 + d1*5352 + 14500
+        L[12 + c] = dot2(xy, K_ROT_B, 7500) >> 12;     // d1*2217 - c1*5352 + 7500
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -82,8 +100,9 @@ __device__ __forceinline__ void fdct4x4(const int in[16], int out[16]) {
         const int a1 = e0 + e3, d1 = e0 - e3, b1 = e1 + e2, c1 = e1 - e2;
         out[4 * i] = (a1 + b1 + 7) >> 4;
         out[4 * i + 2] = (a1 - b1 + 7) >> 4;
-        out[4 * i + 1] = ((c1 * 2217 + d1 * 5352 + 12000) >> 16) + (d1 != 0);
-        out[4 * i + 3] = (d1 * 2217 - c1 * 5352 + 51000) >> 16;
+        const uint32_t xy = pk16(c1, d1);
+        out[4 * i + 1] = (dot2(xy, K_ROT_A, 12000) >> 16) + (d1 != 0);
+        out[4 * i + 3] = dot2(xy, K_ROT_B, 51000) >> 16;
     }
 }
 
@@ -94,8 +113,9 @@ __device__ __forceinline__ void idct4x4(int L[16]) {
     for (int c = 0; c < 4; ++c) {
         const int i0 = L[c], i1 = L[4 + c], i2 = L[8 + c], i3 = L[12 + c];
         const int a1 = i0 + i2, b1 = i0 - i2;
-        const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
-        const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+        // operands are far below 2^23; the low 32 bits of the 24x24 product are the reference's int product
+        const int c1 = (__mul24(i1, 35468) >> 16) - (i3 + (__mul24(i3, 20091) >> 16));
+        const int d1 = (i1 + (__mul24(i1, 20091) >> 16)) + (__mul24(i3, 35468) >> 16);
         T[c] = a1 + d1;
         T[12 + c] = a1 - d1;
         T[4 + c] = b1 + c1;
@@ -105,8 +125,9 @@ __device__ __forceinline__ void idct4x4(int L[16]) {
     for (int r = 0; r < 4; ++r) {
         const int i0 = T[4 * r], i1 = T[4 * r + 1], i2 = T[4 * r + 2], i3 = T[4 * r + 3];
         const int a1 = i0 + i2, b1 = i0 - i2;
-        const int c1 = ((i1 * 35468) >> 16) - (i3 + ((i3 * 20091) >> 16));
-        const int d1 = (i1 + ((i1 * 20091) >> 16)) + ((i3 * 35468) >> 16);
+        // operands are far below 2^23; the low 32 bits of the 24x24 product are the reference's int product
+        const int c1 = (__mul24(i1, 35468) >> 16) - (i3 + (__mul24(i3, 20091) >> 16));
+        const int d1 = (i1 + (__mul24(i1, 20091) >> 16)) + (__mul24(i3, 35468) >> 16);
         L[4 * r] = (a1 + d1 + 4) >> 3;
         L[4 * r + 3] = (a1 - d1 + 4) >> 3;
         L[4 * r + 1] = (b1 + c1 + 4) >> 3;
@@ -116,7 +137,7 @@ __device__ __forceinline__ void idct4x4(int L[16]) {
 
 // WHT_and_quant + dequant_and_iWHT, GPU_kernels.cl:257-401.  X: the 16 luma DCs (raster) in, the
 // reconstructed DCs out; Q: the quantised second-order block (raster).
-__device__ __forceinline__ void wht_roundtrip(int X[16], int Q[16], int dc_q, int ac_q) {
+__device__ __forceinline__ void wht_roundtrip(int X[16], int Q[16], int dc_q, int ac_q, const TDiv &ddc, const TDiv &dac) {
     int T[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -135,11 +156,11 @@ __device__ __forceinline__ void wht_roundtrip(int X[16], int Q[16], int dc_q, in
         for (int k = 0; k < 4; ++k) {
             o[k] += (o[k] > 0);
             o[k] >>= 1;
-            Q[4 * r + k] = o[k] / ((r == 0 && k == 0) ? dc_q : ac_q);
+            Q[4 * r + k] = tdiv(o[k], (r == 0 && k == 0) ? ddc : dac);
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) X[k] = Q[k] * (k == 0 ? dc_q : ac_q);
+    for (int k = 0; k < 16; ++k) X[k] = __mul24(Q[k], k == 0 ? dc_q : ac_q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int x = X[4 * r], y = X[4 * r + 1], z = X[4 * r + 2], w = X[4 * r + 3];
@@ -189,13 +210,47 @@ struct MBArgs {
 };
 
 // LDS per macroblock: current and reconstructed pixels, plane-major (Y 16x16, U 8x8, V 8x8)
-struct MBTile { uint8_t cur[384]; uint8_t rec[384]; };
+// + two float arrays of per-pixel SSIM terms, stored in the order the reference's float4 lanes accumulate them:
+// plane base (0 / 256 / 320) + component * n/4 + sequence index, so a chain reads consecutive floats.
+struct MBTile { uint8_t cur[384]; uint8_t rec[384]; float fa[384]; float fb[384]; };
 
-// one SSIM term chain in the reference's float4 order (count_SSIM_luma/_chroma, :1610-2095): lane-component
-// `comp` accumulates pixels (r, 4j+comp), r outer, j inner; n = 16 (luma) or 8 (chroma).
-// All float ops are written so that nothing can be contracted (the reference's mad is a*b+c, unfused).
+// sums of the pixels of a 384-byte tile: Y over the 32 lanes, U in lanes 0-15, V in lanes 16-31 (exact
+// integers, so the means equal the reference's float accumulation, which is exact too: sums < 2^24)
+__device__ __forceinline__ void tile_sums(const uint32_t *t32, int lane, int &sy, int &sc) {
+    sy = (int)__builtin_amdgcn_sad_u8(t32[lane], 0u, __builtin_amdgcn_sad_u8(t32[lane + 32], 0u, 0u));
+    sc = (int)__builtin_amdgcn_sad_u8(t32[64 + lane], 0u, 0u);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) sy += __shfl_xor(sy, m, 32);
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 32);
+}
+// one accumulation chain of n4 terms in the reference's order (first term assigned, then term + acc)
+__device__ __forceinline__ float chain(const float *p, int n4) {
+    float acc = 0.0f;
+    for (int q = 0; q < n4; q += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + q);
+        acc = q == 0 ? v.x : __fadd_rn(v.x, acc);
+        acc = __fadd_rn(v.y, acc);
+        acc = __fadd_rn(v.z, acc);
+        acc = __fadd_rn(v.w, acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ float sum4(float acc, int lane) {   // (((c0 + c1) + c2) + c3) of the four components
+    const float s0 = __shfl(acc, (lane & ~3) + 0, 32), s1 = __shfl(acc, (lane & ~3) + 1, 32);
+    const float s2 = __shfl(acc, (lane & ~3) + 2, 32), s3 = __shfl(acc, (lane & ~3) + 3, 32);
+    return __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
+}
+
+// SSIM in the reference's float4 order (count_SSIM_luma/_chroma, :1610-2095): lane-component `comp` accumulates
+// pixels (r, 4j+comp), r outer, j inner; n = 16 (luma) or 8 (chroma).  The per-pixel terms (deviation squares and
+// products) are computed by all 32 lanes and parked in LDS in chain order; only the 64- (16-) term accumulation
+// chains, whose order is the result, run on the 12 chain lanes.  All float ops are written so that nothing can
+// be contracted (the reference's mad is a*b+c, unfused).
+// All LDS traffic of a macroblock stays inside its own 32 lanes = half of one wave, so program order is the
+// only synchronisation needed: there is no workgroup barrier in this kernel.
 __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
-    __shared__ MBTile s_t[8];
+    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int mb_raw = blockIdx.x * 8 + g;
     const bool live = mb_raw < a.mbs;
@@ -265,33 +320,38 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
             *reinterpret_cast<uint32_t *>(&s_t[g].cur[tile_off + (by * 4 + r) * msz + bx * 4]) = cw;
         }
     }
-    __syncthreads();
-
     // ---- SSIM terms of the current frame: mean (exact in float) and variance chain ---------------
-    // lanes 0..11: plane sp = lane>>2, float4 component comp = lane&3
+    // chain lanes 0..11: plane sp = lane>>2, float4 component comp = lane&3
     const int sp = (lane >> 2) < 3 ? (lane >> 2) : 2, comp = lane & 3;
-    const int sn = sp == 0 ? 16 : 8;
-    const uint8_t *tc = &s_t[g].cur[sp == 0 ? 0 : (sp == 1 ? 256 : 320)];
-    const uint8_t *tr = &s_t[g].rec[sp == 0 ? 0 : (sp == 1 ? 256 : 320)];
-    const float area = (float)(sn * sn);
-    float M1, D1;
+    const int n4 = sp == 0 ? 64 : 16;                                       // terms per chain
+    const int chain_off = (sp == 0 ? 0 : (sp == 1 ? 256 : 320)) + comp * n4;
+    const float area = sp == 0 ? 256.0f : 64.0f;
+    // term lanes (all 32): Y dwords `lane` and `lane+32` (sequence index = dword index), chroma dword `lane&15`
+    // of U (lanes 0-15) or V (16-31); byte k of a dword belongs to component k
+    const uint32_t *cur32 = reinterpret_cast<const uint32_t *>(s_t[g].cur);
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(s_t[g].rec);
+    const int coff = (lane < 16 ? 256 : 320) + (lane & 15);
+    float *fa = s_t[g].fa, *fb = s_t[g].fb;
+    float M1y, M1c, M1, D1;
     {
-        float acc = 0.0f;
-        for (int r = 0; r < sn; ++r)
-            for (int j = 0; j < sn / 4; ++j) acc = __fadd_rn(acc, (float)tc[r * sn + 4 * j + comp]);
-        const float s0 = __shfl(acc, (lane & ~3) + 0, 32), s1 = __shfl(acc, (lane & ~3) + 1, 32);
-        const float s2 = __shfl(acc, (lane & ~3) + 2, 32), s3 = __shfl(acc, (lane & ~3) + 3, 32);
-        M1 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3), area);
-        acc = 0.0f;
-        for (int r = 0; r < sn; ++r)
-            for (int j = 0; j < sn / 4; ++j) {
-                const float t = __fsub_rn((float)tc[r * sn + 4 * j + comp], M1);
-                const float tt = __fmul_rn(t, t);
-                acc = (r == 0 && j == 0) ? tt : __fadd_rn(tt, acc);
+        int sy, sc;
+        tile_sums(cur32, lane, sy, sc);
+        M1y = __fdiv_rn((float)sy, 256.0f);
+        M1c = __fdiv_rn((float)sc, 64.0f);
+        const float mu = __shfl(M1c, 0, 32), mv = __shfl(M1c, 16, 32);
+        M1 = sp == 0 ? M1y : (sp == 1 ? mu : mv);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const uint32_t w = cur32[h < 2 ? lane + 32 * h : 64 + lane];
+            const float m = h < 2 ? M1y : M1c;
+            const int off = h < 2 ? lane + 32 * h : coff, cs = h < 2 ? 64 : 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = __fsub_rn((float)byte_of(w, k), m);
+                fa[off + k * cs] = __fmul_rn(t, t);
             }
-        const float d0 = __shfl(acc, (lane & ~3) + 0, 32), d1 = __shfl(acc, (lane & ~3) + 1, 32);
-        const float d2 = __shfl(acc, (lane & ~3) + 2, 32), d3 = __shfl(acc, (lane & ~3) + 3, 32);
-        D1 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(d0, d1), d2), d3), area);
+        }
+        D1 = __fdiv_rn(sum4(chain(fa + chain_off, n4), lane), area);
     }
 
     float ssim = -2.0f;  // pack_8x8_into_16x16, :1352
@@ -304,11 +364,10 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
     bool any_pass = false;
 
     for (int seg = 3; seg >= 0; --seg) {        // inter_part.h:329
-        // dct4x4 gate, :1391 (same value in all 32 lanes of a macroblock).  The eight macroblocks of
-        // the workgroup may need different numbers of passes: barriers stay workgroup-uniform.
-        const bool do_pass = !(ssim > a.ssim_target);
-        if (!__syncthreads_or(do_pass)) break;
-        if (do_pass) {
+        // dct4x4 gate, :1391 (same value in all 32 lanes of a macroblock; the two macroblocks of a wave may
+        // leave the loop at different passes)
+        if (ssim > a.ssim_target) break;
+        {
         any_pass = true;
         seg_final = seg;
         const int i = SD[seg * SD_INTS + SD_Y_AC_I];
@@ -322,9 +381,10 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
         }
         if (blk) {
             fdct4x4(res, coef);
-            coef[0] /= dc_q;                     // truncating, :1478-1481
+            const TDiv ddc = tdiv_make(dc_q), dac = tdiv_make(ac_q);
+            coef[0] = tdiv(coef[0], ddc);        // truncating, :1478-1481
 #pragma unroll
-            for (int k = 1; k < 16; ++k) coef[k] /= ac_q;
+            for (int k = 1; k < 16; ++k) coef[k] = tdiv(coef[k], dac);
         }
         if (parts == 0) {                        // wht4x4_iwht4x4, :1498-1543 (all lanes: shuffles)
             int X[16];
@@ -332,7 +392,7 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
             for (int k = 0; k < 16; ++k) X[k] = (int16_t)__shfl(coef[0], k, 32);
             const int y2dc = k_dc_q[qi(SD[SD_Y2_DC_IDELTA] + i)] * 2;
             const int y2ac = imax(31 * k_ac_q[qi(SD[SD_Y2_AC_IDELTA] + i)] / 20, 8);
-            wht_roundtrip(X, q24, y2dc, y2ac);
+            wht_roundtrip(X, q24, y2dc, y2ac, tdiv_make(y2dc), tdiv_make(y2ac));
             if (lane < 16) {
                 int nd = X[0];
 #pragma unroll
@@ -342,9 +402,9 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
         }
         if (blk) {                               // idct4x4, :1545-1608
             int L[16];
-            L[0] = (int16_t)coef[0] * dc_q;
+            L[0] = __mul24((int16_t)coef[0], dc_q);
 #pragma unroll
-            for (int k = 1; k < 16; ++k) L[k] = (int16_t)coef[k] * ac_q;
+            for (int k = 1; k < 16; ++k) L[k] = __mul24((int16_t)coef[k], ac_q);
             idct4x4(L);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -358,33 +418,31 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
             }
         }
         }
-        __syncthreads();
-        if (do_pass) {
+        {
         // count_SSIM_*, gather_SSIM
         float M2, D, C;
         {
-            float acc = 0.0f;
-            for (int r = 0; r < sn; ++r)
-                for (int j = 0; j < sn / 4; ++j) acc = __fadd_rn(acc, (float)tr[r * sn + 4 * j + comp]);
-            const float s0 = __shfl(acc, (lane & ~3) + 0, 32), s1 = __shfl(acc, (lane & ~3) + 1, 32);
-            const float s2 = __shfl(acc, (lane & ~3) + 2, 32), s3 = __shfl(acc, (lane & ~3) + 3, 32);
-            M2 = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3), area);
-            float acc2 = 0.0f, acc3 = 0.0f;
-            for (int r = 0; r < sn; ++r)
-                for (int j = 0; j < sn / 4; ++j) {
-                    const float t1 = __fsub_rn((float)tc[r * sn + 4 * j + comp], M1);
-                    const float t2 = __fsub_rn((float)tr[r * sn + 4 * j + comp], M2);
-                    const float tt = __fmul_rn(t2, t2);
-                    const float tc12 = __fmul_rn(t1, t2);
-                    acc2 = (r == 0 && j == 0) ? tt : __fadd_rn(tt, acc2);
-                    acc3 = (r == 0 && j == 0) ? tc12 : __fadd_rn(acc3, tc12);
+            int sy, sc;
+            tile_sums(rec32, lane, sy, sc);
+            const float M2y = __fdiv_rn((float)sy, 256.0f), M2c = __fdiv_rn((float)sc, 64.0f);
+            const float mu = __shfl(M2c, 0, 32), mv = __shfl(M2c, 16, 32);
+            M2 = sp == 0 ? M2y : (sp == 1 ? mu : mv);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const int di = h < 2 ? lane + 32 * h : 64 + lane;
+                const uint32_t wc = cur32[di], wr = rec32[di];
+                const float m1 = h < 2 ? M1y : M1c, m2 = h < 2 ? M2y : M2c;
+                const int off = h < 2 ? lane + 32 * h : coff, cs = h < 2 ? 64 : 16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t1 = __fsub_rn((float)byte_of(wc, k), m1);
+                    const float t2 = __fsub_rn((float)byte_of(wr, k), m2);
+                    fa[off + k * cs] = __fmul_rn(t2, t2);
+                    fb[off + k * cs] = __fmul_rn(t1, t2);
                 }
-            const float d0 = __shfl(acc2, (lane & ~3) + 0, 32), d1 = __shfl(acc2, (lane & ~3) + 1, 32);
-            const float d2 = __shfl(acc2, (lane & ~3) + 2, 32), d3 = __shfl(acc2, (lane & ~3) + 3, 32);
-            D = __fadd_rn(D1, __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(d0, d1), d2), d3), area));
-            const float c0 = __shfl(acc3, (lane & ~3) + 0, 32), c1_ = __shfl(acc3, (lane & ~3) + 1, 32);
-            const float c2_ = __shfl(acc3, (lane & ~3) + 2, 32), c3 = __shfl(acc3, (lane & ~3) + 3, 32);
-            C = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(c0, c1_), c2_), c3), area);
+            }
+            D = __fadd_rn(D1, __fdiv_rn(sum4(chain(fa + chain_off, n4), lane), area));
+            C = __fdiv_rn(sum4(chain(fb + chain_off, n4), lane), area);
         }
         const float k1 = 0.01f * 0.01f * 255 * 255, k2 = 0.03f * 0.03f * 255 * 255;
         const float num = __fmul_rn(__fadd_rn(__fmul_rn(M1, __fmul_rn(M2, 2.0f)), k1), __fadd_rn(__fmul_rn(C, 2.0f), k2));
