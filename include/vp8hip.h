@@ -30,7 +30,9 @@ typedef enum {
     VP8HIP_ERR_NO_DEVICE = -2, /* no HIP device, or device_ordinal out of range */
     VP8HIP_ERR_HIP = -3,       /* a HIP runtime call failed (vp8hip_last_hip_error) */
     VP8HIP_ERR_STATE = -4,     /* call out of order (e.g. loop filter before any transform) */
-    VP8HIP_ERR_ARCH = -5       /* device is not gfx950: the kernels are built for MI355X only */
+    VP8HIP_ERR_ARCH = -5,      /* device is not gfx950: the kernels are built for MI355X only */
+    VP8HIP_ERR_TIMEOUT = -6    /* a bounded device-side wait of the loop filter expired: the frame is invalid
+                                  (reported by vp8hip_synchronize / vp8hip_download_*; the context stays usable) */
 } vp8hip_status;
 
 /* segment_data[4], vp8enc.h:80-92: 11 ints per segment */

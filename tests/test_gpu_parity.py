@@ -278,6 +278,36 @@ def test_error_behaviour():
     hip.close()
 
 
+def test_loop_filter_waits_are_bounded():
+    """Every device-side wait of the loop filter is bounded: with the inter-band counters sabotaged (test hook)
+    the launch ends by itself, the next synchronising call reports VP8HIP_ERR_TIMEOUT, and the context then
+    filters the same frame correctly."""
+    import time
+    W, H = 256, 192                       # 12 MB rows + flush row = 2 bands
+    f = _frames(W, H, 5)
+    sd = default_segments()
+    hip, ora = api.Vp8Hip(W, H), Oracle(W, H)
+    for be in (hip, ora):
+        be.set_segments(sd); be.upload_last(*f[0]); be.upload_current(*f[1]); be.inter_transform(0, 0, 0, 0)
+    pre = hip.download_results()
+    assert hip.lib.vp8hip_debug_lf_stall(hip.h, 1) == 0
+    t0 = time.perf_counter()
+    hip.loop_filter()
+    rc = hip.lib.vp8hip_synchronize(hip.h)
+    dt = time.perf_counter() - t0
+    assert rc == -6 and hip.lib.vp8hip_status_string(rc).decode().startswith("a bounded"), rc
+    assert dt < 60, f"time-out took {dt:.1f} s"
+    assert hip.lib.vp8hip_synchronize(hip.h) == 0          # reported once, context usable
+    assert hip.lib.vp8hip_debug_lf_stall(hip.h, 0) == 0
+    # same frame again, now for real
+    hip.upload_recon(pre["prefilter_Y"], pre["prefilter_U"], pre["prefilter_V"])
+    hip.loop_filter(); ora.loop_filter()
+    hy, hu, hv = hip.download_last()
+    oy, ou, ov = ora.download_last()
+    assert np.array_equal(hy, oy) and np.array_equal(hu, ou) and np.array_equal(hv, ov)
+    hip.close(); ora.close()
+
+
 # ---- the committed golden vectors (outputs of the reference's own kernels, scripts/gen_golden.py) ----
 import glob as _glob
 import os as _os

@@ -140,6 +140,8 @@ struct Args {
     int32_t *gprog;   // [bands] gbase + macroblocks of the band's bottom strip published so far
     int gbase;        // counters only grow: launch n uses the range (n*(mbw+2), (n+1)*(mbw+2)], so no memset
     int mbw, mbh, nbands;
+    int32_t *err;     // set to 1 if a bounded wait expired (the host reports VP8HIP_ERR_TIMEOUT)
+    int stall_test;   // test hook: publishers count from a wrong base, so every later band must time out
 };
 
 struct Shared {
@@ -148,16 +150,32 @@ struct Shared {
     volatile int flag[8];                         // worker progress, F_TOP, F_PUB
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
+    volatile int abort;                           // a bounded wait expired somewhere in this workgroup: everybody leaves
 };
 
 constexpr int NWAVES = WORKERS + 2;         // workers + loader + publisher
+
+// Every wait in this kernel is bounded (dispatch order and co-residency of workgroups are not architecturally
+// guaranteed): a wait that is still unsatisfied after SPIN_LIMIT polls (>= 0.3 s; a frame takes < 1 ms) raises the
+// workgroup's abort flag and the error word in HBM, and every wave that sees the flag leaves the kernel.  The
+// frame is then invalid -- reported as VP8HIP_ERR_TIMEOUT -- but nothing hangs.
+constexpr int SPIN_LIMIT = 1 << 22;
+#define LF_WAIT(cond_unsatisfied, nap)                                              \
+    {                                                                               \
+        int spins_ = 0;                                                             \
+        while ((cond_unsatisfied) && !sh.abort) {                                   \
+            __builtin_amdgcn_s_sleep(nap);                                          \
+            if (++spins_ > SPIN_LIMIT / (nap)) { sh.abort = 1; *a.err = 1; }        \
+        }                                                                           \
+        if (sh.abort) return;                                                       \
+    }
 
 __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
     const int band = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 8) sh.flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
+    if (threadIdx.x == 0) { sh.first_lf0 = 0x7fffffff; sh.abort = 0; }
     __syncthreads();
     const int mbw = a.mbw, mbh = a.mbh;
     const int band_row0 = band * ROWS;
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         const uint8_t *sp = sh.strip[ROWS] + pl * STRIP_PLANE + rr * SROW;
         for (int x = 0; x <= mbw; ++x) {
             const int done = 2 * (x + ROWS - 1) + 2;   // the last row has finished macroblock x
-            while (sh.flag[WORKERS - 1] < done) __builtin_amdgcn_s_sleep(3);
+            LF_WAIT(sh.flag[WORKERS - 1] < done, 3)
             if (lane < 44) {
                 const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & rmask));
                 st_sc1(reinterpret_cast<uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz - 4) + j, v);
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 sh.flag[F_PUB] = x + 1;
-                __hip_atomic_store(&a.gprog[band], a.gbase + x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.gprog[band], a.gbase + x + 1 - (a.stall_test ? (1 << 20) : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -228,23 +246,24 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         // That store is done here, not by worker 0: a write-through store takes longer than a step to retire and
         // would sit in front of every vmcnt wait of the worker.  Block m = columns m0-4 .. m0+msz-5, final when
         // row 0 has finished macroblock m (row 0: step == macroblock).
-        auto drain_top = [&](int m) {
-            while (sh.flag[0] < 2 * m + 2) __builtin_amdgcn_s_sleep(8);
-            if (lane < 32) st_sc1(reinterpret_cast<uint32_t *>(gp + m * msz - 4), *reinterpret_cast<const uint32_t *>(sp + ((m * msz - 4 + 4 * j) & rmask)));
-        };
+#define DRAIN_TOP(m)                                                                                        \
+    {                                                                                                       \
+        LF_WAIT(sh.flag[0] < 2 * (m) + 2, 8)                                                                 \
+        if (lane < 32) st_sc1(reinterpret_cast<uint32_t *>(gp + (m) * msz - 4),                             \
+                              *reinterpret_cast<const uint32_t *>(sp + (((m) * msz - 4 + 4 * j) & rmask))); \
+    }
         for (int x = 0; x < mbw; ++x) {
             // columns x0+13..15 are final once the previous band's last row has run P1 of macroblock x+1
             const int need = imin(x + 2, mbw + 1);
-            while (__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need)
-                __builtin_amdgcn_s_sleep(2);
+            LF_WAIT(__hip_atomic_load(&a.gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gbase < need, 2)
             // ring space: the slot still holds macroblock x-RING_MB, whose last four columns belong to the block
             // of macroblock x-RING_MB+1
-            if (x >= RING_MB - 1) drain_top(x - (RING_MB - 1));
+            if (x >= RING_MB - 1) DRAIN_TOP(x - (RING_MB - 1))
             if (lane < 32) *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = ld_sc1(reinterpret_cast<const uint32_t *>(gp + x * msz));
             lds_fence();
             if (lane == 0) sh.flag[F_TOP] = x + 1;
         }
-        for (int m = imax(mbw - (RING_MB - 1), 0); m <= mbw; ++m) drain_top(m);
+        for (int m = imax(mbw - (RING_MB - 1), 0); m <= mbw; ++m) DRAIN_TOP(m)
         return;
     }
 
@@ -383,12 +402,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
             const int need_top = imin(x_r0 + 1, mbw);
             // last wave: the publisher must have drained what the second row is about to overwrite in strip[ROWS]
             const int need_pub = (wave + 1 == WORKERS && publishes) ? S - (ROWS - 1) - (RING_MB - 2) : 0;
-            for (;;) {
+            for (int spins = 0;; ++spins) {
                 const int f_up = wave > 0 ? sh.flag[wave - 1] : need_up;
                 const int f_dn = wave + 1 < WORKERS ? sh.flag[wave + 1] : need_dn;
                 const int f_top = top_dep ? sh.flag[F_TOP] : need_top;
                 const int f_pub = sh.flag[F_PUB];
                 if (f_up >= need_up && f_dn >= need_dn && f_top >= need_top && f_pub >= need_pub) break;
+                if (spins > SPIN_LIMIT) { sh.abort = 1; *a.err = 1; }
+                if (sh.abort) return;
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 }  // namespace lf3
 
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no) {
+                         int mbw, int mbh, unsigned launch_no, int stall_test) {
     lf3::Args a;
     a.Y = recon.Y[0];
     a.U = recon.U;
@@ -453,6 +474,8 @@ void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, cons
     const unsigned n = launch_no % window;
     if (n == 0) hipMemsetAsync(progress, 0, sizeof(int32_t) * (a.nbands + 1), s);
     a.gbase = (int)(n * (unsigned)(mbw + 2));
+    a.err = progress + LF_ERR_WORD;
+    a.stall_test = stall_test;
     hipLaunchKernelGGL(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
 }
 

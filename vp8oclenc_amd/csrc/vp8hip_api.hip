@@ -50,6 +50,7 @@ struct vp8hip_ctx {
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
+    int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters time out
     void *scratch = nullptr;        // device staging for debug pyramid downloads
 
     uint32_t prof_mask = 0;
@@ -239,7 +240,8 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->out.first_lf0, 64));
     CR(hipMalloc(&c->d_sd, sizeof(SegData)));
     CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
-    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096)
+    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
+    CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
     CR(hipMalloc(&c->scratch, (size_t)width * height));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
@@ -442,7 +444,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     Frame &f = c->frames[c->recon].f;
     {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++);
+        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
     }
     {
         Timed t(c, VP8HIP_K_BORDER);
@@ -457,6 +459,15 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     return VP8HIP_OK;
 }
 
+// stream idle -> did a bounded device-side wait expire since the last check?  (kernels_lf3.hip, LF_WAIT)
+static int check_device_timeout(vp8hip_ctx *c) {
+    int32_t flag = 0;
+    HIPCHK(c, hipMemcpy(&flag, c->d_progress + LF_ERR_WORD, 4, hipMemcpyDeviceToHost));
+    if (!flag) return VP8HIP_OK;
+    HIPCHK(c, hipMemset(c->d_progress + LF_ERR_WORD, 0, 4));
+    return VP8HIP_ERR_TIMEOUT;
+}
+
 int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
@@ -466,13 +477,13 @@ int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
     if (u && (rc = copy_out(c, u, f.U))) return rc;
     if (v && (rc = copy_out(c, v, f.V))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VP8HIP_OK;
+    return check_device_timeout(c);
 }
 
 int vp8hip_synchronize(vp8hip_ctx *c) {
     if (!c) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VP8HIP_OK;
+    return check_device_timeout(c);
 }
 
 void *vp8hip_stream(vp8hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -486,6 +497,7 @@ const char *vp8hip_status_string(int status) {
         case VP8HIP_ERR_HIP: return "HIP runtime error";
         case VP8HIP_ERR_STATE: return "call out of order";
         case VP8HIP_ERR_ARCH: return "device is not gfx950";
+        case VP8HIP_ERR_TIMEOUT: return "a bounded device-side wait expired; the frame is invalid";
         default: return "unknown";
     }
 }
@@ -564,6 +576,14 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(dd);
     hipFree(dout);
+    return VP8HIP_OK;
+}
+
+// test hook (not in the public header): while on, the loop filter's inter-band counters are published from a wrong
+// base, so every band but the first runs into its bounded wait -> VP8HIP_ERR_TIMEOUT at the next synchronize
+int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
+    if (!c) return VP8HIP_ERR_ARG;
+    c->lf_stall_test = on ? 1 : 0;
     return VP8HIP_OK;
 }
 

@@ -13,6 +13,7 @@ namespace vp8 {
 
 constexpr int PAD = 32;        // allocated margin (pixels) around every plane
 constexpr int EXT = 8;         // replicated-edge width actually filled (max reach of any filter: 3)
+constexpr int LF_ERR_WORD = 1536;   // int index inside the loop filter's progress buffer of its time-out flag
 constexpr int SD_INTS = 11;    // ints per segment_data, src/vp8enc.h:80-92
 enum { SD_Y_AC_I = 0, SD_Y_DC_IDELTA, SD_Y2_DC_IDELTA, SD_Y2_AC_IDELTA, SD_UV_DC_IDELTA, SD_UV_AC_IDELTA,
        SD_LOOP_FILTER_LEVEL, SD_MBEDGE_LIMIT, SD_SUB_BEDGE_LIMIT, SD_INTERIOR_LIMIT, SD_HEV_THRESHOLD };
@@ -62,7 +63,7 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no);  // banded wavefront in LDS, one-step row lag
+                         int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
