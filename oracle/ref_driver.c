@@ -150,3 +150,29 @@ void ref_loop_filter_frame(uint8_t *frame, const int32_t *MB_segment_ids, const 
     else
         loop_filter_frame_chroma(frame, MB_segment_ids, mb_mask, SD, width, height);
 }
+
+/* ---- coefficient entropy stage, src/CPU_kernels.cl:347-778 (run on the CPU device by the reference,
+ * one work-item per partition: src/vp8enc.cpp:48-94) ------------------------------------------------- */
+void count_probs(const int16_t *MB, const int32_t *nz, const int32_t *MB_parts, uint32_t *coeff_probs,
+                 uint32_t *coeff_probs_denom, uint8_t *third_context, int mb_height, int mb_width,
+                 int num_partitions, int partition_step);
+void num_div_denom(uint32_t *coeff_probs, const uint32_t *coeff_probs_denom, int num_partitions);
+void encode_coefficients(const int16_t *MB, const int32_t *nz, const int32_t *MB_parts, uint8_t *output,
+                         int32_t *partition_sizes, const uint8_t *third_context, const uint32_t *coeff_probs,
+                         int mb_height, int mb_width, int num_partitions, int partition_step);
+
+void ref_count_probs(const int16_t *MB, const int32_t *nz, const int32_t *MB_parts, uint32_t *coeff_probs,
+                     uint32_t *coeff_probs_denom, uint8_t *third_context, int mb_height, int mb_width,
+                     int num_partitions) {
+    NDRANGE(num_partitions, 1, count_probs(MB, nz, MB_parts, coeff_probs, coeff_probs_denom, third_context, mb_height,
+                                           mb_width, num_partitions, 0));
+}
+void ref_num_div_denom(uint32_t *coeff_probs, const uint32_t *coeff_probs_denom, int num_partitions) {
+    NDRANGE(num_partitions, 1, num_div_denom(coeff_probs, coeff_probs_denom, num_partitions));
+}
+void ref_encode_coefficients(const int16_t *MB, const int32_t *nz, const int32_t *MB_parts, uint8_t *output,
+                             int32_t *partition_sizes, const uint8_t *third_context, const uint32_t *coeff_probs,
+                             int mb_height, int mb_width, int num_partitions, int partition_step) {
+    NDRANGE(num_partitions, 1, encode_coefficients(MB, nz, MB_parts, output, partition_sizes, third_context,
+                                                   coeff_probs, mb_height, mb_width, num_partitions, partition_step));
+}

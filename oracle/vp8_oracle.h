@@ -89,6 +89,18 @@ void vp8o_prepare_filter_mask(const int16_t *MB, int32_t *MB_non_zero_coeffs, co
 void vp8o_loop_filter_frame(uint8_t *frame, const int32_t *MB_segment_ids, const int32_t *mb_mask,
                             const int32_t *SD, int width, int height, int mb_size);
 
+/* Coefficient entropy stage (vp8_entropy_oracle.c), src/CPU_kernels.cl:347-778; all partitions in one call.
+ * coeff_probs / coeff_probs_denom: uint[num_partitions][4][8][3][11]; third_context: uchar[MBs][25];
+ * after vp8o_num_div_denom the first [4][8][3][11] of coeff_probs are the frame's probabilities. */
+void vp8o_count_probs(const int16_t *MB, const int32_t *MB_non_zero_coeffs, const int32_t *MB_parts,
+                      uint32_t *coeff_probs, uint32_t *coeff_probs_denom, uint8_t *third_context, int mb_height,
+                      int mb_width, int num_partitions);
+void vp8o_num_div_denom(uint32_t *coeff_probs, const uint32_t *coeff_probs_denom, int num_partitions);
+void vp8o_encode_coefficients(const int16_t *MB, const int32_t *MB_non_zero_coeffs, const int32_t *MB_parts,
+                              uint8_t *output, int32_t *partition_sizes, const uint8_t *third_context,
+                              const uint32_t *coeff_probs, int mb_height, int mb_width, int num_partitions,
+                              int partition_step);
+
 /* ------------------------------------------------------------------------------------------
  * Whole inter frame, in the enqueue order of src/inter_part.h:96-384 followed by
  * src/loop_filter.h:25-55,140-183.  One context keeps the three references and their pyramids

@@ -23,6 +23,7 @@ u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 ci = C.c_int
 
 _STAGES = {
@@ -39,16 +40,21 @@ _STAGES = {
     "gather_SSIM": [f32p, f32p, f32p, f32p, ci],
     "prepare_filter_mask": [i16p, i32p, i32p, i32p, ci, ci],
     "loop_filter_frame": [u8p, i32p, i32p, i32p, ci, ci, ci],
+    # coefficient entropy stage (src/CPU_kernels.cl:347-778), all partitions per call
+    "count_probs": [i16p, i32p, i32p, u32p, u32p, u8p, ci, ci, ci],
+    "num_div_denom": [u32p, u32p, ci],
+    "encode_coefficients": [i16p, i32p, i32p, u8p, i32p, u8p, u32p, ci, ci, ci, ci],
 }
 
 
 def build_oracle(force: bool = False) -> str:
     """Compile oracle/liboracle.so (and oracle/_ref when /root/reference is present)."""
-    src = os.path.join(ORACLE_DIR, "vp8_oracle.c")
-    stale = (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vp8_oracle.c", "vp8_entropy_oracle.c", "vp8_oracle.h")]
+    stale = (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO)):
+    drv = os.path.join(ORACLE_DIR, "ref_driver.c")
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO) or os.path.getmtime(REF_SO) < os.path.getmtime(drv)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
