@@ -95,6 +95,19 @@ int vp8hip_prepare_filter_mask(vp8hip_ctx *ctx, int32_t *nz_out);
  * after which that reconstruction IS the LAST reference of the next vp8hip_inter_transform. */
 int vp8hip_loop_filter(vp8hip_ctx *ctx);
 
+/* ---- coefficient entropy stage: the consumer of the coefficient buffer -------------------------
+ * The reference runs it on a CPU OpenCL device, one work-item per partition (vp8enc.cpp:48-94).  Here the
+ * statistics are a device histogram over all blocks.  Input = the context's current coefficients, MB_parts
+ * and non-zero counts (as left by vp8hip_inter_transform, or vp8hip_upload_mb_data + vp8hip_prepare_filter_mask).
+ *
+ * count_probs + num_div_denom + the two read-backs of vp8enc.cpp:58-69.
+ *   new_probs[4][8][3][11]       probability (1..255) of a zero branch per context, summed over the partitions;
+ *   new_probs_denom[4][8][3][11] partition 0's denominators (1 + branches seen), which is what the reference's
+ *                                host code inspects to fall back to the default probabilities (:70-76).
+ * num_partitions: 1, 2, 4 or 8 (partition p owns macroblock rows p, p+n, ...). */
+#define VP8HIP_NUM_COEFF_PROBS 1056
+int vp8hip_count_probs(vp8hip_ctx *ctx, int num_partitions, uint32_t *new_probs, uint32_t *new_probs_denom);
+
 /* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
 int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
 
@@ -119,6 +132,7 @@ typedef enum {
     VP8HIP_K_FILTER_MASK,   /* prepare_filter_mask (recompute)   CPU_kernels.cl:782  */
     VP8HIP_K_LOOP_FILTER,   /* loop_filter_frame_luma/_chroma    CPU_kernels.cl:970,1333 */
     VP8HIP_K_BORDER,        /* edge replication of a new reference */
+    VP8HIP_K_ENT_COUNT,     /* count_probs + num_div_denom       CPU_kernels.cl:536,764 */
     VP8HIP_K_COUNT
 } vp8hip_kernel_id;
 
@@ -134,7 +148,8 @@ typedef enum {
     VP8HIP_DBG_BDIFF,      /* ref, -      : int[b8]                                               */
     VP8HIP_DBG_PYRAMID,    /* ref(3=cur), level 0..4 : tight (W>>l)x(H>>l) plane                   */
     VP8HIP_DBG_MB_MASK,    /* -           : int[MBs]                                              */
-    VP8HIP_DBG_MB_NZ       /* -           : int[MBs]                                              */
+    VP8HIP_DBG_MB_NZ,      /* -           : int[MBs]                                              */
+    VP8HIP_DBG_THIRD_CONTEXT /* -         : uchar[MBs][25] (entries of coded macroblocks, after vp8hip_count_probs) */
 } vp8hip_debug_id;
 int vp8hip_debug_download(vp8hip_ctx *ctx, int what, int ref, int level, void *dst, size_t bytes);
 

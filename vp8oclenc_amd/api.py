@@ -14,10 +14,10 @@ import numpy as np
 from . import build as _build
 
 K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "search1_l1", "search1_l0", "search2",
-           "select", "mb", "filter_mask", "loop_filter", "border"]
+           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count"]
 K_COUNT = len(K_NAMES)
 
-DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ = range(6)
+DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT = range(7)
 
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
-    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done",
@@ -89,6 +89,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8hip_profile_enable.argtypes = [vp, C.c_uint32]
     lib.vp8hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.vp8hip_debug_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.vp8hip_count_probs.argtypes = [vp, C.c_int, C.c_void_p, C.c_void_p]
     i32p = C.POINTER(C.c_int32)
     lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
     lib.vp8host_quantizer_ladders.restype = None
@@ -255,6 +256,12 @@ class Vp8Hip:
     def loop_filter(self):
         self._chk(self.lib.vp8hip_loop_filter(self.h), "loop_filter")
 
+    def count_probs(self, num_partitions: int):
+        """count_probs + num_div_denom (CPU_kernels.cl:536-778): (probs[1056], partition-0 denominators[1056])."""
+        probs, denom = np.zeros(1056, np.uint32), np.zeros(1056, np.uint32)
+        self._chk(self.lib.vp8hip_count_probs(self.h, num_partitions, probs.ctypes.data, denom.ctypes.data), "count_probs")
+        return probs, denom
+
     def download_last(self):
         W, H = self.W, self.H
         y, u, v = np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)
@@ -287,6 +294,8 @@ class Vp8Hip:
             a = np.zeros(self.b8, np.int32)
         elif what == DBG_PYRAMID:
             a = np.zeros((self.H >> level, self.W >> level), np.uint8)
+        elif what == DBG_THIRD_CONTEXT:
+            a = np.zeros((self.mbs, 25), np.uint8)
         else:
             a = np.zeros(self.mbs, np.int32)
         self._chk(self.lib.vp8hip_debug_download(self.h, what, ref, level, a.ctypes.data, a.nbytes), "debug_download")

@@ -52,6 +52,9 @@ struct vp8hip_ctx {
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
     int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters time out
     void *scratch = nullptr;        // device staging for debug pyramid downloads
+    // coefficient entropy stage: per-block flags and third contexts, token counts per partition, probabilities
+    uint8_t *ent_flags = nullptr, *ent_third = nullptr;
+    uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
 
     uint32_t prof_mask = 0;
     hipEvent_t ev[MAX_EVENTS];
@@ -243,6 +246,12 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
     CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
     CR(hipMalloc(&c->scratch, (size_t)width * height));
+    CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
+    CR(hipMalloc(&c->ent_third, (size_t)c->mbs * 25));
+    CR(hipMemsetAsync(c->ent_third, 0, (size_t)c->mbs * 25, c->stream));
+    CR(hipMalloc(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * ENT_MAX_PARTITIONS));
+    CR(hipMalloc(&c->ent_probs, sizeof(uint32_t) * ENT_NCTX));
+    CR(hipMalloc(&c->ent_denom0, sizeof(uint32_t) * ENT_NCTX));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.seg, 0, (size_t)c->mbs * 4, c->stream));
@@ -286,6 +295,11 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
     hipFree(c->d_progress);
     hipFree(c->scratch);
+    hipFree(c->ent_flags);
+    hipFree(c->ent_third);
+    hipFree(c->ent_counts);
+    hipFree(c->ent_probs);
+    hipFree(c->ent_denom0);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -459,6 +473,21 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     return VP8HIP_OK;
 }
 
+int vp8hip_count_probs(vp8hip_ctx *c, int num_partitions, uint32_t *new_probs, uint32_t *new_probs_denom) {
+    if (!c || !new_probs || !new_probs_denom) return VP8HIP_ERR_ARG;
+    if (num_partitions != 1 && num_partitions != 2 && num_partitions != 4 && num_partitions != 8) return VP8HIP_ERR_ARG;
+    {
+        Timed t(c, VP8HIP_K_ENT_COUNT);
+        launch_ent_count(c->stream, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw,
+                         c->mbh, num_partitions);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(new_probs, c->ent_probs, sizeof(uint32_t) * ENT_NCTX, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(new_probs_denom, c->ent_denom0, sizeof(uint32_t) * ENT_NCTX, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the reference's read-backs are blocking (CL_TRUE, vp8enc.cpp:67-68)
+    return VP8HIP_OK;
+}
+
 // stream idle -> did a bounded device-side wait expire since the last check?  (kernels_lf3.hip, LF_WAIT)
 static int check_device_timeout(vp8hip_ctx *c) {
     int32_t flag = 0;
@@ -550,6 +579,10 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
         case VP8HIP_DBG_MB_NZ:
             if (bytes != (size_t)c->mbs * 4) return VP8HIP_ERR_ARG;
             HIPCHK(c, hipMemcpyAsync(dst, what == VP8HIP_DBG_MB_MASK ? c->out.mask : c->out.nz, bytes, hipMemcpyDeviceToHost, s));
+            break;
+        case VP8HIP_DBG_THIRD_CONTEXT:
+            if (bytes != (size_t)c->mbs * 25) return VP8HIP_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(dst, c->ent_third, bytes, hipMemcpyDeviceToHost, s));
             break;
         case 100:  // diagnostic build only (-DLF2_STAMPS): cycle sums written by the loop filter
             if (bytes != 512) return VP8HIP_ERR_ARG;

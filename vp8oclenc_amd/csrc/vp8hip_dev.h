@@ -65,6 +65,12 @@ void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int 
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
                          int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
 
+// coefficient entropy stage (kernels_ent.hip): flags + third context + token histogram + probabilities
+constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
+constexpr int ENT_MAX_PARTITIONS = 8;
+void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
+                      uint32_t *denom0, int mbw, int mbh, int num_partitions);
+
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
