@@ -31,8 +31,9 @@ typedef enum {
     VP8HIP_ERR_HIP = -3,       /* a HIP runtime call failed (vp8hip_last_hip_error) */
     VP8HIP_ERR_STATE = -4,     /* call out of order (e.g. loop filter before any transform) */
     VP8HIP_ERR_ARCH = -5,      /* device is not gfx950: the kernels are built for MI355X only */
-    VP8HIP_ERR_TIMEOUT = -6    /* a bounded device-side wait of the loop filter expired: the frame is invalid
+    VP8HIP_ERR_TIMEOUT = -6,   /* a bounded device-side wait of the loop filter expired: the frame is invalid
                                   (reported by vp8hip_synchronize / vp8hip_download_*; the context stays usable) */
+    VP8HIP_ERR_OVERFLOW = -7   /* vp8hip_encode_coefficients: output or scratch too small for this frame */
 } vp8hip_status;
 
 /* segment_data[4], vp8enc.h:80-92: 11 ints per segment */
@@ -108,6 +109,16 @@ int vp8hip_loop_filter(vp8hip_ctx *ctx);
 #define VP8HIP_NUM_COEFF_PROBS 1056
 int vp8hip_count_probs(vp8hip_ctx *ctx, int num_partitions, uint32_t *new_probs, uint32_t *new_probs_denom);
 
+/* The write-back of the final probabilities, encode_coefficients and the read of the partitions (vp8enc.cpp:77-81,
+ * gather at entropy_host.cpp): codes the macroblock rows of every partition with the boolean coder, on the
+ * device, and returns partition p at partitions + p * partition_step with its length in partition_sizes[p].
+ * coeff_probs[4][8][3][11] (low byte used) = new_probs after the host's default-probability fallback.
+ * Must follow vp8hip_count_probs for the same coefficients and num_partitions (it reuses the block contexts).
+ * VP8HIP_ERR_OVERFLOW if a partition does not fit partition_step or the frame exceeds the device scratch
+ * (64 bools per 4x4 block on average, of at most 304; nothing is written then). */
+int vp8hip_encode_coefficients(vp8hip_ctx *ctx, const uint32_t *coeff_probs, int num_partitions, int partition_step,
+                               uint8_t *partitions, int32_t *partition_sizes);
+
 /* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
 int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
 
@@ -133,6 +144,7 @@ typedef enum {
     VP8HIP_K_LOOP_FILTER,   /* loop_filter_frame_luma/_chroma    CPU_kernels.cl:970,1333 */
     VP8HIP_K_BORDER,        /* edge replication of a new reference */
     VP8HIP_K_ENT_COUNT,     /* count_probs + num_div_denom       CPU_kernels.cl:536,764 */
+    VP8HIP_K_ENT_ENCODE,    /* encode_coefficients               CPU_kernels.cl:347 */
     VP8HIP_K_COUNT
 } vp8hip_kernel_id;
 

@@ -26,13 +26,22 @@ def device_with(coeffs, parts, mbw, mbh):
     return hip, nz
 
 
-def check_counts(hip, exp, nz, P, tag):
+def check_counts(hip, exp, nz, P, tag, parts=None):
     probs, denom0 = hip.count_probs(P)
     assert np.array_equal(probs, exp["probs"]), f"{tag}: probabilities differ at {np.nonzero(probs != exp['probs'])[0][:8]}"
     assert np.array_equal(denom0, exp["denom"][:1056]), f"{tag}: partition-0 denominators"
     third = hip.debug(api.DBG_THIRD_CONTEXT).reshape(-1)
-    m = np.repeat(nz != 0, 25)
+    m = np.repeat(nz != 0, 25)      # only coded blocks have an entry: the rest keeps whatever was there
+    if parts is not None:
+        m &= (np.tile(np.arange(25), len(nz)) < 24) | np.repeat(parts == 0, 25)
     assert np.array_equal(third[m], exp["third_context"][m]), f"{tag}: third_context"
+    if "partitions" in exp:          # the boolean coder: byte-exact partitions
+        got = hip.encode_coefficients(probs, P)
+        for p in range(P):
+            e = np.asarray(exp["partitions"][p])
+            assert len(got[p]) == len(e), f"{tag}: partition {p} is {len(got[p])} bytes, expected {len(e)}"
+            bad = np.nonzero(got[p] != e)[0]
+            assert bad.size == 0, f"{tag}: partition {p} differs at bytes {bad[:8]} of {len(e)}"
 
 
 CASES = [  # mbw, mbh, seed, partitions, kwargs
@@ -66,7 +75,8 @@ def test_count_probs_matches_reference_golden_vectors(path):
     coeffs, parts, nz = (np.ascontiguousarray(z[k]) for k in ("coeffs", "parts", "nz"))
     hip, dnz = device_with(coeffs, parts, mbw, mbh)
     assert np.array_equal(dnz, nz)
-    exp = dict(probs=z["probs"], denom=z["denom"], third_context=z["third_context"])
+    exp = dict(probs=z["probs"], denom=z["denom"], third_context=z["third_context"],
+               partitions=[z[f"partition_{p}"] for p in range(P)])
     check_counts(hip, exp, nz, P, os.path.basename(path))
     hip.close()
 
@@ -87,4 +97,29 @@ def test_count_probs_after_inter_transform():
     for P in (1, 4):
         exp = run_stage(Oracle.stages(), coeffs, parts, nz, s.W // 16, s.H // 16, P)
         check_counts(hip, exp, nz, P, f"after inter_transform, P{P}")
+    hip.close()
+
+
+def test_encode_needs_count_first_and_reports_overflow():
+    mbw, mbh = 6, 4
+    rng = np.random.default_rng(3)
+    coeffs = (rng.integers(67, 2049, size=(mbw * mbh, 25, 16)) * rng.choice([-1, 1], size=(mbw * mbh, 25, 16))).astype(np.int16)
+    parts = np.zeros(mbw * mbh, np.int32)
+    hip, nz = device_with(coeffs, parts, mbw, mbh)
+    probs = np.full(1056, 128, np.uint32)
+    with pytest.raises(api.Vp8HipError, match="out of order"):
+        hip.encode_coefficients(probs, 2)                   # block contexts not computed yet
+    probs, _ = hip.count_probs(2)
+    with pytest.raises(api.Vp8HipError, match="do not fit"):
+        hip.encode_coefficients(probs, 2)                   # 19 bools per coefficient: beyond the device scratch
+    with pytest.raises(api.Vp8HipError, match="out of order"):
+        hip.encode_coefficients(probs, 4)                   # other partition count than the statistics
+    # a frame that fits is fine on the same context afterwards
+    coeffs2, parts2, nz2 = synthetic(mbw, mbh, 9)
+    hip.upload_mb_data(coeffs2, parts2, np.zeros(mbw * mbh, np.int32))
+    assert np.array_equal(hip.prepare_filter_mask(), nz2)
+    exp = run_stage(Oracle.stages(), coeffs2, parts2, nz2, mbw, mbh, 2)
+    check_counts(hip, exp, nz2, 2, "after overflow", parts=parts2)
+    with pytest.raises(api.Vp8HipError, match="do not fit"):
+        hip.encode_coefficients(exp["probs"], 2, partition_step=16)   # caller's buffer too small
     hip.close()

@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "search1_l1", "search1_l0", "search2",
-           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count"]
+           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode"]
 K_COUNT = len(K_NAMES)
 
 DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT = range(7)
@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
-    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done",
@@ -90,6 +90,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.vp8hip_debug_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.vp8hip_count_probs.argtypes = [vp, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vp8hip_encode_coefficients.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     i32p = C.POINTER(C.c_int32)
     lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
     lib.vp8host_quantizer_ladders.restype = None
@@ -261,6 +262,16 @@ class Vp8Hip:
         probs, denom = np.zeros(1056, np.uint32), np.zeros(1056, np.uint32)
         self._chk(self.lib.vp8hip_count_probs(self.h, num_partitions, probs.ctypes.data, denom.ctypes.data), "count_probs")
         return probs, denom
+
+    def encode_coefficients(self, probs, num_partitions: int, partition_step: int = 0):
+        """encode_coefficients (CPU_kernels.cl:347-414) on the device: list of partition byte strings."""
+        probs = np.ascontiguousarray(probs, np.uint32)
+        step = partition_step or (self.mbs * 25 * 16 * 3 // num_partitions + 4096)
+        out = np.zeros(num_partitions * step, np.uint8)
+        sizes = np.zeros(num_partitions, np.int32)
+        self._chk(self.lib.vp8hip_encode_coefficients(self.h, probs.ctypes.data, num_partitions, step, out.ctypes.data,
+                                                      sizes.ctypes.data), "encode_coefficients")
+        return [out[p * step: p * step + sizes[p]].copy() for p in range(num_partitions)]
 
     def download_last(self):
         W, H = self.W, self.H

@@ -161,4 +161,375 @@ void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *th
     hipLaunchKernelGGL(ent::k_ent_probs, dim3((ent::NCTX + 255) / 256), dim3(256), 0, s, counts, probs, denom0, num_partitions);
 }
 
+// ====================================================================================================
+// Part 2: encode_coefficients (src/CPU_kernels.cl:347-414) -- the boolean coder, in parallel.
+//
+// The reference codes one partition per work-item, serially.  The coder's state after each bool is
+// (range, bottom, bit_count): `range` (128..255 after renormalisation) decides every split, `bottom` only
+// accumulates.  Written as exact arithmetic the output of a partition is the big number
+//        sum_i  add_i * 2^(8*nbytes - 8 - W_i)        (add_i = split if bool i is 1, else 0; W_i = shifts before i)
+// in nbytes = emitted + 4 bytes (the reference's flush writes the last 32 bits), carries included.  So:
+//   1. k_ent_boolcount / scan / k_ent_emit: every block turns its tokens into (probability, bit) pairs at its
+//      offset in the partition's bool string (block order = coding order);
+//   2. k_ent_maps: the string is cut into chunks of CHUNK bools; 128 lanes run a chunk from each of the 128
+//      possible start ranges and record (end range, shifts) -- the chunk as a function of its start state;
+//   3. k_ent_walk: one lane per partition composes those functions in order (one LDS lookup per chunk) and so
+//      learns every chunk's true start range and bit position;
+//   4. k_ent_encode: one lane per chunk replays it from its true state and adds each split at its bit position
+//      into 64-bit accumulators, one per 32 bits of output (neighbouring chunks meet in atomics);
+//   5. k_ent_finish: one wave per partition resolves the carries (carry-lookahead over 64 words per step) and
+//      writes the bytes.
+// Every step is checked against the serial reference coder through the byte-exact partitions.
+// ====================================================================================================
+namespace ent {
+
+constexpr int CHUNK = 256;        // bools per chunk
+constexpr int SCAN_TILE = 1024;   // slots per scan tile (256 threads x 4)
+
+__device__ __constant__ const int k_cat_base[6] = {5, 7, 11, 19, 35, 67};
+__device__ __constant__ const int k_cat_bits[6] = {1, 2, 3, 4, 5, 11};
+__device__ __constant__ const uint8_t k_cat_prob[6][11] = {   // :194-199
+    {159}, {165, 145}, {173, 148, 140}, {176, 155, 140, 135}, {180, 157, 141, 134, 130},
+    {254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129}};
+
+struct Geom {
+    int mbw, mbh, P;
+    uint32_t slot_base[ENT_MAX_PARTITIONS + 1];   // first slot of each partition (25 slots per macroblock, coding order)
+    uint32_t cap_bools, cap_chunks, cap_words;
+};
+using Plan = EntPlan;   // written on the device, read back by the host after the launch sequence (vp8hip_dev.h)
+
+// slot of (macroblock, k): k = 0 is block 24, 1..16 are Y 0..15, 17..24 are blocks 16..23
+__device__ __forceinline__ uint32_t slot_of(const Geom &g, int mb_row, int mb_col, int k) {
+    return g.slot_base[mb_row % g.P] + (uint32_t)(((mb_row / g.P) * g.mbw + mb_col) * 25 + k);
+}
+__device__ __forceinline__ int block_of_k(int k) { return k == 0 ? 24 : k - 1; }
+
+// the bools of one block in coding order (encode_block, :202-261): ctx(index into coeff_probs, bit) for tree
+// branches, lit(probability, bit) for extra bits and signs
+template <class Sink>
+__device__ __forceinline__ void walk_block(const int16_t *blk, int ctx1, int ctx3, Sink &sink) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(blk);
+    const uint4 q0 = p[0], q1 = p[1];
+    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    const int first = ctx1 == 0 ? 1 : 0;
+    int last = -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = (int16_t)(w[i >> 1] >> (16 * (i & 1)));
+        if (c != 0 && i >= first) last = i;
+    }
+    bool after_zero = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {   // unrolled: w[] stays in registers
+        if (i < first) continue;
+        const int c = (int16_t)(w[i >> 1] >> (16 * (i & 1)));
+        const int mag = c < 0 ? -c : c;
+        const int t = i > last ? T_EOB : classify(mag);
+        const uint32_t nodes = k_path_nodes[t];
+        const int bits = k_path_bits[t], len = k_path_len[t];
+        const int base = ((ctx1 * 8 + k_band[i]) * 3 + ctx3) * 11;
+        for (int s = after_zero ? 1 : 0; s < len; ++s) sink.ctx(base + ((nodes >> (4 * s)) & 15), (bits >> s) & 1);
+        if (t == T_EOB) break;
+        if (t >= T_CAT1) {
+            const int cat = t - T_CAT1, nb = k_cat_bits[cat], extra = mag - k_cat_base[cat];
+            for (int j = 0; j < nb; ++j) sink.lit(k_cat_prob[cat][j], (extra >> (nb - 1 - j)) & 1);
+        }
+        if (t != T_ZERO) sink.lit(128, c < 0);
+        after_zero = t == T_ZERO;
+        ctx3 = t == T_ZERO ? 0 : (t == T_ONE ? 1 : 2);
+    }
+}
+
+struct CountSink {
+    uint32_t n = 0;
+    __device__ __forceinline__ void ctx(int, int) { ++n; }
+    __device__ __forceinline__ void lit(int, int) { ++n; }
+};
+struct EmitSink {
+    uint16_t *out;
+    const uint32_t *probs;
+    __device__ __forceinline__ void ctx(int idx, int bit) { *out++ = (uint16_t)((probs[idx] & 255u) | (bit << 8)); }
+    __device__ __forceinline__ void lit(int prob, int bit) { *out++ = (uint16_t)(prob | (bit << 8)); }
+};
+
+// is slot k of macroblock mb coded at all?
+__device__ __forceinline__ bool slot_live(const int32_t *nzc, const int32_t *parts, int mb, int k, bool &has_y2) {
+    has_y2 = parts[mb] == 0;
+    return nzc[mb] != 0 && (k > 0 || has_y2);
+}
+
+__global__ __launch_bounds__(256) void k_ent_boolcount(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts, Geom g,
+                                                       uint32_t *cnt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.mbw * g.mbh * 25) return;
+    const int mb = t / 25, k = t % 25, b = block_of_k(k);
+    bool has_y2;
+    CountSink sink;
+    if (slot_live(nzc, parts, mb, k, has_y2)) walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), 0, sink);
+    cnt[slot_of(g, mb / g.mbw, mb % g.mbw, k)] = sink.n;
+}
+
+// ---- exclusive scan of cnt[0..n) in place, total in cnt[n]: tile sums, scan of the sums, per-tile scan -------
+__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *v, uint32_t *tile_sum, int n) {
+    __shared__ uint32_t s[256];
+    const int i0 = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    uint32_t a = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a += i0 + j < n ? v[i0 + j] : 0u;
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) s[threadIdx.x] += s[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *tile_sum, int ntiles) {   // ntiles <= 1024; exclusive, total at [ntiles]
+    __shared__ uint32_t s[1024];
+    const int t = threadIdx.x;
+    const uint32_t own = t < ntiles ? tile_sum[t] : 0u;
+    s[t] = own;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t add = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    if (t < ntiles) tile_sum[t] = s[t] - own;
+    if (t == ntiles - 1) tile_sum[ntiles] = s[t];
+}
+__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *v, const uint32_t *tile_sum, int n, int ntiles) {
+    __shared__ uint32_t s[256];
+    const int t = threadIdx.x, i0 = blockIdx.x * SCAN_TILE + t * 4;
+    uint32_t x[4], a = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = i0 + j < n ? v[i0 + j] : 0u; a += x[j]; }
+    s[t] = a;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t add = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = tile_sum[blockIdx.x] + s[t] - a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < n) v[i0 + j] = run;
+        run += x[j];
+    }
+    if (blockIdx.x == 0 && t == 0) v[n] = tile_sum[ntiles];
+}
+
+// per-partition layout of the bool string, its chunks and its output words
+__global__ void k_ent_plan(const uint32_t *offs, Geom g, Plan *plan) {
+    if (threadIdx.x != 0) return;
+    uint32_t cb = 0, wb = 0;
+    for (int p = 0; p < g.P; ++p) {
+        const uint32_t b0 = offs[g.slot_base[p]], b1 = offs[g.slot_base[p + 1]];
+        plan->bool_base[p] = b0;
+        plan->nbools[p] = b1 - b0;
+        plan->chunk_base[p] = cb;
+        plan->word_base[p] = wb;
+        cb += (b1 - b0 + CHUNK - 1) / CHUNK;
+        wb += ((b1 - b0) * 7 + 31) / 32 + 4;      // a bool shifts at most 7 bits out; + the flush
+    }
+    plan->bool_base[g.P] = offs[g.slot_base[g.P]];
+    plan->chunk_base[g.P] = cb;
+    plan->word_base[g.P] = wb;
+    plan->total_chunks = cb;
+    plan->overflow = (plan->bool_base[g.P] > g.cap_bools || cb > g.cap_chunks || wb > g.cap_words) ? 1u : 0u;
+    if (plan->overflow) {   // the later kernels then see empty partitions and touch nothing outside the scratch
+        plan->total_chunks = 0;
+        for (int p = 0; p <= g.P; ++p) plan->bool_base[p] = plan->chunk_base[p] = plan->word_base[p] = 0;
+        for (int p = 0; p < g.P; ++p) plan->nbools[p] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ent_emit(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
+                                                  const uint8_t *third_ctx, const uint32_t *probs, const uint32_t *offs,
+                                                  const Plan *plan, Geom g, uint16_t *bools) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.mbw * g.mbh * 25 || plan->overflow) return;
+    const int mb = t / 25, k = t % 25, b = block_of_k(k);
+    bool has_y2;
+    if (!slot_live(nzc, parts, mb, k, has_y2)) return;
+    EmitSink sink{bools + offs[slot_of(g, mb / g.mbw, mb % g.mbw, k)], probs};
+    walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), third_ctx[mb * 25 + b], sink);
+}
+
+// chunk -> its partition and its slice of the bool string
+__device__ __forceinline__ void chunk_slice(const Plan *plan, int P, uint32_t chunk, int &p, uint32_t &b0, int &n) {
+    p = 0;
+    while (p + 1 < P && chunk >= plan->chunk_base[p + 1]) ++p;
+    const uint32_t local = chunk - plan->chunk_base[p];
+    b0 = plan->bool_base[p] + local * CHUNK;
+    const uint32_t end = plan->bool_base[p] + plan->nbools[p];
+    n = (int)(end - b0 < (uint32_t)CHUNK ? end - b0 : (uint32_t)CHUNK);
+}
+
+// one step of the coder's range recursion (write_bool, :82-105): returns the shift count
+__device__ __forceinline__ int range_step(uint32_t &r, uint32_t prob, uint32_t bit, uint32_t &split) {
+    split = 1u + (((r - 1u) * prob) >> 8);
+    r = bit ? r - split : split;
+    const int s = __clz((int)r) - 24;
+    r <<= s;
+    return s;
+}
+
+__global__ __launch_bounds__(128) void k_ent_maps(const uint16_t *bools, const Plan *plan, int P, uint32_t *maps) {
+    __shared__ uint16_t s_b[CHUNK];
+    const int tid = threadIdx.x;
+    for (uint32_t chunk = blockIdx.x; chunk < plan->total_chunks; chunk += gridDim.x) {
+        int p, n;
+        uint32_t b0;
+        chunk_slice(plan, P, chunk, p, b0, n);
+        __syncthreads();
+        for (int i = tid; i < n; i += 128) s_b[i] = bools[b0 + i];
+        __syncthreads();
+        uint32_t r = 128u + tid, S = 0, split;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t e = s_b[i];
+            S += range_step(r, e & 255u, e >> 8, split);
+        }
+        maps[(size_t)chunk * 128 + tid] = r | (S << 8);
+    }
+}
+
+constexpr int WALK_TILE = 64;   // chunk maps staged in LDS per step (32 KB)
+__global__ __launch_bounds__(256) void k_ent_walk(const uint32_t *maps, Plan *plan, uint2 *start) {
+    __shared__ uint32_t s_m[WALK_TILE * 128];
+    const int p = blockIdx.x;
+    const uint32_t cb = plan->chunk_base[p], nch = plan->chunk_base[p + 1] - cb;
+    uint32_t r = 255, W = 0;
+    for (uint32_t t0 = 0; t0 < nch; t0 += WALK_TILE) {
+        const uint32_t tn = nch - t0 < (uint32_t)WALK_TILE ? nch - t0 : (uint32_t)WALK_TILE;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tn * 128; i += 256) s_m[i] = maps[(size_t)(cb + t0) * 128 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t k = 0; k < tn; ++k) {
+                start[cb + t0 + k] = make_uint2(r, W);
+                const uint32_t e = s_m[k * 128 + (r - 128u)];
+                r = e & 255u;
+                W += e >> 8;
+            }
+    }
+    if (threadIdx.x == 0) {
+        plan->w_end[p] = W;
+        plan->nbytes[p] = (W >= 24 ? (W - 24) / 8 + 1 : 0) + 4;   // bytes emitted while coding + the flush (:130-146)
+    }
+}
+
+constexpr int ENC_LANES = 64;
+__global__ __launch_bounds__(ENC_LANES) void k_ent_encode(const uint16_t *bools, const Plan *plan, int P, const uint2 *start,
+                                                          unsigned long long *acc) {
+    __shared__ uint16_t s_b[ENC_LANES][CHUNK + 2];   // +2: lanes walk their rows in step, the skew keeps them on different banks
+    const int lane = threadIdx.x;
+    for (uint32_t c0 = blockIdx.x * ENC_LANES; c0 < plan->total_chunks; c0 += gridDim.x * ENC_LANES) {
+        __syncthreads();
+        for (int row = 0; row < ENC_LANES; ++row) {   // coalesced: one chunk per iteration, 64 lanes x 4 bools
+            const uint32_t ch = c0 + row;
+            if (ch >= plan->total_chunks) break;
+            int p, n;
+            uint32_t b0;
+            chunk_slice(plan, P, ch, p, b0, n);
+            for (int i = lane; i < n; i += ENC_LANES) s_b[row][i] = bools[b0 + i];
+        }
+        __syncthreads();
+        const uint32_t chunk = c0 + lane;
+        if (chunk < plan->total_chunks) {
+            int p, n;
+            uint32_t b0;
+            chunk_slice(plan, P, chunk, p, b0, n);
+            unsigned long long *out = acc + plan->word_base[p];
+            const uint2 st = start[chunk];
+            uint32_t r = st.x, W = st.y, widx = W >> 5, split;
+            unsigned long long cur = 0, nxt = 0;   // sums for output words widx and widx+1
+            for (int i = 0; i < n; ++i) {
+                const uint32_t e = s_b[lane][i], bit = e >> 8;
+                const int o = (int)(W & 31u);
+                const int s = range_step(r, e & 255u, bit, split);
+                if (bit) {   // split occupies stream bits W .. W+7 (bit 0 = most significant bit of the first byte)
+                    if (o <= 24) cur += (unsigned long long)split << (24 - o);
+                    else { cur += split >> (o - 24); nxt += ((unsigned long long)split << (56 - o)) & 0xffffffffull; }
+                }
+                W += s;
+                if ((W >> 5) != widx) {
+                    if (cur) atomicAdd(&out[widx], cur);
+                    cur = nxt; nxt = 0; ++widx;
+                }
+            }
+            if (cur) atomicAdd(&out[widx], cur);
+            if (nxt) atomicAdd(&out[widx + 1], nxt);
+        }
+    }
+}
+
+// carries + bytes.  One wave per partition, from the least significant word up, 64 words per step.
+__global__ __launch_bounds__(64) void k_ent_finish(const unsigned long long *acc, const Plan *plan, uint8_t *bytes, int32_t *sizes) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const uint32_t nb = plan->nbytes[p], nw = (nb + 3) / 4;
+    const unsigned long long *in = acc + plan->word_base[p];
+    uint8_t *out = bytes + (size_t)plan->word_base[p] * 4;
+    unsigned long long K = 0;   // what the words below hand up: their high parts + the ripple carry
+    for (int hi_end = (int)nw; hi_end > 0; hi_end -= 64) {
+        const int j = hi_end - 1 - lane;                         // lane 0 = least significant word of the tile
+        const unsigned long long v = j >= 0 ? in[j] : 0ull;
+        const unsigned long long hi = v >> 32;
+        unsigned long long from_below = __shfl_up(hi, 1);
+        if (lane == 0) from_below = K;
+        const unsigned long long t = (v & 0xffffffffull) + from_below;   // < 2^33: the high parts are tiny
+        const uint32_t r = (uint32_t)t;
+        const unsigned long long G = __ballot((t >> 32) != 0), Pm = __ballot(r == 0xffffffffu);
+        // ripple c[i+1] = g[i] | (p[i] & c[i]) for all 64 lanes at once: the carries of the addition (G|P) + G
+        const unsigned long long A = G | Pm, S = A + G;
+        const unsigned long long carries = S ^ Pm;               // bit i = carry into lane i
+        const uint32_t word = r + (uint32_t)((carries >> lane) & 1ull);
+        K = __shfl(hi, 63) + (S < A ? 1ull : 0ull);
+        if (j >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((uint32_t)(4 * j + k) < nb) out[4 * j + k] = (uint8_t)(word >> (24 - 8 * k));
+        }
+    }
+    if (lane == 0) sizes[p] = (int32_t)nb;
+}
+
+}  // namespace ent
+
+void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
+                       int mbw, int mbh, int P) {
+    ent::Geom g;
+    g.mbw = mbw;
+    g.mbh = mbh;
+    g.P = P;
+    uint32_t sb = 0;
+    for (int p = 0; p <= ENT_MAX_PARTITIONS; ++p) {
+        g.slot_base[p] = sb;
+        if (p < P) sb += (uint32_t)((mbh - p + P - 1) / P) * mbw * 25;
+    }
+    g.cap_bools = eb.cap_bools;
+    g.cap_chunks = eb.cap_chunks;
+    g.cap_words = eb.cap_words;
+    const int nslots = mbw * mbh * 25, ntiles = (nslots + ent::SCAN_TILE - 1) / ent::SCAN_TILE;
+    EntPlan *plan = eb.plan;
+    hipLaunchKernelGGL(ent::k_ent_boolcount, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, g, eb.offs);
+    hipLaunchKernelGGL(ent::k_scan_tiles, dim3(ntiles), dim3(256), 0, s, eb.offs, eb.tile_sum, nslots);
+    hipLaunchKernelGGL(ent::k_scan_top, dim3(1), dim3(1024), 0, s, eb.tile_sum, ntiles);
+    hipLaunchKernelGGL(ent::k_scan_apply, dim3(ntiles), dim3(256), 0, s, eb.offs, eb.tile_sum, nslots, ntiles);
+    hipLaunchKernelGGL(ent::k_ent_plan, dim3(1), dim3(64), 0, s, eb.offs, g, plan);
+    hipLaunchKernelGGL(ent::k_ent_emit, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, third_ctx, probs,
+                       eb.offs, plan, g, eb.bools);
+    hipMemsetAsync(eb.acc, 0, (size_t)eb.cap_words * 8, s);
+    hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
+    hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
+    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(ent::ENC_LANES), 0, s, eb.bools, plan, P,
+                       reinterpret_cast<const uint2 *>(eb.start), reinterpret_cast<unsigned long long *>(eb.acc));
+    hipLaunchKernelGGL(ent::k_ent_finish, dim3(P), dim3(64), 0, s, reinterpret_cast<const unsigned long long *>(eb.acc), plan,
+                       eb.bytes, eb.sizes);
+}
+
 }  // namespace vp8

@@ -55,6 +55,8 @@ struct vp8hip_ctx {
     // coefficient entropy stage: per-block flags and third contexts, token counts per partition, probabilities
     uint8_t *ent_flags = nullptr, *ent_third = nullptr;
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
+    int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
+    EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
 
     uint32_t prof_mask = 0;
     hipEvent_t ev[MAX_EVENTS];
@@ -300,6 +302,15 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->ent_counts);
     hipFree(c->ent_probs);
     hipFree(c->ent_denom0);
+    hipFree(c->ent.offs);
+    hipFree(c->ent.tile_sum);
+    hipFree(c->ent.bools);
+    hipFree(c->ent.maps);
+    hipFree(c->ent.start);
+    hipFree(c->ent.acc);
+    hipFree(c->ent.bytes);
+    hipFree(c->ent.sizes);
+    hipFree(c->ent.plan);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -346,6 +357,7 @@ int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
 int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
+    c->ent_counted_partitions = 0;
     hipStream_t s = c->stream;
     // reference rotation, inter_part.h:35-50,72-83: golden/altref := the frame that is LAST now
     if (prev_is_golden) c->slot[1] = c->slot[0];
@@ -415,6 +427,7 @@ int vp8hip_download_results(vp8hip_ctx *c, const vp8hip_results *r) {
 
 int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg) {
     if (!c) return VP8HIP_ERR_ARG;
+    c->ent_counted_partitions = 0;
     hipStream_t s = c->stream;
     const size_t n = c->mbs;
     if (coeffs) HIPCHK(c, hipMemcpyAsync(c->out.coeffs, coeffs, n * 800, hipMemcpyHostToDevice, s));
@@ -440,6 +453,7 @@ int vp8hip_upload_recon(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const
 
 int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
     if (!c) return VP8HIP_ERR_ARG;
+    c->ent_counted_partitions = 0;
     hipStream_t s = c->stream;
     {
         Timed t(c, VP8HIP_K_FILTER_MASK);
@@ -485,6 +499,58 @@ int vp8hip_count_probs(vp8hip_ctx *c, int num_partitions, uint32_t *new_probs, u
     HIPCHK(c, hipMemcpyAsync(new_probs, c->ent_probs, sizeof(uint32_t) * ENT_NCTX, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(new_probs_denom, c->ent_denom0, sizeof(uint32_t) * ENT_NCTX, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the reference's read-backs are blocking (CL_TRUE, vp8enc.cpp:67-68)
+    c->ent_counted_partitions = num_partitions;
+    return VP8HIP_OK;
+}
+
+// scratch of the boolean coder, allocated the first time the stage is used (a context that only runs the
+// inter path never pays for it): 64 bools per 4x4 block on average (of at most 304)
+static int ent_alloc(vp8hip_ctx *c) {
+    if (c->ent.bools) return VP8HIP_OK;
+    EntBuffers &e = c->ent;
+    const size_t nslots = (size_t)c->mbs * 25;
+    e.cap_bools = (uint32_t)(nslots * 64);
+    e.cap_chunks = e.cap_bools / 256 + 2 * ENT_MAX_PARTITIONS;
+    e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 8 * ENT_MAX_PARTITIONS);
+    HIPCHK(c, hipMalloc(&e.offs, (nslots + 1) * 4));
+    HIPCHK(c, hipMalloc(&e.tile_sum, (nslots / 1024 + 8) * 4));
+    HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
+    HIPCHK(c, hipMalloc(&e.maps, (size_t)e.cap_chunks * 128 * 4));
+    HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
+    HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
+    HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
+    HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
+    HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
+    return VP8HIP_OK;
+}
+
+int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int num_partitions, int partition_step,
+                               uint8_t *partitions, int32_t *partition_sizes) {
+    if (!c || !coeff_probs || !partitions || !partition_sizes || partition_step < 4) return VP8HIP_ERR_ARG;
+    if (num_partitions != 1 && num_partitions != 2 && num_partitions != 4 && num_partitions != 8) return VP8HIP_ERR_ARG;
+    if (c->ent_counted_partitions != num_partitions) return VP8HIP_ERR_STATE;   // needs vp8hip_count_probs first
+    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;                       // single-level scan of the tile sums
+    int rc = ent_alloc(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->ent_probs, coeff_probs, sizeof(uint32_t) * ENT_NCTX, hipMemcpyHostToDevice, s));
+    {
+        Timed t(c, VP8HIP_K_ENT_ENCODE);
+        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, num_partitions);
+    }
+    HIPCHK(c, hipGetLastError());
+    EntPlan plan;
+    HIPCHK(c, hipMemcpyAsync(&plan, c->ent.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (plan.overflow) return VP8HIP_ERR_OVERFLOW;
+    for (int p = 0; p < num_partitions; ++p)
+        if (plan.nbytes[p] > (uint32_t)partition_step) return VP8HIP_ERR_OVERFLOW;
+    for (int p = 0; p < num_partitions; ++p) {
+        partition_sizes[p] = (int32_t)plan.nbytes[p];
+        HIPCHK(c, hipMemcpyAsync(partitions + (size_t)p * partition_step, c->ent.bytes + (size_t)plan.word_base[p] * 4,
+                                 plan.nbytes[p], hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
     return VP8HIP_OK;
 }
 
@@ -527,6 +593,7 @@ const char *vp8hip_status_string(int status) {
         case VP8HIP_ERR_STATE: return "call out of order";
         case VP8HIP_ERR_ARCH: return "device is not gfx950";
         case VP8HIP_ERR_TIMEOUT: return "a bounded device-side wait expired; the frame is invalid";
+        case VP8HIP_ERR_OVERFLOW: return "coefficient partitions do not fit the output or the device scratch";
         default: return "unknown";
     }
 }

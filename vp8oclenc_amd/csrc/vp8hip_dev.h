@@ -70,6 +70,25 @@ constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
 constexpr int ENT_MAX_PARTITIONS = 8;
 void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
                       uint32_t *denom0, int mbw, int mbh, int num_partitions);
+// layout of one frame's bool strings / chunks / output words per partition; written by the device, read by the host
+struct EntPlan {
+    uint32_t bool_base[ENT_MAX_PARTITIONS + 1], chunk_base[ENT_MAX_PARTITIONS + 1], word_base[ENT_MAX_PARTITIONS + 1];
+    uint32_t nbools[ENT_MAX_PARTITIONS], w_end[ENT_MAX_PARTITIONS], nbytes[ENT_MAX_PARTITIONS];
+    uint32_t total_chunks, overflow;
+};
+struct EntBuffers {          // device scratch of the boolean coder (allocated on first use)
+    uint32_t *offs, *tile_sum;      // bools per block slot -> exclusive offsets; scan tile sums
+    uint16_t *bools;                // (probability | bit << 8) per bool, partition after partition
+    uint32_t *maps;                 // [chunk][128 start ranges] -> end range | shifts << 8
+    void *start;                    // uint2 [chunk]: true start range and bit position
+    void *acc;                      // uint64 per 32 output bits
+    uint8_t *bytes;                 // the partitions, at 4 * word_base[p]
+    int32_t *sizes;
+    EntPlan *plan;
+    uint32_t cap_bools, cap_chunks, cap_words;
+};
+void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
+                       int mbw, int mbh, int P);
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
