@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct-frames", type=int, default=8)
     ap.add_argument("--gops-per-gpu", type=int, default=16, help="independent GOP chunks in flight per GPU (1 = one stream)")
+    ap.add_argument("--ssim-target", type=float, default=-1.0, help="SSIM_target (reference default -1 = single LQ pass; 0.93 = the 4-pass path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
     return ap.parse_args()
@@ -120,7 +121,7 @@ def main():
         """One closed GOP: its own context/stream, frame-type state machine and position in the sequence."""
 
         def __init__(self, k: int):
-            self.enc = api.Vp8Hip(W, H, -1.0, device=local)
+            self.enc = api.Vp8Hip(W, H, args.ssim_target, device=local)
             self.gop = api.Gop(gop_size=1 << 30, altref_range=5)   # key frame only at the start of the chunk
             self.t = (k * 3) % nd                                   # chunks start at different frames
             self.gop.next()
@@ -211,7 +212,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, LAST+GOLDEN+ALTREF "
                                    f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
-                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": -1, "qi_ladder": lastqi,
+                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": lastqi,
                        "altref_range": 5, "frames_per_gpu": args.steps, "gops_per_gpu": G},
             "roofline": roof,
             "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
@@ -236,7 +237,7 @@ def cpu_baseline(args, host_frames, seg_last, W, H, mbs):
     os.environ["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle_lib import Oracle
-    ora = Oracle(W, H, -1.0)
+    ora = Oracle(W, H, args.ssim_target)
     threads = int(Oracle.lib().vp8o_num_threads())
     ora.upload_last(*host_frames[0])
     ora.set_segments(seg_last[1])
