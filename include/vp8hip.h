@@ -68,6 +68,16 @@ int vp8hip_set_current_device(vp8hip_ctx *ctx, const void *d_y, const void *d_u,
 int vp8hip_upload_last(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 int vp8hip_set_last_device(vp8hip_ctx *ctx, const void *d_y, const void *d_u, const void *d_v);
 
+/* The two per-frame host scans that produce parameters of this path, on the device copy of the
+ * current frame -- at 0.2 ms per 1080p frame a single-threaded 2-Mpixel scan on the host would be the bottleneck.
+ * Both block until the values are back.
+ * get_loopfilter_strength(), vp8enc.cpp:96-127: reductor and sharpness of the current luma plane. */
+int vp8hip_loopfilter_strength(vp8hip_ctx *ctx, int32_t *reductor, int32_t *sharpness);
+/* scene_change()'s inputs, vp8enc.cpp:265-282: mean absolute difference of the U and V planes between this current
+ * frame and the previous current frame (the context keeps both; 0,0 while there is only one).  The decision
+ * logic with its hold-over stays on the host: vp8host_scene_change(), include/vp8hip_host.h. */
+int vp8hip_chroma_change(vp8hip_ctx *ctx, int32_t *Udiff, int32_t *Vdiff);
+
 /* clEnqueueWriteBuffer(segments_data_gpu), vp8enc.cpp:224 */
 int vp8hip_set_segments(vp8hip_ctx *ctx, const int32_t sd[VP8HIP_SD_INTS]);
 

@@ -20,6 +20,13 @@ void vp8host_quantizer_ladders(int qi_min, int qi_max, int32_t lastqi[4], int32_
 /* get_loopfilter_strength(), vp8enc.cpp:96-127: brightness-based divisor and sharpness (0..7) */
 void vp8host_loopfilter_strength(const uint8_t *cur_y, int width, int height, int32_t *reductor, int32_t *sharpness);
 
+/* scene_change(), vp8enc.cpp:265-311: the decision on the two chroma differences (vp8hip_chroma_change), with the
+ * reference's hold-over (its function-static `holdover`) and frames.last_key_detect in `st`.  Returns 1 when the
+ * current frame must be coded as a key frame; the caller then sets st->last_key_detect = frame_number
+ * (intra_transform does, intra_part.h:1091-1098). */
+typedef struct { int32_t holdover, last_key_detect; } vp8host_scene_state;
+int vp8host_scene_change(vp8host_scene_state *st, int Udiff, int Vdiff, int frame_number);
+
 /* prepare_segments_data(), vp8enc.cpp:129-221.  refqi = lastqi or altrefqi (vp8enc.cpp:149-151);
  * update_filter/shrpnss: the second call made from check_SSIM (vp8enc.cpp:260-261). */
 void vp8host_prepare_segments_data(int is_key_frame, const int32_t refqi[4], int qi_min, int reductor,

@@ -308,6 +308,34 @@ def test_loop_filter_waits_are_bounded():
     hip.close(); ora.close()
 
 
+def test_parameter_scans_on_device_match_host_mirror():
+    """get_loopfilter_strength and scene_change's chroma differences (vp8enc.cpp:96-127, 265-282) computed on
+    the device copy of the current frame == the host restatement, incl. a 1080p noise frame whose int
+    accumulator wraps."""
+    rng = np.random.default_rng(9)
+    for (W, H) in ((64, 48), (352, 288), (1920, 1088)):
+        hip = api.Vp8Hip(W, H)
+        prev = None
+        for k in range(3):
+            if k == 0:
+                y = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+            else:
+                y = np.clip(np.add.outer(np.arange(H), np.arange(W)) // (2 + k) % 256 + rng.integers(-9, 10, size=(H, W)), 0, 255).astype(np.uint8)
+            u = rng.integers(0, 256, size=(H // 2, W // 2)).astype(np.uint8) if k != 2 else np.clip(prev[0].astype(int) + 3, 0, 255).astype(np.uint8)
+            v = rng.integers(100, 140, size=(H // 2, W // 2)).astype(np.uint8)
+            hip.upload_current(y, u, v)
+            assert hip.loopfilter_strength() == api.loopfilter_strength(y), (W, H, k)
+            ud, vd = hip.chroma_change()
+            if prev is None:
+                assert (ud, vd) == (0, 0)
+            else:
+                n = (W // 2) * (H // 2)
+                assert ud == int(np.abs(prev[0].astype(int) - u.astype(int)).sum()) // n
+                assert vd == int(np.abs(prev[1].astype(int) - v.astype(int)).sum()) // n
+            prev = (u, v)
+        hip.close()
+
+
 # ---- the committed golden vectors (outputs of the reference's own kernels, scripts/gen_golden.py) ----
 import glob as _glob
 import os as _os

@@ -83,6 +83,64 @@ def test_loopfilter_strength():
     assert sharp == 7
 
 
+def test_loopfilter_strength_matches_python_restatement():
+    """vp8enc.cpp:96-127 with its int accumulators taken modulo 2^32 (large noisy frames overflow them)."""
+    def ref(y):
+        h, w = y.shape
+        a = y.astype(np.int64)
+        avg = (int(a.sum()) + w * h // 2) // (w * h)
+        red = avg * 5 // 255 + 3
+        nb = (a[:-2, :-2] + a[:-2, 1:-1] + a[:-2, 2:] + a[1:-1, :-2] + a[1:-1, 2:] + a[2:, :-2] + a[2:, 1:-1] + a[2:, 2:]) // 8
+        div = int(((a[1:-1, 1:-1] - nb) ** 2).sum()) & 0xffffffff
+        div = div - (1 << 32) if div >= (1 << 31) else div           # int32 wrap
+        n = (h - 1) * (w - 1)
+        div += n // 2
+        div = int(div / n)                                            # C division truncates toward zero
+        sh = int(div / 8)
+        return red, min(sh, 7)
+    rng = np.random.default_rng(5)
+    for shape in ((32, 48), (144, 176), (1088, 1920)):
+        y = rng.integers(0, 256, size=shape).astype(np.uint8)        # 1080p noise: the second accumulator wraps
+        assert api.loopfilter_strength(y) == ref(y), shape
+        y = (np.add.outer(np.arange(shape[0]), np.arange(shape[1])) // 3 % 256).astype(np.uint8)
+        assert api.loopfilter_strength(y) == ref(y), shape
+
+
+def test_scene_change_decision_logic():
+    """vp8enc.cpp:285-310: thresholds, no two forced key frames within 4 frames, hold-over."""
+    def ref_run(diffs, key_sets_detect=True):
+        hold, last, out = 0, 0, []
+        for n, (u, v) in enumerate(diffs):
+            detect = u > 7 or v > 7 or u + v > 10
+            recent = n - last < 4
+            if detect and recent:
+                last, hold, r = n, 1, 0
+            elif detect:
+                r = 1
+            elif hold and recent:
+                r = 0
+            elif hold:
+                hold, r = 0, 1
+            else:
+                r = 0
+            if r and key_sets_detect:
+                last = n                         # intra_transform, intra_part.h:1091-1098
+            out.append(r)
+        return out
+    rng = np.random.default_rng(2)
+    for trial in range(20):
+        diffs = [(int(rng.integers(0, 12)), int(rng.integers(0, 12))) if rng.random() < 0.3 else (1, 2) for _ in range(60)]
+        st = api.SceneState(0, 0)
+        got = []
+        for n, (u, v) in enumerate(diffs):
+            r = api.scene_change(st, u, v, n)
+            if r:
+                st.last_key_detect = n
+            got.append(int(r))
+        assert got == ref_run(diffs), trial
+        assert sum(got) > 0 or all(u <= 7 and v <= 7 and u + v <= 10 for u, v in diffs)
+
+
 def test_gop_state_machine_reference_sequence():
     """Key at 0, golden = key, altref every altref_range frames (vp8enc.cpp:364-374, intra_part.h:1091-1098)."""
     g = api.Gop(gop_size=12, altref_range=5)

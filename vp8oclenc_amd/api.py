@@ -25,10 +25,10 @@ ABI_SYMBOLS = [
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
-    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
-    "vp8host_gop_frame_done",
+    "vp8host_gop_frame_done", "vp8host_scene_change",
 ]
 
 
@@ -90,6 +90,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8hip_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.vp8hip_debug_download.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.vp8hip_count_probs.argtypes = [vp, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vp8hip_loopfilter_strength.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.vp8hip_chroma_change.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.vp8hip_encode_coefficients.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     i32p = C.POINTER(C.c_int32)
     lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
@@ -134,6 +136,17 @@ def loopfilter_strength(y: np.ndarray):
     y = np.ascontiguousarray(y, np.uint8)
     lib.vp8host_loopfilter_strength(y.ctypes.data, y.shape[1], y.shape[0], C.byref(r), C.byref(s))
     return r.value, s.value
+
+
+class SceneState(C.Structure):
+    """vp8host_scene_state: the hold-over of scene_change() and frames.last_key_detect (vp8enc.cpp:265-311)."""
+    _fields_ = [("holdover", C.c_int32), ("last_key_detect", C.c_int32)]
+
+
+def scene_change(state: SceneState, Udiff: int, Vdiff: int, frame_number: int) -> bool:
+    lib = load_library()
+    lib.vp8host_scene_change.argtypes = [C.POINTER(SceneState), C.c_int, C.c_int, C.c_int]
+    return bool(lib.vp8host_scene_change(C.byref(state), int(Udiff), int(Vdiff), int(frame_number)))
 
 
 def prepare_segments_data(is_key: bool, refqi, qi_min: int, reductor: int, sharpness: int, update_filter: bool = False,
@@ -256,6 +269,18 @@ class Vp8Hip:
 
     def loop_filter(self):
         self._chk(self.lib.vp8hip_loop_filter(self.h), "loop_filter")
+
+    def loopfilter_strength(self):
+        """get_loopfilter_strength (vp8enc.cpp:96-127) of the current frame, computed on the device."""
+        red, sh = C.c_int32(), C.c_int32()
+        self._chk(self.lib.vp8hip_loopfilter_strength(self.h, C.byref(red), C.byref(sh)), "loopfilter_strength")
+        return red.value, sh.value
+
+    def chroma_change(self):
+        """scene_change's Udiff, Vdiff (vp8enc.cpp:265-282) between this and the previous current frame."""
+        ud, vd = C.c_int32(), C.c_int32()
+        self._chk(self.lib.vp8hip_chroma_change(self.h, C.byref(ud), C.byref(vd)), "chroma_change")
+        return ud.value, vd.value
 
     def count_probs(self, num_partitions: int):
         """count_probs + num_div_denom (CPU_kernels.cl:536-778): (probs[1056], partition-0 denominators[1056])."""

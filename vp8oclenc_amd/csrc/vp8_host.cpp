@@ -37,26 +37,48 @@ void vp8host_quantizer_ladders(int qi_min, int qi_max, int32_t lastqi[4], int32_
 }
 
 void vp8host_loopfilter_strength(const uint8_t *y, int width, int height, int32_t *reductor, int32_t *sharpness) {
-    // vp8enc.cpp:96-127 (int accumulators as in the reference: they do not overflow below ~8 Mpixel)
+    // vp8enc.cpp:96-127.  The reference's accumulators are `int`; the second one overflows on large noisy
+    // frames.  They are kept modulo 2^32 here -- what that overflow does on every compiler the reference was
+    // built with, and order-independent, so the device reduction (kernels_rc.hip) can match it.
     const int n = width * height;
-    int avg = 0;
-    for (int i = 0; i < n; ++i) avg += y[i];
+    uint32_t sum = 0;
+    for (int i = 0; i < n; ++i) sum += y[i];
+    int avg = (int32_t)sum;
     avg += n / 2;
     avg /= n;
     *reductor = (avg * 5 / 255) + 3;
-    int div = 0;
+    uint32_t acc = 0;
     for (int i = 1; i < height - 1; ++i)
         for (int j = 1; j < width - 1; ++j) {
             const int p = i * width + j;
             int a = y[p - width - 1] + y[p - width] + y[p - width + 1] + y[p - 1] + y[p + 1] + y[p + width - 1] +
                     y[p + width] + y[p + width + 1];
             a /= 8;
-            div += (y[p] - a) * (y[p] - a);
+            acc += (uint32_t)((y[p] - a) * (y[p] - a));
         }
+    int div = (int32_t)acc;
     div += (height - 1) * (width - 1) / 2;
     div /= (height - 1) * (width - 1);
     int sh = div / 8;
     *sharpness = sh > 7 ? 7 : sh;
+}
+
+int vp8host_scene_change(vp8host_scene_state *st, int Udiff, int Vdiff, int frame_number) {
+    // vp8enc.cpp:285-310
+    const int detect = (Udiff > 7) || (Vdiff > 7) || (Udiff + Vdiff > 10);
+    const bool recent = (frame_number - st->last_key_detect) < 4;   // "workaround to exclude serial intra_frames"
+    if (detect && recent) {
+        st->last_key_detect = frame_number;
+        st->holdover = 1;
+        return 0;
+    }
+    if (detect) return 1;            // last_key_detect is set when the key frame is coded
+    if (st->holdover && recent) return 0;
+    if (st->holdover) {
+        st->holdover = 0;
+        return 1;
+    }
+    return 0;
 }
 
 void vp8host_prepare_segments_data(int is_key_frame, const int32_t refqi[4], int qi_min, int reductor, int sharpness,

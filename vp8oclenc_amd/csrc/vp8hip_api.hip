@@ -42,6 +42,9 @@ struct vp8hip_ctx {
     int recon = -1;                 // pool index of the reconstruction being produced
     bool recon_ready = false;       // holds an unfiltered reconstruction
     bool cur_pyramid_valid = false;
+    Frame cur_prev;                 // the previous current frame (the two surfaces swap on every upload)
+    int cur_count = 0;              // current frames received so far
+    uint32_t *d_stats = nullptr;    // reductions of kernels_rc.hip
 
     NetSet nets{};
     MBOut out{};
@@ -224,11 +227,13 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipSetDevice(device_ordinal));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t fb = frame_bytes(width, height);
-    CR(hipMalloc(&c->pixel_pool, fb * (NFRAMES + 1)));
-    CR(hipMemsetAsync(c->pixel_pool, 0, fb * (NFRAMES + 1), c->stream));
+    CR(hipMalloc(&c->pixel_pool, fb * (NFRAMES + 2)));
+    CR(hipMemsetAsync(c->pixel_pool, 0, fb * (NFRAMES + 2), c->stream));
     uint8_t *cur = c->pixel_pool;
     for (int i = 0; i < NFRAMES; ++i) cur = carve_frame(cur, width, height, &c->frames[i].f);
-    carve_frame(cur, width, height, &c->cur);
+    cur = carve_frame(cur, width, height, &c->cur);
+    carve_frame(cur, width, height, &c->cur_prev);
+    CR(hipMalloc(&c->d_stats, 4 * sizeof(uint32_t)));
     for (int r = 0; r < 3; ++r) {
         CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
         CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
@@ -296,6 +301,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->d_sd);
     if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
     hipFree(c->d_progress);
+    hipFree(c->d_stats);
     hipFree(c->scratch);
     hipFree(c->ent_flags);
     hipFree(c->ent_third);
@@ -315,9 +321,19 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     delete c;
 }
 
+// a new current frame goes into the other of the two surfaces: the previous one stays intact for
+// vp8hip_chroma_change (the reference keeps last_U/last_V the same way, encIO.h:207-210)
+static void next_current(vp8hip_ctx *c) {
+    const Frame t = c->cur;
+    c->cur = c->cur_prev;
+    c->cur_prev = t;
+    c->cur_count++;
+    c->cur_pyramid_valid = false;
+}
+
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
-    c->cur_pyramid_valid = false;
+    next_current(c);
     int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice);
     if (rc) return rc;
     // pageable host memory: the call must not return while the copy still reads the host buffer
@@ -327,8 +343,46 @@ int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, con
 
 int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
-    c->cur_pyramid_valid = false;
+    next_current(c);
     return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice);
+}
+
+int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
+    if (!c || !reductor || !sharpness) return VP8HIP_ERR_ARG;
+    if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+    launch_lf_strength(c->stream, c->cur, c->d_stats);
+    HIPCHK(c, hipGetLastError());
+    uint32_t st[2];
+    HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // vp8enc.cpp:100-103, 119-123 on the two sums (the reference's int accumulators, modulo 2^32)
+    const int n = c->W * c->H, ni = (c->H - 1) * (c->W - 1);
+    int avg = (int32_t)st[0];
+    avg += n / 2;
+    avg /= n;
+    *reductor = (avg * 5 / 255) + 3;
+    int div = (int32_t)st[1];
+    div += ni / 2;
+    div /= ni;
+    const int sh = div / 8;
+    *sharpness = sh > 7 ? 7 : sh;
+    return VP8HIP_OK;
+}
+
+int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
+    if (!c || !Udiff || !Vdiff) return VP8HIP_ERR_ARG;
+    if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+    *Udiff = *Vdiff = 0;
+    if (c->cur_count < 2) return VP8HIP_OK;
+    launch_chroma_sad(c->stream, c->cur, c->cur_prev, c->d_stats);
+    HIPCHK(c, hipGetLastError());
+    uint32_t st[2];
+    HIPCHK(c, hipMemcpyAsync(st, c->d_stats + 2, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int nc = (c->W / 2) * (c->H / 2);
+    *Udiff = (int32_t)st[0] / nc;      // vp8enc.cpp:277, 284
+    *Vdiff = (int32_t)st[1] / nc;
+    return VP8HIP_OK;
 }
 
 int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {

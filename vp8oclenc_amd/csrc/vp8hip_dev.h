@@ -65,6 +65,10 @@ void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int 
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
                          int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
 
+// per-frame parameter scans on the device copy of the current frame (kernels_rc.hip); stats = 4 uint32
+void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *stats);                       // [0] sum Y, [1] sum of squared deviations
+void launch_chroma_sad(hipStream_t s, const Frame &cur, const Frame &prev, uint32_t *stats);     // [2] sum |dU|, [3] sum |dV|
+
 // coefficient entropy stage (kernels_ent.hip): flags + third context + token histogram + probabilities
 constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
 constexpr int ENT_MAX_PARTITIONS = 8;
