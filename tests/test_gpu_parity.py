@@ -278,6 +278,18 @@ def test_error_behaviour():
     hip.close()
 
 
+@pytest.mark.parametrize("W,H", [(16, 16), (16, 48), (32, 64), (16, 272), (240, 112), (320, 240), (48, 16), (272, 16),
+                                 (128, 128), (2048, 128), (16, 2160), (1920, 1088), (3840, 2160)])
+def test_loop_filter_alone_on_band_and_ring_edge_geometries(W, H):
+    """The banded loop filter on random reconstructions / masks / segments: one macroblock column (narrower than
+    the strip ring), one macroblock row, heights that end exactly on a band, the flush row alone in a band,
+    more bands than fit one wave of workgroups; three launches each (hand-off races show up as differences)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import lf_check
+    assert lf_check.run(W, H, seed=W + H, reps=2)
+
+
 def test_loop_filter_waits_are_bounded():
     """Every device-side wait of the loop filter is bounded: with the inter-band counters sabotaged (test hook)
     the launch ends by itself, the next synchronising call reports VP8HIP_ERR_TIMEOUT, and the context then
