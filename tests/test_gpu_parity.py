@@ -98,6 +98,8 @@ def _frames(W, H, seed, n=4, **kw):
     (352, 288, 3, (1, 1), 0.95, {}),
     (16, 16, 4, (1, 1), -1.0, {}),        # a single macroblock
     (1280, 720, 6, (0, 0), -1.0, {}),     # BASELINE configs[1] geometry (LAST only)
+    (1920, 1080, 8, (1, 1), -1.0, {}),    # BASELINE configs[2]: the metric's geometry (wrk 1920x1088), 3 references
+    (3840, 2160, 9, (1, 0), -1.0, {}),    # BASELINE configs[3]
 ])
 def test_single_frame_all_stages(W, H, seed, flags, ssim_target, kw):
     f = _frames(W, H, seed, **kw)
