@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--gops-per-gpu", type=int, default=16, help="independent GOP chunks in flight per GPU (1 = one stream)")
     ap.add_argument("--ssim-target", type=float, default=-1.0, help="SSIM_target (reference default -1 = single LQ pass; 0.93 = the 4-pass path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--host-params", action="store_true",
+                    help="take the per-frame segment data from the host mirror (precomputed, untimed) instead of "
+                         "computing loop-filter strength and segment data on the device inside every step")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
     return ap.parse_args()
 
@@ -142,7 +145,10 @@ def main():
             i = self.t % nd
             y, u, v = dev_frames[i]
             self.enc.set_current_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-            self.enc.set_segments(seg_alt[i] if g.current_is_altref else seg_last[i])
+            if args.host_params:   # segment data precomputed by the host mirror, outside the timed region
+                self.enc.set_segments(seg_alt[i] if g.current_is_altref else seg_last[i])
+            else:                  # get_loopfilter_strength + prepare_segments_data on the device, inside the step
+                self.enc.auto_segments(False, altrefqi if g.current_is_altref else lastqi, 0)
             ug, ua = self.gop.inter_flags()
             self.enc.inter_transform(g.prev_is_golden, g.prev_is_altref, ug, ua)
             self.enc.loop_filter()
@@ -220,6 +226,7 @@ def main():
                                    f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
                        "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": lastqi,
                        "altref_range": 5, "frames_per_gpu": args.steps, "gops_per_gpu": G,
+                       "segment_params": "host mirror, precomputed" if args.host_params else "device, inside the step",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roof,
             "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},

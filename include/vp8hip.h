@@ -78,6 +78,14 @@ int vp8hip_loopfilter_strength(vp8hip_ctx *ctx, int32_t *reductor, int32_t *shar
  * logic with its hold-over stays on the host: vp8host_scene_change(), include/vp8hip_host.h. */
 int vp8hip_chroma_change(vp8hip_ctx *ctx, int32_t *Udiff, int32_t *Vdiff);
 
+/* get_loopfilter_strength() + prepare_segments_data() (vp8enc.cpp:96-127, 129-221) evaluated on the device for the
+ * current frame: the segment data of the following vp8hip_inter_transform / vp8hip_loop_filter are produced without
+ * any host round trip (asynchronous on the context's stream) -- what a frame loop at several thousand frames per
+ * second needs.  refqi = the lastqi or altrefqi ladder (vp8enc.cpp:149-151).  vp8hip_get_segments reads back the
+ * segment data in force (the frame header needs them) and the strength pair; it blocks. */
+int vp8hip_auto_segments(vp8hip_ctx *ctx, int is_key_frame, const int32_t refqi[4], int qi_min);
+int vp8hip_get_segments(vp8hip_ctx *ctx, int32_t sd[VP8HIP_SD_INTS], int32_t *reductor, int32_t *sharpness);
+
 /* clEnqueueWriteBuffer(segments_data_gpu), vp8enc.cpp:224 */
 int vp8hip_set_segments(vp8hip_ctx *ctx, const int32_t sd[VP8HIP_SD_INTS]);
 

@@ -339,6 +339,11 @@ def test_parameter_scans_on_device_match_host_mirror():
             v = rng.integers(100, 140, size=(H // 2, W // 2)).astype(np.uint8)
             hip.upload_current(y, u, v)
             assert hip.loopfilter_strength() == api.loopfilter_strength(y), (W, H, k)
+            for is_key, ladder, qmin in ((False, [12, 24, 36, 48], 0), (True, [0, 5, 90, 127], 7)):
+                hip.auto_segments(is_key, ladder, qmin)        # the same two functions, chained on the device
+                sd, red, sh = hip.get_segments()
+                assert (red, sh) == api.loopfilter_strength(y)
+                assert np.array_equal(sd, api.prepare_segments_data(is_key, ladder, qmin, red, sh).reshape(4, 11)), (W, H, k)
             ud, vd = hip.chroma_change()
             if prev is None:
                 assert (ud, vd) == (0, 0)

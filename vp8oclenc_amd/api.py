@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
-    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
@@ -92,6 +92,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8hip_count_probs.argtypes = [vp, C.c_int, C.c_void_p, C.c_void_p]
     lib.vp8hip_loopfilter_strength.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.vp8hip_chroma_change.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.vp8hip_auto_segments.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int]
+    lib.vp8hip_get_segments.argtypes = [vp, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.vp8hip_encode_coefficients.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     i32p = C.POINTER(C.c_int32)
     lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
@@ -275,6 +277,17 @@ class Vp8Hip:
         red, sh = C.c_int32(), C.c_int32()
         self._chk(self.lib.vp8hip_loopfilter_strength(self.h, C.byref(red), C.byref(sh)), "loopfilter_strength")
         return red.value, sh.value
+
+    def auto_segments(self, is_key: bool, refqi, qi_min: int):
+        """get_loopfilter_strength + prepare_segments_data on the device, asynchronous (no host round trip)."""
+        q = (C.c_int32 * 4)(*[int(x) for x in refqi])
+        self._chk(self.lib.vp8hip_auto_segments(self.h, int(bool(is_key)), q, int(qi_min)), "auto_segments")
+
+    def get_segments(self):
+        sd = np.zeros(44, np.int32)
+        r, s = C.c_int32(), C.c_int32()
+        self._chk(self.lib.vp8hip_get_segments(self.h, sd.ctypes.data, C.byref(r), C.byref(s)), "get_segments")
+        return sd.reshape(4, 11), r.value, s.value
 
     def chroma_change(self):
         """scene_change's Udiff, Vdiff (vp8enc.cpp:265-282) between this and the previous current frame."""

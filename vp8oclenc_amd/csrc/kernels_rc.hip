@@ -1,68 +1,172 @@
 // kernels_rc.hip -- the two O(pixels) host scans the reference runs per frame to produce parameters of the
 // inter path: get_loopfilter_strength (src/vp8enc.cpp:96-127) and the chroma differences of
-// scene_change (:265-282).  At the frame rates of this path (0.2 ms per 1080p frame) a single-threaded scan of
-// 2 Mpixel on the host costs 25-50 frame times, and the pixels are already in HBM -- so they are two reductions
-// on the device copy of the current frame.
+// scene_change (:265-282), plus prepare_segments_data (:129-221) chained behind the first one.  At the frame
+// rates of this path (0.2 ms per 1080p frame) a single-threaded scan of 2 Mpixel on the host costs 25-50 frame
+// times, and the pixels are already in HBM -- so they are reductions on the device copy of the current frame.
+// No same-address atomics: every workgroup writes one partial sum, the consumer adds them up (a first version
+// with one atomicAdd per wave onto two words cost 0.1 ms per frame).
 #include "vp8hip_dev.h"
 
 namespace vp8 {
 
 namespace {
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+constexpr int ROWS_PER_BLOCK = 8;     // k_lf_strength: 8 pixel rows x the whole width per workgroup
+constexpr int MAX_PARTIALS = 2048;    // per quantity; height 8192 / 8 rows = 1024 workgroups
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *s_red) {   // sum over 256 threads, valid in thread 0
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return r;
 }
 
-// out[0] += sum of Y, out[1] += sum over interior pixels of (p - (8 neighbours)/8)^2.  Both are the reference's
-// `int` accumulators: they are kept modulo 2^32 here (order-independent), which is what its overflow does.
-__global__ __launch_bounds__(256) void k_lf_strength(Plane y, uint32_t *out) {
-    const int row = blockIdx.y;
-    const uint8_t *p = y.p + (ptrdiff_t)row * y.stride;
+// partial[2b] = sum of Y, partial[2b+1] = sum over interior pixels of (p - (8 neighbours)/8)^2 for the rows of
+// workgroup b.  Both are the reference's `int` accumulators, kept modulo 2^32 (order-independent), which is what
+// their overflow does.  A thread owns four adjacent columns and slides a three-row window down its rows.
+__global__ __launch_bounds__(256) void k_lf_strength(Plane y, uint32_t *partial) {
+    __shared__ uint32_t s_red[4];
+    const int r0 = blockIdx.x * ROWS_PER_BLOCK;
     uint32_t s = 0, d = 0;
-    const bool inner_row = row >= 1 && row < y.h - 1;
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < y.w; x += gridDim.x * 256) {
-        const int c = p[x];
-        s += (uint32_t)c;
-        if (inner_row && x >= 1 && x < y.w - 1) {
-            const uint8_t *u = p - y.stride, *w = p + y.stride;
-            const int a = (u[x - 1] + u[x] + u[x + 1] + p[x - 1] + p[x + 1] + w[x - 1] + w[x] + w[x + 1]) / 8;
-            d += (uint32_t)((c - a) * (c - a));
+    for (int x = threadIdx.x * 4; x < y.w; x += 1024) {
+        // three dwords per row: columns x-4..x-1, x..x+3, x+4..x+7 (the margin makes every load legal)
+        uint32_t a[3], b[3], c[3];
+        const uint8_t *p = y.p + (ptrdiff_t)(r0 - 1) * y.stride + x - 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { a[k] = *reinterpret_cast<const uint32_t *>(p + 4 * k); b[k] = *reinterpret_cast<const uint32_t *>(p + y.stride + 4 * k); }
+        for (int r = r0; r < r0 + ROWS_PER_BLOCK && r < y.h; ++r) {
+            const uint8_t *q = y.p + (ptrdiff_t)(r + 1) * y.stride + x - 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k] = *reinterpret_cast<const uint32_t *>(q + 4 * k);
+            s = __builtin_amdgcn_sad_u8(b[1], 0u, s);
+            if (r >= 1 && r < y.h - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (x + i < 1 || x + i >= y.w - 1) continue;
+                    // pixel i of the strip: bytes 3+i, 4+i, 5+i of the 12-byte rows
+                    auto px = [&](const uint32_t (&w)[3], int j) { return byte_of(w[j >> 2], j & 3); };
+                    const int nb = (px(a, 3 + i) + px(a, 4 + i) + px(a, 5 + i) + px(b, 3 + i) + px(b, 5 + i) + px(c, 3 + i) +
+                                    px(c, 4 + i) + px(c, 5 + i)) / 8;
+                    const int e = px(b, 4 + i) - nb;
+                    d += (uint32_t)(e * e);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a[k] = b[k]; b[k] = c[k]; }
         }
     }
-    s = wave_sum(s);
-    d = wave_sum(d);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out[0], s);
-        atomicAdd(&out[1], d);
-    }
+    s = block_sum(s, s_red);
+    d = block_sum(d, s_red);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = d; }
 }
 
-// out[2] += sum |a.U - b.U|, out[3] += sum |a.V - b.V| (four pixels per thread)
-__global__ __launch_bounds__(256) void k_chroma_sad(Plane au, Plane av, Plane bu, Plane bv, uint32_t *out) {
-    const int pl = blockIdx.z, row = blockIdx.y;
+// partial[2b + plane] = sum |a - b| over the rows of workgroup b (8 chroma rows, four pixels per load)
+__global__ __launch_bounds__(256) void k_chroma_sad(Plane au, Plane av, Plane bu, Plane bv, uint32_t *partial) {
+    __shared__ uint32_t s_red[4];
+    const int pl = blockIdx.y;
     const Plane &a = pl == 0 ? au : av, &b = pl == 0 ? bu : bv;
+    const int r0 = blockIdx.x * ROWS_PER_BLOCK;
     uint32_t s = 0;
-    for (int x = (blockIdx.x * 256 + threadIdx.x) * 4; x < a.w; x += gridDim.x * 1024) {
-        const uint32_t va = *reinterpret_cast<const uint32_t *>(a.p + (ptrdiff_t)row * a.stride + x);
-        const uint32_t vb = *reinterpret_cast<const uint32_t *>(b.p + (ptrdiff_t)row * b.stride + x);
-        s = __builtin_amdgcn_sad_u8(va, vb, s);
+    for (int r = r0; r < r0 + ROWS_PER_BLOCK && r < a.h; ++r)
+        for (int x = threadIdx.x * 4; x < a.w; x += 1024)
+            s = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t *>(a.p + (ptrdiff_t)r * a.stride + x),
+                                        *reinterpret_cast<const uint32_t *>(b.p + (ptrdiff_t)r * b.stride + x), s);
+    s = block_sum(s, s_red);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x + pl] = s;
+}
+
+// stats[o], stats[o+1] = sums of the even / odd partials (one workgroup of 256)
+__device__ __forceinline__ void fold(const uint32_t *partial, int nblocks, uint32_t *s_red, uint32_t &even, uint32_t &odd) {
+    uint32_t e = 0, o = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { e += partial[2 * i]; o += partial[2 * i + 1]; }
+    even = block_sum(e, s_red);
+    odd = block_sum(o, s_red);
+}
+__global__ __launch_bounds__(256) void k_fold(const uint32_t *partial, int nblocks, uint32_t *stats, int o) {
+    __shared__ uint32_t s_red[4];
+    uint32_t e, d;
+    fold(partial, nblocks, s_red, e, d);
+    if (threadIdx.x == 0) { stats[o] = e; stats[o + 1] = d; }
+}
+
+// get_loopfilter_strength's closing arithmetic (vp8enc.cpp:100-103,119-123) + prepare_segments_data
+// (vp8enc.cpp:129-221) on the device: the frame loop then needs no host round trip for its parameters
+__global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, int nblocks, uint32_t *stats, SegData *sd,
+                                                       int32_t *strength_out, int n, int ni, int is_key, int q0, int q1, int q2,
+                                                       int q3, int qi_min) {
+    __shared__ uint32_t s_red[4];
+    uint32_t sum, dev;
+    fold(partial, nblocks, s_red, sum, dev);
+    if (threadIdx.x != 0) return;
+    stats[0] = sum;
+    stats[1] = dev;
+    int avg = (int32_t)sum;
+    avg += n / 2;
+    avg /= n;
+    const int reductor = (avg * 5 / 255) + 3;
+    int div = (int32_t)dev;
+    div += ni / 2;
+    div /= ni;
+    int sharpness = div / 8;
+    sharpness = sharpness > 7 ? 7 : sharpness;
+    strength_out[0] = reductor;
+    strength_out[1] = sharpness;
+    int32_t *v = sd->v;
+    for (int i = 0; i < 4 * SD_INTS; ++i) v[i] = 0;
+    v[SD_Y_DC_IDELTA] = 15;                         // segment 0 carries the deltas, :133-148
+    v[SD_UV_DC_IDELTA] = is_key ? 0 : -15;
+    v[SD_UV_AC_IDELTA] = is_key ? 0 : -15;
+    const int refqi[4] = {q0, q1, q2, q3};
+    for (int i = 0; i < 4; ++i) {
+        int32_t *s = v + SD_INTS * i;
+        s[SD_Y_AC_I] = is_key ? qi_min : refqi[i];  // :164
+        const int y_dc_q = k_dc_q[qi(s[SD_Y_AC_I] + v[SD_Y_DC_IDELTA])];
+        int lvl = y_dc_q / reductor;                // :187-189
+        lvl = lvl > 63 ? 63 : (lvl < 0 ? 0 : lvl);
+        s[SD_LOOP_FILTER_LEVEL] = lvl;
+        int il = lvl;                               // :192-199
+        if (sharpness) {
+            il >>= sharpness > 4 ? 2 : 1;
+            if (il > 9 - sharpness) il = 9 - sharpness;
+        }
+        if (!il) il = 1;
+        s[SD_INTERIOR_LIMIT] = il;
+        s[SD_MBEDGE_LIMIT] = ((lvl + 2) * 2) + il;
+        s[SD_SUB_BEDGE_LIMIT] = (lvl * 2) + il;
+        int hev = 0;                                // :204-220
+        if (is_key) hev = lvl >= 40 ? 2 : (lvl >= 15 ? 1 : 0);
+        else hev = lvl >= 40 ? 3 : (lvl >= 20 ? 2 : (lvl >= 15 ? 1 : 0));
+        s[SD_HEV_THRESHOLD] = hev;
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&out[2 + pl], s);
 }
 
 }  // namespace
 
-void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *stats) {
-    hipMemsetAsync(stats, 0, 8, s);
-    hipLaunchKernelGGL(k_lf_strength, dim3((cur.Y[0].w + 1023) / 1024, cur.Y[0].h), dim3(256), 0, s, cur.Y[0], stats);
+size_t rc_partial_words() { return 2 * MAX_PARTIALS; }
+
+void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats, SegData *sd, int32_t *strength_out,
+                          int is_key, const int32_t refqi[4], int qi_min) {
+    const Plane &y = cur.Y[0];
+    const int nb = (y.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_lf_strength, dim3(nb), dim3(256), 0, s, y, partial);
+    hipLaunchKernelGGL(k_auto_segments, dim3(1), dim3(256), 0, s, partial, nb, stats, sd, strength_out, y.w * y.h,
+                       (y.h - 1) * (y.w - 1), is_key, refqi[0], refqi[1], refqi[2], refqi[3], qi_min);
 }
 
-void launch_chroma_sad(hipStream_t s, const Frame &cur, const Frame &prev, uint32_t *stats) {
-    hipMemsetAsync(stats + 2, 0, 8, s);
-    hipLaunchKernelGGL(k_chroma_sad, dim3((cur.U.w + 1023) / 1024, cur.U.h, 2), dim3(256), 0, s, cur.U, cur.V, prev.U, prev.V, stats);
+void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats) {
+    const Plane &y = cur.Y[0];
+    const int nb = (y.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_lf_strength, dim3(nb), dim3(256), 0, s, y, partial);
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, s, partial, nb, stats, 0);
+}
+
+void launch_chroma_sad(hipStream_t s, const Frame &cur, const Frame &prev, uint32_t *partial, uint32_t *stats) {
+    const int nb = (cur.U.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_chroma_sad, dim3(nb, 2), dim3(256), 0, s, cur.U, cur.V, prev.U, prev.V, partial);
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(256), 0, s, partial, nb, stats, 2);
 }
 
 }  // namespace vp8

@@ -233,7 +233,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     for (int i = 0; i < NFRAMES; ++i) cur = carve_frame(cur, width, height, &c->frames[i].f);
     cur = carve_frame(cur, width, height, &c->cur);
     carve_frame(cur, width, height, &c->cur_prev);
-    CR(hipMalloc(&c->d_stats, 4 * sizeof(uint32_t)));
+    CR(hipMalloc(&c->d_stats, (8 + rc_partial_words()) * sizeof(uint32_t)));   // [0..3] sums, [4] reductor, [5] sharpness, [8..] partials
     for (int r = 0; r < 3; ++r) {
         CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
         CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
@@ -350,7 +350,7 @@ int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const
 int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
     if (!c || !reductor || !sharpness) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
-    launch_lf_strength(c->stream, c->cur, c->d_stats);
+    launch_lf_strength(c->stream, c->cur, c->d_stats + 8, c->d_stats);
     HIPCHK(c, hipGetLastError());
     uint32_t st[2];
     HIPCHK(c, hipMemcpyAsync(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
@@ -374,7 +374,7 @@ int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     *Udiff = *Vdiff = 0;
     if (c->cur_count < 2) return VP8HIP_OK;
-    launch_chroma_sad(c->stream, c->cur, c->cur_prev, c->d_stats);
+    launch_chroma_sad(c->stream, c->cur, c->cur_prev, c->d_stats + 8, c->d_stats);
     HIPCHK(c, hipGetLastError());
     uint32_t st[2];
     HIPCHK(c, hipMemcpyAsync(st, c->d_stats + 2, sizeof(st), hipMemcpyDeviceToHost, c->stream));
@@ -405,6 +405,26 @@ int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
     SegData *slot = c->h_sd_ring + (c->sd_ring_pos++ & 15);
     memcpy(slot, sd, sizeof(SegData));
     HIPCHK(c, hipMemcpyAsync(c->d_sd, slot, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4], int qi_min) {
+    if (!c || !refqi) return VP8HIP_ERR_ARG;
+    if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+    launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, c->d_sd, reinterpret_cast<int32_t *>(c->d_stats + 4),
+                         is_key_frame ? 1 : 0, refqi, qi_min);
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *reductor, int32_t *sharpness) {
+    if (!c || !sd) return VP8HIP_ERR_ARG;
+    int32_t rs[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(sd, c->d_sd, sizeof(SegData), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rs, c->d_stats + 4, sizeof(rs), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (reductor) *reductor = rs[0];
+    if (sharpness) *sharpness = rs[1];
     return VP8HIP_OK;
 }
 

@@ -66,8 +66,11 @@ void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, cons
                          int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
 
 // per-frame parameter scans on the device copy of the current frame (kernels_rc.hip); stats = 4 uint32
-void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *stats);                       // [0] sum Y, [1] sum of squared deviations
-void launch_chroma_sad(hipStream_t s, const Frame &cur, const Frame &prev, uint32_t *stats);     // [2] sum |dU|, [3] sum |dV|
+size_t rc_partial_words();   // uint32 words of per-workgroup partial sums the three launchers below need
+void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats);    // [0] sum Y, [1] sum of squared deviations
+void launch_chroma_sad(hipStream_t s, const Frame &cur, const Frame &prev, uint32_t *partial, uint32_t *stats);   // [2] sum |dU|, [3] sum |dV|
+void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats, SegData *sd, int32_t *strength_out,
+                          int is_key, const int32_t refqi[4], int qi_min);   // strength + prepare_segments_data, all on the device
 
 // coefficient entropy stage (kernels_ent.hip): flags + third context + token histogram + probabilities
 constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
@@ -102,6 +105,23 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int byte_of(uint32_t w, int k) { return (int)((w >> (8 * k)) & 0xffu); }
+
+// VP8 quantiser index -> step tables (RFC 6386 14.1; the reference keeps them at GPU_kernels.cl:58-80)
+static __device__ __constant__ const int k_dc_q[128] = {
+    4,   5,   6,   7,   8,   9,   10,  10,  11,  12,  13,  14,  15,  16,  17,  17,  18,  19,  20,  20,  21,  21,
+    22,  22,  23,  23,  24,  25,  25,  26,  27,  28,  29,  30,  31,  32,  33,  34,  35,  36,  37,  37,  38,  39,
+    40,  41,  42,  43,  44,  45,  46,  46,  47,  48,  49,  50,  51,  52,  53,  54,  55,  56,  57,  58,  59,  60,
+    61,  62,  63,  64,  65,  66,  67,  68,  69,  70,  71,  72,  73,  74,  75,  76,  76,  77,  78,  79,  80,  81,
+    82,  83,  84,  85,  86,  87,  88,  89,  91,  93,  95,  96,  98,  100, 101, 102, 104, 106, 108, 110, 112, 114,
+    116, 118, 122, 124, 126, 128, 130, 132, 134, 136, 138, 140, 143, 145, 148, 151, 154, 157};
+static __device__ __constant__ const int k_ac_q[128] = {
+    4,   5,   6,   7,   8,   9,   10,  11,  12,  13,  14,  15,  16,  17,  18,  19,  20,  21,  22,  23,  24,  25,
+    26,  27,  28,  29,  30,  31,  32,  33,  34,  35,  36,  37,  38,  39,  40,  41,  42,  43,  44,  45,  46,  47,
+    48,  49,  50,  51,  52,  53,  54,  55,  56,  57,  58,  60,  62,  64,  66,  68,  70,  72,  74,  76,  78,  80,
+    82,  84,  86,  88,  90,  92,  94,  96,  98,  100, 102, 104, 106, 108, 110, 112, 114, 116, 119, 122, 125, 128,
+    131, 134, 137, 140, 143, 146, 149, 152, 155, 158, 161, 164, 167, 170, 173, 177, 181, 185, 189, 193, 197, 201,
+    205, 209, 213, 217, 221, 225, 229, 234, 239, 245, 249, 254, 259, 264, 269, 274, 279, 284};
+__device__ __forceinline__ int qi(int v) { return iclamp(v, 0, 127); }
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {  // byte-aligned dword load
     uint32_t v;
