@@ -9,7 +9,7 @@
 //   k_ent_count   one thread per block of every coded macroblock: third context from the neighbours' flags,
 //                 then the token walk of count_probs_in_block (including the reference's quirk of counting an
 //                 EOB at every position after the first one, :478-534) into an LDS histogram per workgroup
-//                 (a workgroup stays inside one macroblock row = one partition), flushed with atomics;
+//                 (one workgroup per macroblock row), written out as that row's histogram;
 //   k_ent_probs   num_div_denom: sums the partitions, divides, clamps to 1..255.
 #include "vp8hip_dev.h"
 
@@ -81,18 +81,20 @@ __device__ __forceinline__ int third_context(const uint8_t *flags, const int32_t
     return ctx;
 }
 
-constexpr int CNT_MBS = 10;   // macroblocks per workgroup of k_ent_count (250 of 256 threads)
-
-// counts[part][NCTX][2] = {zero branches taken, branches seen} (the reference's num / denom - 1)
+// counts[mb_row * CNT_SPLIT + q][NCTX][2] = {zero branches taken, branches seen} of one quarter of a macroblock
+// row (the reference's num and denom - 1 are the sums over the rows of a partition).  Histogram in LDS, written
+// out with plain stores and summed by k_ent_probs: no atomics in HBM.
+constexpr int CNT_SPLIT = 4;   // workgroups per macroblock row
 __global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
-                                                   const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw,
-                                                   int num_partitions) {
+                                                   const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw) {
     __shared__ uint32_t s_h[NCTX * 2];
     for (int i = threadIdx.x; i < NCTX * 2; i += 256) s_h[i] = 0;
     __syncthreads();
-    const int mb_row = blockIdx.y;
-    const int mb_col = blockIdx.x * CNT_MBS + threadIdx.x / 25, b = threadIdx.x % 25;
-    if (threadIdx.x < CNT_MBS * 25 && mb_col < mbw) {
+    const int mb_row = blockIdx.x;
+    const int per = (mbw * 25 + CNT_SPLIT - 1) / CNT_SPLIT, i0 = blockIdx.y * per;
+    const int i1 = i0 + per < mbw * 25 ? i0 + per : mbw * 25;
+    for (int item = i0 + threadIdx.x; item < i1; item += 256) {
+        const int mb_col = item / 25, b = item % 25;
         const int mb = mb_row * mbw + mb_col;
         const bool has_y2 = parts[mb] == 0;
         if (nzc[mb] != 0 && (b < 24 || has_y2)) {
@@ -129,24 +131,35 @@ __global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const 
         }
     }
     __syncthreads();
-    uint32_t *dst = counts + (size_t)(mb_row % num_partitions) * NCTX * 2;
-    for (int i = threadIdx.x; i < NCTX * 2; i += 256)
-        if (s_h[i]) atomicAdd(&dst[i], s_h[i]);
+    uint32_t *dst = counts + (size_t)(mb_row * CNT_SPLIT + blockIdx.y) * NCTX * 2;
+    for (int i = threadIdx.x; i < NCTX * 2; i += 256) dst[i] = s_h[i];
 }
 
 // num_div_denom (:764-778) + the denominators of partition 0 that the host inspects (vp8enc.cpp:69-76):
 // every partition's denominator starts at 1 (:552)
-__global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int num_partitions) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NCTX) return;
-    uint32_t num = 0, den = 0;
-    for (int p = 0; p < num_partitions; ++p) {
-        num += counts[((size_t)p * NCTX + i) * 2];
-        den += counts[((size_t)p * NCTX + i) * 2 + 1] + 1u;
+// 16 contexts per workgroup, 16 lanes per context over the partial histograms
+__global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int mbh,
+                                                   int num_partitions) {
+    const int lane = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);   // NCTX is a multiple of 16
+    uint32_t num = 0, den = 0, den0 = 0;
+    for (int h = lane; h < mbh * CNT_SPLIT; h += 16) {
+        const uint2 c = *reinterpret_cast<const uint2 *>(counts + ((size_t)h * NCTX + i) * 2);
+        num += c.x;
+        den += c.y;
+        if ((h / CNT_SPLIT) % num_partitions == 0) den0 += c.y;
     }
-    num = (num << 8) / den;
-    probs[i] = num > 255u ? 255u : (num == 0u ? 1u : num);
-    denom0[i] = counts[(size_t)i * 2 + 1] + 1u;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        num += (uint32_t)__shfl_xor((int)num, m, 16);
+        den += (uint32_t)__shfl_xor((int)den, m, 16);
+        den0 += (uint32_t)__shfl_xor((int)den0, m, 16);
+    }
+    if (lane == 0) {
+        den += (uint32_t)num_partitions;   // every partition's denominator starts at 1 (:552)
+        num = (num << 8) / den;
+        probs[i] = num > 255u ? 255u : (num == 0u ? 1u : num);
+        denom0[i] = den0 + 1u;
+    }
 }
 
 }  // namespace ent
@@ -154,11 +167,10 @@ __global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint3
 void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
                       uint32_t *denom0, int mbw, int mbh, int num_partitions) {
     const int nblocks = mbw * mbh * 25;
-    hipMemsetAsync(counts, 0, sizeof(uint32_t) * ent::NCTX * 2 * num_partitions, s);
     hipLaunchKernelGGL(ent::k_ent_flags, dim3((nblocks + 255) / 256), dim3(256), 0, s, o.coeffs, flags, nblocks);
-    hipLaunchKernelGGL(ent::k_ent_count, dim3((mbw + ent::CNT_MBS - 1) / ent::CNT_MBS, mbh), dim3(256), 0, s, o.coeffs, o.nz,
-                       o.parts, flags, third_ctx, counts, mbw, num_partitions);
-    hipLaunchKernelGGL(ent::k_ent_probs, dim3((ent::NCTX + 255) / 256), dim3(256), 0, s, counts, probs, denom0, num_partitions);
+    hipLaunchKernelGGL(ent::k_ent_count, dim3(mbh, ent::CNT_SPLIT), dim3(256), 0, s, o.coeffs, o.nz, o.parts, flags, third_ctx,
+                       counts, mbw);
+    hipLaunchKernelGGL(ent::k_ent_probs, dim3(ent::NCTX / 16), dim3(256), 0, s, counts, probs, denom0, mbh, num_partitions);
 }
 
 // ====================================================================================================
@@ -423,35 +435,49 @@ __global__ __launch_bounds__(256) void k_ent_walk(const uint32_t *maps, Plan *pl
     }
 }
 
-constexpr int ENC_LANES = 64;
-__global__ __launch_bounds__(ENC_LANES) void k_ent_encode(const uint16_t *bools, const Plan *plan, int P, const uint2 *start,
-                                                          unsigned long long *acc) {
-    __shared__ uint16_t s_b[ENC_LANES][CHUNK + 2];   // +2: lanes walk their rows in step, the skew keeps them on different banks
-    const int lane = threadIdx.x;
-    for (uint32_t c0 = blockIdx.x * ENC_LANES; c0 < plan->total_chunks; c0 += gridDim.x * ENC_LANES) {
-        __syncthreads();
-        for (int row = 0; row < ENC_LANES; ++row) {   // coalesced: one chunk per iteration, 64 lanes x 4 bools
-            const uint32_t ch = c0 + row;
-            if (ch >= plan->total_chunks) break;
-            int p, n;
-            uint32_t b0;
-            chunk_slice(plan, P, ch, p, b0, n);
-            for (int i = lane; i < n; i += ENC_LANES) s_b[row][i] = bools[b0 + i];
+// Four lanes per chunk: lane j first replays bools [0, 64j) of its chunk for the range and bit position only
+// (cheap), then codes bools [64j, 64j+64) into the accumulators.  Bools come straight from HBM/L2, sixteen loads
+// issued back to back per batch (a version that staged chunks through LDS row by row serialised on load latency:
+// 141 us per 1080p frame).
+constexpr int ENC_SUB = 4, ENC_SUBLEN = CHUNK / ENC_SUB, ENC_CHUNKS = 64;   // chunks per workgroup of 256
+__global__ __launch_bounds__(256) void k_ent_encode(const uint16_t *bools, const Plan *plan, int P, const uint2 *start,
+                                                    unsigned long long *acc) {
+    __shared__ Plan s_plan;   // the plan is consulted per chunk: from LDS, not through a chain of dependent global loads
+    for (int i = threadIdx.x; i < (int)(sizeof(Plan) / 4); i += 256) reinterpret_cast<uint32_t *>(&s_plan)[i] = reinterpret_cast<const uint32_t *>(plan)[i];
+    __syncthreads();
+    plan = &s_plan;
+    const int j = threadIdx.x & (ENC_SUB - 1);
+    for (uint32_t c0 = blockIdx.x * ENC_CHUNKS; c0 < plan->total_chunks; c0 += gridDim.x * ENC_CHUNKS) {
+        const uint32_t chunk = c0 + (threadIdx.x >> 2);
+        if (chunk >= plan->total_chunks) continue;
+        int p, n;
+        uint32_t b0;
+        chunk_slice(plan, P, chunk, p, b0, n);
+        unsigned long long *out = acc + plan->word_base[p];
+        const uint2 st = start[chunk];
+        uint32_t r = st.x, W = st.y, split;
+        const int lo = j * ENC_SUBLEN < n ? j * ENC_SUBLEN : n, hi = lo + ENC_SUBLEN < n ? lo + ENC_SUBLEN : n;
+        const uint16_t *src = bools + b0;
+        for (int i0 = 0; i0 < lo; i0 += 16) {           // lo is a multiple of 16 (or n: then the tail guard below ends it)
+            uint32_t e[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) e[k] = src[i0 + k];   // the buffer has slack behind the last bool
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i0 + k < lo) W += range_step(r, e[k] & 255u, e[k] >> 8, split);
         }
-        __syncthreads();
-        const uint32_t chunk = c0 + lane;
-        if (chunk < plan->total_chunks) {
-            int p, n;
-            uint32_t b0;
-            chunk_slice(plan, P, chunk, p, b0, n);
-            unsigned long long *out = acc + plan->word_base[p];
-            const uint2 st = start[chunk];
-            uint32_t r = st.x, W = st.y, widx = W >> 5, split;
-            unsigned long long cur = 0, nxt = 0;   // sums for output words widx and widx+1
-            for (int i = 0; i < n; ++i) {
-                const uint32_t e = s_b[lane][i], bit = e >> 8;
+        uint32_t widx = W >> 5;
+        unsigned long long cur = 0, nxt = 0;   // sums for output words widx and widx+1
+        for (int i0 = lo; i0 < hi; i0 += 16) {
+            uint32_t e[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) e[k] = src[i0 + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (i0 + k >= hi) continue;
+                const uint32_t bit = e[k] >> 8;
                 const int o = (int)(W & 31u);
-                const int s = range_step(r, e & 255u, bit, split);
+                const int s = range_step(r, e[k] & 255u, bit, split);
                 if (bit) {   // split occupies stream bits W .. W+7 (bit 0 = most significant bit of the first byte)
                     if (o <= 24) cur += (unsigned long long)split << (24 - o);
                     else { cur += split >> (o - 24); nxt += ((unsigned long long)split << (56 - o)) & 0xffffffffull; }
@@ -462,9 +488,9 @@ __global__ __launch_bounds__(ENC_LANES) void k_ent_encode(const uint16_t *bools,
                     cur = nxt; nxt = 0; ++widx;
                 }
             }
-            if (cur) atomicAdd(&out[widx], cur);
-            if (nxt) atomicAdd(&out[widx + 1], nxt);
         }
+        if (cur) atomicAdd(&out[widx], cur);
+        if (nxt) atomicAdd(&out[widx + 1], nxt);
     }
 }
 
@@ -526,7 +552,7 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
     hipMemsetAsync(eb.acc, 0, (size_t)eb.cap_words * 8, s);
     hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
     hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
-    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(ent::ENC_LANES), 0, s, eb.bools, plan, P,
+    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,
                        reinterpret_cast<const uint2 *>(eb.start), reinterpret_cast<unsigned long long *>(eb.acc));
     hipLaunchKernelGGL(ent::k_ent_finish, dim3(P), dim3(64), 0, s, reinterpret_cast<const unsigned long long *>(eb.acc), plan,
                        eb.bytes, eb.sizes);

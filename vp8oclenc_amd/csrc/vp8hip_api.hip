@@ -256,7 +256,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
     CR(hipMalloc(&c->ent_third, (size_t)c->mbs * 25));
     CR(hipMemsetAsync(c->ent_third, 0, (size_t)c->mbs * 25, c->stream));
-    CR(hipMalloc(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * ENT_MAX_PARTITIONS));
+    CR(hipMalloc(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * c->mbh * 4));   // four partial histograms per macroblock row
     CR(hipMalloc(&c->ent_probs, sizeof(uint32_t) * ENT_NCTX));
     CR(hipMalloc(&c->ent_denom0, sizeof(uint32_t) * ENT_NCTX));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
