@@ -157,7 +157,28 @@ def main():
             ref_hist["frames"] += 1
             ref_hist["refs"] += 1 + ug + ua
 
-    streams = [GopStream(k) for k in range(G)]
+    class NativeGopStream:
+        """The same, through the native frame loop (vp8_driver.cpp): one C call per frame, parameters on the device."""
+
+        def __init__(self, k: int):
+            self.drv = api.NativeDriver(W, H, device=local, gop_size=1 << 30, altref_range=5, qi_min=0, qi_max=48,
+                                        ssim_target=args.ssim_target, device_params=1, check_ssim=0)
+            self.enc = self.drv.hip
+            self.t = (k * 3) % nd
+            y, u, v = dev_frames[self.t % nd]
+            assert self.drv.encode_frame_device(y.data_ptr(), u.data_ptr(), v.data_ptr())   # frame 0 of the chunk: key
+            self.t += 1
+            self.ptrs = [tuple(p.data_ptr() for p in f) for f in dev_frames]
+
+        def step(self):
+            self.drv.encode_frame_device(*self.ptrs[self.t % nd])
+            self.t += 1
+            st = self.drv.stats()
+            ref_hist["frames"] += 1
+            ref_hist["refs"] += 1 + st.last_use_golden + st.last_use_altref
+
+    native = not args.host_params
+    streams = [(NativeGopStream if native else GopStream)(k) for k in range(G)]
 
     def barrier():
         if dist is not None:
@@ -227,6 +248,7 @@ def main():
                        "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": lastqi,
                        "altref_range": 5, "frames_per_gpu": args.steps, "gops_per_gpu": G,
                        "segment_params": "host mirror, precomputed" if args.host_params else "device, inside the step",
+                       "frame_loop": "python over the C ABI" if args.host_params else "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roof,
             "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
@@ -240,7 +262,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     for st in streams:
-        st.enc.close()
+        (st.drv if native else st.enc).close()
     if dist is not None:
         dist.destroy_process_group()
 

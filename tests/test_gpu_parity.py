@@ -153,6 +153,38 @@ def test_sequence_through_driver_1080p_like_gop():
     ora.close()
 
 
+@pytest.mark.parametrize("device_params", [0, 1])
+def test_native_frame_loop_matches_reference_loop_on_oracle(device_params):
+    """vp8_driver.cpp (the reference's frame loop as native host code, one call per frame) against the same loop
+    in Python driving the CPU oracle: 24 frames, key + golden + altref, check_SSIM's filter update on."""
+    W, H = 320, 192
+    s = SynthSequence(W, H, seed=21)
+    drv = api.NativeDriver(s.W, s.H, gop_size=150, altref_range=5, device_params=device_params, check_ssim=1)
+    ora = Oracle(s.W, s.H)
+    do = InterPathDriver(ora, s.W, s.H, gop_size=150, altref_range=5)
+    keys = ["MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs", "MB_segment_id", "MB_SSIM"]
+    for t in range(24):
+        y, u, v = s.frame(t)
+        was_key = drv.encode_frame_host(y, u, v)
+        b = do.encode_frame(y, u, v)
+        assert was_key == (b is None), t
+        if b is None:
+            continue
+        st = drv.stats()
+        assert (st.last_use_golden, st.last_use_altref) == (b["use_golden"], b["use_altref"]), t
+        a = drv.hip.download_results(recon=False)
+        _compare(a, b, keys, f"native loop, frame {t}")
+        sd, _, _ = drv.hip.get_segments()
+        assert np.array_equal(sd, np.asarray(b["segments"]).reshape(4, 11)), f"segment data, frame {t}"
+        ly, lu, lv = drv.hip.download_last()
+        oy, ou, ov = ora.download_last()
+        assert np.array_equal(ly, oy) and np.array_equal(lu, ou) and np.array_equal(lv, ov), f"filtered recon, frame {t}"
+    st = drv.stats()
+    assert st.key_frames == 1 and st.inter_frames == 23
+    drv.close()
+    ora.close()
+
+
 def test_ssim_target_multi_pass_sequence():
     """-SSIM-target 97: macroblocks take 1..4 segment passes (inter_part.h:329-378)."""
     W, H = 192, 128

@@ -29,6 +29,8 @@ ABI_SYMBOLS = [
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
+    "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats",
 ]
 
 
@@ -189,6 +191,78 @@ class Gop:
         self.lib.vp8host_gop_frame_done(C.byref(self.s))
 
 
+class DrvConfig(C.Structure):
+    """vp8drv_config, include/vp8hip_driver.h"""
+    _fields_ = [("gop_size", C.c_int32), ("altref_range", C.c_int32), ("qi_min", C.c_int32), ("qi_max", C.c_int32),
+                ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32)]
+
+
+class DrvStats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("frame_number", "inter_frames", "key_frames", "last_use_golden",
+                                          "last_use_altref", "last_prev_is_golden", "last_prev_is_altref",
+                                          "last_was_altref")]
+
+
+class NativeDriver:
+    """The reference's frame loop as native host code (vp8_driver.cpp, include/vp8hip_driver.h): one call per
+    frame.  `.hip` is a view of its context for downloads and taps."""
+
+    def __init__(self, width: int, height: int, device: int = 0, **cfg):
+        self.lib = load_library()
+        lib = self.lib
+        lib.vp8drv_default_config.argtypes = [C.POINTER(DrvConfig)]
+        lib.vp8drv_default_config.restype = None
+        lib.vp8drv_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(DrvConfig)]
+        lib.vp8drv_destroy.argtypes = [C.c_void_p]
+        lib.vp8drv_destroy.restype = None
+        lib.vp8drv_context.argtypes = [C.c_void_p]
+        lib.vp8drv_context.restype = C.c_void_p
+        lib.vp8drv_encode_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.vp8drv_encode_frame_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.vp8drv_get_stats.argtypes = [C.c_void_p, C.POINTER(DrvStats)]
+        lib.vp8drv_get_stats.restype = None
+        self.cfg = DrvConfig()
+        lib.vp8drv_default_config(C.byref(self.cfg))
+        for k, v in cfg.items():
+            setattr(self.cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.vp8drv_create(C.byref(h), width, height, device, C.byref(self.cfg))
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_create({width}x{height}) failed: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+        self.h = h
+        self.hip = Vp8Hip.borrowed(lib.vp8drv_context(h), width, height)
+
+    def _ret(self, rc: int) -> bool:
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_encode_frame: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return rc == 1
+
+    def encode_frame_device(self, d_y: int, d_u: int, d_v: int, force_key: bool = False) -> bool:
+        """True if the frame was handed to the key-frame stand-in, False for an inter frame."""
+        return self._ret(self.lib.vp8drv_encode_frame_device(self.h, d_y, d_u, d_v, int(force_key)))
+
+    def encode_frame_host(self, y, u, v, force_key: bool = False) -> bool:
+        y, u, v = (np.ascontiguousarray(p, np.uint8) for p in (y, u, v))
+        return self._ret(self.lib.vp8drv_encode_frame_host(self.h, y.ctypes.data, u.ctypes.data, v.ctypes.data, int(force_key)))
+
+    def stats(self) -> DrvStats:
+        s = DrvStats()
+        self.lib.vp8drv_get_stats(self.h, C.byref(s))
+        return s
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.hip.close()
+            self.lib.vp8drv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- device path ------------------------------------------------------------------------------
 class Vp8Hip:
     """One encoder context on one MI355X (vp8hip_create ... vp8hip_destroy)."""
@@ -210,7 +284,22 @@ class Vp8Hip:
             raise Vp8HipError(f"{what}: {self.lib.vp8hip_status_string(rc).decode()} ({rc}), hipError "
                               f"{self.lib.vp8hip_last_hip_error(self.h)}")
 
+    @classmethod
+    def borrowed(cls, handle, width: int, height: int):
+        """View of a context owned by somebody else (the native driver): same methods, no destroy."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.W, self.H = width, height
+        self.mbs = (width // 16) * (height // 16)
+        self.b8 = self.mbs * 4
+        self.h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.h = None
+            return
         if getattr(self, "h", None):
             self.lib.vp8hip_destroy(self.h)
             self.h = None

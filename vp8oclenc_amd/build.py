@@ -8,8 +8,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvp8hip.so")
-SOURCES = ["vp8hip_api.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_ent.hip", "kernels_rc.hip", "vp8_host.cpp"]
-HEADERS = ["vp8hip_dev.h", os.path.join("..", "..", "include", "vp8hip.h"), os.path.join("..", "..", "include", "vp8hip_host.h")]
+SOURCES = ["vp8hip_api.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_ent.hip", "kernels_rc.hip", "vp8_host.cpp", "vp8_driver.cpp"]
+HEADERS = ["vp8hip_dev.h"] + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h")]
 
 
 def _hipcc() -> str:
