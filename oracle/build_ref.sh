@@ -49,3 +49,11 @@ $CL -x cl -cl-std=CL1.2 -cl-no-stdinc -target x86_64-unknown-linux-gnu -O2 -w -f
 $CL $CFLAGS -c "$HERE/ref_driver.c" -o "$TMP/driver.o"
 $CL -target x86_64-unknown-linux-gnu -shared -o "$OUT/libvp8ref.so" "$TMP/gpu.o" "$TMP/cpu.o" "$TMP/shim.o" "$TMP/driver.o"
 echo "built $OUT/libvp8ref.so"
+
+# The reference's HOST intra path (src/intra_part.h, check_SSIM in src/vp8enc.cpp): the translation unit is
+# compiled from where it lies, main() renamed, driven by oracle/ref_host_driver.cpp.  It needs the OpenCL headers
+# (ROCm ships them) and libOpenCL (the ICD loader of this image) only to link; no OpenCL call is reached.
+CXX=${CXX:-g++}
+$CXX -O2 -fPIC -shared -ffp-contract=off -w -DCL_TARGET_OPENCL_VERSION=120 -I"$REF/src" -I/opt/rocm/include \
+    "$HERE/ref_host_driver.cpp" "$REF/src/entropy_host.cpp" -o "$OUT/libvp8refhost.so" -lOpenCL
+echo "built $OUT/libvp8refhost.so"

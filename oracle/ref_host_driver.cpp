@@ -1,0 +1,112 @@
+/*
+ * ref_host_driver.cpp -- calls into the reference's own HOST code for the intra path (src/intra_part.h:
+ * predict_and_transform_mb, test_inter_on_intra; src/vp8enc.cpp: check_SSIM), compiled for x86 by
+ * oracle/build_ref.sh into oracle/_ref/libvp8refhost.so.  TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference keeps these functions `static` inside one translation unit (vp8enc.cpp includes every header),
+ * so this file includes that translation unit from where it lies (-I $REF/src) with its main() renamed, fills the
+ * encoder's global state (`video`, `frames`) from plain arrays and calls the functions.  No OpenCL call is
+ * reached: GOP_size is left at 1, which makes intra_transform/prepare_segments_data skip their uploads
+ * (src/intra_part.h:1112, src/vp8enc.cpp:221).  Single-threaded (global state).
+ */
+#define main vp8enc_reference_main
+#include "vp8enc.cpp"
+#undef main
+
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+std::vector<macroblock_extra_data> g_edata;
+
+void bind(int width, int height, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv, uint8_t *ry, uint8_t *ru,
+          uint8_t *rv, int16_t *coeffs, int32_t *parts, int32_t *seg, float *ssim, const int32_t *sd) {
+    video.wrk_width = width;
+    video.wrk_height = height;
+    video.mb_width = width / 16;
+    video.mb_height = height / 16;
+    video.mb_count = video.mb_width * video.mb_height;
+    video.wrk_frame_size_luma = width * height;
+    video.wrk_frame_size_chroma = width * height / 4;
+    video.GOP_size = 1; /* no uploads */
+    video.print_info = 0;
+    frames.current_Y = const_cast<uint8_t *>(cy);
+    frames.current_U = const_cast<uint8_t *>(cu);
+    frames.current_V = const_cast<uint8_t *>(cv);
+    frames.reconstructed_Y = ry;
+    frames.reconstructed_U = ru;
+    frames.reconstructed_V = rv;
+    frames.MB = reinterpret_cast<macroblock_coeffs_t *>(coeffs);
+    frames.MB_parts = parts;
+    frames.MB_segment_id = seg;
+    frames.MB_SSIM = ssim;
+    g_edata.assign(video.mb_count, macroblock_extra_data());
+    frames.e_data = g_edata.data();
+    /* quantizer steps exactly as prepare_segments_data derives them (src/vp8enc.cpp:164-187) from the 4x11 ints */
+    for (int i = 0; i < 4; ++i) {
+        memcpy(&frames.segments_data[i], sd + 11 * i, sizeof(segment_data));
+        const segment_data &s0 = frames.segments_data[0];
+        const int base = frames.segments_data[i].y_ac_i;
+        auto cl = [](int q) { return q > 127 ? 127 : (q < 0 ? 0 : q); };
+        frames.y_ac_q[i] = vp8_ac_qlookup[base];
+        frames.y_dc_q[i] = vp8_dc_qlookup[cl(base + s0.y_dc_idelta)];
+        frames.uv_dc_q[i] = vp8_dc_qlookup[cl(base + s0.uv_dc_idelta)];
+        frames.uv_ac_q[i] = vp8_ac_qlookup[cl(base + s0.uv_ac_idelta)];
+        if (frames.uv_dc_q[i] > 132) frames.uv_dc_q[i] = 132;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+/* intra_transform's loop, src/intra_part.h:1103-1109.  modes: [mbs][16] */
+void ref_intra_transform(int width, int height, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv, const int32_t *sd,
+                         uint8_t *ry, uint8_t *ru, uint8_t *rv, int16_t *coeffs, int32_t *parts, int32_t *seg,
+                         int32_t *modes) {
+    bind(width, height, cy, cu, cv, ry, ru, rv, coeffs, parts, seg, nullptr, sd);
+    for (int mb = 0; mb < video.mb_count; ++mb) predict_and_transform_mb(mb);
+    for (int mb = 0; mb < video.mb_count; ++mb)
+        for (int b = 0; b < 16; ++b) modes[mb * 16 + b] = frames.e_data[mb].mode[b];
+}
+
+/* check_SSIM, src/vp8enc.cpp:231-263, after the frame loop set is_inter_mb = 1 (:437-438).
+ * in/out: recon planes, coeffs, parts, seg, ssim.  out: is_inter[mbs], modes[mbs][16] (0 where never tested),
+ * stats = {replaced, new_SSIM, min1 > 0.95}.  Block 24 of a replaced macroblock is whatever the reference's
+ * uninitialised stack held (src/intra_part.h:858,1066): callers must not compare it. */
+void ref_check_ssim(int width, int height, float ssim_target, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv,
+                    const int32_t *sd, uint8_t *ry, uint8_t *ru, uint8_t *rv, int16_t *coeffs, int32_t *parts,
+                    int32_t *seg, float *ssim, int32_t *is_inter, int32_t *modes, int32_t *replaced, float *new_ssim,
+                    int32_t *filter_updated) {
+    bind(width, height, cy, cu, cv, ry, ru, rv, coeffs, parts, seg, ssim, sd);
+    video.SSIM_target = ssim_target;
+    for (int mb = 0; mb < video.mb_count; ++mb) frames.e_data[mb].is_inter_mb = 1;
+    /* check_SSIM ends in prepare_segments_data(1, 7) when the worst macroblock is above 0.95; that call only
+     * needs the frame-type flags and the quantizer ladder, which do not influence what is compared here */
+    frames.current_is_key_frame = 0;
+    frames.current_is_altref_frame = 0;
+    video.qi_min = 0;
+    for (int i = 0; i < 4; ++i) video.lastqi[i] = video.altrefqi[i] = frames.segments_data[i].y_ac_i;
+    const int sharp_before = video.loop_filter_sharpness = -12345;
+    check_SSIM();
+    *filter_updated = video.loop_filter_sharpness != sharp_before;
+    *replaced = frames.replaced;
+    *new_ssim = frames.new_SSIM;
+    for (int mb = 0; mb < video.mb_count; ++mb) {
+        is_inter[mb] = frames.e_data[mb].is_inter_mb;
+        for (int b = 0; b < 16; ++b) modes[mb * 16 + b] = frames.e_data[mb].mode[b];
+    }
+}
+
+/* count_SSIM_16x16, src/intra_part.h:744-853 */
+float ref_count_ssim_16x16(const uint8_t *y1, const uint8_t *u1, const uint8_t *v1, int w1, const uint8_t *y2,
+                           const uint8_t *u2, const uint8_t *v2, int w2) {
+    return count_SSIM_16x16(y1, u1, v1, w1, y2, u2, v2, w2);
+}
+
+/* pick_luma_predictor, src/intra_part.h:252-515.  top: 8 values, left: 4 */
+int ref_pick_luma_predictor(const uint8_t *orig, uint8_t *pred, int16_t *resid, const int16_t *top, const int16_t *left,
+                            int top_left) {
+    return pick_luma_predictor(orig, pred, resid, top, left, (cl_short)top_left);
+}
+}

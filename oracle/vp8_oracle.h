@@ -101,6 +101,19 @@ void vp8o_encode_coefficients(const int16_t *MB, const int32_t *MB_non_zero_coef
                               const uint32_t *coeff_probs, int mb_height, int mb_width, int num_partitions,
                               int partition_step);
 
+/* Host intra path (vp8_intra_oracle.c): src/intra_part.h and check_SSIM of src/vp8enc.cpp:231-263.  Planes have
+ * stride = width; coeffs [MBs][25][16] (blocks 0..23 written, zigzag order); modes [MBs][16]; sd = 4 x 11 ints. */
+int vp8o_host_weight(const int16_t r[16]);
+int vp8o_pick_luma_predictor(const uint8_t orig[16], uint8_t pred[16], int16_t resid[16], const int16_t top[8],
+                             const int16_t left[4], int top_left);
+float vp8o_count_ssim_16x16(const uint8_t *y1, const uint8_t *u1, const uint8_t *v1, int w1, const uint8_t *y2,
+                            const uint8_t *u2, const uint8_t *v2, int w2);
+void vp8o_intra_transform(int width, int height, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv, const int32_t sd[44],
+                          uint8_t *ry, uint8_t *ru, uint8_t *rv, int16_t *coeffs, int32_t *parts, int32_t *seg, int32_t *modes);
+void vp8o_check_ssim(int width, int height, float ssim_target, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv,
+                     const int32_t sd[44], uint8_t *ry, uint8_t *ru, uint8_t *rv, int16_t *coeffs, int32_t *parts, int32_t *seg,
+                     float *ssim, int32_t *is_inter, int32_t *modes, int32_t *replaced, float *new_ssim, float *min_ssim);
+
 /* ------------------------------------------------------------------------------------------
  * Whole inter frame, in the enqueue order of src/inter_part.h:96-384 followed by
  * src/loop_filter.h:25-55,140-183.  One context keeps the three references and their pyramids

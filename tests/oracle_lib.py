@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8ref.so")
+REF_HOST_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8refhost.so")
 
 SD_INTS = 11
 
@@ -49,12 +50,12 @@ _STAGES = {
 
 def build_oracle(force: bool = False) -> str:
     """Compile oracle/liboracle.so (and oracle/_ref when /root/reference is present)."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vp8_oracle.c", "vp8_entropy_oracle.c", "vp8_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vp8_oracle.c", "vp8_entropy_oracle.c", "vp8_intra_oracle.c", "vp8_oracle.h")]
     stale = (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
-    drv = os.path.join(ORACLE_DIR, "ref_driver.c")
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_SO) or os.path.getmtime(REF_SO) < os.path.getmtime(drv)):
+    drvs = [(REF_SO, os.path.join(ORACLE_DIR, "ref_driver.c")), (REF_HOST_SO, os.path.join(ORACLE_DIR, "ref_host_driver.cpp"))]
+    if os.path.isdir("/root/reference/src") and (force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(d) for so, d in drvs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
@@ -220,3 +221,90 @@ def ref_stages() -> Stages | None:
     if not os.path.exists(REF_SO):
         return None
     return Stages(C.CDLL(REF_SO), "ref_")
+
+
+class Intra:
+    """The host intra path (key frames, check_SSIM's intra fallback) of one library: prefix 'vp8o_' = the restatement
+    oracle/vp8_intra_oracle.c, 'ref_' = the reference's own code (oracle/_ref/libvp8refhost.so)."""
+
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.prefix = prefix
+        self._key = getattr(lib, prefix + "intra_transform")
+        self._key.argtypes = [ci, ci, u8p, u8p, u8p, i32p, u8p, u8p, u8p, i16p, i32p, i32p, i32p]
+        self._key.restype = None
+        self._chk = getattr(lib, prefix + "check_ssim")
+        self._chk.argtypes = [ci, ci, C.c_float, u8p, u8p, u8p, i32p, u8p, u8p, u8p, i16p, i32p, i32p, f32p, i32p, i32p,
+                              C.POINTER(ci), C.POINTER(C.c_float), C.c_void_p]
+        self._chk.restype = None
+        self._ssim = getattr(lib, prefix + ("count_ssim_16x16"))
+        self._ssim.argtypes = [u8p, u8p, u8p, ci, u8p, u8p, u8p, ci]
+        self._ssim.restype = C.c_float
+        self._pick = getattr(lib, prefix + "pick_luma_predictor")
+        self._pick.argtypes = [u8p, u8p, i16p, i16p, i16p, ci]
+        self._pick.restype = ci
+
+    def intra_transform(self, cur, sd):
+        """Key frame.  cur = (Y, U, V) tight planes; returns dict(recon_Y/U/V, MB_coeffs, MB_parts, MB_segment_id, modes)."""
+        y, u, v = (np.ascontiguousarray(p) for p in cur)
+        H, W = y.shape
+        mbs = (W // 16) * (H // 16)
+        o = {"recon_Y": np.zeros_like(y), "recon_U": np.zeros_like(u), "recon_V": np.zeros_like(v),
+             "MB_coeffs": np.zeros((mbs, 25, 16), np.int16), "MB_parts": np.zeros(mbs, np.int32),
+             "MB_segment_id": np.zeros(mbs, np.int32), "modes": np.zeros((mbs, 16), np.int32)}
+        self._key(W, H, y, u, v, np.ascontiguousarray(sd, np.int32).reshape(-1), o["recon_Y"], o["recon_U"], o["recon_V"],
+                  o["MB_coeffs"], o["MB_parts"], o["MB_segment_id"], o["modes"])
+        return o
+
+    def check_ssim(self, cur, sd, ssim_target, inter):
+        """check_SSIM on the results of an inter frame (dict with prefilter recon_Y/U/V, MB_coeffs, MB_parts,
+        MB_segment_id, MB_SSIM); returns the updated copies + is_inter, modes, replaced, new_SSIM, filter_updated."""
+        y, u, v = (np.ascontiguousarray(p) for p in cur)
+        H, W = y.shape
+        mbs = (W // 16) * (H // 16)
+        o = {k: np.ascontiguousarray(inter[k]).copy() for k in ("recon_Y", "recon_U", "recon_V", "MB_coeffs", "MB_parts", "MB_segment_id", "MB_SSIM")}
+        o["is_inter"] = np.zeros(mbs, np.int32)
+        o["modes"] = np.zeros((mbs, 16), np.int32)
+        repl, new = ci(0), C.c_float(0)
+        if self.prefix == "ref_":
+            third = ci(0)
+            self._chk(W, H, ssim_target, y, u, v, np.ascontiguousarray(sd, np.int32).reshape(-1), o["recon_Y"], o["recon_U"], o["recon_V"],
+                      o["MB_coeffs"], o["MB_parts"], o["MB_segment_id"], o["MB_SSIM"], o["is_inter"], o["modes"], C.byref(repl), C.byref(new),
+                      C.cast(C.byref(third), C.c_void_p))
+            o["filter_updated"] = int(third.value)
+        else:
+            third = C.c_float(0)
+            self._chk(W, H, ssim_target, y, u, v, np.ascontiguousarray(sd, np.int32).reshape(-1), o["recon_Y"], o["recon_U"], o["recon_V"],
+                      o["MB_coeffs"], o["MB_parts"], o["MB_segment_id"], o["MB_SSIM"], o["is_inter"], o["modes"], C.byref(repl), C.byref(new),
+                      C.cast(C.byref(third), C.c_void_p))
+            o["min_SSIM"] = float(third.value)
+            o["filter_updated"] = int(third.value > np.float32(0.95))      # src/vp8enc.cpp:260
+        o["replaced"], o["new_SSIM"] = int(repl.value), np.float32(new.value)
+        return o
+
+    def count_ssim_16x16(self, a, b):
+        """a, b = (Y 16x16, U 8x8, V 8x8) blocks."""
+        a = [np.ascontiguousarray(p) for p in a]
+        b = [np.ascontiguousarray(p) for p in b]
+        return np.float32(self._ssim(a[0], a[1], a[2], 16, b[0], b[1], b[2], 16))
+
+    def pick_luma_predictor(self, orig, top, left, top_left):
+        pred, resid = np.zeros(16, np.uint8), np.zeros(16, np.int16)
+        m = self._pick(np.ascontiguousarray(orig, np.uint8).reshape(-1), pred, resid, np.ascontiguousarray(top, np.int16),
+                       np.ascontiguousarray(left, np.int16), int(top_left))
+        return int(m), pred, resid
+
+
+def oracle_intra() -> Intra:
+    return Intra(Oracle.lib(), "vp8o_")
+
+
+def ref_intra() -> Intra | None:
+    """The reference's own host intra code (x86 build) or None when oracle/_ref was not built."""
+    if not os.path.exists(REF_HOST_SO):
+        try:
+            build_oracle()
+        except Exception:
+            return None
+    if not os.path.exists(REF_HOST_SO):
+        return None
+    return Intra(C.CDLL(REF_HOST_SO), "ref_")
