@@ -105,6 +105,30 @@ int vp8hip_upload_mb_data(vp8hip_ctx *ctx, const int16_t *MB_coeffs, const int32
                           const int32_t *MB_segment_id);
 int vp8hip_upload_recon(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 
+/* ---- the host intra path on the device -----------------------------------------------------------
+ * The reference codes key frames and the intra fallback of inter frames on one CPU thread, which forces the
+ * reconstruction and all coefficients across the bus twice per frame (vp8enc.cpp:422-433, 460-470;
+ * loop_filter.h:7,63-65).  Both run here as a row wavefront on the current frame already in HBM.
+ *
+ * intra_transform()'s loop, intra_part.h:1089-1109 (predict_and_transform_mb, :517-741): the current frame as a key
+ * frame -- B_PRED luma with the mode of every 4x4 block picked by pick_luma_predictor (:252-515), TM_PRED chroma,
+ * quantizers of segment 0 of the segment data in force (vp8hip_set_segments / vp8hip_auto_segments with
+ * is_key_frame).  Leaves coefficients (blocks 0..23, zigzag), MB_parts = are4x4, MB_segment_id = 0 and the
+ * unfiltered reconstruction where vp8hip_inter_transform leaves them; continue with vp8hip_prepare_filter_mask and
+ * vp8hip_loop_filter, after which the next vp8hip_inter_transform takes prev_is_golden = prev_is_altref = 1
+ * (intra_part.h:1091-1098).  Asynchronous. */
+int vp8hip_intra_transform(vp8hip_ctx *ctx);
+/* check_SSIM(), vp8enc.cpp:231-263, on the results of the preceding vp8hip_inter_transform: every macroblock whose
+ * SSIM is below the context's ssim_target is tried as intra in segments AQ, HQ, UQ (test_inter_on_intra,
+ * intra_part.h:855-1087) and replaced -- coefficients, MB_parts, MB_segment_id, MB_SSIM, reconstruction -- when that
+ * scores higher.  Returns frames.replaced, frames.new_SSIM and the minimum SSIM (`min1`; the reference updates
+ * the filter parameters when it exceeds 0.95, :260).  Blocks until the three values are back. */
+int vp8hip_check_ssim(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim);
+/* e_data[].mode[16] of the last vp8hip_intra_transform / vp8hip_check_ssim (the sub-block modes the header coder
+ * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference, 0 where none was made) and
+ * e_data[].is_inter_mb (check_ssim only).  Either pointer may be NULL. */
+int vp8hip_download_intra(vp8hip_ctx *ctx, int32_t *modes, int32_t *is_inter_mb);
+
 /* prepare_filter_mask_and_non_zero_coeffs(), loop_filter.h:25-55.  nz_out: [MBs] or NULL.
  * (vp8hip_inter_transform already produced mask and counts for its own coefficients; this call
  * recomputes them from the device copy, e.g. after vp8hip_upload_mb_data.) */
@@ -163,6 +187,7 @@ typedef enum {
     VP8HIP_K_BORDER,        /* edge replication of a new reference */
     VP8HIP_K_ENT_COUNT,     /* count_probs + num_div_denom       CPU_kernels.cl:536,764 */
     VP8HIP_K_ENT_ENCODE,    /* encode_coefficients               CPU_kernels.cl:347 */
+    VP8HIP_K_INTRA,         /* key frame / check_SSIM fallback   intra_part.h:517-1109 */
     VP8HIP_K_COUNT
 } vp8hip_kernel_id;
 

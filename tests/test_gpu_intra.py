@@ -1,0 +1,146 @@
+"""GPU parity of the host intra path moved to the device (kernels_intra.hip) through the C ABI:
+vp8hip_intra_transform (key frames) and vp8hip_check_ssim (intra fallback of inter frames) against the CPU oracle
+(oracle/vp8_intra_oracle.c) and the committed golden vectors of the reference's own code.  Bit-exact, including
+the SSIM of every attempt (it decides comparisons)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from intra_cases import CHECK_KEYS, INTRA_KEYS, compare_check, compare_key, fallback_case, key_case
+from oracle_lib import oracle_intra
+from vp8oclenc_amd import api
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "intra", "*.npz")))
+KEY_GOLDEN = [p for p in GOLDEN if os.path.basename(p).startswith("key_")]
+CHECK_GOLDEN = [p for p in GOLDEN if os.path.basename(p).startswith("check_")]
+
+
+def ids(paths):
+    return [os.path.basename(p)[:-4] for p in paths]
+
+
+def hip_key_frame(cur, sd):
+    H, W = cur[0].shape
+    enc = api.Vp8Hip(W, H)
+    try:
+        enc.upload_current(*cur)
+        enc.set_segments(sd)
+        enc.intra_transform()
+        r = enc.download_results(recon=True)
+        modes, _ = enc.download_intra()
+    finally:
+        enc.close()
+    return {"recon_Y": r["prefilter_Y"], "recon_U": r["prefilter_U"], "recon_V": r["prefilter_V"], "MB_coeffs": r["MB_coeffs"],
+            "MB_parts": r["MB_parts"], "MB_segment_id": r["MB_segment_id"], "modes": modes}
+
+
+def hip_check_ssim(cur, sd, target, inter):
+    """Put the inter results on the device exactly as vp8hip_inter_transform would have left them, then check_ssim."""
+    H, W = cur[0].shape
+    enc = api.Vp8Hip(W, H, target)
+    try:
+        enc.upload_current(*cur)
+        enc.set_segments(sd)
+        enc.upload_recon(inter["recon_Y"], inter["recon_U"], inter["recon_V"])
+        enc.upload_mb_data(inter["MB_coeffs"], inter["MB_parts"], inter["MB_segment_id"])
+        enc._debug_set_ssim(inter["MB_SSIM"])
+        repl, new, mn = enc.check_ssim()
+        r = enc.download_results(recon=True)
+        modes, is_inter = enc.download_intra()
+    finally:
+        enc.close()
+    return {"recon_Y": r["prefilter_Y"], "recon_U": r["prefilter_U"], "recon_V": r["prefilter_V"], "MB_coeffs": r["MB_coeffs"],
+            "MB_parts": r["MB_parts"], "MB_segment_id": r["MB_segment_id"], "MB_SSIM": r["MB_SSIM"], "modes": modes, "is_inter": is_inter,
+            "replaced": repl, "new_SSIM": new, "min_SSIM": mn, "filter_updated": int(mn > np.float32(0.95))}
+
+
+@pytest.mark.parametrize("path", KEY_GOLDEN, ids=ids(KEY_GOLDEN))
+def test_key_frame_matches_reference_golden_vectors(path):
+    z = np.load(path)
+    cur = tuple(np.ascontiguousarray(z["cur_" + p]) for p in "YUV")
+    compare_key(hip_key_frame(cur, z["sd"]), {k: z["out_" + k] for k in INTRA_KEYS}, os.path.basename(path))
+
+
+@pytest.mark.parametrize("W,H,seed,qi,kind", [(16, 16, 1, 0, "synth"), (32, 16, 2, 5, "noise"), (16, 48, 3, 20, "synth"), (176, 144, 4, 0, "synth"),
+                                               (64, 64, 5, 60, "noise"), (80, 48, 6, 127, "synth"), (48, 48, 7, 0, "flat"), (352, 288, 8, 10, "synth"),
+                                               (1040, 32, 9, 30, "noise")])
+def test_key_frame_matches_oracle(W, H, seed, qi, kind):
+    cur, sd = key_case(W, H, seed, qi, kind)
+    compare_key(hip_key_frame(cur, sd), oracle_intra().intra_transform(cur, sd), f"{W}x{H} {kind} q{qi}")
+
+
+def test_key_frame_1080p_matches_oracle():
+    cur, sd = key_case(1920, 1088, 21, 0, "synth")
+    compare_key(hip_key_frame(cur, sd), oracle_intra().intra_transform(cur, sd), "1080p")
+
+
+@pytest.mark.parametrize("path", CHECK_GOLDEN, ids=ids(CHECK_GOLDEN))
+def test_check_ssim_matches_reference_golden_vectors(path):
+    z = np.load(path)
+    cur = tuple(np.ascontiguousarray(z["cur_" + p]) for p in "YUV")
+    inter = {k[3:]: np.ascontiguousarray(z[k]) for k in z.files if k.startswith("in_")}
+    exp = {k: z["out_" + k] for k in CHECK_KEYS}
+    exp.update(replaced=int(z["replaced"]), new_SSIM=np.float32(z["new_SSIM"]), filter_updated=int(z["filter_updated"]))
+    compare_check(hip_check_ssim(cur, z["sd"], float(z["target"]), inter), exp, os.path.basename(path))
+
+
+@pytest.mark.parametrize("W,H,seed,target,cut,qi", [(64, 48, 11, 0.97, True, (40, 100)), (96, 64, 12, 0.93, True, (70, 127)), (176, 144, 13, 0.995, False, (0, 48)),
+                                                     (48, 48, 14, 0.99, True, (10, 60)), (64, 32, 15, -1.0, True, (0, 48)), (128, 64, 16, 2.0, True, (30, 90)),
+                                                     (352, 288, 17, 0.97, True, (40, 100)), (1280, 720, 18, 0.98, True, (30, 90))])
+def test_check_ssim_matches_oracle(W, H, seed, target, cut, qi):
+    H = H // 16 * 16
+    cur, sd, inter = fallback_case(W, H, seed, target if 0 < target < 1 else 0.9, scene_cut=cut, qi=qi)
+    a = hip_check_ssim(cur, sd, target, inter)
+    b = oracle_intra().check_ssim(cur, sd, target, inter)
+    compare_check(a, b, f"{W}x{H} t{target}")
+    assert np.float32(a["min_SSIM"]) == np.float32(b["min_SSIM"])
+
+
+def test_key_frame_then_inter_frames_follow_the_reference_flow():
+    """intra_transform -> filter mask -> loop filter -> LAST = GOLDEN = ALTREF, then an inter frame on top: the
+    device chain against the same chain on the CPU oracle."""
+    from oracle_lib import Oracle
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H = 176, 144
+    seq = SynthSequence(W, H, seed=31)
+    key, nxt = seq.frame(0), seq.frame(1)
+    last, _ = api.quantizer_ladders(0, 48)
+    red, sh = api.loopfilter_strength(key[0])
+    sd_key = api.prepare_segments_data(True, last, 0, red, sh)
+    red, sh = api.loopfilter_strength(nxt[0])
+    sd_int = api.prepare_segments_data(False, last, 0, red, sh)
+
+    enc = api.Vp8Hip(W, H)
+    enc.upload_current(*key)
+    enc.set_segments(sd_key)
+    enc.intra_transform()
+    enc.prepare_filter_mask(False)
+    enc.loop_filter()
+    got_key = enc.download_last()
+    enc.upload_current(*nxt)
+    enc.set_segments(sd_int)
+    enc.inter_transform(1, 1, 0, 0)
+    got = enc.download_results(recon=True)
+    enc.close()
+
+    k = oracle_intra().intra_transform(key, sd_key)
+    orc = Oracle(W, H)
+    orc.set_segments(sd_key)
+    orc.upload_recon(k["recon_Y"], k["recon_U"], k["recon_V"])
+    orc.upload_mb_data(k["MB_coeffs"], k["MB_parts"], k["MB_segment_id"])
+    orc.prepare_filter_mask(False)
+    orc.loop_filter()
+    exp_key = orc.download_last()
+    for a, b, n in zip(got_key, exp_key, "YUV"):
+        assert np.array_equal(a, b), f"loop-filtered key frame, plane {n}"
+    orc.set_segments(sd_int)
+    orc.upload_current(*nxt)
+    orc.inter_transform(1, 1, 0, 0)
+    exp = orc.download_results(recon=True)
+    orc.close()
+    for kk in ("MB_parts", "MB_vectors", "MB_coeffs", "MB_segment_id", "prefilter_Y", "prefilter_U", "prefilter_V"):
+        assert np.array_equal(got[kk], exp[kk]), kk

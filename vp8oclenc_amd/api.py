@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "search1_l1", "search1_l0", "search2",
-           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode"]
+           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode", "intra"]
 K_COUNT = len(K_NAMES)
 
 DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT = range(7)
@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
@@ -97,6 +98,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8hip_auto_segments.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_int]
     lib.vp8hip_get_segments.argtypes = [vp, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.vp8hip_encode_coefficients.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vp8hip_intra_transform.argtypes = [vp]
+    lib.vp8hip_check_ssim.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.vp8hip_download_intra.argtypes = [vp, C.c_void_p, C.c_void_p]
     i32p = C.POINTER(C.c_int32)
     lib.vp8host_quantizer_ladders.argtypes = [C.c_int, C.c_int, i32p, i32p]
     lib.vp8host_quantizer_ladders.restype = None
@@ -349,6 +353,28 @@ class Vp8Hip:
         if recon:  # before the loop filter these are the unfiltered planes
             out["prefilter_Y"], out["prefilter_U"], out["prefilter_V"] = out.pop("recon_Y"), out.pop("recon_U"), out.pop("recon_V")
         return out
+
+    def intra_transform(self):
+        """intra_transform (intra_part.h:1089-1109): the current frame as a key frame, on the device."""
+        self._chk(self.lib.vp8hip_intra_transform(self.h), "intra_transform")
+
+    def check_ssim(self):
+        """check_SSIM (vp8enc.cpp:231-263) on the device: (replaced, new_SSIM, min SSIM)."""
+        repl, new, mn = C.c_int32(), C.c_float(), C.c_float()
+        self._chk(self.lib.vp8hip_check_ssim(self.h, C.byref(repl), C.byref(new), C.byref(mn)), "check_ssim")
+        return repl.value, np.float32(new.value), np.float32(mn.value)
+
+    def download_intra(self):
+        """(modes[MBs][16], is_inter[MBs]) of the last intra_transform / check_ssim."""
+        modes, is_inter = np.zeros((self.mbs, 16), np.int32), np.zeros(self.mbs, np.int32)
+        self._chk(self.lib.vp8hip_download_intra(self.h, modes.ctypes.data, is_inter.ctypes.data), "download_intra")
+        return modes, is_inter
+
+    def _debug_set_ssim(self, ssim):
+        s = np.ascontiguousarray(ssim, np.float32)
+        assert s.size == self.mbs
+        self.lib.vp8hip_debug_upload_ssim.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.lib.vp8hip_debug_upload_ssim(self.h, s.ctypes.data), "debug_upload_ssim")
 
     def upload_mb_data(self, coeffs=None, parts=None, seg=None):
         self._chk(self.lib.vp8hip_upload_mb_data(self.h, _ptr(coeffs), _ptr(parts), _ptr(seg)), "upload_mb_data")

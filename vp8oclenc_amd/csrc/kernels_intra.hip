@@ -1,0 +1,503 @@
+// kernels_intra.hip -- the reference's HOST intra path on the device:
+//   key frames            intra_transform / predict_and_transform_mb, src/intra_part.h:517-741,1089-1109
+//   intra fallback        check_SSIM -> test_inter_on_intra, src/vp8enc.cpp:231-263, src/intra_part.h:855-1087
+//
+// The reference walks the macroblocks in raster order on one CPU thread: a macroblock predicts from the
+// reconstruction of its left, top-left, top and top-right neighbours, and inside a macroblock each of the 16 luma
+// 4x4 blocks predicts from the blocks before it.  Here one wavefront owns one macroblock ROW and the rows run as a
+// lag-2 wavefront over the frame: row r may code macroblock c once row r-1 has finished c+1 (progress counters in
+// HBM, data and counters at agent scope like the loop filter's band hand-off).  Inside the wavefront the 64 lanes are
+// 10 candidate modes x 4 pixel rows: every lane predicts one row of one B_PRED mode, the 4x4 transforms run on
+// quads (row pass in the lane, LDS transpose, column pass in the lane), all ten quads quantise and reconstruct, and
+// only the quad of the winning mode (first strict minimum of the reference's `weight`) writes.  Chroma (TM_PRED)
+// codes its 8 blocks at once on 8 quads.  Everything stays in LDS until the macroblock is committed.
+//
+// In fallback mode a macroblock is touched only if its SSIM is below the target, and a row never waits for rows
+// above it unless it has such a macroblock: untouched macroblocks are final as the inter kernels left them.
+#include "vp8hip_dev.h"
+
+namespace vp8 {
+namespace {
+
+constexpr int IMG_S = 32;                 // bytes per row of the luma work tile: x = -4 .. 27 at byte x + 4
+constexpr int CIMG_S = 16;                // chroma work tiles: x = -4 .. 11
+constexpr int INTRA_SPIN_LIMIT = 1 << 21; // polls (~1 us each) before a wait gives up
+
+struct Sh {
+    uint8_t img[17 * IMG_S];       // rows y = -1 .. 15: neighbours in row 0 / bytes 0..3, the reconstruction inside
+    uint8_t cimg[2][9 * CIMG_S];
+    uint8_t srcY[256];
+    uint8_t srcC[2][64];
+    int16_t tr[64 * 4];            // 4x4 transposes, one 8-byte row per lane
+    int16_t coef[24 * 16];         // quantised coefficients of the macroblock, already in zigzag order
+};
+
+// Sub-block predictors over one edge array e[0..14] = { L3, L3, L2, L1, L0, TL, T0 .. T7, T7 } (the doubled ends turn
+// the three "3x" taps of B_HE/B_LD/B_HU, src/intra_part.h:330,352,499, into the ordinary 1-2-1 filter).  An entry is
+// kind << 4 | k:  kind 0 = (e[k-1] + 2 e[k] + e[k+1] + 2) >> 2,  kind 1 = (e[k] + e[k+1] + 1) >> 1,  kind 2 = e[k];
+// on the device all three are the first form with the taps (e[k], e[k+1], e[k]) resp. (e[k], e[k], e[k]).
+#define F3(k) (0x00 | (k))
+#define F2(k) (0x10 | (k))
+#define CP(k) (0x20 | (k))
+__device__ __constant__ const uint8_t k_bpred[8][16] = {
+    /* B_VE */ {F3(6), F3(7), F3(8), F3(9), F3(6), F3(7), F3(8), F3(9), F3(6), F3(7), F3(8), F3(9), F3(6), F3(7), F3(8), F3(9)},
+    /* B_HE */ {F3(4), F3(4), F3(4), F3(4), F3(3), F3(3), F3(3), F3(3), F3(2), F3(2), F3(2), F3(2), F3(1), F3(1), F3(1), F3(1)},
+    /* B_LD */ {F3(7), F3(8), F3(9), F3(10), F3(8), F3(9), F3(10), F3(11), F3(9), F3(10), F3(11), F3(12), F3(10), F3(11), F3(12), F3(13)},
+    /* B_RD */ {F3(5), F3(6), F3(7), F3(8), F3(4), F3(5), F3(6), F3(7), F3(3), F3(4), F3(5), F3(6), F3(2), F3(3), F3(4), F3(5)},
+    /* B_VR */ {F2(5), F2(6), F2(7), F2(8), F3(5), F3(6), F3(7), F3(8), F3(4), F2(5), F2(6), F2(7), F3(3), F3(5), F3(6), F3(7)},
+    /* B_VL */ {F2(6), F2(7), F2(8), F2(9), F3(7), F3(8), F3(9), F3(10), F2(7), F2(8), F2(9), F3(11), F3(8), F3(9), F3(10), F3(12)},
+    /* B_HD */ {F2(4), F3(5), F3(6), F3(7), F2(3), F3(4), F2(4), F3(5), F2(2), F3(3), F2(3), F3(4), F2(1), F3(2), F2(2), F3(3)},
+    /* B_HU */ {F2(3), F3(3), F2(2), F3(2), F2(2), F3(2), F2(1), F3(1), F2(1), F3(1), CP(1), CP(1), CP(1), CP(1), CP(1), CP(1)},
+};
+#undef F3
+#undef F2
+#undef CP
+// byte offset of e[k] in the luma tile relative to the block's top-left neighbour (row 4*br, byte 4*bc + 3)
+__device__ __constant__ const uint8_t k_eoff[15] = {4 * IMG_S, 4 * IMG_S, 3 * IMG_S, 2 * IMG_S, IMG_S, 0, 1, 2, 3, 4, 5, 6, 7, 8, 8};
+// position of raster coefficient j in the reference's zigzag_block order (src/intra_part.h:13-37)
+__device__ __constant__ const uint8_t k_zzpos[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
+
+// 2^32 / q + 1 for every quantizer step: trunc(t / q) = mulhi(t, M) - (t >> 31) for |t| < 2^32 / q
+struct Recip { uint32_t m[285]; };
+constexpr Recip make_recip() {
+    Recip r{};
+    for (int q = 0; q < 285; ++q) r.m[q] = q < 2 ? 0u : (uint32_t)((1ull << 32) / (unsigned)q) + 1u;
+    return r;
+}
+__device__ __constant__ const Recip k_recip = make_recip();
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+// sums over the 16 lanes of a row land in its lane 15; over the wavefront in lane 63
+__device__ __forceinline__ int row_sum(int v) {
+    v += dpp<0xB1>(0, v);    // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(0, v);    // quad_perm [2,3,0,1]
+    v += dpp<0x114>(0, v);   // row_shr:4
+    v += dpp<0x118>(0, v);   // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v = row_sum(v);
+    v += dpp<0x142, 0xa>(0, v);   // row_bcast:15
+    v += dpp<0x143, 0xc>(0, v);   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // LDS operations of one wavefront execute in order
+
+__device__ __forceinline__ uint32_t ld_agent(const uint8_t *p) {
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint8_t *p, uint32_t v) {
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Steps { int y_dc, y_ac, uv_dc, uv_ac; };   // prepare_segments_data, src/vp8enc.cpp:164-187 (deltas of segment 0)
+__device__ __forceinline__ Steps steps_of(const SegData *sd, int id) {
+    const int base = sd->v[id * SD_INTS + SD_Y_AC_I];
+    Steps s;
+    s.y_ac = k_ac_q[qi(base)];
+    s.y_dc = k_dc_q[qi(base + sd->v[SD_Y_DC_IDELTA])];
+    s.uv_dc = imin(k_dc_q[qi(base + sd->v[SD_UV_DC_IDELTA])], 132);
+    s.uv_ac = k_ac_q[qi(base + sd->v[SD_UV_AC_IDELTA])];
+    return s;
+}
+
+// quantizer of one lane: coefficient row 0 of its column is DC for column 0; everything else is AC
+struct LaneQ { int q0, h0, qa, ha; uint32_t m0, ma; };
+__device__ __forceinline__ LaneQ lane_q(int dc, int ac, int col) {
+    LaneQ q;
+    q.qa = ac; q.ha = ac / 2; q.ma = k_recip.m[ac];
+    q.q0 = col == 0 ? dc : ac; q.h0 = q.q0 / 2; q.m0 = k_recip.m[q.q0];
+    return q;
+}
+__device__ __forceinline__ int quant1(int w, int sign_of, int h, uint32_t m) {   // quant4x4, src/intra_part.h:212-250
+    const int t = w + (sign_of < 0 ? -h : h);
+    return __mulhi(t, (int)m) - (t >> 31);
+}
+
+// One 4x4 unit on a quad of lanes (lane i of the quad = pixel row i on entry, coefficient column i in the middle):
+// residual -> DCT4x4 (:114-157) -> weight (:159-210) -> quant4x4 -> dequantise + iDCT4x4 (:42-111) -> reconstruction.
+// p = this lane's predictor row, sdw = its source row.  Returns the packed reconstructed row; qc[j] = quantised
+// coefficient 4*j + (lane & 3); weight = the reference's `weight` of the residual, identical in the four lanes.
+__device__ __forceinline__ uint32_t code_unit(Sh &sh, int lane, const int p[4], uint32_t sdw, const LaneQ &q, int qc[4], int &weight) {
+    const int d0 = byte_of(sdw, 0) - p[0], d1 = byte_of(sdw, 1) - p[1], d2 = byte_of(sdw, 2) - p[2], d3 = byte_of(sdw, 3) - p[3];
+    const int s03 = d0 + d3, s12 = d1 + d2, m12 = d1 - d2, m03 = d0 - d3;
+    const int o0 = (s03 + s12) * 8, o2 = (s03 - s12) * 8;
+    const int o1 = (__mul24(m12, 17736) + __mul24(m03, 42816) + 14500) >> 12;   // c1 = m12 << 3, d1 = m03 << 3
+    const int o3 = (__mul24(m03, 17736) - __mul24(m12, 42816) + 7500) >> 12;
+    int16_t *mine = sh.tr + lane * 4;
+    const int16_t *col = sh.tr + (lane & ~3) * 4 + (lane & 3);
+    *reinterpret_cast<uint2 *>(mine) = make_uint2(pk16(o0, o1), pk16(o2, o3));
+    lds_order();
+    const int v0 = col[0], v1 = col[4], v2 = col[8], v3 = col[12];
+    lds_order();
+    const int a = v0 + v3, b = v1 + v2, c = v1 - v2, d = v0 - v3;
+    const int w0 = (a + b + 7) >> 4, w2 = (a - b + 7) >> 4;
+    const int w1 = ((__mul24(c, 2217) + __mul24(d, 5352) + 12000) >> 16) + (d != 0);
+    const int w3 = (__mul24(d, 2217) - __mul24(c, 5352) + 51000) >> 16;
+    {
+        const int t0 = (lane & 3) == 0 ? w0 / 4 : w0;
+        int s = iabs(t0) + iabs(w1) + iabs(w2) + iabs(w3);
+        s += dpp<0xB1>(0, s);
+        s += dpp<0x4E>(0, s);
+        weight = s;
+    }
+    // coefficient 11 (row 2, column 3) is rounded by the sign of coefficient 10 (row 2, column 2), :227
+    const int w2sign = dpp<0xA4>(0, w2);   // quad_perm [0,1,2,2]
+    qc[0] = quant1(w0, w0, q.h0, q.m0);
+    qc[1] = quant1(w1, w1, q.ha, q.ma);
+    qc[2] = quant1(w2, w2sign, q.ha, q.ma);
+    qc[3] = quant1(w3, w3, q.ha, q.ma);
+    const int x0 = __mul24(qc[0], q.q0), x1 = __mul24(qc[1], q.qa), x2 = __mul24(qc[2], q.qa), x3 = __mul24(qc[3], q.qa);
+    {
+        const int ia = x0 + x2, ib = x0 - x2;
+        const int ic = ((__mul24(x1, 35468)) >> 16) - (x3 + ((__mul24(x3, 20091)) >> 16));
+        const int id = (x1 + ((__mul24(x1, 20091)) >> 16)) + ((__mul24(x3, 35468)) >> 16);
+        *reinterpret_cast<uint2 *>(mine) = make_uint2(pk16(ia + id, ib + ic), pk16(ib - ic, ia - id));   // 16-bit stores, as :54-75
+    }
+    lds_order();
+    const int t0 = col[0], t1 = col[4], t2 = col[8], t3 = col[12];
+    lds_order();
+    const int ha = t0 + t2, hb = t0 - t2;
+    const int hc = ((__mul24(t1, 35468)) >> 16) - (t3 + ((__mul24(t3, 20091)) >> 16));
+    const int hd = (t1 + ((__mul24(t1, 20091)) >> 16)) + ((__mul24(t3, 35468)) >> 16);
+    const int y0 = sat8(((ha + hd + 4) >> 3) + p[0]), y1 = sat8(((hb + hc + 4) >> 3) + p[1]);
+    const int y2 = sat8(((hb - hc + 4) >> 3) + p[2]), y3 = sat8(((ha - hd + 4) >> 3) + p[3]);
+    return (uint32_t)y0 | ((uint32_t)y1 << 8) | ((uint32_t)y2 << 16) | ((uint32_t)y3 << 24);
+}
+
+// per-lane constants of the luma mode decision: lane = 4 * mode + pixel row, modes 0..9 (lanes 40..63 idle)
+struct LaneK {
+    int a[4], b[4], c[4];   // tile offsets of the three taps of each of the 4 pixels
+    int zz[4];              // zigzag position of coefficient 4*j + (lane & 3)
+    int mode, row;
+    bool is_dc, is_tm, active;
+};
+__device__ __forceinline__ LaneK lane_consts(int lane) {
+    LaneK k;
+    k.mode = lane >> 2;
+    k.row = lane & 3;
+    k.active = k.mode < 10;
+    k.is_dc = k.mode == 0;
+    k.is_tm = k.mode == 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ea = 5, eb = 5, ec = 5;
+        if (k.mode == 0) ea = 1 + j;                        // B_DC: the four left neighbours; the top row comes as a dword
+        else if (k.mode == 1) { ea = 4 - k.row; eb = 5; }   // B_TM: L[row] and TL
+        else if (k.mode < 10) {
+            const int e = k_bpred[k.mode - 2][4 * k.row + j], kind = e >> 4, kk = e & 15;
+            ea = kind == 0 ? kk - 1 : kk;
+            eb = kind == 1 ? kk + 1 : kk;
+            ec = kind == 0 ? kk + 1 : kk;
+        }
+        k.a[j] = k_eoff[ea];
+        k.b[j] = k_eoff[eb];
+        k.c[j] = k_eoff[ec];
+        k.zz[j] = k_zzpos[4 * j + (lane & 3)];
+    }
+    return k;
+}
+
+// one luma 4x4 block: pick_luma_predictor (:252-515) + transform + reconstruction; returns the chosen mode
+template <int BR, int BC>
+__device__ __forceinline__ int luma_block(Sh &sh, int lane, const LaneK &k, const LaneQ &q) {
+    constexpr int B = 4 * BR * IMG_S + 4 * BC + 3;   // the block's top-left neighbour
+    int A[4], Bt[4], C[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        A[j] = sh.img[B + k.a[j]];
+        Bt[j] = sh.img[B + k.b[j]];
+        C[j] = sh.img[B + k.c[j]];
+    }
+    const uint32_t tdw = *reinterpret_cast<const uint32_t *>(&sh.img[B + 1]);                          // T0..T3
+    const uint32_t sdw = *reinterpret_cast<const uint32_t *>(&sh.srcY[(4 * BR + k.row) * 16 + 4 * BC]);
+    const int dc = (int)(__builtin_amdgcn_sad_u8(tdw, 0u, (uint32_t)(A[0] + A[1] + A[2] + A[3])) + 4u) >> 3;
+    const int tm_d = A[0] - Bt[0];
+    int p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (A[j] + 2 * Bt[j] + C[j] + 2) >> 2;
+        const int tm = sat8(byte_of(tdw, j) + tm_d);
+        p[j] = k.is_dc ? dc : (k.is_tm ? tm : g);
+    }
+    int qc[4], w;
+    const uint32_t rec = code_unit(sh, lane, p, sdw, q, qc, w);
+    // first strict minimum in mode order = minimum of (weight, mode)
+    int key = k.active ? (w << 4) | k.mode : 0x7fffffff;
+    key = imin(key, dpp<0x114>(0x7fffffff, key));
+    key = imin(key, dpp<0x118>(0x7fffffff, key));
+    key = imin(key, dpp<0x142, 0xa>(0x7fffffff, key));
+    key = imin(key, dpp<0x143, 0xc>(0x7fffffff, key));
+    const int best = __builtin_amdgcn_readlane(key, 63) & 15;
+    if (k.mode == best) {
+        *reinterpret_cast<uint32_t *>(&sh.img[(4 * BR + 1 + k.row) * IMG_S + 4 + 4 * BC]) = rec;
+        int16_t *cf = sh.coef + (4 * BR + BC) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cf[k.zz[j]] = (int16_t)qc[j];
+    }
+    lds_order();
+    return best;
+}
+
+// the 8 chroma blocks (TM_PRED from the macroblock's edges, :674-739) on lanes 0..31: quad = plane * 4 + block
+__device__ __forceinline__ void chroma_blocks(Sh &sh, int lane, const LaneK &k, int uv_dc, int uv_ac) {
+    const int l = lane & 31, pl = l >> 4, bb = (l >> 2) & 3, br = bb >> 1, bc = bb & 1, i = l & 3;
+    const uint8_t *t = sh.cimg[pl];
+    const uint32_t tdw = *reinterpret_cast<const uint32_t *>(t + 4 + 4 * bc);
+    const int dl = (int)t[(4 * br + i + 1) * CIMG_S + 3] - (int)t[3];
+    const uint32_t sdw = *reinterpret_cast<const uint32_t *>(&sh.srcC[pl][(4 * br + i) * 8 + 4 * bc]);
+    int p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = sat8(byte_of(tdw, j) + dl);
+    const LaneQ q = lane_q(uv_dc, uv_ac, lane & 3);
+    int qc[4], w;
+    const uint32_t rec = code_unit(sh, lane, p, sdw, q, qc, w);
+    if (lane < 32) {
+        *reinterpret_cast<uint32_t *>(&sh.cimg[pl][(4 * br + i + 1) * CIMG_S + 4 + 4 * bc]) = rec;
+        int16_t *cf = sh.coef + (16 + 4 * pl + bb) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cf[k.zz[j]] = (int16_t)qc[j];
+    }
+    lds_order();
+}
+
+// count_SSIM_16x16 (src/intra_part.h:744-853) of the work tiles against the source tiles.  The reference's integer
+// accumulators are NOT reset between planes: M1 enters chroma as |M1 - M2|, M2/D1/D2/C with their luma results.
+// Central moments come from raw moments (exact in integers): sum (x - m)^2 = sum x^2 - 2 m sum x + n m^2.
+__device__ __forceinline__ int tdiv_pow2(int v, int sh) { return (v + ((v >> 31) & ((1 << sh) - 1))) >> sh; }   // C division
+__device__ float mb_ssim(Sh &sh, int lane) {
+    const float c1 = 0.01f * 0.01f * 255 * 255, c2 = 0.03f * 0.03f * 255 * 255;
+    int M1 = 0, M2 = 0, D1 = 0, D2 = 0, C = 0;
+    float ssim = 0.0f;
+    // raw moments of the three planes: luma on all lanes, U on lanes 0..15, V on lanes 16..31
+    const uint32_t ty = *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]);
+    const uint32_t sy = *reinterpret_cast<const uint32_t *>(&sh.srcY[lane * 4]);
+    const int l = lane & 31, pl = l >> 4;
+    const uint32_t tc = *reinterpret_cast<const uint32_t *>(&sh.cimg[pl][(((l >> 1) & 7) + 1) * CIMG_S + 4 + 4 * (l & 1)]);
+    const uint32_t sc = *reinterpret_cast<const uint32_t *>(&sh.srcC[pl][(l & 15) * 4]);
+    int S1[3], S2[3], Q1[3], Q2[3], X[3];
+    S1[0] = wave_sum((int)__builtin_amdgcn_sad_u8(ty, 0u, 0u));
+    S2[0] = wave_sum((int)__builtin_amdgcn_sad_u8(sy, 0u, 0u));
+    Q1[0] = wave_sum((int)__builtin_amdgcn_udot4(ty, ty, 0u, false));
+    Q2[0] = wave_sum((int)__builtin_amdgcn_udot4(sy, sy, 0u, false));
+    X[0] = wave_sum((int)__builtin_amdgcn_udot4(ty, sy, 0u, false));
+    {
+        const int a = row_sum((int)__builtin_amdgcn_sad_u8(tc, 0u, 0u)), b = row_sum((int)__builtin_amdgcn_sad_u8(sc, 0u, 0u));
+        const int cq = row_sum((int)__builtin_amdgcn_udot4(tc, tc, 0u, false)), dq = row_sum((int)__builtin_amdgcn_udot4(sc, sc, 0u, false));
+        const int e = row_sum((int)__builtin_amdgcn_udot4(tc, sc, 0u, false));
+        S1[1] = __builtin_amdgcn_readlane(a, 15); S1[2] = __builtin_amdgcn_readlane(a, 31);
+        S2[1] = __builtin_amdgcn_readlane(b, 15); S2[2] = __builtin_amdgcn_readlane(b, 31);
+        Q1[1] = __builtin_amdgcn_readlane(cq, 15); Q1[2] = __builtin_amdgcn_readlane(cq, 31);
+        Q2[1] = __builtin_amdgcn_readlane(dq, 15); Q2[2] = __builtin_amdgcn_readlane(dq, 31);
+        X[1] = __builtin_amdgcn_readlane(e, 15); X[2] = __builtin_amdgcn_readlane(e, 31);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int n = p ? 64 : 256, lg = p ? 6 : 8;
+        M1 = (M1 + S1[p] + n / 2) >> lg;     // sums are non-negative
+        M2 = (M2 + S2[p] + n / 2) >> lg;
+        D1 = tdiv_pow2(D1 + Q1[p] - 2 * M1 * S1[p] + n * M1 * M1 + n / 2, lg);
+        D2 = tdiv_pow2(D2 + Q2[p] - 2 * M2 * S2[p] + n * M2 * M2 + n / 2, lg);
+        C = tdiv_pow2(C + X[p] - M1 * S2[p] - M2 * S1[p] + n * M1 * M2 + n / 2, lg);
+        const float m1 = (float)M1, m2 = (float)M2;
+        const float num = (m1 * m2 * 2 + c1) * ((float)C * 2 + c2);
+        const float den = (m1 * m1 + m2 * m2 + c1) * ((float)D1 + (float)D2 + c2);
+        ssim = p == 0 ? __fdiv_rn(num, den) : ssim + __fdiv_rn(num, den);
+        M1 = iabs(M1 - M2);
+        ssim -= M1 > 4 ? (float)M1 * 0.02f : 0.0f;
+    }
+    return __fdiv_rn(ssim, 3.0f);
+}
+
+struct IntraArgs {
+    Plane cy, cu, cv;       // current frame
+    Plane ry, ru, rv;       // reconstruction (unfiltered), read for the neighbours and written
+    MBOut o;
+    const SegData *sd;
+    int32_t *modes;         // [MBs][16] sub-block modes of the last attempt (e_data.mode)
+    int32_t *is_inter;      // [MBs] 0 where check_SSIM replaced the macroblock
+    int32_t *prog;          // [mbh] macroblocks of the row that are final
+    int32_t *err;           // set to 1 when a bounded wait expired (shared with the loop filter: VP8HIP_ERR_TIMEOUT)
+    float target;
+    int key;                // 1: key frame (every macroblock, segment 0); 0: fallback of an inter frame
+    int mbw, mbh;
+};
+
+__global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
+    __shared__ __attribute__((aligned(16))) Sh sh;
+    const int lane = threadIdx.x, r = blockIdx.x, mbw = a.mbw;
+    const LaneK k = lane_consts(lane);
+    int32_t *err = a.err;
+    const int mb_row0 = r * mbw;
+    if (!a.key) {   // frame loop + check_SSIM defaults: every macroblock inter, no modes (vp8enc.cpp:437-438)
+        for (int i = lane; i < mbw; i += 64) a.is_inter[mb_row0 + i] = 1;
+        for (int i = lane; i < mbw * 16; i += 64) a.modes[(size_t)mb_row0 * 16 + i] = 0;
+    }
+    int c = 0;
+    while (c < mbw) {
+        if (!a.key) {   // next macroblock below the target
+            const int idx = c + lane;
+            const bool f = idx < mbw && a.o.ssim[mb_row0 + idx] < a.target;
+            const unsigned long long m = __ballot(f);
+            if (!m) { c += 64; continue; }
+            c += __builtin_ctzll(m);
+        }
+        if (lane == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everything before c is final
+        const int mb = mb_row0 + c;
+        // ---- source tiles --------------------------------------------------------------------------------------
+        *reinterpret_cast<uint32_t *>(&sh.srcY[lane * 4]) =
+            *reinterpret_cast<const uint32_t *>(a.cy.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.cy.stride + 16 * c + 4 * (lane & 3));
+        if (lane < 32) {
+            const Plane &P = lane < 16 ? a.cu : a.cv;
+            const int l = lane & 15;
+            *reinterpret_cast<uint32_t *>(&sh.srcC[lane >> 4][l * 4]) =
+                *reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1));
+        }
+        // ---- neighbours: the row above must have finished its macroblock c + 1 -----------------------------------
+        if (r > 0) {
+            const int need = imin(c + 2, mbw);
+            int spins = 0;
+            while (__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > INTRA_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+        }
+        if (lane < 44) {
+            // lanes 0..5 / 6..8 / 9..11: the row above (x = -4 .. 19 / -4 .. 7); lanes 12..27 / 28..35 / 36..43: the column left
+            const bool top = lane < 12;
+            const int pl = top ? (lane < 6 ? 0 : (lane < 9 ? 1 : 2)) : (lane < 28 ? 0 : (lane < 36 ? 1 : 2));
+            const int j = top ? (pl == 0 ? lane : (pl == 1 ? lane - 6 : lane - 9)) : (pl == 0 ? lane - 12 : (pl == 1 ? lane - 28 : lane - 36));
+            const Plane &P = pl == 0 ? a.ry : (pl == 1 ? a.ru : a.rv);
+            const int msz = pl == 0 ? 16 : 8;
+            const bool last_col_ar = top && pl == 0 && j == 5 && c == mbw - 1;      // no macroblock above-right: repeat top[15] (:596-601)
+            const int x = top ? msz * c - 4 + 4 * (last_col_ar ? 4 : j) : msz * c - 4;
+            const int y = top ? msz * r - 1 : msz * r + j;
+            uint32_t v = ld_agent(P.p + (ptrdiff_t)y * P.stride + x);
+            if (last_col_ar) v = (v >> 24) * 0x01010101u;
+            if (top && r == 0) v = 0x7f7f7f7fu;                                     // 127 above the frame, also in the corner (:575-589)
+            else if (c == 0 && (!top || j == 0)) v = 0x81818181u;                   // 129 left of the frame (:540-551)
+            uint8_t *dst = pl == 0 ? sh.img : sh.cimg[pl - 1];
+            const int S = pl == 0 ? IMG_S : CIMG_S;
+            *reinterpret_cast<uint32_t *>(dst + (top ? 4 * j : (j + 1) * S)) = v;
+            if (top && pl == 0 && j == 5) {   // blocks 7, 11, 15 take T4..T7 from the row above the macroblock too (:630, top_pred_Y[16..19])
+                *reinterpret_cast<uint32_t *>(sh.img + 4 * IMG_S + 20) = v;
+                *reinterpret_cast<uint32_t *>(sh.img + 8 * IMG_S + 20) = v;
+                *reinterpret_cast<uint32_t *>(sh.img + 12 * IMG_S + 20) = v;
+            }
+        }
+        lds_order();
+        float cur_ssim = a.key ? 0.0f : a.o.ssim[mb];
+        // ---- attempts: key frame = segment 0 once; fallback = AQ (2), HQ (1), UQ (0) while below the target --------
+        for (int att = 0; att < (a.key ? 1 : 3); ++att) {
+            const int seg = a.key ? 0 : 2 - att;
+            if (!a.key && !(cur_ssim < a.target)) break;
+            const Steps st = steps_of(a.sd, seg);
+            const LaneQ ql = lane_q(st.y_dc, st.y_ac, lane & 3);
+            int mymode = 0;
+#define LUMA(BR, BC)                                                   \
+            {                                                          \
+                const int m_ = luma_block<BR, BC>(sh, lane, k, ql);    \
+                if (lane == 4 * BR + BC) mymode = m_;                  \
+            }
+            LUMA(0, 0) LUMA(0, 1) LUMA(0, 2) LUMA(0, 3)
+            LUMA(1, 0) LUMA(1, 1) LUMA(1, 2) LUMA(1, 3)
+            LUMA(2, 0) LUMA(2, 1) LUMA(2, 2) LUMA(2, 3)
+            LUMA(3, 0) LUMA(3, 1) LUMA(3, 2) LUMA(3, 3)
+#undef LUMA
+            chroma_blocks(sh, lane, k, st.uv_dc, st.uv_ac);
+            if (lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode is overwritten by every attempt (:970)
+            bool commit = true;
+            float s = 0.0f;
+            if (!a.key) {
+                s = mb_ssim(sh, lane);
+                commit = s > cur_ssim;
+            }
+            if (commit) {
+                cur_ssim = s;
+                st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
+                         *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
+                if (lane < 32) {
+                    const Plane &P = lane < 16 ? a.ru : a.rv;
+                    const int l = lane & 15;
+                    st_agent(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1),
+                             *reinterpret_cast<const uint32_t *>(&sh.cimg[lane >> 4][((l >> 1) + 1) * CIMG_S + 4 + 4 * (l & 1)]));
+                }
+                uint32_t *gc = reinterpret_cast<uint32_t *>(a.o.coeffs + (size_t)mb * 400);
+                const uint32_t *lc = reinterpret_cast<const uint32_t *>(sh.coef);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gc[lane + 64 * i] = lc[lane + 64 * i];   // blocks 0..23; block 24 (Y2) stays
+                if (lane == 0) {
+                    a.o.parts[mb] = 2;    // are4x4
+                    a.o.seg[mb] = seg;
+                    if (!a.key) {
+                        a.o.ssim[mb] = s;
+                        a.is_inter[mb] = 0;
+                    }
+                }
+            }
+        }
+        ++c;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_store(&a.prog[r], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what check_SSIM reports (src/vp8enc.cpp:237-258): replaced count, the raster-order float sum / count, the minimum
+__global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, int32_t *out) {
+    __shared__ int s_repl;
+    __shared__ float s_min[256];
+    if (threadIdx.x == 0) s_repl = 0;
+    __syncthreads();
+    int repl = 0;
+    float mn = 2.0f;
+    for (int i = threadIdx.x; i < mbs; i += 256) {
+        repl += is_inter[i] == 0;
+        const float v = ssim[i];
+        mn = v < mn ? v : mn;
+    }
+    atomicAdd(&s_repl, repl);
+    s_min[threadIdx.x] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sum = 0.0f;
+        for (int i = 0; i < mbs; ++i) sum = __fadd_rn(sum, ssim[i]);
+        for (int i = 0; i < 256; ++i) mn = s_min[i] < mn ? s_min[i] : mn;
+        out[0] = s_repl;
+        out[1] = __float_as_int(__fdiv_rn(sum, (float)mbs));
+        out[2] = __float_as_int(mn);
+    }
+}
+
+}  // namespace
+
+void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh) {
+    IntraArgs a;
+    a.cy = cur.Y[0]; a.cu = cur.U; a.cv = cur.V;
+    a.ry = recon.Y[0]; a.ru = recon.U; a.rv = recon.V;
+    a.o = o;
+    a.sd = d_sd;
+    a.modes = modes;
+    a.is_inter = is_inter;
+    a.prog = prog;
+    a.err = err;
+    a.target = target;
+    a.key = key;
+    a.mbw = mbw;
+    a.mbh = mbh;
+    (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
+    hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
+}
+
+void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, int32_t *out) {
+    hipLaunchKernelGGL(k_ssim_stats, dim3(1), dim3(256), 0, s, o.ssim, is_inter, mbs, out);
+}
+
+}  // namespace vp8

@@ -60,6 +60,8 @@ struct vp8hip_ctx {
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
+    // host intra path on the device: sub-block modes, replaced flags, row progress, {replaced, new_SSIM, min SSIM}
+    int32_t *intra_modes = nullptr, *intra_is_inter = nullptr, *intra_prog = nullptr, *intra_stats = nullptr;
 
     uint32_t prof_mask = 0;
     hipEvent_t ev[MAX_EVENTS];
@@ -259,6 +261,12 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * c->mbh * 4));   // four partial histograms per macroblock row
     CR(hipMalloc(&c->ent_probs, sizeof(uint32_t) * ENT_NCTX));
     CR(hipMalloc(&c->ent_denom0, sizeof(uint32_t) * ENT_NCTX));
+    CR(hipMalloc(&c->intra_modes, (size_t)c->mbs * 64));
+    CR(hipMalloc(&c->intra_is_inter, (size_t)c->mbs * 4));
+    CR(hipMalloc(&c->intra_prog, (size_t)c->mbh * 4));
+    CR(hipMalloc(&c->intra_stats, 16));
+    CR(hipMemsetAsync(c->intra_modes, 0, (size_t)c->mbs * 64, c->stream));
+    CR(hipMemsetAsync(c->intra_is_inter, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.seg, 0, (size_t)c->mbs * 4, c->stream));
@@ -317,6 +325,10 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->ent.bytes);
     hipFree(c->ent.sizes);
     hipFree(c->ent.plan);
+    hipFree(c->intra_modes);
+    hipFree(c->intra_is_inter);
+    hipFree(c->intra_prog);
+    hipFree(c->intra_stats);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -522,6 +534,65 @@ int vp8hip_upload_recon(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->recon_ready = true;
+    return VP8HIP_OK;
+}
+
+static int claim_recon(vp8hip_ctx *c) {
+    if (c->recon < 0 || c->recon == c->slot[0] || c->recon == c->slot[1] || c->recon == c->slot[2]) {
+        c->recon = -1;
+        c->recon = pick_free_frame(c);
+        if (c->recon < 0) return VP8HIP_ERR_STATE;
+    }
+    return VP8HIP_OK;
+}
+
+int vp8hip_intra_transform(vp8hip_ctx *c) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+    int rc = claim_recon(c);
+    if (rc) return rc;
+    c->ent_counted_partitions = 0;
+    {
+        Timed t(c, VP8HIP_K_INTRA);
+        launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
+                     c->d_progress + LF_ERR_WORD, 0.0f, 1, c->mbw, c->mbh);
+    }
+    c->recon_ready = true;
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *min_ssim) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (!c->recon_ready || c->recon < 0 || c->cur_count == 0) return VP8HIP_ERR_STATE;
+    c->ent_counted_partitions = 0;
+    {
+        Timed t(c, VP8HIP_K_INTRA);
+        launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
+                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh);
+    }
+    launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->intra_stats);
+    HIPCHK(c, hipGetLastError());
+    int32_t st[3];
+    HIPCHK(c, hipMemcpyAsync(st, c->intra_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (replaced) *replaced = st[0];
+    if (new_ssim) memcpy(new_ssim, &st[1], 4);
+    if (min_ssim) memcpy(min_ssim, &st[2], 4);
+    int32_t flag = 0;
+    HIPCHK(c, hipMemcpy(&flag, c->d_progress + LF_ERR_WORD, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIPCHK(c, hipMemset(c->d_progress + LF_ERR_WORD, 0, 4));
+        return VP8HIP_ERR_TIMEOUT;
+    }
+    return VP8HIP_OK;
+}
+
+int vp8hip_download_intra(vp8hip_ctx *c, int32_t *modes, int32_t *is_inter) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (modes) HIPCHK(c, hipMemcpyAsync(modes, c->intra_modes, (size_t)c->mbs * 64, hipMemcpyDeviceToHost, c->stream));
+    if (is_inter) HIPCHK(c, hipMemcpyAsync(is_inter, c->intra_is_inter, (size_t)c->mbs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VP8HIP_OK;
 }
 
@@ -758,6 +829,15 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
 int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
     if (!c) return VP8HIP_ERR_ARG;
     c->lf_stall_test = on ? 1 : 0;
+    return VP8HIP_OK;
+}
+
+// test hook (not in the public header): MB_SSIM as an inter frame would have left it, so vp8hip_check_ssim can be
+// driven from stored inter-frame results (the golden vectors of tests/golden/intra)
+int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
+    if (!c || !ssim) return VP8HIP_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->out.ssim, ssim, (size_t)c->mbs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VP8HIP_OK;
 }
 

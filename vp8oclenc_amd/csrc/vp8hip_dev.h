@@ -97,6 +97,12 @@ struct EntBuffers {          // device scratch of the boolean coder (allocated o
 void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
                        int mbw, int mbh, int P);
 
+// host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
+// prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM}
+void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh);
+void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, int32_t *out);
+
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
