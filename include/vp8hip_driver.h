@@ -1,12 +1,13 @@
 /*
- * vp8hip_driver.h -- the reference's frame loop (main(), src/vp8enc.cpp:351-488) reduced to the inter-frame
- * path, as native host code over include/vp8hip.h and include/vp8hip_host.h.
+ * vp8hip_driver.h -- the reference's frame loop (main(), src/vp8enc.cpp:351-488) as native host code over
+ * include/vp8hip.h and include/vp8hip_host.h.
  *
  * The reference host is C++ and this is its C++ counterpart (vp8oclenc_amd/csrc/vp8_driver.cpp): frame-type
- * state machine, per-frame loop-filter strength and segment data, inter_transform, check_SSIM's filter-parameter
- * update, filter mask, loop filter -- in the reference's order.  Out of the path and therefore not here: intra
- * coding of key frames (a key frame is handed to a stand-in that takes the source planes as its reconstruction,
- * which is all the inter path needs from it), the per-macroblock intra fallback, the header entropy coder.
+ * state machine, per-frame loop-filter strength and segment data, key frames (intra_transform), inter_transform,
+ * check_SSIM with its intra fallback, its filter-parameter update and its "redo as key frame" decision, filter
+ * mask, loop filter -- in the reference's order, every stage on the device.  Not here: scene_change()'s decision
+ * (the caller passes force_key; vp8hip_chroma_change + vp8host_scene_change produce it), the header/MV entropy
+ * coder and the container.
  * vp8oclenc_amd/driver.py is the same loop in Python for the parity tests (it also runs the CPU oracle).
  */
 #ifndef VP8HIP_DRIVER_H
@@ -29,8 +30,9 @@ typedef struct {
     float ssim_target;       /* -SSIM-target (init.h:1512,1576) */
     int32_t device_params;   /* 1: loop-filter strength + segment data on the device, no host round trip
                                 (vp8hip_auto_segments); 0: host mirror on the caller's luma plane */
-    int32_t check_ssim;      /* 1: read MB_SSIM back every frame and apply check_SSIM's filter update
-                                (vp8enc.cpp:231-263; blocks); 0: skip it (throughput mode) */
+    int32_t check_ssim;      /* 1: check_SSIM after every inter_transform (vp8enc.cpp:231-263, 442-453): intra fallback,
+                                filter update, redo as key frame; blocks for three words per frame.
+                                0: skip it (what the reference's defaults amount to except for the filter update) */
 } vp8drv_config;
 
 void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0 */
@@ -40,7 +42,7 @@ void vp8drv_destroy(vp8drv *d);
 vp8hip_ctx *vp8drv_context(vp8drv *d);   /* for downloads, the entropy stage, profiling */
 
 /* One iteration of the while-loop body, vp8enc.cpp:351-488, for a frame whose planes are already in this
- * device's memory (tight stride).  Returns 1 = coded as a key frame (stand-in), 0 = inter frame, < 0 = vp8hip_status.
+ * device's memory (tight stride).  Returns 1 = coded as a key frame, 0 = inter frame, < 0 = vp8hip_status.
  * force_key: the caller's scene_change() verdict (vp8enc.cpp:408-416).  Asynchronous unless check_ssim is on. */
 int vp8drv_encode_frame_device(vp8drv *d, const void *d_y, const void *d_u, const void *d_v, int force_key);
 /* same for host planes (blocks for the upload).  With device_params == 0 the host mirror scans y. */
@@ -50,6 +52,9 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
 typedef struct {
     int32_t frame_number, inter_frames, key_frames;
     int32_t last_use_golden, last_use_altref, last_prev_is_golden, last_prev_is_altref, last_was_altref;
+    int32_t redone_as_key;            /* inter frames recoded as key frames by check_SSIM's verdict (vp8enc.cpp:443-453) */
+    int32_t last_replaced;            /* frames.replaced, frames.new_SSIM and min1 of the last check_SSIM */
+    float last_new_ssim, last_min_ssim;
 } vp8drv_stats;
 void vp8drv_get_stats(const vp8drv *d, vp8drv_stats *s);
 

@@ -136,6 +136,7 @@ class Oracle:
     def __init__(self, W: int, H: int, ssim_target: float = -1.0):
         self.W, self.H = W, H
         self.mbs = (W // 16) * (H // 16)
+        self.ssim_target = float(ssim_target)
         self.h = self.lib().vp8o_create(W, H, ssim_target)
         if not self.h:
             raise ValueError("vp8o_create failed (size must be a multiple of 16)")
@@ -152,7 +153,38 @@ class Oracle:
         self.lib().vp8o_upload_last(self.h, y, u, v)
 
     def set_segments(self, sd):
-        self.lib().vp8o_set_segments(self.h, np.ascontiguousarray(sd, np.int32).reshape(-1))
+        self._sd = np.ascontiguousarray(sd, np.int32).reshape(-1).copy()
+        self.lib().vp8o_set_segments(self.h, self._sd)
+
+    # -- host intra path (vp8_intra_oracle.c), with the ABI's method names ------------------------
+    def intra_transform(self):
+        k = oracle_intra().intra_transform(self._cur, self._sd)
+        self._out = alloc_results(self.W, self.H)
+        for key in ("MB_coeffs", "MB_parts", "MB_segment_id"):
+            self._out[key][...] = k[key]
+        for p in "YUV":
+            self._out["prefilter_" + p][...] = k["recon_" + p]
+        self._intra = (k["modes"], np.zeros(self.mbs, np.int32))
+        self.upload_recon(k["recon_Y"], k["recon_U"], k["recon_V"])
+        self.upload_mb_data(k["MB_coeffs"], k["MB_parts"], k["MB_segment_id"])
+
+    def check_ssim(self):
+        o = self._out
+        inter = {"recon_Y": o["prefilter_Y"], "recon_U": o["prefilter_U"], "recon_V": o["prefilter_V"], "MB_coeffs": o["MB_coeffs"],
+                 "MB_parts": o["MB_parts"], "MB_segment_id": o["MB_segment_id"], "MB_SSIM": o["MB_SSIM"]}
+        r = oracle_intra().check_ssim(self._cur, self._sd, self.ssim_target, inter)
+        for key in ("MB_coeffs", "MB_parts", "MB_segment_id", "MB_SSIM"):
+            o[key][...] = r[key]
+        for p in "YUV":
+            o["prefilter_" + p][...] = r["recon_" + p]
+        self._intra = (r["modes"], r["is_inter"])
+        if r["replaced"]:
+            self.upload_recon(r["recon_Y"], r["recon_U"], r["recon_V"])
+            self.upload_mb_data(r["MB_coeffs"], r["MB_parts"], r["MB_segment_id"])
+        return r["replaced"], np.float32(r["new_SSIM"]), np.float32(r["min_SSIM"])
+
+    def download_intra(self):
+        return self._intra
 
     # -- same call sequence as the C ABI (include/vp8hip.h) ------------------------------------
     def upload_current(self, y, u, v):

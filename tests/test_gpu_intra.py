@@ -100,6 +100,54 @@ def test_check_ssim_matches_oracle(W, H, seed, target, cut, qi):
     assert np.float32(a["min_SSIM"]) == np.float32(b["min_SSIM"])
 
 
+@pytest.mark.parametrize("device_params", [0, 1])
+def test_native_frame_loop_with_intra_fallback_and_scene_cut(device_params):
+    """The native frame loop (vp8_driver.cpp) with check_SSIM on, coarse quantizers and a scene cut in the middle:
+    macroblocks get replaced by intra ones, the cut frame is recoded as a key frame (vp8enc.cpp:443-453) -- against
+    the same loop in Python driving the CPU oracle, frame by frame."""
+    from oracle_lib import Oracle
+    from vp8oclenc_amd.driver import InterPathDriver
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H, target, qmin, qmax = 320, 192, 0.90, 50, 110
+    a_seq, b_seq = SynthSequence(W, H, seed=41), SynthSequence(W, H, seed=97)
+    frames = [a_seq.frame(t) for t in range(4)] + [b_seq.frame(t) for t in range(4)]   # the cut hits an ordinary P frame
+    drv = api.NativeDriver(W, H, gop_size=150, altref_range=5, qi_min=qmin, qi_max=qmax, ssim_target=target,
+                           device_params=device_params, check_ssim=1)
+    ora = Oracle(W, H, target)
+    do = InterPathDriver(ora, W, H, gop_size=150, altref_range=5, qi_min=qmin, qi_max=qmax, ssim_target=target)
+    replaced_total = 0
+    for t, (y, u, v) in enumerate(frames):
+        was_key = drv.encode_frame_host(y, u, v)
+        b = do.encode_frame(y, u, v)
+        assert was_key == (b is None), f"frame {t}: key decision"
+        st = drv.stats()
+        assert st.key_frames == do.key_frames and st.redone_as_key == do.redone_as_key, t
+        ly, lu, lv = drv.hip.download_last()
+        oy, ou, ov = ora.download_last()
+        assert np.array_equal(ly, oy) and np.array_equal(lu, ou) and np.array_equal(lv, ov), f"filtered recon, frame {t}"
+        got = drv.hip.download_results(recon=False)
+        modes, is_inter = drv.hip.download_intra()
+        if b is None:
+            exp = do.last_key
+            assert np.array_equal(got["MB_coeffs"][:, :24], exp["MB_coeffs"][:, :24]) and np.array_equal(modes, exp["modes"]), t
+            assert (got["MB_parts"] == 2).all()
+            continue
+        assert st.last_replaced == b["replaced"] and np.float32(st.last_new_ssim) == np.float32(b["new_SSIM"]), t
+        replaced_total += b["replaced"]
+        repl = b["is_inter"] == 0
+        assert np.array_equal(is_inter, b["is_inter"]) and np.array_equal(modes, b["modes"]), t
+        assert np.array_equal(got["MB_coeffs"][:, :24], b["MB_coeffs"][:, :24]), t
+        y2 = b["MB_parts"] == 0        # only 16x16 macroblocks have a Y2 block; elsewhere block 24 is stale in every implementation
+        assert np.array_equal(got["MB_coeffs"][y2, 24], b["MB_coeffs"][y2, 24]), t
+        for k in ("MB_parts", "MB_segment_id", "MB_vectors", "MB_reference_frame"):
+            assert np.array_equal(got[k], b[k]), (t, k)
+        assert np.array_equal(got["MB_SSIM"].view(np.uint32), b["MB_SSIM"].view(np.uint32)), t
+    assert replaced_total > 0, "the case must exercise the fallback"
+    assert do.redone_as_key >= 1, "the scene cut must be recoded as a key frame"
+    drv.close()
+    ora.close()
+
+
 def test_key_frame_then_inter_frames_follow_the_reference_flow():
     """intra_transform -> filter mask -> loop filter -> LAST = GOLDEN = ALTREF, then an inter frame on top: the
     device chain against the same chain on the CPU oracle."""

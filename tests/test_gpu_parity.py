@@ -13,16 +13,18 @@ from vp8oclenc_amd.synth import SynthSequence, noise_frames
 
 pytestmark = pytest.mark.gpu
 
-SSIM_TOL = 1e-4  # tolerance for the only floating-point output of the path
+SSIM_TOL = 1e-4  # north_star's tolerance for the only floating-point output (used against the reference's golden vectors)
 
 
 def _compare(a: dict, b: dict, keys, tag=""):
     bad = []
     for k in keys:
         if k == "MB_SSIM":
-            d = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
-            if not d <= SSIM_TOL:
-                bad.append((k, d))
+            # against the oracle the bar is the bit pattern: check_SSIM compares these values with the target and
+            # with the SSIM of every intra attempt, so one ulp could flip a decision
+            x, y = np.asarray(a[k], np.float32).view(np.uint32), np.asarray(b[k], np.float32).view(np.uint32)
+            if not np.array_equal(x, y):
+                bad.append((k, int((x != y).sum()), float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())))
         elif not np.array_equal(a[k], b[k]):
             bad.append((k, int((a[k] != b[k]).sum()), int(a[k].size)))
     assert not bad, f"{tag}: HIP differs from oracle: {bad}"

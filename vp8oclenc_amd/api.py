@@ -204,7 +204,8 @@ class DrvConfig(C.Structure):
 class DrvStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame_number", "inter_frames", "key_frames", "last_use_golden",
                                           "last_use_altref", "last_prev_is_golden", "last_prev_is_altref",
-                                          "last_was_altref")]
+                                          "last_was_altref", "redone_as_key", "last_replaced")] + \
+               [("last_new_ssim", C.c_float), ("last_min_ssim", C.c_float)]
 
 
 class NativeDriver:
