@@ -71,3 +71,14 @@ def run_stage(st, coeffs, parts, nz, mbw, mbh, P, step=None):
     parts_bytes = [out[p * step: p * step + sizes[p]].copy() for p in range(P)]
     return dict(counts=counted, denom=denom, third_context=ctx3, probs=probs[:1056].copy(), sizes=sizes,
                 partitions=parts_bytes)
+
+
+def from_key_frame(W: int, H: int, seed: int, qi_min: int = 10):
+    """Coefficients of a key frame (every macroblock B_PRED: MB_parts = are4x4 = 2, no Y2) from the intra oracle."""
+    from intra_cases import key_case
+    from oracle_lib import oracle_intra
+    cur, sd = key_case(W, H, seed, qi_min)
+    k = oracle_intra().intra_transform(cur, sd)
+    coeffs = np.ascontiguousarray(k["MB_coeffs"], np.int16)
+    parts = np.ascontiguousarray(k["MB_parts"], np.int32)
+    return coeffs, parts, nz_counts(coeffs, parts)

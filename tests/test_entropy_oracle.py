@@ -76,3 +76,18 @@ def test_restatement_matches_reference_kernels_on_real_frame():
         a = run_stage(Oracle.stages(), coeffs, parts, nz, W // 16, H // 16, P)
         b = run_stage(ref, coeffs, parts, nz, W // 16, H // 16, P)
         same(a, b, P, f"real frame P{P}", coded_only=nz != 0)
+
+
+def test_restatement_matches_reference_kernels_on_key_frame():
+    """MB_parts = are4x4 (intra macroblocks): no Y2 block, luma blocks coded from coefficient 0."""
+    from entropy_cases import from_key_frame
+    ref = ref_stages()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no reference checkout here)")
+    W, H = 176, 144
+    coeffs, parts, nz = from_key_frame(W, H, 9)
+    assert (parts == 2).all() and (nz > 0).any()
+    for P in (1, 2):
+        a = run_stage(Oracle.stages(), coeffs, parts, nz, W // 16, H // 16, P)
+        b = run_stage(ref, coeffs, parts, nz, W // 16, H // 16, P)
+        same(a, b, P, f"key frame P{P}", coded_only=nz != 0)

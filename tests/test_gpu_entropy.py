@@ -123,3 +123,24 @@ def test_encode_needs_count_first_and_reports_overflow():
     with pytest.raises(api.Vp8HipError, match="do not fit"):
         hip.encode_coefficients(exp["probs"], 2, partition_step=16)   # caller's buffer too small
     hip.close()
+
+
+def test_entropy_stage_after_key_frame():
+    """vp8hip_intra_transform -> filter mask -> count_probs / encode_coefficients: intra macroblocks (MB_parts = 2)
+    through the device entropy stage, against the oracle chain."""
+    from intra_cases import key_case
+    from oracle_lib import oracle_intra
+    W, H = 352, 288
+    cur, sd = key_case(W, H, 19, 10)
+    hip = api.Vp8Hip(W, H)
+    hip.upload_current(*cur)
+    hip.set_segments(sd)
+    hip.intra_transform()
+    nz = hip.prepare_filter_mask()
+    k = oracle_intra().intra_transform(cur, sd)
+    coeffs, parts = np.ascontiguousarray(k["MB_coeffs"]), np.ascontiguousarray(k["MB_parts"])
+    assert np.array_equal(nz, nz_counts(coeffs, parts))
+    for P in (1, 4):
+        exp = run_stage(Oracle.stages(), coeffs, parts, nz, W // 16, H // 16, P)
+        check_counts(hip, exp, nz, P, f"key frame P{P}", parts=parts)
+    hip.close()
