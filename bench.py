@@ -68,6 +68,19 @@ def pmc_traffic(kernel: str, W: int, H: int):
     return None, None
 
 
+def pmc_valu(W: int, H: int, nrefs: float):
+    """wave64 VALU instructions per launch of every kernel (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_valu.json) and
+    the measured chip-wide issue rate of this instruction mix (scripts/ubench/valu_peak.hip), or (None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_valu.json")) as f:
+            t = json.load(f)
+        g = t[f"{W}x{H}"]
+        per = {k: (e["per_ref"] * nrefs if "per_ref" in e else e["fixed"]) for k, e in g.items()}
+        return per, t
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +251,24 @@ def main():
             a = b / (ms / n * 1e-3) / 1e9 if b else None
             extra[k] = {"avg_launch_ms": round(ms / n, 5), "achieved_GBs": None if a is None else round(a, 3),
                         "frac": None if a is None else round(a / HBM_PEAK_GBS, 6)}
+        # the resource that actually bounds the path: integer VALU issue.  Instructions per
+        # launch from the committed PMC pass, durations measured live, peak from the committed micro-benchmark.
+        issue = None
+        insts, vt = pmc_valu(W, H, nrefs_avg)
+        if insts:
+            peak = vt["peak_mix_winstr_per_ns"]
+            path_keys = ["search2", "search1_l0", "search1_l1", "search1_l2", "search1_l3", "search1_l4", "mb", "loop_filter",
+                         "downsample", "pack", "border"] + ([] if args.host_params else ["lf_strength"])
+            per_frame_insts = sum(insts[k] for k in path_keys)
+            path_rate = per_frame_insts / (elapsed / (args.steps * world) * 1e9)
+            issue = {"bound": "valu_issue", "unit": "wave64-instr/ns", "peak": peak, "peak_source": vt["peak_source"],
+                     "path": {"instructions_per_frame": int(per_frame_insts), "achieved": round(path_rate, 1), "frac": round(path_rate / peak, 4)},
+                     "instructions_source": vt["source"], "kernels": {}}
+            for k in ("search2", "search1_l0", "mb"):
+                if k in prof and prof[k][1]:
+                    r = insts[k] / (prof[k][0] / prof[k][1] * 1e6)
+                    issue["kernels"][k] = {"instructions_per_launch": int(insts[k]), "avg_launch_ms": round(prof[k][0] / prof[k][1], 5),
+                                           "achieved": round(r, 1), "frac": round(r / peak, 4)}
         out = {
             "metric": "macroblocks/sec inter-frame (ME+DCT+loopfilter), 1080p", "value": round(value, 1),
             "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,6 +282,7 @@ def main():
                        "frame_loop": "python over the C ABI" if args.host_params else "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
             "roofline": roof,
+            "issue_roofline": issue,
             "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
             "other_kernels": extra,
             "fps": round(args.steps * world / elapsed, 2),

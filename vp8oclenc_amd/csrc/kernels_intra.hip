@@ -450,28 +450,49 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
 }
 
 // what check_SSIM reports (src/vp8enc.cpp:237-258): replaced count, the raster-order float sum / count, the minimum
-__global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, int32_t *out) {
+// The sum must be the reference's: one float accumulator over the macroblocks in raster order.  The values are staged
+// in LDS by all threads, 8192 at a time, so that the one summing thread reads four per ds_read_b128 instead of
+// waiting for HBM once per element.
+constexpr int STATS_CHUNK = 8192;
+__global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
     __shared__ int s_repl;
     __shared__ float s_min[256];
+    __shared__ __attribute__((aligned(16))) float s_val[STATS_CHUNK];
     if (threadIdx.x == 0) s_repl = 0;
-    __syncthreads();
     int repl = 0;
-    float mn = 2.0f;
-    for (int i = threadIdx.x; i < mbs; i += 256) {
-        repl += is_inter[i] == 0;
-        const float v = ssim[i];
-        mn = v < mn ? v : mn;
+    float mn = 2.0f, sum = 0.0f;
+    for (int base = 0; base < mbs; base += STATS_CHUNK) {
+        const int n = imin(STATS_CHUNK, mbs - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < STATS_CHUNK; i += 256) {
+            float v = 0.0f;
+            if (i < n) {
+                v = ssim[base + i];
+                repl += is_inter[base + i] == 0;
+                mn = v < mn ? v : mn;
+            }
+            s_val[i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float4 *q = reinterpret_cast<const float4 *>(s_val);
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const float4 v = q[i >> 2];
+                sum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum, v.x), v.y), v.z), v.w);
+            }
+            for (; i < n; ++i) sum = __fadd_rn(sum, s_val[i]);
+        }
     }
     atomicAdd(&s_repl, repl);
     s_min[threadIdx.x] = mn;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float sum = 0.0f;
-        for (int i = 0; i < mbs; ++i) sum = __fadd_rn(sum, ssim[i]);
         for (int i = 0; i < 256; ++i) mn = s_min[i] < mn ? s_min[i] : mn;
         out[0] = s_repl;
         out[1] = __float_as_int(__fdiv_rn(sum, (float)mbs));
         out[2] = __float_as_int(mn);
+        out[3] = *err;   // the time-out flag of the wavefront kernels travels with the statistics: one read-back
     }
 }
 
@@ -496,8 +517,8 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
 }
 
-void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, int32_t *out) {
-    hipLaunchKernelGGL(k_ssim_stats, dim3(1), dim3(256), 0, s, o.ssim, is_inter, mbs, out);
+void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
+    hipLaunchKernelGGL(k_ssim_stats, dim3(1), dim3(256), 0, s, o.ssim, is_inter, mbs, err, out);
 }
 
 }  // namespace vp8

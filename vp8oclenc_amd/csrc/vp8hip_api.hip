@@ -571,17 +571,15 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
                      c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh);
     }
-    launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->intra_stats);
+    launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->d_progress + LF_ERR_WORD, c->intra_stats);
     HIPCHK(c, hipGetLastError());
-    int32_t st[3];
+    int32_t st[4];
     HIPCHK(c, hipMemcpyAsync(st, c->intra_stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (replaced) *replaced = st[0];
     if (new_ssim) memcpy(new_ssim, &st[1], 4);
     if (min_ssim) memcpy(min_ssim, &st[2], 4);
-    int32_t flag = 0;
-    HIPCHK(c, hipMemcpy(&flag, c->d_progress + LF_ERR_WORD, 4, hipMemcpyDeviceToHost));
-    if (flag) {
+    if (st[3]) {   // a bounded device-side wait expired (this frame or an earlier, unchecked one)
         HIPCHK(c, hipMemset(c->d_progress + LF_ERR_WORD, 0, 4));
         return VP8HIP_ERR_TIMEOUT;
     }
