@@ -110,3 +110,47 @@ int ref_pick_luma_predictor(const uint8_t *orig, uint8_t *pred, int16_t *resid, 
     return pick_luma_predictor(orig, pred, resid, top, left, (cl_short)top_left);
 }
 }
+
+/* ---- frame header / first partition (src/entropy_host.cpp), container (src/encIO.h) ------------------------------- */
+extern "C" {
+
+/* encode_header (src/entropy_host.cpp:709-1256) on plain arrays.  Returns frames.encoded_frame_size.
+ * vectors: [MBs][4] (x, y) shorts; modes [MBs][16]; probs/denom [4][8][3][11]; flags = {key, golden, altref} */
+int ref_encode_header(int width, int height, int dst_width, int dst_height, const int32_t *flags, const int32_t *sd,
+                      int loop_filter_type, int sharpness, int partitions_ind, const int32_t *seg, const int32_t *nz,
+                      const int32_t *ref_frame, const int32_t *parts, const int16_t *vectors, const int32_t *is_inter,
+                      const int32_t *modes, const uint32_t *probs, const uint32_t *denom, int skip_prob, int replaced,
+                      uint8_t *out) {
+    video.wrk_width = width;
+    video.wrk_height = height;
+    video.mb_width = width / 16;
+    video.mb_height = height / 16;
+    video.mb_count = video.mb_width * video.mb_height;
+    video.dst_width = dst_width;
+    video.dst_height = dst_height;
+    video.loop_filter_type = loop_filter_type;
+    video.loop_filter_sharpness = sharpness;
+    video.number_of_partitions_ind = partitions_ind;
+    frames.current_is_key_frame = flags[0];
+    frames.current_is_golden_frame = flags[1];
+    frames.current_is_altref_frame = flags[2];
+    memcpy(frames.segments_data, sd, sizeof frames.segments_data);
+    frames.MB_segment_id = const_cast<int32_t *>(seg);
+    frames.MB_non_zero_coeffs = const_cast<int32_t *>(nz);
+    frames.MB_reference_frame = const_cast<int32_t *>(ref_frame);
+    frames.MB_parts = const_cast<int32_t *>(parts);
+    frames.MB_vectors = reinterpret_cast<macroblock_vectors_t *>(const_cast<int16_t *>(vectors));
+    g_edata.assign(video.mb_count, macroblock_extra_data());
+    for (int mb = 0; mb < video.mb_count; ++mb) {
+        g_edata[mb].is_inter_mb = is_inter ? is_inter[mb] : 1;
+        for (int b = 0; b < 16; ++b) g_edata[mb].mode[b] = modes ? modes[mb * 16 + b] : 0;
+    }
+    frames.e_data = g_edata.data();
+    memcpy(frames.new_probs, probs, sizeof frames.new_probs);
+    memcpy(frames.new_probs_denom, denom, sizeof frames.new_probs_denom);
+    frames.skip_prob = skip_prob;
+    frames.replaced = replaced;
+    encode_header(out);
+    return (int)frames.encoded_frame_size;
+}
+}

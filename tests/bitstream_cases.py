@@ -1,0 +1,95 @@
+"""Inputs and the reference binding for the first-partition / container tests (include/vp8hip_bitstream.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle_lib import REF_HOST_SO, Oracle, build_oracle, oracle_intra
+from vp8oclenc_amd import api
+
+_ref = None
+
+
+def ref_header_lib():
+    """The reference's own encode_header (oracle/_ref/libvp8refhost.so) or None."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_HOST_SO):
+            try:
+                build_oracle()
+            except Exception:
+                return None
+        if not os.path.exists(REF_HOST_SO):
+            return None
+        lib = C.CDLL(REF_HOST_SO)
+        lib.ref_encode_header.restype = C.c_int
+        lib.ref_encode_header.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + \
+                                         [C.c_int, C.c_int, C.c_void_p]
+        _ref = lib
+    return _ref
+
+
+def ref_encode_header(width, height, flags, segments, seg, nz, probs, denom, skip_prob, ref_frame=None, parts=None, vectors=None,
+                      is_inter=None, modes=None, replaced=0, loop_filter_type=0, sharpness=0, partitions_log2=0, dst=None):
+    lib = ref_header_lib()
+    mbs = (width // 16) * (height // 16)
+    keep = []
+
+    def ptr(a, dt, default=None):
+        if a is None:
+            a = default
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    out = np.zeros(4096 + mbs * 96, np.uint8)
+    dw, dh = dst or (width, height)
+    n = lib.ref_encode_header(width, height, dw, dh, ptr(np.asarray(flags), np.int32), ptr(np.asarray(segments).reshape(-1), np.int32),
+                              loop_filter_type, sharpness, partitions_log2, ptr(seg, np.int32), ptr(nz, np.int32),
+                              ptr(ref_frame, np.int32, np.zeros(mbs)), ptr(parts, np.int32, np.zeros(mbs)),
+                              ptr(vectors, np.int16, np.zeros((mbs, 4, 2))), ptr(is_inter, np.int32), ptr(modes, np.int32),
+                              ptr(probs, np.uint32), ptr(denom, np.uint32), int(skip_prob), int(replaced), out.ctypes.data)
+    return out[:n].copy()
+
+
+def random_inter_case(mbw, mbh, seed, long_mv=0.1, split=0.4, intra=0.0, zero=0.2, copy_neighbour=0.3):
+    """Stress input for the mode / motion-vector coder: every mv_ref and sub_mv_ref branch, short and long components,
+    neighbours that agree or not, all three references, optional intra macroblocks."""
+    rng = np.random.default_rng(seed)
+    mbs = mbw * mbh
+    parts = (rng.random(mbs) < split).astype(np.int32)
+    vec = np.zeros((mbs, 4, 2), np.int16)
+    for mb in range(mbs):
+        def one():
+            r = rng.random()
+            if r < zero:
+                return (0, 0)
+            if r < zero + long_mv:
+                return (int(rng.integers(-1023, 1024)), int(rng.integers(-1023, 1024)))
+            return (int(rng.integers(-9, 10)), int(rng.integers(-9, 10)))
+        base = one()
+        if rng.random() < copy_neighbour and mb > 0:
+            src = mb - 1 if (mb % mbw and rng.random() < 0.5) else (mb - mbw if mb >= mbw else mb - 1)
+            base = tuple(vec[src, 3])
+        if parts[mb] == 0:
+            vec[mb, :] = base
+        else:
+            for k in range(4):
+                vec[mb, k] = base if rng.random() < 0.4 else one()
+    is_inter = (rng.random(mbs) >= intra).astype(np.int32)
+    modes = rng.integers(0, 10, (mbs, 16)).astype(np.int32)
+    ref_frame = rng.choice([0, 0, 0, 1, 2], mbs).astype(np.int32)
+    seg = rng.integers(0, 4, mbs).astype(np.int32)
+    nz = (rng.random(mbs) < 0.7).astype(np.int32) * rng.integers(1, 500, mbs).astype(np.int32)
+    denom = (rng.random(1056) < 0.5).astype(np.uint32) * rng.integers(2, 1000, 1056).astype(np.uint32)
+    probs = rng.integers(1, 256, 1056).astype(np.uint32)
+    return dict(parts=parts, vectors=vec, is_inter=is_inter, modes=modes, ref_frame=ref_frame, seg=seg, nz=nz, probs=probs,
+                denom=denom, replaced=int((is_inter == 0).sum()), skip_prob=api.skip_prob(nz))
+
+
+def default_sd(key=False, qi=(12, 24, 36, 48)):
+    return api.prepare_segments_data(key, list(qi), 5, 4, 2)

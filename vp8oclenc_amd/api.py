@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_frame_done", "vp8host_scene_change",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
     "vp8drv_encode_frame_host", "vp8drv_get_stats",
+    "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
 

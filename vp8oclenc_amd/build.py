@@ -8,8 +8,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvp8hip.so")
-SOURCES = ["vp8hip_api.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_ent.hip", "kernels_rc.hip", "kernels_intra.hip", "vp8_host.cpp", "vp8_driver.cpp"]
-HEADERS = ["vp8hip_dev.h"] + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h")]
+SOURCES = ["vp8hip_api.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_ent.hip", "kernels_rc.hip", "kernels_intra.hip", "vp8_host.cpp", "vp8_driver.cpp", "vp8_bitstream.cpp"]
+HEADERS = ["vp8hip_dev.h", "vp8_rfc6386_tables.inc"] + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h")]
 
 
 def _hipcc() -> str:
@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     odir = os.path.join(PKG, "build")
     os.makedirs(odir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-unused-value",
+    flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-unused-value", "-Wno-missing-braces",
              "-I", os.path.join(PKG, "..", "include")] + os.environ.get("VP8HIP_EXTRA_FLAGS", "").split()
     for src in SOURCES:
         path = os.path.join(CSRC, src)
