@@ -13,6 +13,7 @@
 #ifndef VP8HIP_DRIVER_H
 #define VP8HIP_DRIVER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "vp8hip.h"
@@ -33,9 +34,11 @@ typedef struct {
     int32_t check_ssim;      /* 1: check_SSIM after every inter_transform (vp8enc.cpp:231-263, 442-453): intra fallback,
                                 filter update, redo as key frame; blocks for three words per frame.
                                 0: skip it (what the reference's defaults amount to except for the filter update) */
+    int32_t num_partitions;  /* -partitions: 1, 2, 4 or 8 coefficient partitions (init.h:1451-1469, default 1) */
+    int32_t display_width, display_height;   /* video.dst_width/height written into key frames; 0 = the coded size */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);
@@ -47,6 +50,14 @@ vp8hip_ctx *vp8drv_context(vp8drv *d);   /* for downloads, the entropy stage, pr
 int vp8drv_encode_frame_device(vp8drv *d, const void *d_y, const void *d_u, const void *d_v, int force_key);
 /* same for host planes (blocks for the upload).  With device_params == 0 the host mirror scans y. */
 int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v, int force_key);
+
+/* The frame just coded, as bytes: entropy_encode() + gather_frame() of the reference (vp8enc.cpp:48-94, 476-481;
+ * encIO.h:1-30) -- coefficient statistics and the coefficient partitions on the device (vp8hip_count_probs,
+ * vp8hip_encode_coefficients), frame header with the macroblock modes and motion vectors on the host
+ * (include/vp8hip_bitstream.h), assembled into `out`.  Call it after vp8drv_encode_frame_* and before the next one.
+ * Blocks.  *size = bytes written; VP8HIP_ERR_OVERFLOW if `capacity` is too small.  With vp8bs_ivf_file_header /
+ * vp8bs_ivf_frame_header around the frames this is the reference's .ivf output, byte for byte. */
+int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

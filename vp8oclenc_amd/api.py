@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_get_frame",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -199,7 +199,8 @@ class Gop:
 class DrvConfig(C.Structure):
     """vp8drv_config, include/vp8hip_driver.h"""
     _fields_ = [("gop_size", C.c_int32), ("altref_range", C.c_int32), ("qi_min", C.c_int32), ("qi_max", C.c_int32),
-                ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32)]
+                ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32),
+                ("num_partitions", C.c_int32), ("display_width", C.c_int32), ("display_height", C.c_int32)]
 
 
 class DrvStats(C.Structure):
@@ -250,6 +251,18 @@ class NativeDriver:
     def encode_frame_host(self, y, u, v, force_key: bool = False) -> bool:
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in (y, u, v))
         return self._ret(self.lib.vp8drv_encode_frame_host(self.h, y.ctypes.data, u.ctypes.data, v.ctypes.data, int(force_key)))
+
+    def get_frame(self) -> bytes:
+        """The frame just coded as the reference's entropy_encode() + gather_frame() emit it (vp8drv_get_frame)."""
+        self.lib.vp8drv_get_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        cap = self.hip.mbs * 900 + 65536
+        if getattr(self, "_frame_buf", None) is None or len(self._frame_buf) < cap:
+            self._frame_buf = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        rc = self.lib.vp8drv_get_frame(self.h, self._frame_buf.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_get_frame: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return self._frame_buf[:n.value].tobytes()
 
     def stats(self) -> DrvStats:
         s = DrvStats()

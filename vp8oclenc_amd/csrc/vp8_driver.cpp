@@ -2,7 +2,9 @@
 // (include/vp8hip_driver.h).  No GPU code here: it only sequences vp8hip_* calls with the parameters the host
 // mirror (vp8_host.cpp) or the device (vp8hip_auto_segments) produces.
 #include <new>
+#include <vector>
 
+#include "../../include/vp8hip_bitstream.h"
 #include "../../include/vp8hip_driver.h"
 #include "../../include/vp8hip_host.h"
 
@@ -14,6 +16,14 @@ struct vp8drv {
     int32_t lastqi[4]{}, altrefqi[4]{};
     int qi_min = 0;
     vp8drv_stats st{};
+    // what vp8drv_get_frame needs to know about the frame just coded
+    bool have_frame = false, last_key = false, last_altref = false, checked = false;
+    int sharpness = -1;              // video.loop_filter_sharpness in force; -1 = still on the device (vp8hip_get_segments)
+    int replaced = 0;
+    // read-back buffers of vp8drv_get_frame
+    std::vector<int32_t> seg, nz, ref, parts, is_inter, modes;
+    std::vector<int16_t> vectors;
+    std::vector<uint8_t> partitions;
 };
 
 extern "C" {
@@ -27,6 +37,9 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->ssim_target = -1.0f;
     c->device_params = 1;
     c->check_ssim = 0;
+    c->num_partitions = 1;
+    c->display_width = 0;
+    c->display_height = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -74,10 +87,12 @@ namespace {
 
 // segment data of the current frame: on the device, or from the host mirror on the caller's luma plane
 int segments(vp8drv *d, const uint8_t *host_y, bool key, const int32_t *refqi) {
+    d->sharpness = -1;
     if (d->cfg.device_params || !host_y) return vp8hip_auto_segments(d->hip, key ? 1 : 0, refqi, d->qi_min);
     int32_t red = 0, sharp = 0, sd[VP8HIP_SD_INTS];
     vp8host_loopfilter_strength(host_y, d->W, d->H, &red, &sharp);
     vp8host_prepare_segments_data(key ? 1 : 0, refqi, d->qi_min, red, sharp, 0, 0, sd);
+    d->sharpness = sharp;
     return vp8hip_set_segments(d->hip, sd);
 }
 
@@ -92,6 +107,10 @@ int key_frame(vp8drv *d, const uint8_t *host_y) {
     vp8host_gop_frame_done(&d->gop);
     d->st.key_frames++;
     d->st.frame_number = d->gop.frame_number;
+    d->have_frame = true;
+    d->last_key = d->last_altref = true;
+    d->checked = false;
+    d->replaced = 0;
     return 1;
 }
 
@@ -109,6 +128,8 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     d->st.last_prev_is_golden = d->gop.prev_is_golden;
     d->st.last_prev_is_altref = d->gop.prev_is_altref;
     d->st.last_was_altref = d->gop.current_is_altref;
+    d->checked = false;
+    d->replaced = 0;
     if (d->cfg.check_ssim) {
         // check_SSIM, vp8enc.cpp:231-263, on the device: intra fallback of the macroblocks below the target
         int32_t replaced = 0;
@@ -117,6 +138,8 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
         d->st.last_replaced = replaced;
         d->st.last_new_ssim = new_ssim;
         d->st.last_min_ssim = min1;
+        d->checked = true;
+        d->replaced = replaced;
         if (min1 > 0.95f) {
             // even the worst macroblock is good: weaken the loop filter (reductor * 2, sharpness 7; :155-159, :260-261)
             int32_t red = 0, sharp = 0, sd[VP8HIP_SD_INTS];
@@ -124,6 +147,7 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
             else vp8host_loopfilter_strength(host_y, d->W, d->H, &red, &sharp);
             vp8host_prepare_segments_data(0, refqi, d->qi_min, red, sharp, 1, 7, sd);
             DRV_CHK(vp8hip_set_segments(d->hip, sd));
+            d->sharpness = 7;
         }
         if (replaced > d->mbs / 6 || new_ssim < d->cfg.ssim_target) {   // vp8enc.cpp:443-453: redo as a key frame
             d->st.redone_as_key++;
@@ -138,7 +162,77 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     vp8host_gop_frame_done(&d->gop);
     d->st.inter_frames++;
     d->st.frame_number = d->gop.frame_number;
+    d->have_frame = true;
+    d->last_key = false;
+    d->last_altref = d->st.last_was_altref != 0;
     return 0;
+}
+
+// entropy_encode() + gather_frame() (vp8enc.cpp:48-94, 476-481; encIO.h:1-30) for the frame just coded:
+// coefficient statistics and partitions on the device, first partition on the host
+int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
+    const int P = d->cfg.num_partitions;
+    const size_t n = (size_t)d->mbs;
+    uint32_t probs[VP8BS_NUM_COEFF_PROBS], denom[VP8BS_NUM_COEFF_PROBS];
+    d->nz.resize(n);
+    DRV_CHK(vp8hip_prepare_filter_mask(d->hip, d->nz.data()));                   // counts of the final coefficients (vp8enc.cpp:472)
+    DRV_CHK(vp8hip_count_probs(d->hip, P, probs, denom));                        // :58-68
+    vp8bs_default_probs(probs, denom);                                           // :69-76
+    const size_t step = n * 800 / (size_t)P;                                     // video.partition_step, init.h:409,1190
+    d->partitions.resize(step * (size_t)P);
+    int32_t sizes[8] = {0};
+    DRV_CHK(vp8hip_encode_coefficients(d->hip, probs, P, (int)step, d->partitions.data(), sizes));   // :77-81
+    // what encode_header reads from the frame's results (entropy_host.cpp:221-223, 808, 986-987, 1086)
+    d->seg.resize(n);
+    d->ref.resize(n);
+    d->parts.resize(n);
+    d->vectors.resize(n * 8);
+    vp8hip_results r{};
+    r.MB_segment_id = d->seg.data();
+    if (!d->last_key) {
+        r.MB_reference_frame = d->ref.data();
+        r.MB_parts = d->parts.data();
+        r.MB_vectors = d->vectors.data();
+    }
+    DRV_CHK(vp8hip_download_results(d->hip, &r));
+    const bool intra_info = d->last_key || d->checked;
+    if (intra_info) {
+        d->modes.resize(n * 16);
+        d->is_inter.resize(n);
+        DRV_CHK(vp8hip_download_intra(d->hip, d->modes.data(), d->last_key ? nullptr : d->is_inter.data()));
+    }
+    int32_t sd[VP8HIP_SD_INTS], red = 0, sharp = 0;
+    DRV_CHK(vp8hip_get_segments(d->hip, sd, &red, &sharp));
+    if (d->sharpness >= 0) sharp = d->sharpness;
+    vp8bs_frame f{};
+    f.width = d->cfg.display_width > 0 ? d->cfg.display_width : d->W;
+    f.height = d->cfg.display_height > 0 ? d->cfg.display_height : d->H;
+    f.mb_width = d->W / 16;
+    f.mb_height = d->H / 16;
+    f.is_key = d->last_key;
+    f.is_golden = d->last_key;                  // current_is_golden_frame = current_is_key_frame (vp8enc.cpp:369)
+    f.is_altref = d->last_altref;
+    f.loop_filter_type = 0;                     // init.h:1583
+    f.loop_filter_sharpness = sharp;
+    f.partitions_log2 = P == 8 ? 3 : (P == 4 ? 2 : (P == 2 ? 1 : 0));
+    f.skip_prob = vp8host_skip_prob(d->nz.data(), d->mbs);
+    f.replaced = d->last_key ? 0 : d->replaced;
+    f.segments = sd;
+    f.MB_segment_id = d->seg.data();
+    f.MB_non_zero_coeffs = d->nz.data();
+    f.MB_reference_frame = d->last_key ? nullptr : d->ref.data();
+    f.MB_parts = d->last_key ? nullptr : d->parts.data();
+    f.MB_vectors = d->last_key ? nullptr : d->vectors.data();
+    f.is_inter_mb = (!d->last_key && d->checked) ? d->is_inter.data() : nullptr;
+    f.modes = intra_info ? d->modes.data() : nullptr;
+    f.new_probs = probs;
+    f.new_probs_denom = denom;
+    const size_t head = vp8bs_encode_header(&f, out, capacity, nullptr);          // :84
+    if (!head) return VP8HIP_ERR_OVERFLOW;
+    const size_t total = vp8bs_gather_frame(out, head, capacity, P, d->partitions.data(), step, sizes);
+    if (!total) return VP8HIP_ERR_OVERFLOW;
+    *size = total;
+    return VP8HIP_OK;
 }
 
 }  // namespace
@@ -157,6 +251,14 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
     vp8host_gop_next(&d->gop);
     DRV_CHK(vp8hip_upload_current(d->hip, y, u, v));
     return frame_body(d, y, d->gop.current_is_key || force_key);
+}
+
+int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
+    if (!d || !out || !size) return VP8HIP_ERR_ARG;
+    if (!d->have_frame) return VP8HIP_ERR_STATE;
+    const int P = d->cfg.num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    return get_frame(d, out, capacity, size);
 }
 
 }  // extern "C"

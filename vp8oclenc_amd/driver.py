@@ -37,6 +37,7 @@ class InterPathDriver:
     def segments_for(self, y: np.ndarray, is_key: bool, is_altref: bool, update_filter: bool = False) -> np.ndarray:
         reductor, sharp = api.loopfilter_strength(y)
         refqi = self.altrefqi if is_altref else self.lastqi
+        self.sharpness = 7 if update_filter else sharp      # video.loop_filter_sharpness, which the frame header carries
         return api.prepare_segments_data(is_key, refqi, self.qi_min, reductor, sharp, update_filter, 7)
 
     def _key_frame(self, y, u, v):
@@ -55,6 +56,7 @@ class InterPathDriver:
             self.last_key = self.be.download_results(recon=True)
             self.last_key["segments"] = sd
             self.last_key["modes"] = self.be.download_intra()[0]
+            self.last_key["sharpness"] = self.sharpness
         self.be.prepare_filter_mask(want_nz=False)                              # vp8enc.cpp:472
         self.be.loop_filter()                                                   # vp8enc.cpp:473
         self.gop.frame_done()
@@ -71,7 +73,7 @@ class InterPathDriver:
         self.be.set_segments(sd)
         use_golden, use_altref = self.gop.inter_flags()                         # inter_part.h:103-104
         self.be.inter_transform(g.prev_is_golden, g.prev_is_altref, use_golden, use_altref)
-        out = {"segments": sd, "use_golden": use_golden, "use_altref": use_altref}
+        out = {"segments": sd, "use_golden": use_golden, "use_altref": use_altref, "is_altref": int(g.current_is_altref)}
         if self.check:
             replaced, new_ssim, min1 = self.be.check_ssim()                     # vp8enc.cpp:442, 231-263
             out.update(replaced=replaced, new_SSIM=new_ssim, min_SSIM=min1)
@@ -86,6 +88,7 @@ class InterPathDriver:
             out.update(self.be.download_results(recon=True))                    # vp8enc.cpp:422-440, after the fallback
             if self.check:
                 out["modes"], out["is_inter"] = self.be.download_intra()
+        out["sharpness"] = self.sharpness
         self.be.prepare_filter_mask(want_nz=False)                             # vp8enc.cpp:472
         self.be.loop_filter()                                                   # vp8enc.cpp:473
         self.gop.frame_done()
