@@ -161,6 +161,27 @@ int vp8hip_count_probs(vp8hip_ctx *ctx, int num_partitions, uint32_t *new_probs,
 int vp8hip_encode_coefficients(vp8hip_ctx *ctx, const uint32_t *coeff_probs, int num_partitions, int partition_step,
                                uint8_t *partitions, int32_t *partition_sizes);
 
+/* encode_header(), entropy_host.cpp:709-1256 -- the first partition (frame header, then segment id / skip flag /
+ * reference frame / motion-vector mode and vectors or intra modes of every macroblock) -- coded on the device from
+ * the results that are already there, instead of on one host thread after downloading them (2-3 ms per 1080p frame
+ * there).  Uses MB_segment_id, the non-zero counts, MB_reference_frame, MB_parts, MB_vectors as the transform and
+ * vp8hip_prepare_filter_mask left them, the segment data in force, the coefficient statistics of the preceding
+ * vp8hip_count_probs (the header transmits the probability of every context that occurred) and, for key frames or
+ * with use_intra_info, e_data.mode / is_inter_mb of vp8hip_intra_transform / vp8hip_check_ssim.  skip_prob,
+ * prob_intra, prob_last/prob_gf, the segment-map and motion-vector probabilities are derived on the device as
+ * encode_header derives them.  Writes the partition with its 3- or 10-byte uncompressed chunk to `out`; *size = its
+ * size (frames.encoded_frame_size after encode_header).  Blocks.  The host implementation of the same function is
+ * vp8bs_encode_header (include/vp8hip_bitstream.h); vp8bs_gather_frame appends the coefficient partitions. */
+typedef struct {
+    int32_t is_key, is_golden, is_altref;    /* frames.current_is_{key,golden,altref}_frame */
+    int32_t loop_filter_type;                /* video.loop_filter_type (0) */
+    int32_t loop_filter_sharpness;           /* video.loop_filter_sharpness; -1 = the value vp8hip_auto_segments computed */
+    int32_t partitions_log2;                 /* video.number_of_partitions_ind */
+    int32_t width, height;                   /* video.dst_width/height for key frames; 0 = the coded size */
+    int32_t use_intra_info;                  /* inter frames: 1 = vp8hip_check_ssim ran on this frame */
+} vp8hip_header_params;
+int vp8hip_encode_header(vp8hip_ctx *ctx, const vp8hip_header_params *params, uint8_t *out, size_t capacity, size_t *size);
+
 /* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
 int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
 
@@ -188,6 +209,7 @@ typedef enum {
     VP8HIP_K_ENT_COUNT,     /* count_probs + num_div_denom       CPU_kernels.cl:536,764 */
     VP8HIP_K_ENT_ENCODE,    /* encode_coefficients               CPU_kernels.cl:347 */
     VP8HIP_K_INTRA,         /* key frame / check_SSIM fallback   intra_part.h:517-1109 */
+    VP8HIP_K_HDR_ENCODE,    /* encode_header (first partition)   entropy_host.cpp:709 */
     VP8HIP_K_COUNT
 } vp8hip_kernel_id;
 

@@ -76,3 +76,75 @@ def test_bitstream_from_device_resident_frames_and_device_parameters():
         assert got == expected_frame(W, H, do.last_key if out is None else out, out is None, 1), t
     drv.close()
     ora.close()
+
+
+# ---- the first partition coded on the device (vp8hip_encode_header, kernels_hdr.hip) ------------------------------------
+import ctypes as C
+import glob
+import os
+
+from bitstream_cases import default_sd, random_inter_case, ref_encode_header, ref_header_lib
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "bitstream", "*.npz")))
+
+
+def device_header(W, H, flags, sd, c, sharpness=0, partitions_log2=0, dst=None):
+    """Drive the device coder with explicit inputs (hidden test hook vp8hip_debug_upload_header_inputs)."""
+    hip = api.Vp8Hip(W, H)
+    lib = hip.lib
+    lib.vp8hip_debug_upload_header_inputs.argtypes = [C.c_void_p] * 11
+    keep = []
+
+    def ptr(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    key = flags[0] == 1
+    rc = lib.vp8hip_debug_upload_header_inputs(hip.h, ptr(c["seg"], np.int32), ptr(c["nz"], np.int32), ptr(None if key else c["ref_frame"], np.int32),
+                                               ptr(None if key else c["parts"], np.int32), ptr(None if key else c["vectors"], np.int16),
+                                               ptr(c.get("is_inter"), np.int32), ptr(c.get("modes"), np.int32), ptr(c["probs"], np.uint32),
+                                               ptr(c["denom"], np.uint32), ptr(np.asarray(sd).reshape(-1), np.int32))
+    assert rc == 0
+    use_intra = (not key) and c.get("is_inter") is not None
+    out = hip.encode_header(flags[0], flags[1], flags[2], sharpness=sharpness, partitions_log2=partitions_log2, use_intra_info=use_intra,
+                            width=(dst or (0, 0))[0], height=(dst or (0, 0))[1])
+    hip.close()
+    return out
+
+
+@pytest.mark.parametrize("mbw,mbh,seed,kw", [(4, 3, 1, {}), (11, 9, 2, {}), (22, 18, 3, dict(long_mv=0.5)), (7, 5, 4, dict(split=1.0)),
+                                             (7, 5, 5, dict(split=0.0, zero=0.6)), (9, 6, 6, dict(intra=0.2)), (9, 6, 7, dict(intra=0.02)),
+                                             (5, 4, 8, dict(intra=1.0)), (30, 17, 9, dict(copy_neighbour=0.8)), (1, 1, 10, {}), (1, 6, 11, {}), (6, 1, 12, {}),
+                                             (120, 68, 13, {}), (240, 135, 14, dict(long_mv=0.3))])
+def test_device_header_matches_host_coder_on_stress_inputs(mbw, mbh, seed, kw):
+    c = random_inter_case(mbw, mbh, seed, **kw)
+    # the device derives skip_prob and `replaced` itself: they must come out as the host computes them
+    for flags, sharp, plog in (((0, 0, 0), 0, 0), ((0, 0, 1), 7, 3)):
+        host, _ = bitstream.encode_header(mbw * 16, mbh * 16, flags, default_sd(), c["seg"], c["nz"], c["probs"], c["denom"], c["skip_prob"],
+                                          ref_frame=c["ref_frame"], parts=c["parts"], vectors=c["vectors"], is_inter=c["is_inter"], modes=c["modes"],
+                                          replaced=c["replaced"], sharpness=sharp, partitions_log2=plog)
+        dev = device_header(mbw * 16, mbh * 16, flags, default_sd(), c, sharpness=sharp, partitions_log2=plog)
+        assert len(dev) == len(host), (flags, len(dev), len(host))
+        assert np.array_equal(dev, host), (flags, np.nonzero(dev != host)[0][:8], len(host))
+
+
+@pytest.mark.parametrize("mbw,mbh,seed", [(1, 1, 1), (4, 3, 2), (11, 9, 3), (120, 68, 4)])
+def test_device_key_frame_header_matches_host_coder(mbw, mbh, seed):
+    c = random_inter_case(mbw, mbh, seed)
+    c.update(is_inter=None, replaced=0)
+    host, _ = bitstream.encode_header(mbw * 16, mbh * 16, (1, 1, 1), default_sd(True), c["seg"], c["nz"], c["probs"], c["denom"], c["skip_prob"],
+                                      modes=c["modes"], sharpness=3, dst=(mbw * 16 - 5, mbh * 16 - 2))
+    dev = device_header(mbw * 16, mbh * 16, (1, 1, 1), default_sd(True), c, sharpness=3, dst=(mbw * 16 - 5, mbh * 16 - 2))
+    assert np.array_equal(dev, host), np.nonzero(dev[:min(len(dev), len(host))] != host[:min(len(dev), len(host))])[0][:8]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_device_header_matches_reference_golden_vectors(path):
+    z = np.load(path)
+    c = {k: (np.ascontiguousarray(z[k]) if k in z.files else None) for k in ("seg", "nz", "ref_frame", "parts", "vectors", "is_inter", "modes", "probs", "denom")}
+    flags = tuple(int(x) for x in z["flags"])
+    dev = device_header(int(z["W"]), int(z["H"]), flags, z["sd"], c, sharpness=int(z["sharpness"]), partitions_log2=int(z["partitions_log2"]))
+    assert np.array_equal(dev, z["header"]), np.nonzero(dev[:min(len(dev), len(z["header"]))] != z["header"][:min(len(dev), len(z["header"]))])[0][:8]

@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "search1_l1", "search1_l0", "search2",
-           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode", "intra"]
+           "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode", "intra", "hdr_encode"]
 K_COUNT = len(K_NAMES)
 
 DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT = range(7)
@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_encode_header",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
@@ -384,6 +384,20 @@ class Vp8Hip:
         modes, is_inter = np.zeros((self.mbs, 16), np.int32), np.zeros(self.mbs, np.int32)
         self._chk(self.lib.vp8hip_download_intra(self.h, modes.ctypes.data, is_inter.ctypes.data), "download_intra")
         return modes, is_inter
+
+    def encode_header(self, is_key, is_golden=0, is_altref=0, sharpness=-1, partitions_log2=0, use_intra_info=False,
+                      loop_filter_type=0, width=0, height=0) -> np.ndarray:
+        """encode_header (entropy_host.cpp:709-1256) on the device: the first partition with its frame tag."""
+        class P(C.Structure):
+            _fields_ = [(n, C.c_int32) for n in ("is_key", "is_golden", "is_altref", "loop_filter_type", "loop_filter_sharpness",
+                                                  "partitions_log2", "width", "height", "use_intra_info")]
+        p = P(int(is_key), int(is_golden), int(is_altref), loop_filter_type, int(sharpness), partitions_log2, width, height, int(use_intra_info))
+        self.lib.vp8hip_encode_header.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        cap = self.mbs * 96 + 16384
+        out = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.lib.vp8hip_encode_header(self.h, C.byref(p), out.ctypes.data, cap, C.byref(n)), "encode_header")
+        return out[:n.value].copy()
 
     def _debug_set_ssim(self, ssim):
         s = np.ascontiguousarray(ssim, np.float32)

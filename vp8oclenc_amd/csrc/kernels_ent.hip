@@ -526,6 +526,26 @@ __global__ __launch_bounds__(64) void k_ent_finish(const unsigned long long *acc
 
 }  // namespace ent
 
+// exclusive prefix sum of v[0..n) in place, total in v[n]; n <= 1024 * 1024
+void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n) {
+    const int ntiles = (n + ent::SCAN_TILE - 1) / ent::SCAN_TILE;
+    hipLaunchKernelGGL(ent::k_scan_tiles, dim3(ntiles), dim3(256), 0, s, v, tile_sum, n);
+    hipLaunchKernelGGL(ent::k_scan_top, dim3(1), dim3(1024), 0, s, tile_sum, ntiles);
+    hipLaunchKernelGGL(ent::k_scan_apply, dim3(ntiles), dim3(256), 0, s, v, tile_sum, n, ntiles);
+}
+
+// the boolean coder proper on bool strings that are laid out as eb.plan says (steps 2-5 above): P partitions
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
+    EntPlan *plan = eb.plan;
+    (void)hipMemsetAsync(eb.acc, 0, (size_t)eb.cap_words * 8, s);
+    hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
+    hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
+    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,
+                       reinterpret_cast<const uint2 *>(eb.start), reinterpret_cast<unsigned long long *>(eb.acc));
+    hipLaunchKernelGGL(ent::k_ent_finish, dim3(P), dim3(64), 0, s, reinterpret_cast<const unsigned long long *>(eb.acc), plan,
+                       eb.bytes, eb.sizes);
+}
+
 void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
                        int mbw, int mbh, int P) {
     ent::Geom g;
@@ -540,22 +560,14 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
     g.cap_bools = eb.cap_bools;
     g.cap_chunks = eb.cap_chunks;
     g.cap_words = eb.cap_words;
-    const int nslots = mbw * mbh * 25, ntiles = (nslots + ent::SCAN_TILE - 1) / ent::SCAN_TILE;
+    const int nslots = mbw * mbh * 25;
     EntPlan *plan = eb.plan;
     hipLaunchKernelGGL(ent::k_ent_boolcount, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, g, eb.offs);
-    hipLaunchKernelGGL(ent::k_scan_tiles, dim3(ntiles), dim3(256), 0, s, eb.offs, eb.tile_sum, nslots);
-    hipLaunchKernelGGL(ent::k_scan_top, dim3(1), dim3(1024), 0, s, eb.tile_sum, ntiles);
-    hipLaunchKernelGGL(ent::k_scan_apply, dim3(ntiles), dim3(256), 0, s, eb.offs, eb.tile_sum, nslots, ntiles);
+    launch_scan_exclusive(s, eb.offs, eb.tile_sum, nslots);
     hipLaunchKernelGGL(ent::k_ent_plan, dim3(1), dim3(64), 0, s, eb.offs, g, plan);
     hipLaunchKernelGGL(ent::k_ent_emit, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, third_ctx, probs,
                        eb.offs, plan, g, eb.bools);
-    hipMemsetAsync(eb.acc, 0, (size_t)eb.cap_words * 8, s);
-    hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
-    hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
-    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,
-                       reinterpret_cast<const uint2 *>(eb.start), reinterpret_cast<unsigned long long *>(eb.acc));
-    hipLaunchKernelGGL(ent::k_ent_finish, dim3(P), dim3(64), 0, s, reinterpret_cast<const unsigned long long *>(eb.acc), plan,
-                       eb.bytes, eb.sizes);
+    launch_bool_code(s, eb, P);
 }
 
 }  // namespace vp8

@@ -62,6 +62,10 @@ struct vp8hip_ctx {
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
     // host intra path on the device: sub-block modes, replaced flags, row progress, {replaced, new_SSIM, min SSIM}
     int32_t *intra_modes = nullptr, *intra_is_inter = nullptr, *intra_prog = nullptr, *intra_stats = nullptr;
+    // first partition on the device: its own coder scratch, per-workgroup statistics, probability table, {H, skip_prob, replaced}
+    EntBuffers hdr{};
+    uint32_t *hdr_partial = nullptr, *hdr_info = nullptr;
+    uint8_t *hdr_sym = nullptr;
 
     uint32_t prof_mask = 0;
     hipEvent_t ev[MAX_EVENTS];
@@ -329,6 +333,18 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->intra_is_inter);
     hipFree(c->intra_prog);
     hipFree(c->intra_stats);
+    hipFree(c->hdr.offs);
+    hipFree(c->hdr.tile_sum);
+    hipFree(c->hdr.bools);
+    hipFree(c->hdr.maps);
+    hipFree(c->hdr.start);
+    hipFree(c->hdr.acc);
+    hipFree(c->hdr.bytes);
+    hipFree(c->hdr.sizes);
+    hipFree(c->hdr.plan);
+    hipFree(c->hdr_partial);
+    hipFree(c->hdr_info);
+    hipFree(c->hdr_sym);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -697,6 +713,72 @@ int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int n
     return VP8HIP_OK;
 }
 
+static int hdr_alloc(vp8hip_ctx *c) {
+    if (c->hdr.bools) return VP8HIP_OK;
+    EntBuffers &e = c->hdr;
+    const size_t n = (size_t)c->mbs;
+    e.cap_bools = (uint32_t)(n * 128 + 16384);   // a macroblock header is at most ~125 bools, the frame header < 10 k
+    e.cap_chunks = e.cap_bools / 256 + 4;
+    e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 16);
+    HIPCHK(c, hipMalloc(&e.offs, (n + 1) * 4));
+    HIPCHK(c, hipMalloc(&e.tile_sum, (n / 1024 + 8) * 4));
+    HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
+    HIPCHK(c, hipMalloc(&e.maps, (size_t)e.cap_chunks * 128 * 4));
+    HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
+    HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
+    HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
+    HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
+    HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
+    HIPCHK(c, hipMalloc(&c->hdr_partial, ((n + 255) / 256) * HDR_STAT_WORDS * 4));
+    HIPCHK(c, hipMalloc(&c->hdr_info, 16));
+    HIPCHK(c, hipMalloc(&c->hdr_sym, 64));
+    return VP8HIP_OK;
+}
+
+int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
+    if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
+    if (c->ent_counted_partitions == 0) return VP8HIP_ERR_STATE;    // the coefficient probabilities of this frame: vp8hip_count_probs first
+    const size_t head = p->is_key ? 10 : 3;
+    if (capacity < head + 8) return VP8HIP_ERR_OVERFLOW;
+    int rc = hdr_alloc(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HdrFrame f;
+    f.is_key = p->is_key ? 1 : 0;
+    f.is_golden = p->is_golden ? 1 : 0;
+    f.is_altref = p->is_altref ? 1 : 0;
+    f.loop_filter_type = p->loop_filter_type;
+    f.sharpness = p->loop_filter_sharpness;
+    f.partitions_log2 = p->partitions_log2;
+    const bool intra_info = p->is_key || p->use_intra_info;
+    {
+        Timed t(c, VP8HIP_K_HDR_ENCODE);
+        launch_hdr_encode(s, c->out, (!p->is_key && p->use_intra_info) ? c->intra_is_inter : nullptr, intra_info ? c->intra_modes : nullptr, f,
+                          c->d_sd, reinterpret_cast<const int32_t *>(c->d_stats + 4), c->ent_probs, c->ent_denom0, c->hdr, c->hdr_partial,
+                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh);
+    }
+    HIPCHK(c, hipGetLastError());
+    EntPlan plan;
+    HIPCHK(c, hipMemcpyAsync(&plan, c->hdr.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (plan.overflow || head + plan.nbytes[0] > capacity) return VP8HIP_ERR_OVERFLOW;
+    HIPCHK(c, hipMemcpyAsync(out + head, c->hdr.bytes, plan.nbytes[0], hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // frame tag (entropy_host.cpp:1214-1247): key/inter bit, version 0, show_frame, size of the first partition
+    const uint32_t tag = (p->is_key ? 0u : 1u) | 0x10u | (plan.nbytes[0] << 5);
+    out[0] = (uint8_t)tag;
+    out[1] = (uint8_t)(tag >> 8);
+    out[2] = (uint8_t)(tag >> 16);
+    if (p->is_key) {
+        const int w = p->width > 0 ? p->width : c->W, h = p->height > 0 ? p->height : c->H;
+        out[3] = 0x9d; out[4] = 0x01; out[5] = 0x2a;
+        out[6] = (uint8_t)w; out[7] = (uint8_t)(w >> 8);
+        out[8] = (uint8_t)h; out[9] = (uint8_t)(h >> 8);
+    }
+    *size = head + plan.nbytes[0];
+    return VP8HIP_OK;
+}
+
 // stream idle -> did a bounded device-side wait expire since the last check?  (kernels_lf3.hip, LF_WAIT)
 static int check_device_timeout(vp8hip_ctx *c) {
     int32_t flag = 0;
@@ -836,6 +918,29 @@ int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
     if (!c || !ssim) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipMemcpyAsync(c->out.ssim, ssim, (size_t)c->mbs * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VP8HIP_OK;
+}
+
+// test hook (not in the public header): everything vp8hip_encode_header reads, set directly -- lets the tests drive the
+// device coder with the stress inputs of tests/bitstream_cases.py and the golden vectors.  NULL = leave as is.
+int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const int32_t *nz, const int32_t *ref, const int32_t *parts,
+                                      const int16_t *vectors, const int32_t *is_inter, const int32_t *modes, const uint32_t *probs,
+                                      const uint32_t *denom, const int32_t *sd) {
+    if (!c) return VP8HIP_ERR_ARG;
+    hipStream_t s = c->stream;
+    const size_t n = c->mbs;
+    if (seg) HIPCHK(c, hipMemcpyAsync(c->out.seg, seg, n * 4, hipMemcpyHostToDevice, s));
+    if (nz) HIPCHK(c, hipMemcpyAsync(c->out.nz, nz, n * 4, hipMemcpyHostToDevice, s));
+    if (ref) HIPCHK(c, hipMemcpyAsync(c->out.ref, ref, n * 4, hipMemcpyHostToDevice, s));
+    if (parts) HIPCHK(c, hipMemcpyAsync(c->out.parts, parts, n * 4, hipMemcpyHostToDevice, s));
+    if (vectors) HIPCHK(c, hipMemcpyAsync(c->out.vec, vectors, n * 16, hipMemcpyHostToDevice, s));
+    if (is_inter) HIPCHK(c, hipMemcpyAsync(c->intra_is_inter, is_inter, n * 4, hipMemcpyHostToDevice, s));
+    if (modes) HIPCHK(c, hipMemcpyAsync(c->intra_modes, modes, n * 64, hipMemcpyHostToDevice, s));
+    if (probs) HIPCHK(c, hipMemcpyAsync(c->ent_probs, probs, sizeof(uint32_t) * ENT_NCTX, hipMemcpyHostToDevice, s));
+    if (denom) HIPCHK(c, hipMemcpyAsync(c->ent_denom0, denom, sizeof(uint32_t) * ENT_NCTX, hipMemcpyHostToDevice, s));
+    if (sd) HIPCHK(c, hipMemcpyAsync(c->d_sd, sd, sizeof(SegData), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (probs || denom) c->ent_counted_partitions = 1;
     return VP8HIP_OK;
 }
 

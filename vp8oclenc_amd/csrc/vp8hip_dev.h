@@ -97,6 +97,17 @@ struct EntBuffers {          // device scratch of the boolean coder (allocated o
 void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
                        int mbw, int mbh, int P);
 
+void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n);   // in place, total in v[n]
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P);                    // the coder on bool strings laid out per eb.plan
+
+// first partition on the device (kernels_hdr.hip): encode_header, src/entropy_host.cpp:709-1256
+struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* < 0: the device's */, partitions_log2; };
+void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0);   // vp8enc.cpp:69-76
+constexpr int HDR_STAT_WORDS = 84;   // per-workgroup partial sums of k_hdr_count
+void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
+                       const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
+                       uint8_t *sym, uint32_t *info, int mbw, int mbh);
+
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
