@@ -182,6 +182,15 @@ typedef struct {
 } vp8hip_header_params;
 int vp8hip_encode_header(vp8hip_ctx *ctx, const vp8hip_header_params *params, uint8_t *out, size_t capacity, size_t *size);
 
+/* entropy_encode() + gather_frame() (vp8enc.cpp:48-94, encIO.h:1-30) in one call and entirely on the device:
+ * count_probs, num_div_denom, the default-probability fallback, encode_coefficients, encode_header, then the frame
+ * is assembled in `out` -- first partition, the sizes of all coefficient partitions but the last, the partitions.
+ * Two read-backs (the two layouts, then the bytes) instead of the eight blocking transfers of the step-by-step
+ * calls.  params->partitions_log2 is ignored (derived from num_partitions).  *size = bytes of the finished frame:
+ * what the reference hands to write_output_file(). */
+int vp8hip_encode_frame(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params, uint8_t *out, size_t capacity,
+                        size_t *size);
+
 /* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
 int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
 

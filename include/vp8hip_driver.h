@@ -36,9 +36,12 @@ typedef struct {
                                 0: skip it (what the reference's defaults amount to except for the filter update) */
     int32_t num_partitions;  /* -partitions: 1, 2, 4 or 8 coefficient partitions (init.h:1451-1469, default 1) */
     int32_t display_width, display_height;   /* video.dst_width/height written into key frames; 0 = the coded size */
+    int32_t host_bitstream;  /* vp8drv_get_frame: 0 = the whole entropy stage on the device (vp8hip_encode_frame);
+                                1 = first partition on the host (vp8bs_encode_header) after downloading what it reads,
+                                the way the reference does it -- kept as the cross-check */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);
@@ -52,9 +55,9 @@ int vp8drv_encode_frame_device(vp8drv *d, const void *d_y, const void *d_u, cons
 int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v, int force_key);
 
 /* The frame just coded, as bytes: entropy_encode() + gather_frame() of the reference (vp8enc.cpp:48-94, 476-481;
- * encIO.h:1-30) -- coefficient statistics and the coefficient partitions on the device (vp8hip_count_probs,
- * vp8hip_encode_coefficients), frame header with the macroblock modes and motion vectors on the host
- * (include/vp8hip_bitstream.h), assembled into `out`.  Call it after vp8drv_encode_frame_* and before the next one.
+ * encIO.h:1-30) -- coefficient statistics, coefficient partitions and the first partition (frame header, macroblock
+ * modes, motion vectors) coded on the device and assembled into `out` (vp8hip_encode_frame; with host_bitstream the
+ * first partition comes from the host coder of include/vp8hip_bitstream.h instead).  Call it after vp8drv_encode_frame_* and before the next one.
  * Blocks.  *size = bytes written; VP8HIP_ERR_OVERFLOW if `capacity` is too small.  With vp8bs_ivf_file_header /
  * vp8bs_ivf_frame_header around the frames this is the reference's .ivf output, byte for byte. */
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);

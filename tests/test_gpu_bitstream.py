@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def run_sequence(W, H, frames, P=1, **cfg):
     drv = api.NativeDriver(W, H, num_partitions=P, check_ssim=1, **cfg)
+    cfg = {k: v for k, v in cfg.items() if k != "host_bitstream"}
     ora = Oracle(W, H, cfg.get("ssim_target", -1.0))
     do = InterPathDriver(ora, W, H, gop_size=cfg.get("gop_size", 150), altref_range=cfg.get("altref_range", 5),
                          qi_min=cfg.get("qi_min", 0), qi_max=cfg.get("qi_max", 48), ssim_target=cfg.get("ssim_target", -1.0))
@@ -37,11 +38,11 @@ def run_sequence(W, H, frames, P=1, **cfg):
     return stream, stats, do
 
 
-@pytest.mark.parametrize("P", [1, 4])
-def test_bitstream_of_a_gop_with_golden_and_altref(P):
+@pytest.mark.parametrize("P,host_bitstream", [(1, 0), (4, 0), (8, 0), (2, 1)])
+def test_bitstream_of_a_gop_with_golden_and_altref(P, host_bitstream):
     W, H = 320, 192
     s = SynthSequence(W, H, seed=51)
-    stream, st, _ = run_sequence(W, H, [s.frame(t) for t in range(13)], P=P, gop_size=12, altref_range=5)
+    stream, st, _ = run_sequence(W, H, [s.frame(t) for t in range(13)], P=P, gop_size=12, altref_range=5, host_bitstream=host_bitstream)
     assert st.key_frames == 2 and st.inter_frames == 11          # a second key frame at the GOP boundary
     assert stream[0][3:6] == b"\x9d\x01\x2a" and stream[12][3:6] == b"\x9d\x01\x2a"
     assert all(f[0] & 1 for f in stream[1:12])                    # inter frames
@@ -50,11 +51,12 @@ def test_bitstream_of_a_gop_with_golden_and_altref(P):
     assert ivf[:4] == b"DKIF" and len(ivf) == 32 + sum(12 + len(f) for f in stream)
 
 
-def test_bitstream_with_intra_fallback_and_scene_cut():
+@pytest.mark.parametrize("host_bitstream", [0, 1])
+def test_bitstream_with_intra_fallback_and_scene_cut(host_bitstream):
     W, H = 320, 192
     a, b = SynthSequence(W, H, seed=41), SynthSequence(W, H, seed=97)
     frames = [a.frame(t) for t in range(4)] + [b.frame(t) for t in range(3)]
-    _, st, do = run_sequence(W, H, frames, P=2, qi_min=50, qi_max=110, ssim_target=0.90)
+    _, st, do = run_sequence(W, H, frames, P=2, qi_min=50, qi_max=110, ssim_target=0.90, host_bitstream=host_bitstream)
     assert st.redone_as_key >= 1 and do.redone_as_key == st.redone_as_key
 
 

@@ -40,6 +40,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->num_partitions = 1;
     c->display_width = 0;
     c->display_height = 0;
+    c->host_bitstream = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -173,6 +174,18 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
 int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     const int P = d->cfg.num_partitions;
     const size_t n = (size_t)d->mbs;
+    if (!d->cfg.host_bitstream) {   // the whole entropy stage on the device, two read-backs
+        vp8hip_header_params hp{};
+        hp.is_key = d->last_key;
+        hp.is_golden = d->last_key;                 // current_is_golden_frame = current_is_key_frame (vp8enc.cpp:369)
+        hp.is_altref = d->last_altref;
+        hp.loop_filter_type = 0;                    // init.h:1583
+        hp.loop_filter_sharpness = d->sharpness;    // -1: still on the device
+        hp.width = d->cfg.display_width;
+        hp.height = d->cfg.display_height;
+        hp.use_intra_info = d->checked;
+        return vp8hip_encode_frame(d->hip, P, &hp, out, capacity, size);
+    }
     uint32_t probs[VP8BS_NUM_COEFF_PROBS], denom[VP8BS_NUM_COEFF_PROBS];
     d->nz.resize(n);
     DRV_CHK(vp8hip_prepare_filter_mask(d->hip, d->nz.data()));                   // counts of the final coefficients (vp8enc.cpp:472)

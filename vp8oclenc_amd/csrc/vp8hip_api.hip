@@ -729,7 +729,7 @@ static int hdr_alloc(vp8hip_ctx *c) {
     HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
     HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
     HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
-    HIPCHK(c, hipMalloc(&c->hdr_partial, ((n + 255) / 256) * HDR_STAT_WORDS * 4));
+    HIPCHK(c, hipMalloc(&c->hdr_partial, ((n + 63) / 64) * HDR_STAT_WORDS * 4));   // one row per workgroup of k_hdr_count (64 macroblocks)
     HIPCHK(c, hipMalloc(&c->hdr_info, 16));
     HIPCHK(c, hipMalloc(&c->hdr_sym, 64));
     return VP8HIP_OK;
@@ -776,6 +776,77 @@ int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *
         out[8] = (uint8_t)h; out[9] = (uint8_t)(h >> 8);
     }
     *size = head + plan.nbytes[0];
+    return VP8HIP_OK;
+}
+
+int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
+    if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
+    const int P = num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;
+    int rc = ent_alloc(c);
+    if (rc) return rc;
+    if ((rc = hdr_alloc(c))) return rc;
+    hipStream_t s = c->stream;
+    {   // count_probs + num_div_denom, the default-probability fallback (vp8enc.cpp:58-76), encode_coefficients (:77-81)
+        Timed t(c, VP8HIP_K_ENT_COUNT);
+        launch_ent_count(s, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw, c->mbh, P);
+        launch_default_probs(s, c->ent_probs, c->ent_denom0);
+    }
+    c->ent_counted_partitions = P;
+    {
+        Timed t(c, VP8HIP_K_ENT_ENCODE);
+        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, P);
+    }
+    HdrFrame f;
+    f.is_key = p->is_key ? 1 : 0;
+    f.is_golden = p->is_golden ? 1 : 0;
+    f.is_altref = p->is_altref ? 1 : 0;
+    f.loop_filter_type = p->loop_filter_type;
+    f.sharpness = p->loop_filter_sharpness;
+    f.partitions_log2 = P == 8 ? 3 : (P == 4 ? 2 : (P == 2 ? 1 : 0));
+    const bool intra_info = p->is_key || p->use_intra_info;
+    {   // encode_header (:84)
+        Timed t(c, VP8HIP_K_HDR_ENCODE);
+        launch_hdr_encode(s, c->out, (!p->is_key && p->use_intra_info) ? c->intra_is_inter : nullptr, intra_info ? c->intra_modes : nullptr, f,
+                          c->d_sd, reinterpret_cast<const int32_t *>(c->d_stats + 4), c->ent_probs, c->ent_denom0, c->hdr, c->hdr_partial,
+                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh);
+    }
+    HIPCHK(c, hipGetLastError());
+    EntPlan pc, ph;
+    HIPCHK(c, hipMemcpyAsync(&pc, c->ent.plan, sizeof(pc), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&ph, c->hdr.plan, sizeof(ph), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (pc.overflow || ph.overflow) return VP8HIP_ERR_OVERFLOW;
+    // gather_frame (encIO.h:1-30): first partition, sizes of all coefficient partitions but the last, the partitions
+    const size_t head = p->is_key ? 10 : 3;
+    size_t need = head + ph.nbytes[0] + 3 * (size_t)(P - 1);
+    for (int q = 0; q < P; ++q) need += pc.nbytes[q];
+    if (need > capacity) return VP8HIP_ERR_OVERFLOW;
+    size_t n = head;
+    HIPCHK(c, hipMemcpyAsync(out + n, c->hdr.bytes, ph.nbytes[0], hipMemcpyDeviceToHost, s));
+    n += ph.nbytes[0];
+    for (int q = 0; q < P - 1; ++q) {
+        out[n++] = (uint8_t)pc.nbytes[q];
+        out[n++] = (uint8_t)(pc.nbytes[q] >> 8);
+        out[n++] = (uint8_t)(pc.nbytes[q] >> 16);
+    }
+    for (int q = 0; q < P; ++q) {
+        HIPCHK(c, hipMemcpyAsync(out + n, c->ent.bytes + (size_t)pc.word_base[q] * 4, pc.nbytes[q], hipMemcpyDeviceToHost, s));
+        n += pc.nbytes[q];
+    }
+    const uint32_t tag = (p->is_key ? 0u : 1u) | 0x10u | (ph.nbytes[0] << 5);
+    out[0] = (uint8_t)tag;
+    out[1] = (uint8_t)(tag >> 8);
+    out[2] = (uint8_t)(tag >> 16);
+    if (p->is_key) {
+        const int w = p->width > 0 ? p->width : c->W, h = p->height > 0 ? p->height : c->H;
+        out[3] = 0x9d; out[4] = 0x01; out[5] = 0x2a;
+        out[6] = (uint8_t)w; out[7] = (uint8_t)(w >> 8);
+        out[8] = (uint8_t)h; out[9] = (uint8_t)(h >> 8);
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    *size = n;
     return VP8HIP_OK;
 }
 
