@@ -524,10 +524,92 @@ __global__ __launch_bounds__(64) void k_ent_finish(const unsigned long long *acc
     if (lane == 0) sizes[p] = (int32_t)nb;
 }
 
+// the accumulators the plan actually uses (a memset of the whole scratch would write tens of MB per frame)
+__global__ __launch_bounds__(256) void k_zero_acc(const Plan *plan, int P, unsigned long long *acc) {
+    const uint32_t n = plan->word_base[P];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc[i] = 0ull;
+}
+
+// exclusive scan of up to 64 k values by one workgroup (the macroblock-header counts): one launch instead of three
+__global__ __launch_bounds__(1024) void k_scan_small(uint32_t *v, int n) {
+    __shared__ uint32_t s[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024, i0 = t * per;
+    uint32_t a = 0;
+    for (int j = 0; j < per; ++j) a += i0 + j < n ? v[i0 + j] : 0u;
+    s[t] = a;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t add = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = s[t] - a;
+    for (int j = 0; j < per; ++j) {
+        if (i0 + j >= n) break;
+        const uint32_t x = v[i0 + j];
+        v[i0 + j] = run;
+        run += x;
+    }
+    if (t == 1023) v[n] = s[1023];
+}
+
+// gather_frame (src/encIO.h:1-30) on the device: first partition, the 3-byte sizes of all coefficient partitions but
+// the last, the partitions -- contiguous behind a 16-byte slot whose first word receives the frame size (0 = one of
+// the two coders overflowed its scratch).  `head` bytes (the uncompressed chunk) are left for the host to fill in.
+__global__ __launch_bounds__(256) void k_frame_gather(const Plan *pc, const Plan *ph, const uint8_t *hdr_bytes, const uint8_t *ent_bytes, int P,
+                                                      uint32_t head, uint32_t capacity, uint8_t *out) {
+    __shared__ uint32_t s_off[ENT_MAX_PARTITIONS + 3];   // start of: first partition, size table, partitions 0..P-1; [P+2] = end
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        uint32_t o = head;
+        s_off[0] = o;
+        o += ph->nbytes[0];
+        s_off[1] = o;
+        o += 3u * (uint32_t)(P - 1);
+        for (int q = 0; q < P; ++q) {
+            s_off[2 + q] = o;
+            o += pc->nbytes[q];
+        }
+        s_off[2 + P] = o;
+        s_ok = !(pc->overflow || ph->overflow || o > capacity);
+        if (blockIdx.x == 0) {
+            reinterpret_cast<uint32_t *>(out)[0] = s_ok ? o : 0u;
+            reinterpret_cast<uint32_t *>(out)[1] = ph->nbytes[0];
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    uint8_t *frame = out + 16;
+    const uint32_t total = s_off[2 + P];
+    for (uint32_t i = head + blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint8_t b;
+        if (i < s_off[1]) {
+            b = hdr_bytes[i - s_off[0]];
+        } else if (i < s_off[2]) {
+            const uint32_t k = i - s_off[1];
+            b = (uint8_t)(pc->nbytes[k / 3] >> (8 * (k % 3)));
+        } else {
+            int q = 0;
+            while (q + 1 < P && i >= s_off[3 + q]) ++q;
+            b = ent_bytes[(size_t)pc->word_base[q] * 4 + (i - s_off[2 + q])];
+        }
+        frame[i] = b;
+    }
+}
+
 }  // namespace ent
+
+void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out) {
+    hipLaunchKernelGGL(ent::k_frame_gather, dim3(128), dim3(256), 0, s, coef.plan, hdr.plan, hdr.bytes, coef.bytes, P, head, capacity, out);
+}
 
 // exclusive prefix sum of v[0..n) in place, total in v[n]; n <= 1024 * 1024
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n) {
+    if (n <= 65536) {
+        hipLaunchKernelGGL(ent::k_scan_small, dim3(1), dim3(1024), 0, s, v, n);
+        return;
+    }
     const int ntiles = (n + ent::SCAN_TILE - 1) / ent::SCAN_TILE;
     hipLaunchKernelGGL(ent::k_scan_tiles, dim3(ntiles), dim3(256), 0, s, v, tile_sum, n);
     hipLaunchKernelGGL(ent::k_scan_top, dim3(1), dim3(1024), 0, s, tile_sum, ntiles);
@@ -537,7 +619,7 @@ void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n
 // the boolean coder proper on bool strings that are laid out as eb.plan says (steps 2-5 above): P partitions
 void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
     EntPlan *plan = eb.plan;
-    (void)hipMemsetAsync(eb.acc, 0, (size_t)eb.cap_words * 8, s);
+    hipLaunchKernelGGL(ent::k_zero_acc, dim3(64), dim3(256), 0, s, plan, P, reinterpret_cast<unsigned long long *>(eb.acc));
     hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
     hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
     hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,

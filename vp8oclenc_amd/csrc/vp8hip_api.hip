@@ -66,6 +66,9 @@ struct vp8hip_ctx {
     EntBuffers hdr{};
     uint32_t *hdr_partial = nullptr, *hdr_info = nullptr;
     uint8_t *hdr_sym = nullptr;
+    uint8_t *h_frame = nullptr;     // pinned staging of vp8hip_encode_frame's read-back (pageable targets serialise inside the runtime)
+    uint8_t *d_frame = nullptr;     // the frame as gathered on the device: [0] size, [1] first-partition size, bytes from +16
+    size_t h_frame_cap = 0;
 
     uint32_t prof_mask = 0;
     hipEvent_t ev[MAX_EVENTS];
@@ -312,6 +315,8 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->out.first_lf0);
     hipFree(c->d_sd);
     if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
+    if (c->h_frame) hipHostFree(c->h_frame);
+    hipFree(c->d_frame);
     hipFree(c->d_progress);
     hipFree(c->d_stats);
     hipFree(c->scratch);
@@ -813,29 +818,29 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
                           c->hdr_sym, c->hdr_info, c->mbw, c->mbh);
     }
     HIPCHK(c, hipGetLastError());
-    EntPlan pc, ph;
-    HIPCHK(c, hipMemcpyAsync(&pc, c->ent.plan, sizeof(pc), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&ph, c->hdr.plan, sizeof(ph), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (pc.overflow || ph.overflow) return VP8HIP_ERR_OVERFLOW;
-    // gather_frame (encIO.h:1-30): first partition, sizes of all coefficient partitions but the last, the partitions
+    // gather_frame (encIO.h:1-30) on the device, then ONE read-back through pinned memory: the frame size and the
+    // first FIRST_COPY bytes travel together; only a frame larger than that needs a second copy.
+    if (!c->h_frame) {
+        c->h_frame_cap = (size_t)c->hdr.cap_words * 4 + (size_t)c->ent.cap_words * 4 + 64;
+        HIPCHK(c, hipHostMalloc(&c->h_frame, c->h_frame_cap));
+        HIPCHK(c, hipMalloc(&c->d_frame, c->h_frame_cap));
+    }
     const size_t head = p->is_key ? 10 : 3;
-    size_t need = head + ph.nbytes[0] + 3 * (size_t)(P - 1);
-    for (int q = 0; q < P; ++q) need += pc.nbytes[q];
-    if (need > capacity) return VP8HIP_ERR_OVERFLOW;
-    size_t n = head;
-    HIPCHK(c, hipMemcpyAsync(out + n, c->hdr.bytes, ph.nbytes[0], hipMemcpyDeviceToHost, s));
-    n += ph.nbytes[0];
-    for (int q = 0; q < P - 1; ++q) {
-        out[n++] = (uint8_t)pc.nbytes[q];
-        out[n++] = (uint8_t)(pc.nbytes[q] >> 8);
-        out[n++] = (uint8_t)(pc.nbytes[q] >> 16);
+    constexpr size_t FIRST_COPY = 192 * 1024;
+    launch_frame_gather(s, c->ent, c->hdr, P, (uint32_t)head, (uint32_t)(c->h_frame_cap - 16), c->d_frame);
+    HIPCHK(c, hipGetLastError());
+    const size_t first = c->h_frame_cap < FIRST_COPY ? c->h_frame_cap : FIRST_COPY;
+    HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const size_t n = *reinterpret_cast<const uint32_t *>(c->h_frame);
+    if (n == 0 || n > capacity) return VP8HIP_ERR_OVERFLOW;
+    if (16 + n > first) {
+        HIPCHK(c, hipMemcpyAsync(c->h_frame + first, c->d_frame + first, 16 + n - first, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
     }
-    for (int q = 0; q < P; ++q) {
-        HIPCHK(c, hipMemcpyAsync(out + n, c->ent.bytes + (size_t)pc.word_base[q] * 4, pc.nbytes[q], hipMemcpyDeviceToHost, s));
-        n += pc.nbytes[q];
-    }
-    const uint32_t tag = (p->is_key ? 0u : 1u) | 0x10u | (ph.nbytes[0] << 5);
+    memcpy(out + head, c->h_frame + 16 + head, n - head);
+    const uint32_t first_part = reinterpret_cast<const uint32_t *>(c->h_frame)[1];   // size of the first partition, for the frame tag
+    const uint32_t tag = (p->is_key ? 0u : 1u) | 0x10u | (first_part << 5);
     out[0] = (uint8_t)tag;
     out[1] = (uint8_t)(tag >> 8);
     out[2] = (uint8_t)(tag >> 16);
@@ -845,7 +850,6 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
         out[6] = (uint8_t)w; out[7] = (uint8_t)(w >> 8);
         out[8] = (uint8_t)h; out[9] = (uint8_t)(h >> 8);
     }
-    HIPCHK(c, hipStreamSynchronize(s));
     *size = n;
     return VP8HIP_OK;
 }

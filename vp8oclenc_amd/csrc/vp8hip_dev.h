@@ -99,6 +99,8 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
 
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n);   // in place, total in v[n]
 void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P);                    // the coder on bool strings laid out per eb.plan
+// gather_frame on the device: out[0] = frame size (0 = overflow), out[1] = first-partition size, frame bytes from out + 16
+void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out);
 
 // first partition on the device (kernels_hdr.hip): encode_header, src/entropy_host.cpp:709-1256
 struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* < 0: the device's */, partitions_log2; };
