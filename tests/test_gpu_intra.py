@@ -192,3 +192,29 @@ def test_key_frame_then_inter_frames_follow_the_reference_flow():
     orc.close()
     for kk in ("MB_parts", "MB_vectors", "MB_coeffs", "MB_segment_id", "prefilter_Y", "prefilter_U", "prefilter_V"):
         assert np.array_equal(got[kk], exp[kk]), kk
+
+
+def test_intra_wavefront_waits_are_bounded():
+    """Row 0 of the key-frame wavefront never publishes (test hook): every other row runs into its bounded wait, the
+    launch ends by itself, the next synchronising call reports VP8HIP_ERR_TIMEOUT once, and the context then codes the
+    same key frame correctly."""
+    import time
+    W, H = 128, 96
+    cur, sd = key_case(W, H, 3, 10)
+    enc = api.Vp8Hip(W, H)
+    enc.upload_current(*cur)
+    enc.set_segments(sd)
+    assert enc.lib.vp8hip_debug_lf_stall(enc.h, 1) == 0
+    t0 = time.perf_counter()
+    enc.intra_transform()
+    rc = enc.lib.vp8hip_synchronize(enc.h)
+    dt = time.perf_counter() - t0
+    assert rc == -6, rc
+    assert dt < 60, f"time-out took {dt:.1f} s"
+    assert enc.lib.vp8hip_synchronize(enc.h) == 0
+    assert enc.lib.vp8hip_debug_lf_stall(enc.h, 0) == 0
+    enc.intra_transform()
+    r = enc.download_results(recon=True)
+    exp = oracle_intra().intra_transform(cur, sd)
+    assert np.array_equal(r["prefilter_Y"], exp["recon_Y"]) and np.array_equal(r["MB_coeffs"][:, :24], exp["MB_coeffs"][:, :24])
+    enc.close()

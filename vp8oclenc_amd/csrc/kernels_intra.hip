@@ -324,6 +324,7 @@ struct IntraArgs {
     float target;
     int key;                // 1: key frame (every macroblock, segment 0); 0: fallback of an inter frame
     int mbw, mbh;
+    int stall_test;         // test hook: row 0 never publishes, so every other row must run into its bounded wait
 };
 
 __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
     const int lane = threadIdx.x, r = blockIdx.x, mbw = a.mbw;
     const LaneK k = lane_consts(lane);
     int32_t *err = a.err;
+    if (a.stall_test && r == 0) return;
     const int mb_row0 = r * mbw;
     if (!a.key) {   // frame loop + check_SSIM defaults: every macroblock inter, no modes (vp8enc.cpp:437-438)
         for (int i = lane; i < mbw; i += 64) a.is_inter[mb_row0 + i] = 1;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int
 }  // namespace
 
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh) {
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test) {
     IntraArgs a;
     a.cy = cur.Y[0]; a.cu = cur.U; a.cv = cur.V;
     a.ry = recon.Y[0]; a.ru = recon.U; a.rv = recon.V;
@@ -513,6 +515,7 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.key = key;
     a.mbw = mbw;
     a.mbh = mbh;
+    a.stall_test = stall_test;
     (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
     hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
 }

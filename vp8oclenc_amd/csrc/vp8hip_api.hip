@@ -53,7 +53,7 @@ struct vp8hip_ctx {
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
-    int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters time out
+    int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters / intra wavefronts time out
     void *scratch = nullptr;        // device staging for debug pyramid downloads
     // coefficient entropy stage: per-block flags and third contexts, token counts per partition, probabilities
     uint8_t *ent_flags = nullptr, *ent_third = nullptr;
@@ -576,7 +576,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
-                     c->d_progress + LF_ERR_WORD, 0.0f, 1, c->mbw, c->mbh);
+                     c->d_progress + LF_ERR_WORD, 0.0f, 1, c->mbw, c->mbh, c->lf_stall_test);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
@@ -590,7 +590,7 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
-                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh);
+                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh, c->lf_stall_test);
     }
     launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->d_progress + LF_ERR_WORD, c->intra_stats);
     HIPCHK(c, hipGetLastError());

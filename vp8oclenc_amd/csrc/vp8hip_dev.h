@@ -113,7 +113,7 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh);
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0);
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out);   // out[3] = *err
 
 // ---- device helpers ---------------------------------------------------------------------------
