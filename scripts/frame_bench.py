@@ -17,7 +17,10 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--partitions", type=int, default=8)
 ap.add_argument("--check-ssim", type=int, default=0)
+ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (0 = Python's default 5 ms)")
 a = ap.parse_args()
+if a.switch_interval > 0:
+    sys.setswitchinterval(a.switch_interval)
 seq = SynthSequence(a.width, a.height, seed=1)
 W, H = seq.W, seq.H
 mbs = (W // 16) * (H // 16)
