@@ -246,7 +246,7 @@ class NativeDriver:
         return rc == 1
 
     def encode_frame_device(self, d_y: int, d_u: int, d_v: int, force_key: bool = False) -> bool:
-        """True if the frame was handed to the key-frame stand-in, False for an inter frame."""
+        """True if the frame was coded as a key frame (vp8hip_intra_transform), False for an inter frame."""
         return self._ret(self.lib.vp8drv_encode_frame_device(self.h, d_y, d_u, d_v, int(force_key)))
 
     def encode_frame_host(self, y, u, v, force_key: bool = False) -> bool:
