@@ -156,8 +156,9 @@ int vp8hip_count_probs(vp8hip_ctx *ctx, int num_partitions, uint32_t *new_probs,
  * device, and returns partition p at partitions + p * partition_step with its length in partition_sizes[p].
  * coeff_probs[4][8][3][11] (low byte used) = new_probs after the host's default-probability fallback.
  * Must follow vp8hip_count_probs for the same coefficients and num_partitions (it reuses the block contexts).
- * VP8HIP_ERR_OVERFLOW if a partition does not fit partition_step or the frame exceeds the device scratch
- * (64 bools per 4x4 block on average, of at most 304; nothing is written then). */
+ * VP8HIP_ERR_OVERFLOW if a partition does not fit partition_step (nothing is written then).  The device scratch
+ * starts at 64 bools per 4x4 block on average and is doubled -- the frame is then coded again -- up to the 304 a
+ * block can produce at most, so no frame is refused for the device's sake. */
 int vp8hip_encode_coefficients(vp8hip_ctx *ctx, const uint32_t *coeff_probs, int num_partitions, int partition_step,
                                uint8_t *partitions, int32_t *partition_sizes);
 

@@ -100,7 +100,7 @@ def test_count_probs_after_inter_transform():
     hip.close()
 
 
-def test_encode_needs_count_first_and_reports_overflow():
+def test_encode_needs_count_first_grows_its_scratch_and_reports_overflow():
     mbw, mbh = 6, 4
     rng = np.random.default_rng(3)
     coeffs = (rng.integers(67, 2049, size=(mbw * mbh, 25, 16)) * rng.choice([-1, 1], size=(mbw * mbh, 25, 16))).astype(np.int16)
@@ -109,9 +109,16 @@ def test_encode_needs_count_first_and_reports_overflow():
     probs = np.full(1056, 128, np.uint32)
     with pytest.raises(api.Vp8HipError, match="out of order"):
         hip.encode_coefficients(probs, 2)                   # block contexts not computed yet
-    probs, _ = hip.count_probs(2)
-    with pytest.raises(api.Vp8HipError, match="do not fit"):
-        hip.encode_coefficients(probs, 2)                   # 19 bools per coefficient: beyond the device scratch
+    # 19 bools per coefficient, 304 per block: far beyond what the device scratch is sized for at first (64 per block);
+    # the stage enlarges it and codes the frame again -- byte-exact like any other frame
+    big = mbw * mbh * 25 * 400
+    dense = run_stage(Oracle.stages(), coeffs, parts, nz, mbw, mbh, 2, step=big)
+    probs, denom0 = hip.count_probs(2)
+    assert np.array_equal(probs, dense["probs"])
+    got = hip.encode_coefficients(probs, 2, partition_step=big)
+    for p in range(2):
+        assert np.array_equal(got[p], dense["partitions"][p]), f"dense frame, partition {p}"
+    assert sum(len(x) for x in got) > 20000      # ~180 k bools, three times the initial scratch
     with pytest.raises(api.Vp8HipError, match="out of order"):
         hip.encode_coefficients(probs, 4)                   # other partition count than the statistics
     # a frame that fits is fine on the same context afterwards

@@ -60,6 +60,7 @@ struct vp8hip_ctx {
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
+    int ent_bools_per_block = 64;   // what that scratch is sized for; doubled (up to 304, the maximum) when a frame needs more
     // host intra path on the device: sub-block modes, replaced flags, row progress, {replaced, new_SSIM, min SSIM}
     int32_t *intra_modes = nullptr, *intra_is_inter = nullptr, *intra_prog = nullptr, *intra_stats = nullptr;
     // first partition on the device: its own coder scratch, per-workgroup statistics, probability table, {H, skip_prob, replaced}
@@ -669,11 +670,22 @@ int vp8hip_count_probs(vp8hip_ctx *c, int num_partitions, uint32_t *new_probs, u
 
 // scratch of the boolean coder, allocated the first time the stage is used (a context that only runs the
 // inter path never pays for it): 64 bools per 4x4 block on average (of at most 304)
+static void ent_free(vp8hip_ctx *c) {
+    EntBuffers &e = c->ent;
+    hipFree(e.offs); hipFree(e.tile_sum); hipFree(e.bools); hipFree(e.maps); hipFree(e.start); hipFree(e.acc); hipFree(e.bytes);
+    hipFree(e.sizes); hipFree(e.plan);
+    e = EntBuffers{};
+    if (c->h_frame) hipHostFree(c->h_frame);   // sized from the scratch: reallocated with it
+    hipFree(c->d_frame);
+    c->h_frame = nullptr;
+    c->d_frame = nullptr;
+}
+
 static int ent_alloc(vp8hip_ctx *c) {
     if (c->ent.bools) return VP8HIP_OK;
     EntBuffers &e = c->ent;
     const size_t nslots = (size_t)c->mbs * 25;
-    e.cap_bools = (uint32_t)(nslots * 64);
+    e.cap_bools = (uint32_t)(nslots * (size_t)c->ent_bools_per_block);
     e.cap_chunks = e.cap_bools / 256 + 2 * ENT_MAX_PARTITIONS;
     e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 8 * ENT_MAX_PARTITIONS);
     HIPCHK(c, hipMalloc(&e.offs, (nslots + 1) * 4));
@@ -688,6 +700,16 @@ static int ent_alloc(vp8hip_ctx *c) {
     return VP8HIP_OK;
 }
 
+// A frame denser than the scratch was sized for (64 bools per 4x4 block to begin with): double it, up to the 304 bools a
+// block can produce at most, so that no frame is ever refused for the device's sake.  false = already at the maximum.
+static bool ent_grow(vp8hip_ctx *c) {
+    if (c->ent_bools_per_block >= 304) return false;
+    hipStreamSynchronize(c->stream);
+    ent_free(c);
+    c->ent_bools_per_block = c->ent_bools_per_block * 2 > 304 ? 304 : c->ent_bools_per_block * 2;
+    return ent_alloc(c) == VP8HIP_OK;
+}
+
 int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int num_partitions, int partition_step,
                                uint8_t *partitions, int32_t *partition_sizes) {
     if (!c || !coeff_probs || !partitions || !partition_sizes || partition_step < 4) return VP8HIP_ERR_ARG;
@@ -698,15 +720,18 @@ int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int n
     if (rc) return rc;
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->ent_probs, coeff_probs, sizeof(uint32_t) * ENT_NCTX, hipMemcpyHostToDevice, s));
-    {
-        Timed t(c, VP8HIP_K_ENT_ENCODE);
-        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, num_partitions);
-    }
-    HIPCHK(c, hipGetLastError());
     EntPlan plan;
-    HIPCHK(c, hipMemcpyAsync(&plan, c->ent.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (plan.overflow) return VP8HIP_ERR_OVERFLOW;
+    for (;;) {
+        {
+            Timed t(c, VP8HIP_K_ENT_ENCODE);
+            launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, num_partitions);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&plan, c->ent.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!plan.overflow) break;
+        if (!ent_grow(c)) return VP8HIP_ERR_OVERFLOW;   // denser than the scratch: enlarge it and code the frame again
+    }
     for (int p = 0; p < num_partitions; ++p)
         if (plan.nbytes[p] > (uint32_t)partition_step) return VP8HIP_ERR_OVERFLOW;
     for (int p = 0; p < num_partitions; ++p) {
@@ -833,7 +858,11 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
     HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const size_t n = *reinterpret_cast<const uint32_t *>(c->h_frame);
-    if (n == 0 || n > capacity) return VP8HIP_ERR_OVERFLOW;
+    if (n == 0) {   // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
+        if (ent_grow(c)) return vp8hip_encode_frame(c, num_partitions, p, out, capacity, size);
+        return VP8HIP_ERR_OVERFLOW;
+    }
+    if (n > capacity) return VP8HIP_ERR_OVERFLOW;
     if (16 + n > first) {
         HIPCHK(c, hipMemcpyAsync(c->h_frame + first, c->d_frame + first, 16 + n - first, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
