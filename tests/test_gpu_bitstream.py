@@ -150,3 +150,19 @@ def test_device_header_matches_reference_golden_vectors(path):
     flags = tuple(int(x) for x in z["flags"])
     dev = device_header(int(z["W"]), int(z["H"]), flags, z["sd"], c, sharpness=int(z["sharpness"]), partitions_log2=int(z["partitions_log2"]))
     assert np.array_equal(dev, z["header"]), np.nonzero(dev[:min(len(dev), len(z["header"]))] != z["header"][:min(len(dev), len(z["header"]))])[0][:8]
+
+
+def test_sharded_encoder_writes_the_reference_ivf(tmp_path):
+    """gop_shard (closed-GOP chunks, one encoder per chunk) with the native encoder on the GPU against the same chunks
+    on the CPU oracle: the two .ivf files are byte-identical."""
+    from test_gop_shard import FRAMES, GOP, OracleEncoder
+    from vp8oclenc_amd import gop_shard
+    W, H = 64, 48
+    seq = SynthSequence(W, H, seed=5)
+    chunks = gop_shard.gop_chunks(FRAMES, GOP)
+    dev = gop_shard.encode_chunks_frames(lambda: gop_shard.NativeEncoder(seq.W, seq.H, num_partitions=2, check_ssim=1), seq, chunks)
+    cpu = gop_shard.encode_chunks_frames(lambda: OracleEncoder(seq.W, seq.H), seq, chunks)
+    a, b = str(tmp_path / "dev.ivf"), str(tmp_path / "cpu.ivf")
+    gop_shard.write_ivf(a, gop_shard.gather_frames(dev, FRAMES), seq.W, seq.H)
+    gop_shard.write_ivf(b, gop_shard.gather_frames(cpu, FRAMES), seq.W, seq.H)
+    assert open(a, "rb").read() == open(b, "rb").read()

@@ -64,3 +64,72 @@ def gather_digests(local: dict[int, int], total_frames: int, dist=None) -> np.nd
     allv = torch.stack(bufs).numpy()
     assert ((allv >= 0).sum(axis=0) == 1).all(), "every frame must be encoded by exactly one rank"
     return allv.max(axis=0)
+
+
+# ---- the same with the bitstream: every rank codes its GOP chunks to complete VP8 frames, rank order is restored ----
+class NativeEncoder:
+    """One GOP chunk on one GPU through the native frame loop: encode(y, u, v) -> the frame's bytes."""
+
+    def __init__(self, width: int, height: int, device: int = 0, **cfg):
+        from . import api
+        cfg.setdefault("gop_size", 1 << 30)          # the chunk starts with its key frame; no other forced one inside
+        self.drv = api.NativeDriver(width, height, device=device, **cfg)
+
+    def encode(self, y, u, v) -> bytes:
+        self.drv.encode_frame_host(y, u, v)
+        return self.drv.get_frame()
+
+    def close(self):
+        self.drv.close()
+
+
+def encode_chunks_frames(make_encoder, sequence, chunks) -> dict[int, bytes]:
+    """{frame number: VP8 frame} of the given GOP chunks; make_encoder() -> object with encode(y, u, v) and close()."""
+    frames = {}
+    for start, length in chunks:
+        enc = make_encoder()
+        for t in range(start, start + length):
+            frames[t] = enc.encode(*sequence.frame(t))
+        enc.close()
+    return frames
+
+
+def gather_frames(local: dict[int, bytes], total_frames: int, dist=None) -> list[bytes]:
+    """Every rank's frames in frame order on every rank (lengths, then one padded byte matrix: two all_gathers)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert len(local) == total_frames
+        return [local[t] for t in range(total_frames)]
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    lens = torch.full((total_frames,), -1, dtype=torch.int64)
+    for t, b in local.items():
+        lens[t] = len(b)
+    lens = lens.to(dev)
+    all_lens = [torch.empty_like(lens) for _ in range(dist.get_world_size())]
+    dist.all_gather(all_lens, lens)
+    all_lens = torch.stack(all_lens).cpu()
+    assert ((all_lens >= 0).sum(dim=0) == 1).all(), "every frame must be encoded by exactly one rank"
+    width = int(all_lens.max())
+    mine = torch.zeros((total_frames, width), dtype=torch.uint8)
+    for t, b in local.items():
+        mine[t, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    mine = mine.to(dev)
+    bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, mine)
+    owner = all_lens.argmax(dim=0)
+    out = []
+    for t in range(total_frames):
+        r = int(owner[t])
+        out.append(bufs[r][t, :int(all_lens[r, t])].cpu().numpy().tobytes())
+    return out
+
+
+def write_ivf(path: str, frames: list[bytes], width: int, height: int, framerate: int = 30, timescale: int = 1) -> int:
+    """The reference's output file (encIO.h:32-139): 32-byte header, then a 12-byte header + the bytes of every frame."""
+    from . import bitstream
+    with open(path, "wb") as f:
+        f.write(bitstream.ivf_file_header(width, height, framerate, timescale, len(frames)))
+        for t, b in enumerate(frames):
+            f.write(bitstream.ivf_frame_header(len(b), t))
+            f.write(b)
+    return 32 + sum(12 + len(b) for b in frames)
