@@ -14,6 +14,8 @@
 //
 // In fallback mode a macroblock is touched only if its SSIM is below the target, and a row never waits for rows
 // above it unless it has such a macroblock: untouched macroblocks are final as the inter kernels left them.
+#include <stdlib.h>
+
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -121,14 +123,14 @@ __device__ __forceinline__ int quant1(int w, int sign_of, int h, uint32_t m) {  
 // residual -> DCT4x4 (:114-157) -> weight (:159-210) -> quant4x4 -> dequantise + iDCT4x4 (:42-111) -> reconstruction.
 // p = this lane's predictor row, sdw = its source row.  Returns the packed reconstructed row; qc[j] = quantised
 // coefficient 4*j + (lane & 3); weight = the reference's `weight` of the residual, identical in the four lanes.
-__device__ __forceinline__ uint32_t code_unit(Sh &sh, int lane, const int p[4], uint32_t sdw, const LaneQ &q, int qc[4], int &weight) {
+__device__ __forceinline__ uint32_t code_unit(int16_t *tr, int lane, const int p[4], uint32_t sdw, const LaneQ &q, int qc[4], int &weight) {
     const int d0 = byte_of(sdw, 0) - p[0], d1 = byte_of(sdw, 1) - p[1], d2 = byte_of(sdw, 2) - p[2], d3 = byte_of(sdw, 3) - p[3];
     const int s03 = d0 + d3, s12 = d1 + d2, m12 = d1 - d2, m03 = d0 - d3;
     const int o0 = (s03 + s12) * 8, o2 = (s03 - s12) * 8;
     const int o1 = (__mul24(m12, 17736) + __mul24(m03, 42816) + 14500) >> 12;   // c1 = m12 << 3, d1 = m03 << 3
     const int o3 = (__mul24(m03, 17736) - __mul24(m12, 42816) + 7500) >> 12;
-    int16_t *mine = sh.tr + lane * 4;
-    const int16_t *col = sh.tr + (lane & ~3) * 4 + (lane & 3);
+    int16_t *mine = tr + lane * 4;                          // tr: 64 x 4 shorts of this wavefront
+    const int16_t *col = tr + (lane & ~3) * 4 + (lane & 3);
     *reinterpret_cast<uint2 *>(mine) = make_uint2(pk16(o0, o1), pk16(o2, o3));
     lds_order();
     const int v0 = col[0], v1 = col[4], v2 = col[8], v3 = col[12];
@@ -224,7 +226,7 @@ __device__ __forceinline__ int luma_block(Sh &sh, int lane, const LaneK &k, cons
         p[j] = k.is_dc ? dc : (k.is_tm ? tm : g);
     }
     int qc[4], w;
-    const uint32_t rec = code_unit(sh, lane, p, sdw, q, qc, w);
+    const uint32_t rec = code_unit(sh.tr, lane, p, sdw, q, qc, w);
     // first strict minimum in mode order = minimum of (weight, mode)
     int key = k.active ? (w << 4) | k.mode : 0x7fffffff;
     key = imin(key, dpp<0x114>(0x7fffffff, key));
@@ -254,7 +256,7 @@ __device__ __forceinline__ void chroma_blocks(Sh &sh, int lane, const LaneK &k, 
     for (int j = 0; j < 4; ++j) p[j] = sat8(byte_of(tdw, j) + dl);
     const LaneQ q = lane_q(uv_dc, uv_ac, lane & 3);
     int qc[4], w;
-    const uint32_t rec = code_unit(sh, lane, p, sdw, q, qc, w);
+    const uint32_t rec = code_unit(sh.tr, lane, p, sdw, q, qc, w);
     if (lane < 32) {
         *reinterpret_cast<uint32_t *>(&sh.cimg[pl][(4 * br + i + 1) * CIMG_S + 4 + 4 * bc]) = rec;
         int16_t *cf = sh.coef + (16 + 4 * pl + bb) * 16;
@@ -451,6 +453,236 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
     if (lane == 0) __hip_atomic_store(&a.prog[r], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Key frames, pipelined at 4x4-block granularity.  In k_intra one wavefront walks the 16 luma blocks of a macroblock
+// one after the other, so the frame's critical path is 16 * (mbw + 2 mbh) block steps.  A luma block only needs the
+// block to its left, the row of pixels above it and four pixels above-right -- so here a workgroup still owns one
+// macroblock row but splits it over five wavefronts: wave k (0..3) codes the k-th row of 4x4 blocks of EVERY
+// macroblock of the row, running two blocks behind wave k-1 (one where the above-right pixels come from the
+// macroblock row above, :630), and wave 4 codes the chroma blocks and publishes the row's progress.  The rows of
+// pixels the waves hand to each other live in LDS for the whole width (bot[k] = the pixel row above block row k), the
+// hand-off is a counter in LDS; only the macroblock row's last pixel row crosses to the next workgroup through HBM.
+// Critical path: 4 mbw + ~14 mbh block steps (1080p: 2.8 ms -> 1 ms).  A key frame commits every macroblock, which
+// is what makes this legal; check_SSIM's fallback decides per macroblock and stays on k_intra.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int K4_WAVES = 5;
+#define K4_WAIT(cond_unsatisfied, nap)                                                                  \
+    {                                                                                                   \
+        int spins_ = 0;                                                                                 \
+        while ((cond_unsatisfied) && !*abort_flag) {                                                    \
+            __builtin_amdgcn_s_sleep(nap);                                                              \
+            if (++spins_ > 8 * INTRA_SPIN_LIMIT) {   /* LDS polls are ~0.1 us: about a second */          \
+                *abort_flag = 1;                                                                        \
+                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+            }                                                                                           \
+        }                                                                                               \
+        if (*abort_flag) return;                                                                        \
+    }
+
+__global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x, mbw = a.mbw;
+    const int BW = mbw * 16 + 16;                      // bytes per pixel row: x = -4 .. W + 11 at byte x + 4
+    uint8_t *bot = smem;                               // [5][BW]  bot[k] = pixel row above block row k (bot[4]: the row's last)
+    uint8_t *lcol = bot + 5 * BW;                      // [4][4]   right column of each luma wave's previous block
+    uint8_t *E = lcol + 16;                            // [4][16]  edge array of the block in work
+    uint8_t *src = E + 64;                             // [4][2][64] source rows of the macroblock in work / the next one
+    int16_t *tr = reinterpret_cast<int16_t *>(src + 512);           // [5][256] transposes
+    uint8_t *cimg = reinterpret_cast<uint8_t *>(tr + K4_WAVES * 256);   // [2][9 * 16] chroma tiles as in k_intra
+    uint8_t *csrc = cimg + 2 * 9 * CIMG_S;             // [2][64]
+    int16_t *ccoef = reinterpret_cast<int16_t *>(csrc + 128);       // [8][16]
+    volatile int *done = reinterpret_cast<volatile int *>(ccoef + 128);   // [4] blocks finished by each luma wave
+    volatile int *abort_flag = done + 4;
+    if (a.stall_test && r == 0) return;
+    for (int i = threadIdx.x; i < 5 * BW; i += 64 * K4_WAVES) {
+        const int k = i / BW, x = i % BW;
+        bot[i] = k == 0 ? 127 : (x < 4 ? 129 : 0);     // above the frame 127; left of it 129 (the corners of block rows 1..3)
+    }
+    if (threadIdx.x < 16) lcol[threadIdx.x] = 129;
+    if (threadIdx.x < 5) done[threadIdx.x] = 0;        // done[4] is the abort flag
+    __syncthreads();
+    const Steps st = steps_of(a.sd, 0);
+
+    if (wave < 4) {
+        // ---- luma block row `wave` ---------------------------------------------------------------------------------
+        LaneK k = lane_consts(lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // taps as indices into the edge array instead of tile offsets
+            int ea = 5, eb = 5, ec = 5;
+            if (k.mode == 0) ea = 1 + j;
+            else if (k.mode == 1) { ea = 4 - k.row; eb = 5; }
+            else if (k.mode < 10) {
+                const int e = k_bpred[k.mode - 2][4 * k.row + j], kind = e >> 4, kk = e & 15;
+                ea = kind == 0 ? kk - 1 : kk;
+                eb = kind == 1 ? kk + 1 : kk;
+                ec = kind == 0 ? kk + 1 : kk;
+            }
+            k.a[j] = ea; k.b[j] = eb; k.c[j] = ec;
+        }
+        const LaneQ ql = lane_q(st.y_dc, st.y_ac, lane & 3);
+        uint8_t *myE = E + 16 * wave, *mytop = bot + wave * BW, *mybot = bot + (wave + 1) * BW, *mycol = lcol + 4 * wave;
+        uint8_t *mysrc = src + 128 * wave;
+        int16_t *mytr = tr + 256 * wave;
+        const int y0 = 16 * r + 4 * wave;
+        // lane l < 16 fetches source row l >> 2, dword l & 3 of a macroblock
+        auto fetch = [&](int c) -> uint32_t {
+            return *reinterpret_cast<const uint32_t *>(a.cy.p + (ptrdiff_t)(y0 + ((lane & 15) >> 2)) * a.cy.stride + 16 * c + 4 * (lane & 3));
+        };
+        uint32_t nxt = fetch(0);
+        if (lane < 16) *reinterpret_cast<uint32_t *>(mysrc + 4 * lane) = nxt;
+        for (int c = 0; c < mbw; ++c) {
+            if (c + 1 < mbw) nxt = fetch(c + 1);        // in flight while this macroblock is coded
+            const uint8_t *s_mb = mysrc + 64 * (c & 1);
+            if (wave == 0 && r > 0) {
+                // the pixel row above this macroblock row, x = 16c - 4 .. 16c + 19, once the row above has finished c + 1
+                const int need = imin(c + 2, mbw);
+                K4_WAIT(__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need, 2)
+                if (lane < 6) {
+                    const bool ar_last = lane == 5 && c == mbw - 1;   // no macroblock above-right: repeat top[15] (:596-601)
+                    uint32_t v = ld_agent(a.ry.p + (ptrdiff_t)(16 * r - 1) * a.ry.stride + 16 * c - 4 + 4 * (ar_last ? 4 : lane));
+                    if (ar_last) v = (v >> 24) * 0x01010101u;
+                    if (c == 0 && lane == 0) v = 0x81818181u;         // top-left of the first macroblock: 129 (:540-551)
+                    *reinterpret_cast<uint32_t *>(bot + 16 * c + 4 * lane) = v;
+                }
+                lds_order();
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * c + q;
+                if (wave > 0) {
+                    const int need = imin(q == 3 ? j + 1 : j + 2, 4 * mbw);
+                    K4_WAIT(done[wave - 1] < need, 1)
+                }
+                // edge array { L3, L3, L2, L1, L0, TL, T0 .. T7, T7 }: T4..T7 of a macroblock's last column come from the
+                // row above the macroblock (bot[0]), like top_pred_Y[16..19] in the reference
+                if (lane < 15) {
+                    int v;
+                    if (lane < 5) v = mycol[lane < 2 ? 3 : 4 - lane];
+                    else {
+                        const int t = lane == 14 ? 8 : lane - 5;          // 0 = TL, 1..8 = T0..T7
+                        const uint8_t *row = (q == 3 && t >= 5) ? bot : mytop;
+                        v = row[4 * j + 3 + t];
+                    }
+                    myE[lane] = (uint8_t)v;
+                }
+                lds_order();
+                int A[4], Bt[4], C[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    A[t] = myE[k.a[t]];
+                    Bt[t] = myE[k.b[t]];
+                    C[t] = myE[k.c[t]];
+                }
+                const uint32_t tdw = *reinterpret_cast<const uint32_t *>(mytop + 4 * j + 4);
+                const uint32_t sdw = *reinterpret_cast<const uint32_t *>(s_mb + 16 * k.row + 4 * q);
+                const int dc = (int)(__builtin_amdgcn_sad_u8(tdw, 0u, (uint32_t)(A[0] + A[1] + A[2] + A[3])) + 4u) >> 3;
+                const int tm_d = A[0] - Bt[0];
+                int p[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int g = (A[t] + 2 * Bt[t] + C[t] + 2) >> 2;
+                    const int tm = sat8(byte_of(tdw, t) + tm_d);
+                    p[t] = k.is_dc ? dc : (k.is_tm ? tm : g);
+                }
+                int qc[4], w;
+                const uint32_t rec = code_unit(mytr, lane, p, sdw, ql, qc, w);
+                int key = k.active ? (w << 4) | k.mode : 0x7fffffff;
+                key = imin(key, dpp<0x114>(0x7fffffff, key));
+                key = imin(key, dpp<0x118>(0x7fffffff, key));
+                key = imin(key, dpp<0x142, 0xa>(0x7fffffff, key));
+                key = imin(key, dpp<0x143, 0xc>(0x7fffffff, key));
+                const int best = __builtin_amdgcn_readlane(key, 63) & 15;
+                const int mb = r * mbw + c, blk = 4 * wave + q;
+                if (k.mode == best) {
+                    *reinterpret_cast<uint32_t *>(a.ry.p + (ptrdiff_t)(y0 + k.row) * a.ry.stride + 4 * j) = rec;
+                    if (k.row == 3) *reinterpret_cast<uint32_t *>(mybot + 4 * j + 4) = rec;
+                    mycol[k.row] = (uint8_t)(rec >> 24);
+                    int16_t *cf = a.o.coeffs + ((size_t)mb * 25 + blk) * 16;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cf[k.zz[t]] = (int16_t)qc[t];
+                }
+                if (lane == 0) a.modes[(size_t)mb * 16 + blk] = best;
+                lds_order();
+                if (lane == 0) done[wave] = j + 1;
+            }
+            if (c + 1 < mbw && lane < 16) *reinterpret_cast<uint32_t *>(mysrc + 64 * ((c + 1) & 1) + 4 * lane) = nxt;
+            lds_order();
+        }
+        return;
+    }
+
+    // ---- wave 4: chroma (TM_PRED, 8 blocks at once) and the row's progress ---------------------------------------------
+    const LaneK k = lane_consts(lane);
+    const LaneQ qc_l = lane_q(st.uv_dc, st.uv_ac, lane & 3);
+    int16_t *mytr = tr + 256 * 4;
+    for (int c = 0; c < mbw; ++c) {
+        const int mb = r * mbw + c;
+        if (lane < 32) {
+            const Plane &P = lane < 16 ? a.cu : a.cv;
+            const int l = lane & 15;
+            *reinterpret_cast<uint32_t *>(csrc + 64 * (lane >> 4) + 4 * l) =
+                *reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1));
+        }
+        if (r > 0) K4_WAIT(__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c + 1, 2)
+        if (lane < 22) {
+            // lanes 0..2 / 3..5: the chroma row above (x = -4 .. 7); lanes 6..13 / 14..21: the column left (first macroblock: 129)
+            const bool top = lane < 6;
+            const int pl = top ? lane / 3 : (lane - 6) / 8, jj = top ? lane % 3 : (lane - 6) % 8;
+            const Plane &P = pl == 0 ? a.ru : a.rv;
+            uint32_t v;
+            if (top) {
+                v = r == 0 ? 0x7f7f7f7fu : ld_agent(P.p + (ptrdiff_t)(8 * r - 1) * P.stride + 8 * c - 4 + 4 * jj);
+                if (r > 0 && c == 0 && jj == 0) v = 0x81818181u;
+                *reinterpret_cast<uint32_t *>(cimg + pl * 9 * CIMG_S + 4 * jj) = v;
+            } else {
+                // left neighbours: the right column of this wave's previous macroblock, still in the tile
+                const uint8_t *t = cimg + pl * 9 * CIMG_S + (jj + 1) * CIMG_S;
+                const int px = c == 0 ? 129 : t[4 + 7];
+                cimg[pl * 9 * CIMG_S + (jj + 1) * CIMG_S + 3] = (uint8_t)px;
+            }
+        }
+        lds_order();
+        {
+            const int l = lane & 31, pl = l >> 4, bb = (l >> 2) & 3, br = bb >> 1, bc = bb & 1, i = l & 3;
+            const uint8_t *t = cimg + pl * 9 * CIMG_S;
+            const uint32_t tdw = *reinterpret_cast<const uint32_t *>(t + 4 + 4 * bc);
+            const int dl = (int)t[(4 * br + i + 1) * CIMG_S + 3] - (int)t[3];
+            const uint32_t sdw = *reinterpret_cast<const uint32_t *>(csrc + 64 * pl + (4 * br + i) * 8 + 4 * bc);
+            int p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = sat8(byte_of(tdw, j) + dl);
+            int qc[4], w;
+            const uint32_t rec = code_unit(mytr, lane, p, sdw, qc_l, qc, w);
+            lds_order();
+            if (lane < 32) {
+                *reinterpret_cast<uint32_t *>(cimg + pl * 9 * CIMG_S + (4 * br + i + 1) * CIMG_S + 4 + 4 * bc) = rec;
+                int16_t *cf = ccoef + (4 * pl + bb) * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cf[k.zz[j]] = (int16_t)qc[j];
+            }
+            lds_order();
+        }
+        if (lane < 32) {
+            const Plane &P = lane < 16 ? a.ru : a.rv;
+            const int l = lane & 15;
+            st_agent(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1),
+                     *reinterpret_cast<const uint32_t *>(cimg + (lane >> 4) * 9 * CIMG_S + ((l >> 1) + 1) * CIMG_S + 4 + 4 * (l & 1)));
+        }
+        reinterpret_cast<uint32_t *>(a.o.coeffs + ((size_t)mb * 25 + 16) * 16)[lane] = reinterpret_cast<const uint32_t *>(ccoef)[lane];   // blocks 16..23
+        if (lane == 0) {
+            a.o.parts[mb] = 2;   // are4x4
+            a.o.seg[mb] = 0;
+        }
+        // publish: the luma row below block row 3 goes to HBM at agent scope (wave 3's own stores are not waited for)
+        K4_WAIT(done[3] < 4 * c + 4, 1)
+        if (lane < 4)
+            st_agent(a.ry.p + (ptrdiff_t)(16 * r + 15) * a.ry.stride + 16 * c + 4 * lane, *reinterpret_cast<const uint32_t *>(bot + 4 * BW + 16 * c + 4 + 4 * lane));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&a.prog[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#undef K4_WAIT
+
 // what check_SSIM reports (src/vp8enc.cpp:237-258): replaced count, the raster-order float sum / count, the minimum
 // The sum must be the reference's: one float accumulator over the macroblocks in raster order.  The values are staged
 // in LDS by all threads, 8192 at a time, so that the one summing thread reads four per ds_read_b128 instead of
@@ -517,7 +749,13 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.mbh = mbh;
     a.stall_test = stall_test;
     (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
-    hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
+    static const bool legacy_key = getenv("VP8HIP_INTRA_KEY_MB") != nullptr;   // A/B switch: key frames on the per-macroblock wavefront
+    if (key && !legacy_key) {
+        const size_t shmem = 5 * (size_t)(mbw * 16 + 16) + 3856;
+        hipLaunchKernelGGL(k_intra_key4, dim3(mbh), dim3(64 * K4_WAVES), shmem, s, a);
+    } else {
+        hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
+    }
 }
 
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
