@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const 
 // num_div_denom (:764-778) + the denominators of partition 0 that the host inspects (vp8enc.cpp:69-76):
 // every partition's denominator starts at 1 (:552)
 // 16 contexts per workgroup, 16 lanes per context over the partial histograms
+// defaults (may be null): the format's default probabilities, taken for contexts that never occurred (vp8enc.cpp:69-76)
 __global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int mbh,
-                                                   int num_partitions) {
+                                                   int num_partitions, const uint8_t *defaults) {
     const int lane = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);   // NCTX is a multiple of 16
     uint32_t num = 0, den = 0, den0 = 0;
     for (int h = lane; h < mbh * CNT_SPLIT; h += 16) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint3
     if (lane == 0) {
         den += (uint32_t)num_partitions;   // every partition's denominator starts at 1 (:552)
         num = (num << 8) / den;
-        probs[i] = num > 255u ? 255u : (num == 0u ? 1u : num);
+        probs[i] = (defaults && den0 + 1u < 2u) ? (uint32_t)defaults[i] : (num > 255u ? 255u : (num == 0u ? 1u : num));
         denom0[i] = den0 + 1u;
     }
 }
@@ -165,12 +166,12 @@ __global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint3
 }  // namespace ent
 
 void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
-                      uint32_t *denom0, int mbw, int mbh, int num_partitions) {
+                      uint32_t *denom0, int mbw, int mbh, int num_partitions, const uint8_t *defaults) {
     const int nblocks = mbw * mbh * 25;
     hipLaunchKernelGGL(ent::k_ent_flags, dim3((nblocks + 255) / 256), dim3(256), 0, s, o.coeffs, flags, nblocks);
     hipLaunchKernelGGL(ent::k_ent_count, dim3(mbh, ent::CNT_SPLIT), dim3(256), 0, s, o.coeffs, o.nz, o.parts, flags, third_ctx,
                        counts, mbw);
-    hipLaunchKernelGGL(ent::k_ent_probs, dim3(ent::NCTX / 16), dim3(256), 0, s, counts, probs, denom0, mbh, num_partitions);
+    hipLaunchKernelGGL(ent::k_ent_probs, dim3(ent::NCTX / 16), dim3(256), 0, s, counts, probs, denom0, mbh, num_partitions, defaults);
 }
 
 // ====================================================================================================
@@ -362,8 +363,9 @@ __global__ void k_ent_plan(const uint32_t *offs, Geom g, Plan *plan) {
 
 __global__ __launch_bounds__(256) void k_ent_emit(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
                                                   const uint8_t *third_ctx, const uint32_t *probs, const uint32_t *offs,
-                                                  const Plan *plan, Geom g, uint16_t *bools) {
+                                                  const Plan *plan, Geom g, uint16_t *bools, unsigned long long *acc) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    for (uint32_t i = (uint32_t)t, n = plan->word_base[g.P]; i < n; i += gridDim.x * 256) acc[i] = 0ull;   // the coder's accumulators (was a launch of its own)
     if (t >= g.mbw * g.mbh * 25 || plan->overflow) return;
     const int mb = t / 25, k = t % 25, b = block_of_k(k);
     bool has_y2;
@@ -617,9 +619,9 @@ void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n
 }
 
 // the boolean coder proper on bool strings that are laid out as eb.plan says (steps 2-5 above): P partitions
-void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P, bool acc_zeroed) {
     EntPlan *plan = eb.plan;
-    hipLaunchKernelGGL(ent::k_zero_acc, dim3(64), dim3(256), 0, s, plan, P, reinterpret_cast<unsigned long long *>(eb.acc));
+    if (!acc_zeroed) hipLaunchKernelGGL(ent::k_zero_acc, dim3(64), dim3(256), 0, s, plan, P, reinterpret_cast<unsigned long long *>(eb.acc));
     hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
     hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
     hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,
@@ -648,8 +650,8 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
     launch_scan_exclusive(s, eb.offs, eb.tile_sum, nslots);
     hipLaunchKernelGGL(ent::k_ent_plan, dim3(1), dim3(64), 0, s, eb.offs, g, plan);
     hipLaunchKernelGGL(ent::k_ent_emit, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, third_ctx, probs,
-                       eb.offs, plan, g, eb.bools);
-    launch_bool_code(s, eb, P);
+                       eb.offs, plan, g, eb.bools, reinterpret_cast<unsigned long long *>(eb.acc));
+    launch_bool_code(s, eb, P, true);
 }
 
 }  // namespace vp8

@@ -8,8 +8,8 @@
 //                 host coder compiles) with a counting sink: bools per macroblock, the motion-vector statistics
 //                 behind mv_prob_update() and the frame's census (segments, references, skipped, replaced) as
 //                 per-workgroup partial sums -- no same-address HBM atomics;
-//   scan          exclusive prefix sum of the counts (the tile scan of kernels_ent.hip);
-//   k_hdr_frame   one workgroup folds the partials into the frame's probability table, writes the frame-level
+//   k_hdr_frame   one workgroup turns the counts into offsets (exclusive scan), folds the partials into the frame's
+//                 probability table, writes the frame-level
 //                 bools (the 1056 coefficient-probability updates in parallel, the rest by one lane) and the plan;
 //   k_hdr_emit    one thread per macroblock again, now emitting (probability, bit) pairs at its offset;
 // followed by the generic coder on that string.  Byte-exact against the host coder and the reference.
@@ -117,14 +117,36 @@ struct Lane {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// frame header (encode_header :735-1061).  One workgroup.  cnt_total = cnt[mbs] after the scan.
-__global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *partial, int nparts, const uint32_t *cnt_total, uint16_t *bools,
+// frame header (encode_header :735-1061).  One workgroup.  cnt: bools per macroblock in, their exclusive prefix sums out.
+__global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *partial, int nparts, uint32_t *cnt, uint16_t *bools,
                                                    uint8_t *sym_out, EntPlan *plan, uint32_t *info) {
     __shared__ uint32_t s_tot[NSTAT];
     __shared__ uint32_t s_scan[256];
-    __shared__ uint32_t s_n1;
+    __shared__ uint32_t s_n1, s_total;
     __shared__ uint8_t s_sym[64];
     const int t = threadIdx.x;
+    {   // exclusive scan of the per-macroblock bool counts, in place (at most 127 values per thread at 4K): the offsets
+        // k_hdr_emit writes at; done here rather than by the three-launch tile scan
+        const int per = (a.mbs + 255) / 256, i0 = t * per;
+        uint32_t acc = 0;
+        for (int j = 0; j < per; ++j) acc += i0 + j < a.mbs ? cnt[i0 + j] : 0u;
+        s_scan[t] = acc;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint32_t add = t >= d ? s_scan[t - d] : 0u;
+            __syncthreads();
+            s_scan[t] += add;
+            __syncthreads();
+        }
+        uint32_t run = s_scan[t] - acc;
+        for (int j = 0; j < per && i0 + j < a.mbs; ++j) {
+            const uint32_t x = cnt[i0 + j];
+            cnt[i0 + j] = run;
+            run += x;
+        }
+        if (t == 255) s_total = s_scan[255];
+        __syncthreads();
+    }
     for (int i = t; i < NSTAT; i += 256) s_tot[i] = 0;
     __syncthreads();
     for (int i = t; i < nparts * NSTAT; i += 256) atomicAdd(&s_tot[i % NSTAT], partial[i]);   // coalesced reads, LDS adds
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *par
                 w.literal(s_sym[SYM_MV + i] >> 1, 7);
             }
         }
-        const uint32_t H = s_n1 + n2 + w.n, total = H + *cnt_total;
+        const uint32_t H = s_n1 + n2 + w.n, total = H + s_total;
         const uint32_t chunks = (total + 255) / 256, words = (total * 7 + 31) / 32 + 4;
         const bool over = total > a.cap_bools || chunks > a.cap_chunks || words > a.cap_words;
         for (int p = 0; p <= ENT_MAX_PARTITIONS; ++p) plan->bool_base[p] = plan->chunk_base[p] = plan->word_base[p] = 0;
@@ -269,7 +291,8 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *par
 }
 
 __global__ __launch_bounds__(256) void k_hdr_emit(Params a, const uint32_t *offs, const uint8_t *sym, const EntPlan *plan, const uint32_t *info,
-                                                  uint16_t *bools) {
+                                                  uint16_t *bools, unsigned long long *acc) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x, n = plan->word_base[1]; i < n; i += gridDim.x * 256) acc[i] = 0ull;   // the coder's accumulators
     __shared__ uint8_t s_sym[64];
     if (threadIdx.x < 64) s_sym[threadIdx.x] = sym[threadIdx.x];
     __syncthreads();
@@ -286,6 +309,15 @@ __global__ __launch_bounds__(256) void k_default_probs(uint32_t *probs, const ui
 }
 
 }  // namespace hdr
+
+const uint8_t *hdr_default_coeff_probs() {
+    static const uint8_t *p = nullptr;
+    if (!p) {
+        void *q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(hdr::k_default_coeff_probs)) == hipSuccess) p = static_cast<const uint8_t *>(q);
+    }
+    return p;
+}
 
 void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0) {
     hipLaunchKernelGGL(hdr::k_default_probs, dim3((ENT_NCTX + 255) / 256), dim3(256), 0, s, probs, denom0);
@@ -314,10 +346,10 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
     a.cap_words = eb.cap_words;
     const int nwg = (a.mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
     hipLaunchKernelGGL(hdr::k_hdr_count, dim3(nwg), dim3(256), 0, s, a, eb.offs, partial);
-    launch_scan_exclusive(s, eb.offs, eb.tile_sum, a.mbs);
-    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs + a.mbs, eb.bools, sym, eb.plan, info);
-    hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools);
-    launch_bool_code(s, eb, 1);
+    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs, eb.bools, sym, eb.plan, info);
+    hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
+                       reinterpret_cast<unsigned long long *>(eb.acc));
+    launch_bool_code(s, eb, 1, true);
 }
 
 }  // namespace vp8

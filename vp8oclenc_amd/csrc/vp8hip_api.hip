@@ -820,8 +820,9 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
     hipStream_t s = c->stream;
     {   // count_probs + num_div_denom, the default-probability fallback (vp8enc.cpp:58-76), encode_coefficients (:77-81)
         Timed t(c, VP8HIP_K_ENT_COUNT);
-        launch_ent_count(s, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw, c->mbh, P);
-        launch_default_probs(s, c->ent_probs, c->ent_denom0);
+        const uint8_t *defaults = hdr_default_coeff_probs();   // the fallback rides along in num_div_denom's kernel
+        launch_ent_count(s, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw, c->mbh, P, defaults);
+        if (!defaults) launch_default_probs(s, c->ent_probs, c->ent_denom0);
     }
     c->ent_counted_partitions = P;
     {

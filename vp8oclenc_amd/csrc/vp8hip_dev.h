@@ -76,7 +76,7 @@ void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, ui
 constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
 constexpr int ENT_MAX_PARTITIONS = 8;
 void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
-                      uint32_t *denom0, int mbw, int mbh, int num_partitions);
+                      uint32_t *denom0, int mbw, int mbh, int num_partitions, const uint8_t *defaults = nullptr);   // defaults: see hdr_default_coeff_probs
 // layout of one frame's bool strings / chunks / output words per partition; written by the device, read by the host
 struct EntPlan {
     uint32_t bool_base[ENT_MAX_PARTITIONS + 1], chunk_base[ENT_MAX_PARTITIONS + 1], word_base[ENT_MAX_PARTITIONS + 1];
@@ -98,13 +98,15 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
                        int mbw, int mbh, int P);
 
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n);   // in place, total in v[n]
-void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P);                    // the coder on bool strings laid out per eb.plan
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P, bool acc_zeroed = false);   // the coder on bool strings laid out per eb.plan
+                                                                                       // acc_zeroed: the emit kernel already cleared eb.acc
 // gather_frame on the device: out[0] = frame size (0 = overflow), out[1] = first-partition size, frame bytes from out + 16
 void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out);
 
 // first partition on the device (kernels_hdr.hip): encode_header, src/entropy_host.cpp:709-1256
 struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* < 0: the device's */, partitions_log2; };
 void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0);   // vp8enc.cpp:69-76
+const uint8_t *hdr_default_coeff_probs();   // device address of the default coefficient probabilities [4][8][3][11] (RFC 6386 13.5)
 constexpr int HDR_STAT_WORDS = 84;   // per-workgroup partial sums of k_hdr_count
 void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
