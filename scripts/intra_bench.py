@@ -56,3 +56,16 @@ for target_frac in (0.02, 0.10, 0.30):
     e2.close()
     enc.prepare_filter_mask(False); enc.loop_filter()
 enc.close()
+
+# nothing below the target: what the call costs when it has nothing to do
+e3 = api.Vp8Hip(W, H, -1.0)
+e3.upload_current(*f1)
+e3.set_segments(api.prepare_segments_data(False, last, 0, 4, 0))
+e3.upload_last(*f0)
+e3.inter_transform(1, 1, 0, 0)
+e3.synchronize()
+ts = []
+for _ in range(20):
+    t = time.perf_counter(); e3.check_ssim(); ts.append(time.perf_counter() - t)
+print(f"check_ssim with no macroblock below the target: {1e3 * sorted(ts)[len(ts) // 2]:.3f} ms per call")
+e3.close()

@@ -454,6 +454,142 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// check_SSIM's fallback with the three attempts of a macroblock side by side.  The reference tries segment AQ, then
+// HQ, then UQ, each only while the macroblock is still below the target -- but an attempt never reads what an earlier
+// one committed (a macroblock is not its own neighbour), so the three are independent computations and only the
+// DECISIONS are sequential.  Three wavefronts code the three attempts at once into their own tiles; then every
+// thread replays the reference's chain on the three SSIM values: which attempts "ran" (the last of them owns
+// e_data.mode), which one is kept (the last that raised the SSIM).  A flagged macroblock costs one attempt's time
+// instead of up to three.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
+    __shared__ __attribute__((aligned(16))) Sh sh3[3];
+    __shared__ float s_ssim[3];
+    __shared__ int s_abort;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x, mbw = a.mbw;
+    Sh &sh = sh3[wave];
+    const LaneK k = lane_consts(lane);
+    const int mb_row0 = r * mbw;
+    if (a.stall_test && r == 0) return;
+    for (int i = threadIdx.x; i < mbw; i += 192) a.is_inter[mb_row0 + i] = 1;
+    for (int i = threadIdx.x; i < mbw * 16; i += 192) a.modes[(size_t)mb_row0 * 16 + i] = 0;
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    const int seg = 2 - wave;                         // AQ, HQ, UQ
+    const Steps st = steps_of(a.sd, seg);
+    const LaneQ ql = lane_q(st.y_dc, st.y_ac, lane & 3);
+    int c = 0;
+    while (c < mbw) {
+        {   // next macroblock below the target (every wave reads the same values and arrives at the same c)
+            const int idx = c + lane;
+            const bool f = idx < mbw && a.o.ssim[mb_row0 + idx] < a.target;
+            const unsigned long long m = __ballot(f);
+            if (!m) { c += 64; continue; }
+            c += __builtin_ctzll(m);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int mb = mb_row0 + c;
+        const float cur0 = a.o.ssim[mb];   // read before anybody may replace it
+        *reinterpret_cast<uint32_t *>(&sh.srcY[lane * 4]) =
+            *reinterpret_cast<const uint32_t *>(a.cy.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.cy.stride + 16 * c + 4 * (lane & 3));
+        if (lane < 32) {
+            const Plane &P = lane < 16 ? a.cu : a.cv;
+            const int l = lane & 15;
+            *reinterpret_cast<uint32_t *>(&sh.srcC[lane >> 4][l * 4]) =
+                *reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1));
+        }
+        if (r > 0 && wave == 0) {
+            const int need = imin(c + 2, mbw);
+            int spins = 0;
+            while (__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > INTRA_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_abort = 1;
+                    }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_abort) return;
+        if (lane < 44) {   // neighbours, as in k_intra (each wave fills its own tile)
+            const bool top = lane < 12;
+            const int pl = top ? (lane < 6 ? 0 : (lane < 9 ? 1 : 2)) : (lane < 28 ? 0 : (lane < 36 ? 1 : 2));
+            const int j = top ? (pl == 0 ? lane : (pl == 1 ? lane - 6 : lane - 9)) : (pl == 0 ? lane - 12 : (pl == 1 ? lane - 28 : lane - 36));
+            const Plane &P = pl == 0 ? a.ry : (pl == 1 ? a.ru : a.rv);
+            const int msz = pl == 0 ? 16 : 8;
+            const bool last_col_ar = top && pl == 0 && j == 5 && c == mbw - 1;
+            const int x = top ? msz * c - 4 + 4 * (last_col_ar ? 4 : j) : msz * c - 4;
+            const int y = top ? msz * r - 1 : msz * r + j;
+            uint32_t v = ld_agent(P.p + (ptrdiff_t)y * P.stride + x);
+            if (last_col_ar) v = (v >> 24) * 0x01010101u;
+            if (top && r == 0) v = 0x7f7f7f7fu;
+            else if (c == 0 && (!top || j == 0)) v = 0x81818181u;
+            uint8_t *dst = pl == 0 ? sh.img : sh.cimg[pl - 1];
+            const int S = pl == 0 ? IMG_S : CIMG_S;
+            *reinterpret_cast<uint32_t *>(dst + (top ? 4 * j : (j + 1) * S)) = v;
+            if (top && pl == 0 && j == 5) {
+                *reinterpret_cast<uint32_t *>(sh.img + 4 * IMG_S + 20) = v;
+                *reinterpret_cast<uint32_t *>(sh.img + 8 * IMG_S + 20) = v;
+                *reinterpret_cast<uint32_t *>(sh.img + 12 * IMG_S + 20) = v;
+            }
+        }
+        lds_order();
+        int mymode = 0;
+#define LUMA(BR, BC)                                                   \
+        {                                                              \
+            const int m_ = luma_block<BR, BC>(sh, lane, k, ql);        \
+            if (lane == 4 * BR + BC) mymode = m_;                      \
+        }
+        LUMA(0, 0) LUMA(0, 1) LUMA(0, 2) LUMA(0, 3)
+        LUMA(1, 0) LUMA(1, 1) LUMA(1, 2) LUMA(1, 3)
+        LUMA(2, 0) LUMA(2, 1) LUMA(2, 2) LUMA(2, 3)
+        LUMA(3, 0) LUMA(3, 1) LUMA(3, 2) LUMA(3, 3)
+#undef LUMA
+        chroma_blocks(sh, lane, k, st.uv_dc, st.uv_ac);
+        const float s = mb_ssim(sh, lane);
+        if (lane == 0) s_ssim[wave] = s;
+        __syncthreads();
+        // the reference's decision chain (vp8enc.cpp:245-250, intra_part.h:1058-1086) on the three results
+        float cur = cur0;
+        int last_run = -1, kept = -1;
+        for (int t = 0; t < 3; ++t) {
+            if (!(cur < a.target)) break;
+            last_run = t;
+            if (s_ssim[t] > cur) { kept = t; cur = s_ssim[t]; }
+        }
+        if (wave == last_run && lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode: of the last attempt made (:970)
+        if (wave == kept) {
+            st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
+                     *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
+            if (lane < 32) {
+                const Plane &P = lane < 16 ? a.ru : a.rv;
+                const int l = lane & 15;
+                st_agent(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1),
+                         *reinterpret_cast<const uint32_t *>(&sh.cimg[lane >> 4][((l >> 1) + 1) * CIMG_S + 4 + 4 * (l & 1)]));
+            }
+            uint32_t *gc = reinterpret_cast<uint32_t *>(a.o.coeffs + (size_t)mb * 400);
+            const uint32_t *lc = reinterpret_cast<const uint32_t *>(sh.coef);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gc[lane + 64 * i] = lc[lane + 64 * i];
+            if (lane == 0) {
+                a.o.parts[mb] = 2;
+                a.o.seg[mb] = seg;
+                a.o.ssim[mb] = cur;
+                a.is_inter[mb] = 0;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ++c;
+        __syncthreads();   // the kept attempt's stores are complete: the row may advance
+        if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Key frames, pipelined at 4x4-block granularity.  In k_intra one wavefront walks the 16 luma blocks of a macroblock
 // one after the other, so the frame's critical path is 16 * (mbw + 2 mbh) block steps.  A luma block only needs the
 // block to its left, the row of pixels above it and four pixels above-right -- so here a workgroup still owns one
@@ -750,9 +886,12 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.stall_test = stall_test;
     (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
     static const bool legacy_key = getenv("VP8HIP_INTRA_KEY_MB") != nullptr;   // A/B switch: key frames on the per-macroblock wavefront
+    static const bool legacy_check = getenv("VP8HIP_INTRA_CHECK_1WAVE") != nullptr;   // A/B switch: the three attempts one after the other
     if (key && !legacy_key) {
         const size_t shmem = 5 * (size_t)(mbw * 16 + 16) + 3856;
         hipLaunchKernelGGL(k_intra_key4, dim3(mbh), dim3(64 * K4_WAVES), shmem, s, a);
+    } else if (!key && !legacy_check) {
+        hipLaunchKernelGGL(k_intra_check3, dim3(mbh), dim3(192), 0, s, a);
     } else {
         hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
     }
