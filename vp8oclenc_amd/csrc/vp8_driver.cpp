@@ -191,7 +191,9 @@ int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     DRV_CHK(vp8hip_prepare_filter_mask(d->hip, d->nz.data()));                   // counts of the final coefficients (vp8enc.cpp:472)
     DRV_CHK(vp8hip_count_probs(d->hip, P, probs, denom));                        // :58-68
     vp8bs_default_probs(probs, denom);                                           // :69-76
-    const size_t step = n * 800 / (size_t)P;                                     // video.partition_step, init.h:409,1190
+    // four times video.partition_step (init.h:409,1190): a partition that outgrows the reference's buffer overruns it
+    // there; found by the randomised parity run with noise at a low quantizer on a frame of two macroblock rows
+    const size_t step = n * 3200 / (size_t)P + 4096;
     d->partitions.resize(step * (size_t)P);
     int32_t sizes[8] = {0};
     DRV_CHK(vp8hip_encode_coefficients(d->hip, probs, P, (int)step, d->partitions.data(), sizes));   // :77-81
