@@ -847,6 +847,13 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int
         if (threadIdx.x == 0) {
             const float4 *q = reinterpret_cast<const float4 *>(s_val);
             int i = 0;
+            for (; i + 32 <= n; i += 32) {   // eight reads in flight, then the 32 dependent additions
+                float4 v[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) v[k2] = q[(i >> 2) + k2];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) sum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum, v[k2].x), v[k2].y), v[k2].z), v[k2].w);
+            }
             for (; i + 4 <= n; i += 4) {
                 const float4 v = q[i >> 2];
                 sum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum, v.x), v.y), v.z), v.w);
