@@ -192,6 +192,13 @@ int vp8hip_encode_header(vp8hip_ctx *ctx, const vp8hip_header_params *params, ui
 int vp8hip_encode_frame(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params, uint8_t *out, size_t capacity,
                         size_t *size);
 
+/* The same in two halves, for a host thread that drives several contexts (GOP chunks): _begin enqueues the whole
+ * entropy stage and the read-back on the context's stream and returns at once; _end waits for it and fills `out`.
+ * Between the two no other call may be made on this context (the next frame would overwrite what a recode after a
+ * scratch overflow has to read again): VP8HIP_ERR_STATE from _begin while a frame is pending, from _end when none is. */
+int vp8hip_encode_frame_begin(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params);
+int vp8hip_encode_frame_end(vp8hip_ctx *ctx, uint8_t *out, size_t capacity, size_t *size);
+
 /* filtered planes = the current LAST (debug.h:8-36 dump; host intra fallback input) */
 int vp8hip_download_last(vp8hip_ctx *ctx, uint8_t *y, uint8_t *u, uint8_t *v);
 

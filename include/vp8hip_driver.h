@@ -61,6 +61,12 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
  * Blocks.  *size = bytes written; VP8HIP_ERR_OVERFLOW if `capacity` is too small.  With vp8bs_ivf_file_header /
  * vp8bs_ivf_frame_header around the frames this is the reference's .ivf output, byte for byte. */
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
+/* The same in two halves (device entropy stage only: VP8HIP_ERR_STATE with host_bitstream): _begin enqueues the
+ * stage and returns, _end waits and fills `out`.  One host thread can thus keep many GOP chunks in flight:
+ * encode_frame + get_frame_begin on every chunk, then get_frame_end on every chunk.  No other call on this driver
+ * between the two. */
+int vp8drv_get_frame_begin(vp8drv *d);
+int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

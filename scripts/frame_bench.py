@@ -18,6 +18,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--partitions", type=int, default=8)
 ap.add_argument("--check-ssim", type=int, default=0)
 ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (0 = Python's default 5 ms)")
+ap.add_argument("--only", choices=("both", "on", "off"), default="both", help="which of the two legs to time")
+ap.add_argument("--pipeline", action="store_true", help="one host thread: encode + get_frame_begin on every stream, then get_frame_end on every stream")
 a = ap.parse_args()
 if a.switch_interval > 0:
     sys.setswitchinterval(a.switch_interval)
@@ -39,7 +41,23 @@ def work(k, n, emit):
             sizes[k] += len(d.get_frame())
     d.hip.synchronize()
 
+def run_pipeline(n, emit):
+    t0 = time.perf_counter()
+    for t in range(n):
+        for k, d in enumerate(drvs):
+            y, u, v = dev[(t + 3 * k) % nd]
+            d.encode_frame_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+            if emit:
+                d.get_frame_begin()
+        if emit:
+            for k, d in enumerate(drvs):
+                sizes[k] += len(d.get_frame_end())
+    for d in drvs: d.hip.synchronize()
+    return time.perf_counter() - t0
+
 def run(n, emit):
+    if a.pipeline:
+        return run_pipeline(n, emit)
     th = [threading.Thread(target=work, args=(k, n, emit)) for k in range(a.streams)]
     t0 = time.perf_counter()
     for t in th: t.start()
@@ -47,7 +65,7 @@ def run(n, emit):
     return time.perf_counter() - t0
 
 run(4, True)
-for emit in (False, True):
+for emit in {"both": (False, True), "on": (True,), "off": (False,)}[a.only]:
     for k in range(a.streams): sizes[k] = 0
     el = run(a.frames, emit)
     fps = a.streams * a.frames / el

@@ -166,3 +166,39 @@ def test_sharded_encoder_writes_the_reference_ivf(tmp_path):
     gop_shard.write_ivf(a, gop_shard.gather_frames(dev, FRAMES), seq.W, seq.H)
     gop_shard.write_ivf(b, gop_shard.gather_frames(cpu, FRAMES), seq.W, seq.H)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_get_frame_in_two_halves_across_chunks_equals_get_frame():
+    """vp8drv_get_frame_begin/_end: one host thread keeps several GOP chunks in flight; same bytes as the blocking call,
+    and the call order is enforced."""
+    W, H, P = 320, 192, 4
+    seqs = [SynthSequence(W, H, seed=s) for s in (61, 62, 63)]
+    blocking = []
+    for s in seqs:
+        d = api.NativeDriver(W, H, num_partitions=P, check_ssim=1, gop_size=4)
+        frames = []
+        for t in range(6):
+            d.encode_frame_host(*s.frame(t))
+            frames.append(d.get_frame())
+        blocking.append(frames)
+        d.close()
+    drvs = [api.NativeDriver(W, H, num_partitions=P, check_ssim=1, gop_size=4) for _ in seqs]
+    with pytest.raises(api.Vp8HipError):
+        drvs[0].get_frame_begin()                     # nothing coded yet
+    for t in range(6):
+        for d, s in zip(drvs, seqs):
+            d.encode_frame_host(*s.frame(t))
+            d.get_frame_begin()
+        with pytest.raises(api.Vp8HipError):
+            drvs[0].get_frame_begin()                 # one frame pending already
+        for k, d in enumerate(drvs):
+            assert d.get_frame_end() == blocking[k][t], (k, t)
+        with pytest.raises(api.Vp8HipError):
+            drvs[0].get_frame_end()                   # nothing pending
+    host = api.NativeDriver(W, H, num_partitions=P, host_bitstream=1)
+    host.encode_frame_host(*seqs[0].frame(0))
+    with pytest.raises(api.Vp8HipError):
+        host.get_frame_begin()                        # the host coder has no asynchronous half
+    host.close()
+    for d in drvs:
+        d.close()

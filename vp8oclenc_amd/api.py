@@ -27,11 +27,12 @@ ABI_SYMBOLS = [
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
     "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_get_frame",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -263,6 +264,24 @@ class NativeDriver:
         rc = self.lib.vp8drv_get_frame(self.h, self._frame_buf.ctypes.data, cap, C.byref(n))
         if rc != 0:
             raise Vp8HipError(f"vp8drv_get_frame: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return self._frame_buf[:n.value].tobytes()
+
+    def get_frame_begin(self) -> None:
+        """Enqueue the entropy stage of the frame just coded and return (vp8drv_get_frame_begin); get_frame_end collects."""
+        self.lib.vp8drv_get_frame_begin.argtypes = [C.c_void_p]
+        rc = self.lib.vp8drv_get_frame_begin(self.h)
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_get_frame_begin: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+
+    def get_frame_end(self) -> bytes:
+        self.lib.vp8drv_get_frame_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        cap = self.hip.mbs * 900 + 65536
+        if getattr(self, "_frame_buf", None) is None or len(self._frame_buf) < cap:
+            self._frame_buf = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        rc = self.lib.vp8drv_get_frame_end(self.h, self._frame_buf.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_get_frame_end: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return self._frame_buf[:n.value].tobytes()
 
     def stats(self) -> DrvStats:

@@ -393,39 +393,105 @@ __device__ __forceinline__ int range_step(uint32_t &r, uint32_t prob, uint32_t b
     return s;
 }
 
-__global__ __launch_bounds__(128) void k_ent_maps(const uint16_t *bools, const Plan *plan, int P, uint32_t *maps) {
-    __shared__ uint16_t s_b[CHUNK];
-    const int tid = threadIdx.x;
-    for (uint32_t chunk = blockIdx.x; chunk < plan->total_chunks; chunk += gridDim.x) {
-        int p, n;
-        uint32_t b0;
-        chunk_slice(plan, P, chunk, p, b0, n);
-        __syncthreads();
-        for (int i = tid; i < n; i += 128) s_b[i] = bools[b0 + i];
-        __syncthreads();
-        uint32_t r = 128u + tid, S = 0, split;
-        for (int i = 0; i < n; ++i) {
-            const uint32_t e = s_b[i];
-            S += range_step(r, e & 255u, e >> 8, split);
+// One or two coder jobs per launch (the coefficient partitions and the first partition of a frame go through the coder
+// together: blockIdx.y picks the job).
+struct CodeJob {
+    const uint16_t *bools;
+    Plan *plan;
+    uint32_t *maps, *smaps;   // per chunk / per super-chunk: [128 start ranges] -> end range | shifts << 8
+    uint2 *start;
+    unsigned long long *acc;
+    uint8_t *bytes;
+    int32_t *sizes;
+    int P;
+};
+struct CodeJobs { CodeJob j[2]; };
+
+constexpr int SUP = 8;   // chunks per super-chunk (never across a partition boundary)
+
+__device__ __forceinline__ uint32_t supers_of(const Plan *plan, int p) {
+    return (plan->chunk_base[p + 1] - plan->chunk_base[p] + SUP - 1) / SUP;
+}
+// super-chunk (counted through all partitions of the job) -> partition, first chunk, number of chunks
+__device__ __forceinline__ bool super_slice(const Plan *plan, int P, uint32_t sup, int &p, uint32_t &c0, int &nc) {
+    uint32_t sb = 0;
+    for (p = 0; p < P; ++p) {
+        const uint32_t nch = plan->chunk_base[p + 1] - plan->chunk_base[p], ns = (nch + SUP - 1) / SUP;
+        if (sup < sb + ns) {
+            const uint32_t l = (sup - sb) * SUP;
+            c0 = plan->chunk_base[p] + l;
+            nc = (int)(nch - l < (uint32_t)SUP ? nch - l : (uint32_t)SUP);
+            return true;
         }
-        maps[(size_t)chunk * 128 + tid] = r | (S << 8);
+        sb += ns;
+    }
+    return false;
+}
+
+// A workgroup takes a super-chunk: 128 lanes per chunk run it from each possible start range, then 128 lanes compose
+// the eight chunk maps into the super-chunk's map, which is what the serial walk steps through.
+__global__ __launch_bounds__(1024) void k_ent_maps(CodeJobs jobs) {
+    const CodeJob &J = jobs.j[blockIdx.y];
+    __shared__ uint16_t s_b[SUP][CHUNK];
+    __shared__ uint32_t s_m[SUP][128];
+    const int tid = threadIdx.x, w = tid >> 7, l = tid & 127;
+    const Plan *plan = J.plan;
+    for (uint32_t sup = blockIdx.x;; sup += gridDim.x) {
+        int p, nc;
+        uint32_t c0;
+        if (!super_slice(plan, J.P, sup, p, c0, nc)) break;
+        int n = 0;
+        __syncthreads();
+        if (w < nc) {
+            const uint32_t b0 = plan->bool_base[p] + (c0 + w - plan->chunk_base[p]) * CHUNK, end = plan->bool_base[p] + plan->nbools[p];
+            n = (int)(end - b0 < (uint32_t)CHUNK ? end - b0 : (uint32_t)CHUNK);
+            for (int i = l; i < n; i += 128) s_b[w][i] = J.bools[b0 + i];
+        }
+        __syncthreads();
+        if (w < nc) {
+            uint32_t r = 128u + l, S = 0, split;
+            for (int i = 0; i < n; ++i) {
+                const uint32_t e = s_b[w][i];
+                S += range_step(r, e & 255u, e >> 8, split);
+            }
+            const uint32_t e = r | (S << 8);
+            J.maps[(size_t)(c0 + w) * 128 + l] = e;
+            s_m[w][l] = e;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            uint32_t r = 128u + tid, S = 0;
+            for (int k = 0; k < nc; ++k) {
+                const uint32_t e = s_m[k][r - 128u];
+                r = e & 255u;
+                S += e >> 8;
+            }
+            J.smaps[(size_t)sup * 128 + tid] = r | (S << 8);   // S < 8 * 256 * 7
+        }
     }
 }
 
-constexpr int WALK_TILE = 64;   // chunk maps staged in LDS per step (32 KB)
-__global__ __launch_bounds__(256) void k_ent_walk(const uint32_t *maps, Plan *plan, uint2 *start) {
-    __shared__ uint32_t s_m[WALK_TILE * 128];
+// One workgroup per partition.  Lane 0 steps through the super-chunk maps (one LDS lookup each) and leaves every
+// super-chunk's true start state; then one lane per super-chunk steps through its chunks.
+constexpr int WALK_TILE = 64;   // super-chunk maps staged in LDS per step (32 KB)
+__global__ __launch_bounds__(256) void k_ent_walk(CodeJobs jobs) {
+    const CodeJob &J = jobs.j[blockIdx.y];
     const int p = blockIdx.x;
-    const uint32_t cb = plan->chunk_base[p], nch = plan->chunk_base[p + 1] - cb;
+    if (p >= J.P) return;
+    __shared__ uint32_t s_m[WALK_TILE * 128];
+    Plan *plan = J.plan;
+    uint32_t sb = 0;
+    for (int q = 0; q < p; ++q) sb += supers_of(plan, q);
+    const uint32_t cb = plan->chunk_base[p], nch = plan->chunk_base[p + 1] - cb, ns = (nch + SUP - 1) / SUP;
     uint32_t r = 255, W = 0;
-    for (uint32_t t0 = 0; t0 < nch; t0 += WALK_TILE) {
-        const uint32_t tn = nch - t0 < (uint32_t)WALK_TILE ? nch - t0 : (uint32_t)WALK_TILE;
+    for (uint32_t t0 = 0; t0 < ns; t0 += WALK_TILE) {
+        const uint32_t tn = ns - t0 < (uint32_t)WALK_TILE ? ns - t0 : (uint32_t)WALK_TILE;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < tn * 128; i += 256) s_m[i] = maps[(size_t)(cb + t0) * 128 + i];
+        for (uint32_t i = threadIdx.x; i < tn * 128; i += 256) s_m[i] = J.smaps[(size_t)(sb + t0) * 128 + i];
         __syncthreads();
         if (threadIdx.x == 0)
             for (uint32_t k = 0; k < tn; ++k) {
-                start[cb + t0 + k] = make_uint2(r, W);
+                J.start[cb + (t0 + k) * SUP] = make_uint2(r, W);
                 const uint32_t e = s_m[k * 128 + (r - 128u)];
                 r = e & 255u;
                 W += e >> 8;
@@ -435,6 +501,18 @@ __global__ __launch_bounds__(256) void k_ent_walk(const uint32_t *maps, Plan *pl
         plan->w_end[p] = W;
         plan->nbytes[p] = (W >= 24 ? (W - 24) / 8 + 1 : 0) + 4;   // bytes emitted while coding + the flush (:130-146)
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ns; i += 256) {
+        const uint32_t c = cb + i * SUP, nc = nch - i * SUP < (uint32_t)SUP ? nch - i * SUP : (uint32_t)SUP;
+        const uint2 st = J.start[c];
+        uint32_t rr = st.x, WW = st.y;
+        for (uint32_t k = 1; k < nc; ++k) {
+            const uint32_t e = J.maps[(size_t)(c + k - 1) * 128 + (rr - 128u)];
+            rr = e & 255u;
+            WW += e >> 8;
+            J.start[c + k] = make_uint2(rr, WW);
+        }
+    }
 }
 
 // Four lanes per chunk: lane j first replays bools [0, 64j) of its chunk for the range and bit position only
@@ -442,12 +520,16 @@ __global__ __launch_bounds__(256) void k_ent_walk(const uint32_t *maps, Plan *pl
 // issued back to back per batch (a version that staged chunks through LDS row by row serialised on load latency:
 // 141 us per 1080p frame).
 constexpr int ENC_SUB = 4, ENC_SUBLEN = CHUNK / ENC_SUB, ENC_CHUNKS = 64;   // chunks per workgroup of 256
-__global__ __launch_bounds__(256) void k_ent_encode(const uint16_t *bools, const Plan *plan, int P, const uint2 *start,
-                                                    unsigned long long *acc) {
+__global__ __launch_bounds__(256) void k_ent_encode(CodeJobs jobs) {
+    const CodeJob &J = jobs.j[blockIdx.y];
     __shared__ Plan s_plan;   // the plan is consulted per chunk: from LDS, not through a chain of dependent global loads
-    for (int i = threadIdx.x; i < (int)(sizeof(Plan) / 4); i += 256) reinterpret_cast<uint32_t *>(&s_plan)[i] = reinterpret_cast<const uint32_t *>(plan)[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(Plan) / 4); i += 256) reinterpret_cast<uint32_t *>(&s_plan)[i] = reinterpret_cast<const uint32_t *>(J.plan)[i];
     __syncthreads();
-    plan = &s_plan;
+    const Plan *plan = &s_plan;
+    const int P = J.P;
+    const uint16_t *bools = J.bools;
+    const uint2 *start = J.start;
+    unsigned long long *acc = J.acc;
     const int j = threadIdx.x & (ENC_SUB - 1);
     for (uint32_t c0 = blockIdx.x * ENC_CHUNKS; c0 < plan->total_chunks; c0 += gridDim.x * ENC_CHUNKS) {
         const uint32_t chunk = c0 + (threadIdx.x >> 2);
@@ -496,40 +578,55 @@ __global__ __launch_bounds__(256) void k_ent_encode(const uint16_t *bools, const
     }
 }
 
-// carries + bytes.  One wave per partition, from the least significant word up, 64 words per step.
-__global__ __launch_bounds__(64) void k_ent_finish(const unsigned long long *acc, const Plan *plan, uint8_t *bytes, int32_t *sizes) {
-    const int p = blockIdx.x, lane = threadIdx.x;
+// carries + bytes.  One workgroup of sixteen waves per partition, from the least significant word up, 1024 words per
+// step: every word adds the high half of the word below it; what is left is a ripple of single carries, resolved by
+// carry-lookahead inside each wave (the ballot trick), across the sixteen waves, and from step to step.
+constexpr int FIN_WAVES = 16;
+__global__ __launch_bounds__(64 * FIN_WAVES) void k_ent_finish(CodeJobs jobs) {
+    const CodeJob &J = jobs.j[blockIdx.y];
+    const int p = blockIdx.x;
+    if (p >= J.P) return;
+    __shared__ uint32_t s_gp[2][2][FIN_WAVES];
+    const Plan *plan = J.plan;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nb = plan->nbytes[p], nw = (nb + 3) / 4;
-    const unsigned long long *in = acc + plan->word_base[p];
-    uint8_t *out = bytes + (size_t)plan->word_base[p] * 4;
-    unsigned long long K = 0;   // what the words below hand up: their high parts + the ripple carry
-    for (int hi_end = (int)nw; hi_end > 0; hi_end -= 64) {
-        const int j = hi_end - 1 - lane;                         // lane 0 = least significant word of the tile
+    const unsigned long long *in = J.acc + plan->word_base[p];
+    uint8_t *out = J.bytes + (size_t)plan->word_base[p] * 4;
+    uint32_t C = 0;   // carry into the least significant word of the step
+    int par = 0;
+    for (int hi_end = (int)nw; hi_end > 0; hi_end -= 64 * FIN_WAVES, par ^= 1) {
+        const int j = hi_end - 1 - (wv * 64 + lane);            // wave 0, lane 0 = least significant word of the step
         const unsigned long long v = j >= 0 ? in[j] : 0ull;
-        const unsigned long long hi = v >> 32;
-        unsigned long long from_below = __shfl_up(hi, 1);
-        if (lane == 0) from_below = K;
+        unsigned long long from_below = __shfl_up(v >> 32, 1);
+        if (lane == 0) from_below = (j >= 0 && j + 1 < (int)nw) ? in[j + 1] >> 32 : 0ull;
         const unsigned long long t = (v & 0xffffffffull) + from_below;   // < 2^33: the high parts are tiny
         const uint32_t r = (uint32_t)t;
         const unsigned long long G = __ballot((t >> 32) != 0), Pm = __ballot(r == 0xffffffffu);
-        // ripple c[i+1] = g[i] | (p[i] & c[i]) for all 64 lanes at once: the carries of the addition (G|P) + G
-        const unsigned long long A = G | Pm, S = A + G;
-        const unsigned long long carries = S ^ Pm;               // bit i = carry into lane i
+        // ripple c[i+1] = g[i] | (p[i] & c[i]) for all 64 lanes at once: the carries of the addition (G|P) + G + carry-in
+        const unsigned long long A = G | Pm, S0 = A + G;
+        if (lane == 0) {
+            s_gp[par][0][wv] = S0 < A ? 1u : 0u;           // the wave hands a carry up whatever comes in
+            s_gp[par][1][wv] = S0 == ~0ull ? 1u : 0u;      // ... only if one comes in
+        }
+        __syncthreads();
+        uint32_t Gw = 0, Pw = 0;
+#pragma unroll
+        for (int k = 0; k < FIN_WAVES; ++k) {
+            Gw |= s_gp[par][0][k] << k;
+            Pw |= s_gp[par][1][k] << k;
+        }
+        const uint32_t Sw = (Gw | Pw) + Gw + C, into = Sw ^ Pw;   // bit k = carry into wave k, bit FIN_WAVES = out of the step
+        const unsigned long long S = S0 + ((into >> wv) & 1u);
+        const unsigned long long carries = S ^ Pm;                // bit i = carry into lane i
         const uint32_t word = r + (uint32_t)((carries >> lane) & 1ull);
-        K = __shfl(hi, 63) + (S < A ? 1ull : 0ull);
+        C = (into >> FIN_WAVES) & 1u;
         if (j >= 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if ((uint32_t)(4 * j + k) < nb) out[4 * j + k] = (uint8_t)(word >> (24 - 8 * k));
         }
     }
-    if (lane == 0) sizes[p] = (int32_t)nb;
-}
-
-// the accumulators the plan actually uses (a memset of the whole scratch would write tens of MB per frame)
-__global__ __launch_bounds__(256) void k_zero_acc(const Plan *plan, int P, unsigned long long *acc) {
-    const uint32_t n = plan->word_base[P];
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc[i] = 0ull;
+    if (threadIdx.x == 0) J.sizes[p] = (int32_t)nb;
 }
 
 // exclusive scan of up to 64 k values by one workgroup (the macroblock-header counts): one launch instead of three
@@ -618,20 +715,42 @@ void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n
     hipLaunchKernelGGL(ent::k_scan_apply, dim3(ntiles), dim3(256), 0, s, v, tile_sum, n, ntiles);
 }
 
-// the boolean coder proper on bool strings that are laid out as eb.plan says (steps 2-5 above): P partitions
-void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P, bool acc_zeroed) {
-    EntPlan *plan = eb.plan;
-    if (!acc_zeroed) hipLaunchKernelGGL(ent::k_zero_acc, dim3(64), dim3(256), 0, s, plan, P, reinterpret_cast<unsigned long long *>(eb.acc));
-    hipLaunchKernelGGL(ent::k_ent_maps, dim3(2048), dim3(128), 0, s, eb.bools, plan, P, eb.maps);
-    hipLaunchKernelGGL(ent::k_ent_walk, dim3(P), dim3(256), 0, s, eb.maps, plan, reinterpret_cast<uint2 *>(eb.start));
-    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512), dim3(256), 0, s, eb.bools, plan, P,
-                       reinterpret_cast<const uint2 *>(eb.start), reinterpret_cast<unsigned long long *>(eb.acc));
-    hipLaunchKernelGGL(ent::k_ent_finish, dim3(P), dim3(64), 0, s, reinterpret_cast<const unsigned long long *>(eb.acc), plan,
-                       eb.bytes, eb.sizes);
+// the boolean coder proper on bool strings that are laid out as eb.plan says (steps 2-5 above), the emit kernel having
+// cleared the accumulators; one job (P partitions of a) or two (+ Pb partitions of b) in the same four launches
+static ent::CodeJob code_job(const EntBuffers &eb, int P) {
+    ent::CodeJob j;
+    j.bools = eb.bools;
+    j.plan = eb.plan;
+    j.maps = eb.maps;
+    j.smaps = eb.maps + (size_t)eb.cap_chunks * 128;
+    j.start = reinterpret_cast<uint2 *>(eb.start);
+    j.acc = reinterpret_cast<unsigned long long *>(eb.acc);
+    j.bytes = eb.bytes;
+    j.sizes = eb.sizes;
+    j.P = P;
+    return j;
+}
+static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs) {
+    const int maxP = jobs.j[0].P > jobs.j[njobs - 1].P ? jobs.j[0].P : jobs.j[njobs - 1].P;
+    hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(1024), 0, s, jobs);
+    hipLaunchKernelGGL(ent::k_ent_walk, dim3(maxP, njobs), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512, njobs), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(ent::k_ent_finish, dim3(maxP, njobs), dim3(64 * ent::FIN_WAVES), 0, s, jobs);
+}
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
+    ent::CodeJobs jobs;
+    jobs.j[0] = jobs.j[1] = code_job(eb, P);
+    bool_code(s, jobs, 1);
+}
+void launch_bool_code2(hipStream_t s, const EntBuffers &a, int Pa, const EntBuffers &b, int Pb) {
+    ent::CodeJobs jobs;
+    jobs.j[0] = code_job(a, Pa);
+    jobs.j[1] = code_job(b, Pb);
+    bool_code(s, jobs, 2);
 }
 
 void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
-                       int mbw, int mbh, int P) {
+                       int mbw, int mbh, int P, bool code) {
     ent::Geom g;
     g.mbw = mbw;
     g.mbh = mbh;
@@ -651,7 +770,7 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
     hipLaunchKernelGGL(ent::k_ent_plan, dim3(1), dim3(64), 0, s, eb.offs, g, plan);
     hipLaunchKernelGGL(ent::k_ent_emit, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, third_ctx, probs,
                        eb.offs, plan, g, eb.bools, reinterpret_cast<unsigned long long *>(eb.acc));
-    launch_bool_code(s, eb, P, true);
+    if (code) launch_bool_code(s, eb, P);
 }
 
 }  // namespace vp8

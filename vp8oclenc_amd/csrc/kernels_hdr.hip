@@ -325,7 +325,7 @@ void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0
 
 void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
-                       uint8_t *sym, uint32_t *info, int mbw, int mbh) {
+                       uint8_t *sym, uint32_t *info, int mbw, int mbh, bool code) {
     hdr::Params a;
     a.v.seg_ = o.seg; a.v.nz_ = o.nz; a.v.ref_ = o.ref; a.v.parts_ = o.parts; a.v.is_inter_ = is_inter; a.v.modes_ = modes;
     a.v.vec_ = o.vec;
@@ -349,7 +349,7 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
     hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs, eb.bools, sym, eb.plan, info);
     hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
                        reinterpret_cast<unsigned long long *>(eb.acc));
-    launch_bool_code(s, eb, 1, true);
+    if (code) launch_bool_code(s, eb, 1);
 }
 
 }  // namespace vp8

@@ -171,19 +171,24 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
 
 // entropy_encode() + gather_frame() (vp8enc.cpp:48-94, 476-481; encIO.h:1-30) for the frame just coded:
 // coefficient statistics and partitions on the device, first partition on the host
+vp8hip_header_params header_params(const vp8drv *d) {
+    vp8hip_header_params hp{};
+    hp.is_key = d->last_key;
+    hp.is_golden = d->last_key;                 // current_is_golden_frame = current_is_key_frame (vp8enc.cpp:369)
+    hp.is_altref = d->last_altref;
+    hp.loop_filter_type = 0;                    // init.h:1583
+    hp.loop_filter_sharpness = d->sharpness;    // -1: still on the device
+    hp.width = d->cfg.display_width;
+    hp.height = d->cfg.display_height;
+    hp.use_intra_info = d->checked;
+    return hp;
+}
+
 int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     const int P = d->cfg.num_partitions;
     const size_t n = (size_t)d->mbs;
-    if (!d->cfg.host_bitstream) {   // the whole entropy stage on the device, two read-backs
-        vp8hip_header_params hp{};
-        hp.is_key = d->last_key;
-        hp.is_golden = d->last_key;                 // current_is_golden_frame = current_is_key_frame (vp8enc.cpp:369)
-        hp.is_altref = d->last_altref;
-        hp.loop_filter_type = 0;                    // init.h:1583
-        hp.loop_filter_sharpness = d->sharpness;    // -1: still on the device
-        hp.width = d->cfg.display_width;
-        hp.height = d->cfg.display_height;
-        hp.use_intra_info = d->checked;
+    if (!d->cfg.host_bitstream) {   // the whole entropy stage on the device, one read-back
+        const vp8hip_header_params hp = header_params(d);
         return vp8hip_encode_frame(d->hip, P, &hp, out, capacity, size);
     }
     uint32_t probs[VP8BS_NUM_COEFF_PROBS], denom[VP8BS_NUM_COEFF_PROBS];
@@ -274,6 +279,20 @@ int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     const int P = d->cfg.num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
     return get_frame(d, out, capacity, size);
+}
+
+int vp8drv_get_frame_begin(vp8drv *d) {
+    if (!d) return VP8HIP_ERR_ARG;
+    if (!d->have_frame || d->cfg.host_bitstream) return VP8HIP_ERR_STATE;
+    const int P = d->cfg.num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    const vp8hip_header_params hp = header_params(d);
+    return vp8hip_encode_frame_begin(d->hip, P, &hp);
+}
+
+int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
+    if (!d || !out || !size) return VP8HIP_ERR_ARG;
+    return vp8hip_encode_frame_end(d->hip, out, capacity, size);
 }
 
 }  // extern "C"

@@ -60,6 +60,9 @@ struct vp8hip_ctx {
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
+    bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
+    vp8hip_header_params frame_params{};
+    int frame_partitions = 0;
     int ent_bools_per_block = 64;   // what that scratch is sized for; doubled (up to 304, the maximum) when a frame needs more
     // host intra path on the device: sub-block modes, replaced flags, row progress, {replaced, new_SSIM, min SSIM}
     int32_t *intra_modes = nullptr, *intra_is_inter = nullptr, *intra_prog = nullptr, *intra_stats = nullptr;
@@ -691,7 +694,7 @@ static int ent_alloc(vp8hip_ctx *c) {
     HIPCHK(c, hipMalloc(&e.offs, (nslots + 1) * 4));
     HIPCHK(c, hipMalloc(&e.tile_sum, (nslots / 1024 + 8) * 4));
     HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
-    HIPCHK(c, hipMalloc(&e.maps, (size_t)e.cap_chunks * 128 * 4));
+    HIPCHK(c, hipMalloc(&e.maps, ent_maps_entries(e.cap_chunks) * 4));
     HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
     HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
     HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
@@ -753,7 +756,7 @@ static int hdr_alloc(vp8hip_ctx *c) {
     HIPCHK(c, hipMalloc(&e.offs, (n + 1) * 4));
     HIPCHK(c, hipMalloc(&e.tile_sum, (n / 1024 + 8) * 4));
     HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
-    HIPCHK(c, hipMalloc(&e.maps, (size_t)e.cap_chunks * 128 * 4));
+    HIPCHK(c, hipMalloc(&e.maps, ent_maps_entries(e.cap_chunks) * 4));
     HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
     HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
     HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
@@ -809,11 +812,9 @@ int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *
     return VP8HIP_OK;
 }
 
-int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
-    if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
-    const int P = num_partitions;
-    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
-    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;
+// Everything of a frame's entropy stage up to the read-back, enqueued; nothing waits.
+static constexpr size_t FRAME_FIRST_COPY = 192 * 1024;
+static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     int rc = ent_alloc(c);
     if (rc) return rc;
     if ((rc = hdr_alloc(c))) return rc;
@@ -827,7 +828,7 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
     c->ent_counted_partitions = P;
     {
         Timed t(c, VP8HIP_K_ENT_ENCODE);
-        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, P);
+        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, P, false);   // bool strings only
     }
     HdrFrame f;
     f.is_key = p->is_key ? 1 : 0;
@@ -841,29 +842,58 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
         Timed t(c, VP8HIP_K_HDR_ENCODE);
         launch_hdr_encode(s, c->out, (!p->is_key && p->use_intra_info) ? c->intra_is_inter : nullptr, intra_info ? c->intra_modes : nullptr, f,
                           c->d_sd, reinterpret_cast<const int32_t *>(c->d_stats + 4), c->ent_probs, c->ent_denom0, c->hdr, c->hdr_partial,
-                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh);
+                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh, false);
+        launch_bool_code2(s, c->ent, P, c->hdr, 1);   // the coefficient partitions and the first partition through the coder together
     }
     HIPCHK(c, hipGetLastError());
     // gather_frame (encIO.h:1-30) on the device, then ONE read-back through pinned memory: the frame size and the
-    // first FIRST_COPY bytes travel together; only a frame larger than that needs a second copy.
+    // first FRAME_FIRST_COPY bytes travel together; only a frame larger than that needs a second copy.
     if (!c->h_frame) {
         c->h_frame_cap = (size_t)c->hdr.cap_words * 4 + (size_t)c->ent.cap_words * 4 + 64;
         HIPCHK(c, hipHostMalloc(&c->h_frame, c->h_frame_cap));
         HIPCHK(c, hipMalloc(&c->d_frame, c->h_frame_cap));
     }
     const size_t head = p->is_key ? 10 : 3;
-    constexpr size_t FIRST_COPY = 192 * 1024;
     launch_frame_gather(s, c->ent, c->hdr, P, (uint32_t)head, (uint32_t)(c->h_frame_cap - 16), c->d_frame);
     HIPCHK(c, hipGetLastError());
-    const size_t first = c->h_frame_cap < FIRST_COPY ? c->h_frame_cap : FIRST_COPY;
+    const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const size_t n = *reinterpret_cast<const uint32_t *>(c->h_frame);
-    if (n == 0) {   // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
-        if (ent_grow(c)) return vp8hip_encode_frame(c, num_partitions, p, out, capacity, size);
-        return VP8HIP_ERR_OVERFLOW;
+    return VP8HIP_OK;
+}
+
+int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p) {
+    if (!c || !p) return VP8HIP_ERR_ARG;
+    const int P = num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;
+    if (c->frame_pending) return VP8HIP_ERR_STATE;
+    const int rc = frame_enqueue(c, P, p);
+    if (rc) return rc;
+    c->frame_params = *p;
+    c->frame_partitions = P;
+    c->frame_pending = true;
+    return VP8HIP_OK;
+}
+
+int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t *size) {
+    if (!c || !out || !size) return VP8HIP_ERR_ARG;
+    if (!c->frame_pending) return VP8HIP_ERR_STATE;
+    c->frame_pending = false;
+    const vp8hip_header_params *p = &c->frame_params;
+    hipStream_t s = c->stream;
+    size_t n;
+    for (;;) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        n = *reinterpret_cast<const uint32_t *>(c->h_frame);
+        if (n) break;
+        // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
+        if (!ent_grow(c)) return VP8HIP_ERR_OVERFLOW;
+        const int rc = frame_enqueue(c, c->frame_partitions, p);
+        if (rc) return rc;
     }
     if (n > capacity) return VP8HIP_ERR_OVERFLOW;
+    const size_t head = p->is_key ? 10 : 3;
+    const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     if (16 + n > first) {
         HIPCHK(c, hipMemcpyAsync(c->h_frame + first, c->d_frame + first, 16 + n - first, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -882,6 +912,12 @@ int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_p
     }
     *size = n;
     return VP8HIP_OK;
+}
+
+int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
+    if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
+    const int rc = vp8hip_encode_frame_begin(c, num_partitions, p);
+    return rc ? rc : vp8hip_encode_frame_end(c, out, capacity, size);
 }
 
 // stream idle -> did a bounded device-side wait expire since the last check?  (kernels_lf3.hip, LF_WAIT)

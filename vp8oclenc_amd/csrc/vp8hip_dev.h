@@ -95,11 +95,14 @@ struct EntBuffers {          // device scratch of the boolean coder (allocated o
     uint32_t cap_bools, cap_chunks, cap_words;
 };
 void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
-                       int mbw, int mbh, int P);
+                       int mbw, int mbh, int P, bool code = true);   // code = false: bool strings only, the coder is launched by the caller
 
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n);   // in place, total in v[n]
-void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P, bool acc_zeroed = false);   // the coder on bool strings laid out per eb.plan
-                                                                                       // acc_zeroed: the emit kernel already cleared eb.acc
+// the coder on bool strings laid out per eb.plan (accumulators cleared by the emit kernel); eb.maps holds
+// cap_chunks chunk maps followed by the super-chunk maps (ent_maps_entries)
+void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P);
+void launch_bool_code2(hipStream_t s, const EntBuffers &a, int Pa, const EntBuffers &b, int Pb);   // two jobs in the same four launches
+inline size_t ent_maps_entries(uint32_t cap_chunks) { return ((size_t)cap_chunks + cap_chunks / 8 + 2 * ENT_MAX_PARTITIONS) * 128; }
 // gather_frame on the device: out[0] = frame size (0 = overflow), out[1] = first-partition size, frame bytes from out + 16
 void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out);
 
@@ -110,7 +113,7 @@ const uint8_t *hdr_default_coeff_probs();   // device address of the default coe
 constexpr int HDR_STAT_WORDS = 84;   // per-workgroup partial sums of k_hdr_count
 void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
-                       uint8_t *sym, uint32_t *info, int mbw, int mbh);
+                       uint8_t *sym, uint32_t *info, int mbw, int mbh, bool code = true);
 
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
