@@ -36,14 +36,17 @@ __device__ __forceinline__ int classify(int mag) {   // tokenize_block, :263-345
 // block order inside a macroblock as coded (:371-403): [24 if 16x16], 0..15, 16..23; plane context ctx1
 __device__ __forceinline__ int plane_ctx(int b, bool has_y2) { return b == 24 ? 1 : (b < 16 ? (has_y2 ? 0 : 3) : 2); }
 
-__global__ __launch_bounds__(256) void k_ent_flags(const int16_t *coeffs, uint8_t *flags, int nblocks) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// (the *_body functions take the workgroup index as an argument: the frame path runs several of them in one launch,
+// kernels_entropy_stage.hip)
+__device__ __forceinline__ void flags_body(int vb, const int16_t *coeffs, uint8_t *flags, int nblocks) {
+    const int i = vb * 256 + threadIdx.x;
     if (i >= nblocks) return;
     const uint4 *p = reinterpret_cast<const uint4 *>(coeffs + (size_t)i * 16);
     const uint4 a = p[0], b = p[1];
     const uint32_t rest = (a.x & 0xffff0000u) | a.y | a.z | a.w | b.x | b.y | b.z | b.w;
     flags[i] = (uint8_t)(((a.x & 0xffffu) | rest ? 1 : 0) | (rest ? 2 : 0));   // bit0: any coefficient, bit1: any past the first
 }
+__global__ __launch_bounds__(256) void k_ent_flags(const int16_t *coeffs, uint8_t *flags, int nblocks) { flags_body(blockIdx.x, coeffs, flags, nblocks); }
 
 // third context of block b of macroblock mb (count_probs, :560-760)
 __device__ __forceinline__ int third_context(const uint8_t *flags, const int32_t *parts, int mb, int b, int mb_row, int mb_col,
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const 
 // every partition's denominator starts at 1 (:552)
 // 16 contexts per workgroup, 16 lanes per context over the partial histograms
 // defaults (may be null): the format's default probabilities, taken for contexts that never occurred (vp8enc.cpp:69-76)
-__global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int mbh,
-                                                   int num_partitions, const uint8_t *defaults) {
-    const int lane = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);   // NCTX is a multiple of 16
+__device__ __forceinline__ void probs_body(int vb, const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int mbh,
+                                           int num_partitions, const uint8_t *defaults) {
+    const int lane = threadIdx.x & 15, i = vb * 16 + (threadIdx.x >> 4);   // NCTX is a multiple of 16
     uint32_t num = 0, den = 0, den0 = 0;
     for (int h = lane; h < mbh * CNT_SPLIT; h += 16) {
         const uint2 c = *reinterpret_cast<const uint2 *>(counts + ((size_t)h * NCTX + i) * 2);
@@ -161,6 +164,10 @@ __global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint3
         probs[i] = (defaults && den0 + 1u < 2u) ? (uint32_t)defaults[i] : (num > 255u ? 255u : (num == 0u ? 1u : num));
         denom0[i] = den0 + 1u;
     }
+}
+__global__ __launch_bounds__(256) void k_ent_probs(const uint32_t *counts, uint32_t *probs, uint32_t *denom0, int mbh,
+                                                   int num_partitions, const uint8_t *defaults) {
+    probs_body(blockIdx.x, counts, probs, denom0, mbh, num_partitions, defaults);
 }
 
 }  // namespace ent
@@ -374,6 +381,118 @@ __global__ __launch_bounds__(256) void k_ent_emit(const int16_t *coeffs, const i
     walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), third_ctx[mb * 25 + b], sink);
 }
 
+// ---- the same three steps for the frame path, in SLOT order (slot = position in coding order through the partitions), so
+// that the prefix sums need no pass of their own: counts + per-workgroup sums, one workgroup scans the sums and lays
+// out the plan, the emit kernel scans its own 256 counts -----------------------------------------------------------
+__device__ __forceinline__ bool slot_to_block(const Geom &g, uint32_t s, int &mb, int &k) {
+    if (s >= g.slot_base[g.P]) return false;
+    int p = 0;
+    while (p + 1 < g.P && s >= g.slot_base[p + 1]) ++p;
+    const uint32_t local = s - g.slot_base[p], per_row = (uint32_t)g.mbw * 25u;
+    const uint32_t r = local / per_row, rem = local % per_row;
+    mb = (int)((r * (uint32_t)g.P + (uint32_t)p) * (uint32_t)g.mbw + rem / 25u);
+    k = (int)(rem % 25u);
+    return true;
+}
+// exclusive scan over the 256 threads of a workgroup (s_w: 4 words of LDS); total = sum over the workgroup
+__device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *s_w, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();   // s_w may still be read from an earlier call
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return base + x - v;
+}
+__device__ __forceinline__ void boolcount_slots_body(int vb, const int16_t *coeffs, const int32_t *nzc, const int32_t *parts, const Geom &g,
+                                                     uint32_t *cnt, uint32_t *tile_sum) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t s = (uint32_t)vb * 256u + threadIdx.x;
+    int mb, k;
+    CountSink sink;
+    if (slot_to_block(g, s, mb, k)) {
+        bool has_y2;
+        const int b = block_of_k(k);
+        if (slot_live(nzc, parts, mb, k, has_y2)) walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), 0, sink);
+        cnt[s] = sink.n;
+    }
+    uint32_t total;
+    wg_scan256(sink.n, s_w, total);
+    if (threadIdx.x == 0) tile_sum[vb] = total;
+}
+// one workgroup: exclusive scan of the ntiles (<= 4096) workgroup sums in place, then the plan
+__device__ __forceinline__ void scan_plan_body(const uint32_t *cnt, uint32_t *tile_sum, int ntiles, const Geom &g, Plan *plan) {
+    __shared__ uint32_t s_w[4], s_off[ENT_MAX_PARTITIONS + 1];
+    const int t = threadIdx.x, per = (ntiles + 255) / 256, i0 = t * per;
+    uint32_t a = 0;
+    for (int j = 0; j < per; ++j) a += i0 + j < ntiles ? tile_sum[i0 + j] : 0u;
+    uint32_t total;
+    uint32_t run = wg_scan256(a, s_w, total);
+    for (int j = 0; j < per && i0 + j < ntiles; ++j) {
+        const uint32_t x = tile_sum[i0 + j];
+        tile_sum[i0 + j] = run;
+        run += x;
+    }
+    __syncthreads();
+    if (t <= g.P) {   // bools before the first slot of partition t
+        const uint32_t sb = g.slot_base[t], tile = sb >> 8;
+        uint32_t o = total;
+        if ((int)tile < ntiles) {
+            o = tile_sum[tile];
+            for (uint32_t i = tile << 8; i < sb; ++i) o += cnt[i];
+        }
+        s_off[t] = o;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    uint32_t cb = 0, wb = 0;
+    for (int p = 0; p < g.P; ++p) {
+        const uint32_t b0 = s_off[p], b1 = s_off[p + 1];
+        plan->bool_base[p] = b0;
+        plan->nbools[p] = b1 - b0;
+        plan->chunk_base[p] = cb;
+        plan->word_base[p] = wb;
+        cb += (b1 - b0 + CHUNK - 1) / CHUNK;
+        wb += ((b1 - b0) * 7 + 31) / 32 + 4;      // a bool shifts at most 7 bits out; + the flush
+    }
+    plan->bool_base[g.P] = s_off[g.P];
+    plan->chunk_base[g.P] = cb;
+    plan->word_base[g.P] = wb;
+    plan->total_chunks = cb;
+    plan->overflow = (s_off[g.P] > g.cap_bools || cb > g.cap_chunks || wb > g.cap_words) ? 1u : 0u;
+    if (plan->overflow) {   // the later kernels then see empty partitions and touch nothing outside the scratch
+        plan->total_chunks = 0;
+        for (int p = 0; p <= g.P; ++p) plan->bool_base[p] = plan->chunk_base[p] = plan->word_base[p] = 0;
+        for (int p = 0; p < g.P; ++p) plan->nbools[p] = 0;
+    }
+}
+__device__ __forceinline__ void emit_slots_body(int vb, int nvb, const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
+                                                const uint8_t *third_ctx, const uint32_t *probs, const uint32_t *cnt,
+                                                const uint32_t *tile_pre, const Plan *plan, const Geom &g, uint16_t *bools,
+                                                unsigned long long *acc) {
+    __shared__ uint32_t s_w[4];
+    for (uint32_t i = (uint32_t)vb * 256u + threadIdx.x, n = plan->word_base[g.P]; i < n; i += (uint32_t)nvb * 256u) acc[i] = 0ull;   // the coder's accumulators
+    if (plan->overflow) return;
+    const uint32_t s = (uint32_t)vb * 256u + threadIdx.x;
+    int mb = 0, k = 0;
+    const bool valid = slot_to_block(g, s, mb, k);
+    const uint32_t n = valid ? cnt[s] : 0u;
+    uint32_t total;
+    const uint32_t off = tile_pre[vb] + wg_scan256(n, s_w, total);
+    if (!n) return;   // dead slot (a live one has at least its end-of-block)
+    const int b = block_of_k(k);
+    const bool has_y2 = parts[mb] == 0;
+    EmitSink sink{bools + off, probs};
+    walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), third_ctx[mb * 25 + b], sink);
+}
+
 // chunk -> its partition and its slice of the bool string
 __device__ __forceinline__ void chunk_slice(const Plan *plan, int P, uint32_t chunk, int &p, uint32_t &b0, int &n) {
     p = 0;
@@ -405,7 +524,11 @@ struct CodeJob {
     int32_t *sizes;
     int P;
 };
-struct CodeJobs { CodeJob j[2]; };
+struct CodeJobs {
+    CodeJob j[2];
+    uint8_t *frame;            // not null: j[0] = coefficient partitions, j[1] = first partition, and k_ent_finish lays the
+    uint32_t head, capacity;   // finished frame out at frame + 16 (gather_frame, src/encIO.h:1-30); see k_ent_finish
+};
 
 constexpr int SUP = 8;   // chunks per super-chunk (never across a partition boundary)
 
@@ -592,6 +715,28 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void k_ent_finish(CodeJobs jobs) {
     const uint32_t nb = plan->nbytes[p], nw = (nb + 3) / 4;
     const unsigned long long *in = J.acc + plan->word_base[p];
     uint8_t *out = J.bytes + (size_t)plan->word_base[p] * 4;
+    if (jobs.frame) {
+        // gather_frame on the fly: `head` bytes left for the host, first partition, the 3-byte sizes of all coefficient
+        // partitions but the last, the partitions.  frame[0] = frame size (0 = a coder overflowed its scratch or the
+        // frame does not fit), frame[1] = size of the first partition; the sizes are known since k_ent_walk.
+        const Plan *pc = jobs.j[0].plan, *ph = jobs.j[1].plan;
+        const int P = jobs.j[0].P;
+        const uint32_t table = jobs.head + ph->nbytes[0];
+        uint32_t o = table + 3u * (uint32_t)(P - 1), mine = jobs.head;
+        for (int q = 0; q < P; ++q) {
+            if (blockIdx.y == 0 && q == p) mine = o;
+            o += pc->nbytes[q];
+        }
+        const bool ok = !(pc->overflow || ph->overflow || o > jobs.capacity);
+        if (blockIdx.y == 1 && threadIdx.x == 0) {
+            reinterpret_cast<uint32_t *>(jobs.frame)[0] = ok ? o : 0u;
+            reinterpret_cast<uint32_t *>(jobs.frame)[1] = ph->nbytes[0];
+        }
+        if (!ok) return;
+        if (blockIdx.y == 1 && threadIdx.x < 3u * (uint32_t)(P - 1))
+            jobs.frame[16 + table + threadIdx.x] = (uint8_t)(pc->nbytes[threadIdx.x / 3] >> (8 * (threadIdx.x % 3)));
+        out = jobs.frame + 16 + mine;
+    }
     uint32_t C = 0;   // carry into the least significant word of the step
     int par = 0;
     for (int hi_end = (int)nw; hi_end > 0; hi_end -= 64 * FIN_WAVES, par ^= 1) {
@@ -653,55 +798,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(uint32_t *v, int n) {
     if (t == 1023) v[n] = s[1023];
 }
 
-// gather_frame (src/encIO.h:1-30) on the device: first partition, the 3-byte sizes of all coefficient partitions but
-// the last, the partitions -- contiguous behind a 16-byte slot whose first word receives the frame size (0 = one of
-// the two coders overflowed its scratch).  `head` bytes (the uncompressed chunk) are left for the host to fill in.
-__global__ __launch_bounds__(256) void k_frame_gather(const Plan *pc, const Plan *ph, const uint8_t *hdr_bytes, const uint8_t *ent_bytes, int P,
-                                                      uint32_t head, uint32_t capacity, uint8_t *out) {
-    __shared__ uint32_t s_off[ENT_MAX_PARTITIONS + 3];   // start of: first partition, size table, partitions 0..P-1; [P+2] = end
-    __shared__ uint32_t s_ok;
-    if (threadIdx.x == 0) {
-        uint32_t o = head;
-        s_off[0] = o;
-        o += ph->nbytes[0];
-        s_off[1] = o;
-        o += 3u * (uint32_t)(P - 1);
-        for (int q = 0; q < P; ++q) {
-            s_off[2 + q] = o;
-            o += pc->nbytes[q];
-        }
-        s_off[2 + P] = o;
-        s_ok = !(pc->overflow || ph->overflow || o > capacity);
-        if (blockIdx.x == 0) {
-            reinterpret_cast<uint32_t *>(out)[0] = s_ok ? o : 0u;
-            reinterpret_cast<uint32_t *>(out)[1] = ph->nbytes[0];
-        }
-    }
-    __syncthreads();
-    if (!s_ok) return;
-    uint8_t *frame = out + 16;
-    const uint32_t total = s_off[2 + P];
-    for (uint32_t i = head + blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        uint8_t b;
-        if (i < s_off[1]) {
-            b = hdr_bytes[i - s_off[0]];
-        } else if (i < s_off[2]) {
-            const uint32_t k = i - s_off[1];
-            b = (uint8_t)(pc->nbytes[k / 3] >> (8 * (k % 3)));
-        } else {
-            int q = 0;
-            while (q + 1 < P && i >= s_off[3 + q]) ++q;
-            b = ent_bytes[(size_t)pc->word_base[q] * 4 + (i - s_off[2 + q])];
-        }
-        frame[i] = b;
-    }
-}
-
 }  // namespace ent
-
-void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out) {
-    hipLaunchKernelGGL(ent::k_frame_gather, dim3(128), dim3(256), 0, s, coef.plan, hdr.plan, hdr.bytes, coef.bytes, P, head, capacity, out);
-}
 
 // exclusive prefix sum of v[0..n) in place, total in v[n]; n <= 1024 * 1024
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n) {
@@ -738,19 +835,21 @@ static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs) {
     hipLaunchKernelGGL(ent::k_ent_finish, dim3(maxP, njobs), dim3(64 * ent::FIN_WAVES), 0, s, jobs);
 }
 void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
-    ent::CodeJobs jobs;
+    ent::CodeJobs jobs{};
     jobs.j[0] = jobs.j[1] = code_job(eb, P);
     bool_code(s, jobs, 1);
 }
-void launch_bool_code2(hipStream_t s, const EntBuffers &a, int Pa, const EntBuffers &b, int Pb) {
-    ent::CodeJobs jobs;
-    jobs.j[0] = code_job(a, Pa);
-    jobs.j[1] = code_job(b, Pb);
+void launch_frame_code(hipStream_t s, const EntBuffers &coef, int P, const EntBuffers &hdr, uint32_t head, uint32_t capacity, uint8_t *frame) {
+    ent::CodeJobs jobs{};
+    jobs.j[0] = code_job(coef, P);
+    jobs.j[1] = code_job(hdr, 1);
+    jobs.frame = frame;
+    jobs.head = head;
+    jobs.capacity = capacity;
     bool_code(s, jobs, 2);
 }
 
-void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
-                       int mbw, int mbh, int P, bool code) {
+static ent::Geom make_geom(const EntBuffers &eb, int mbw, int mbh, int P) {
     ent::Geom g;
     g.mbw = mbw;
     g.mbh = mbh;
@@ -763,6 +862,12 @@ void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, 
     g.cap_bools = eb.cap_bools;
     g.cap_chunks = eb.cap_chunks;
     g.cap_words = eb.cap_words;
+    return g;
+}
+
+void launch_ent_encode(hipStream_t s, const MBOut &o, const uint8_t *third_ctx, const uint32_t *probs, const EntBuffers &eb,
+                       int mbw, int mbh, int P, bool code) {
+    const ent::Geom g = make_geom(eb, mbw, mbh, P);
     const int nslots = mbw * mbh * 25;
     EntPlan *plan = eb.plan;
     hipLaunchKernelGGL(ent::k_ent_boolcount, dim3((nslots + 255) / 256), dim3(256), 0, s, o.coeffs, o.nz, o.parts, g, eb.offs);

@@ -1,0 +1,140 @@
+// kernels_entropy_stage.hip -- the whole entropy stage of a frame (entropy_encode + gather_frame, src/vp8enc.cpp:48-94,
+// src/encIO.h:1-30) in NINE launches instead of the twenty-one its steps take one by one.
+//
+// On this part a frame's entropy stage is bound by the number of kernels it takes, not by their work: every launch is a
+// packet for the command processor and a link in a dependency chain ("Complete frames out").  So steps
+// that do not depend on each other share a launch (the workgroup index picks the step), the prefix sums ride along in
+// the kernels on either side of them, and the last kernel of the coder writes the finished frame:
+//   1  k_fe_first   bools per macroblock header + census | bools per coefficient block + per-workgroup sums | block flags
+//   2  k_ent_count  token histogram (needs every flag)
+//   3  k_fe_mid     coefficient probabilities | scan of the workgroup sums + layout of the partitions
+//   4  k_hdr_frame  frame header bools (needs the probabilities) + layout of the first partition
+//   5  k_fe_emit    macroblock header bools | coefficient bools, each workgroup scanning its own 256 counts
+//   6..9            the boolean coder on both strings at once (kernels_ent.hip), its last kernel writing the frame.
+// Both halves live in this one translation unit for that; each still has its step-by-step launchers (vp8hip_count_probs,
+// vp8hip_encode_coefficients, vp8hip_encode_header) on kernels of their own, which the parity tests compare with.
+#include "kernels_ent.hip"
+#include "kernels_hdr.hip"
+
+namespace vp8 {
+namespace fe {
+
+struct FirstArgs {
+    const int16_t *coeffs;
+    const int32_t *nzc, *parts;
+    uint8_t *flags;
+    int nblocks;
+    ent::Geom g;
+    uint32_t *cnt, *tile_sum;
+    hdr::Params h;
+    uint32_t *hcnt, *hpartial;
+    int nb_hdr, nb_slots;
+};
+__global__ __launch_bounds__(256) void k_fe_first(FirstArgs a) {
+    int vb = blockIdx.x;   // the longest-running step first
+    if (vb < a.nb_hdr) { hdr::hdr_count_body(vb, a.h, a.hcnt, a.hpartial); return; }
+    vb -= a.nb_hdr;
+    if (vb < a.nb_slots) { ent::boolcount_slots_body(vb, a.coeffs, a.nzc, a.parts, a.g, a.cnt, a.tile_sum); return; }
+    ent::flags_body(vb - a.nb_slots, a.coeffs, a.flags, a.nblocks);
+}
+
+struct MidArgs {
+    const uint32_t *counts;
+    uint32_t *probs, *denom0;
+    int mbh, P;
+    const uint8_t *defaults;
+    const uint32_t *cnt;
+    uint32_t *tile_sum;
+    int ntiles;
+    ent::Geom g;
+    EntPlan *plan;
+};
+__global__ __launch_bounds__(256) void k_fe_mid(MidArgs a) {
+    if (blockIdx.x == 0) ent::scan_plan_body(a.cnt, a.tile_sum, a.ntiles, a.g, a.plan);
+    else ent::probs_body((int)blockIdx.x - 1, a.counts, a.probs, a.denom0, a.mbh, a.P, a.defaults);
+}
+
+struct EmitArgs {
+    const int16_t *coeffs;
+    const int32_t *nzc, *parts;
+    const uint8_t *third_ctx;
+    const uint32_t *probs, *cnt, *tile_pre;
+    const EntPlan *plan;
+    ent::Geom g;
+    uint16_t *bools;
+    unsigned long long *acc;
+    hdr::Params h;
+    const uint32_t *hoffs, *hinfo;
+    const uint8_t *hsym;
+    const EntPlan *hplan;
+    uint16_t *hbools;
+    unsigned long long *hacc;
+    int nb_hdr, nb_slots;
+};
+__global__ __launch_bounds__(256) void k_fe_emit(EmitArgs a) {
+    const int vb = blockIdx.x;
+    if (vb < a.nb_hdr) hdr::hdr_emit_body(vb, a.nb_hdr, a.h, a.hoffs, a.hsym, a.hplan, a.hinfo, a.hbools, a.hacc);
+    else ent::emit_slots_body(vb - a.nb_hdr, a.nb_slots, a.coeffs, a.nzc, a.parts, a.third_ctx, a.probs, a.cnt, a.tile_pre, a.plan, a.g,
+                              a.bools, a.acc);
+}
+
+}  // namespace fe
+
+// steps 1-3: everything up to the probabilities and the layout of the coefficient partitions
+void launch_fe_count(hipStream_t s, const FrameEntropy &e) {
+    const EntBuffers &c = *e.coef, &h = *e.hdr;
+    const int mbs = e.mbw * e.mbh, nblocks = mbs * 25;
+    const ent::Geom g = make_geom(c, e.mbw, e.mbh, e.P);
+    const hdr::Params hp = make_hdr_params(e.o, e.is_inter, e.modes, e.f, e.d_sd, e.strength, e.probs, e.denom0, h, e.mbw, e.mbh);
+    fe::FirstArgs a;
+    a.coeffs = e.o.coeffs; a.nzc = e.o.nz; a.parts = e.o.parts;
+    a.flags = e.flags;
+    a.nblocks = nblocks;
+    a.g = g;
+    a.cnt = c.offs; a.tile_sum = c.tile_sum;
+    a.h = hp;
+    a.hcnt = h.offs; a.hpartial = e.hdr_partial;
+    a.nb_hdr = (mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    a.nb_slots = (nblocks + 255) / 256;
+    hipLaunchKernelGGL(fe::k_fe_first, dim3(a.nb_hdr + a.nb_slots + (nblocks + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ent::k_ent_count, dim3(e.mbh, ent::CNT_SPLIT), dim3(256), 0, s, e.o.coeffs, e.o.nz, e.o.parts, e.flags, e.third,
+                       e.counts, e.mbw);
+    fe::MidArgs m;
+    m.counts = e.counts; m.probs = e.probs; m.denom0 = e.denom0;
+    m.mbh = e.mbh; m.P = e.P;
+    m.defaults = hdr_default_coeff_probs();   // the fallback for contexts that never occurred (vp8enc.cpp:69-76) rides along
+    m.cnt = c.offs; m.tile_sum = c.tile_sum;
+    m.ntiles = a.nb_slots;
+    m.g = g;
+    m.plan = c.plan;
+    hipLaunchKernelGGL(fe::k_fe_mid, dim3(1 + ent::NCTX / 16), dim3(256), 0, s, m);
+    if (!m.defaults) launch_default_probs(s, e.probs, e.denom0);
+}
+
+// steps 4-5: the two bool strings
+void launch_fe_emit(hipStream_t s, const FrameEntropy &e) {
+    const EntBuffers &c = *e.coef, &h = *e.hdr;
+    const int mbs = e.mbw * e.mbh, nblocks = mbs * 25;
+    const hdr::Params hp = make_hdr_params(e.o, e.is_inter, e.modes, e.f, e.d_sd, e.strength, e.probs, e.denom0, h, e.mbw, e.mbh);
+    const int nb_hdr = (mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, hp, e.hdr_partial, nb_hdr, h.offs, h.bools, e.hdr_sym, h.plan, e.hdr_info);
+    fe::EmitArgs a;
+    a.coeffs = e.o.coeffs; a.nzc = e.o.nz; a.parts = e.o.parts;
+    a.third_ctx = e.third;
+    a.probs = e.probs; a.cnt = c.offs; a.tile_pre = c.tile_sum;
+    a.plan = c.plan;
+    a.g = make_geom(c, e.mbw, e.mbh, e.P);
+    a.bools = c.bools;
+    a.acc = reinterpret_cast<unsigned long long *>(c.acc);
+    a.h = hp;
+    a.hoffs = h.offs; a.hinfo = e.hdr_info;
+    a.hsym = e.hdr_sym;
+    a.hplan = h.plan;
+    a.hbools = h.bools;
+    a.hacc = reinterpret_cast<unsigned long long *>(h.acc);
+    a.nb_hdr = nb_hdr;
+    a.nb_slots = (nblocks + 255) / 256;
+    hipLaunchKernelGGL(fe::k_fe_emit, dim3(a.nb_hdr + a.nb_slots), dim3(256), 0, s, a);
+}
+
+}  // namespace vp8

@@ -72,14 +72,14 @@ struct Params {
     uint32_t cap_bools, cap_chunks, cap_words;
 };
 
-__global__ __launch_bounds__(256) void k_hdr_count(Params a, uint32_t *cnt, uint32_t *partial) {
+__device__ __forceinline__ void hdr_count_body(int vb, const Params &a, uint32_t *cnt, uint32_t *partial) {
     __shared__ uint32_t s_stat[NSTAT];
     for (int i = threadIdx.x; i < NSTAT; i += 256) s_stat[i] = 0;
     __syncthreads();
     // Every macroblock takes its own path through the header template, so the lanes of a wavefront serialise; with one
     // macroblock per FOUR lanes a wavefront walks 16 paths instead of 64 and the frame spreads over four times as
     // many SIMDs (104 -> ~30 us at 1080p).
-    const int mb = blockIdx.x * HDR_MB_PER_WG + (threadIdx.x >> 2);
+    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x >> 2);
     if ((threadIdx.x & 3) == 0 && mb < a.mbs) {
         CountSink s;
         s.stat = s_stat;
@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_hdr_count(Params a, uint32_t *cnt, uint
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NSTAT; i += 256) partial[blockIdx.x * NSTAT + i] = s_stat[i];
+    for (int i = threadIdx.x; i < NSTAT; i += 256) partial[vb * NSTAT + i] = s_stat[i];
 }
+__global__ __launch_bounds__(256) void k_hdr_count(Params a, uint32_t *cnt, uint32_t *partial) { hdr_count_body(blockIdx.x, a, cnt, partial); }
 
 // frame-level bool writer of one lane
 struct Lane {
@@ -290,16 +291,20 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *par
     if (t < 64) sym_out[t] = s_sym[t];
 }
 
-__global__ __launch_bounds__(256) void k_hdr_emit(Params a, const uint32_t *offs, const uint8_t *sym, const EntPlan *plan, const uint32_t *info,
-                                                  uint16_t *bools, unsigned long long *acc) {
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x, n = plan->word_base[1]; i < n; i += gridDim.x * 256) acc[i] = 0ull;   // the coder's accumulators
+__device__ __forceinline__ void hdr_emit_body(int vb, int nvb, const Params &a, const uint32_t *offs, const uint8_t *sym, const EntPlan *plan,
+                                              const uint32_t *info, uint16_t *bools, unsigned long long *acc) {
+    for (uint32_t i = vb * 256 + threadIdx.x, n = plan->word_base[1]; i < n; i += nvb * 256) acc[i] = 0ull;   // the coder's accumulators
     __shared__ uint8_t s_sym[64];
     if (threadIdx.x < 64) s_sym[threadIdx.x] = sym[threadIdx.x];
     __syncthreads();
-    const int mb = blockIdx.x * HDR_MB_PER_WG + (threadIdx.x >> 2);
+    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x >> 2);
     if ((threadIdx.x & 3) != 0 || mb >= a.mbs || plan->overflow) return;
     EmitSink s{bools + info[0] + offs[mb], s_sym};
     mb_header(a.v, mb, a.key != 0, k_kf_bmode_probs, s);
+}
+__global__ __launch_bounds__(256) void k_hdr_emit(Params a, const uint32_t *offs, const uint8_t *sym, const EntPlan *plan, const uint32_t *info,
+                                                  uint16_t *bools, unsigned long long *acc) {
+    hdr_emit_body(blockIdx.x, gridDim.x, a, offs, sym, plan, info, bools, acc);
 }
 
 // vp8enc.cpp:69-76 on the device: contexts that never occurred take the default probability
@@ -323,9 +328,27 @@ void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0
     hipLaunchKernelGGL(hdr::k_default_probs, dim3((ENT_NCTX + 255) / 256), dim3(256), 0, s, probs, denom0);
 }
 
+static hdr::Params make_hdr_params_impl(const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
+                                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, int mbw, int mbh);
+static inline hdr::Params make_hdr_params(const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
+                                          const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, int mbw, int mbh) {
+    return make_hdr_params_impl(o, is_inter, modes, f, d_sd, strength, probs, denom0, eb, mbw, mbh);
+}
+
 void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
                        uint8_t *sym, uint32_t *info, int mbw, int mbh, bool code) {
+    const hdr::Params a = make_hdr_params(o, is_inter, modes, f, d_sd, strength, probs, denom0, eb, mbw, mbh);
+    const int nwg = (a.mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    hipLaunchKernelGGL(hdr::k_hdr_count, dim3(nwg), dim3(256), 0, s, a, eb.offs, partial);
+    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs, eb.bools, sym, eb.plan, info);
+    hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
+                       reinterpret_cast<unsigned long long *>(eb.acc));
+    if (code) launch_bool_code(s, eb, 1);
+}
+
+static hdr::Params make_hdr_params_impl(const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
+                                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, int mbw, int mbh) {
     hdr::Params a;
     a.v.seg_ = o.seg; a.v.nz_ = o.nz; a.v.ref_ = o.ref; a.v.parts_ = o.parts; a.v.is_inter_ = is_inter; a.v.modes_ = modes;
     a.v.vec_ = o.vec;
@@ -344,12 +367,7 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
     a.cap_bools = eb.cap_bools;
     a.cap_chunks = eb.cap_chunks;
     a.cap_words = eb.cap_words;
-    const int nwg = (a.mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
-    hipLaunchKernelGGL(hdr::k_hdr_count, dim3(nwg), dim3(256), 0, s, a, eb.offs, partial);
-    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs, eb.bools, sym, eb.plan, info);
-    hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
-                       reinterpret_cast<unsigned long long *>(eb.acc));
-    if (code) launch_bool_code(s, eb, 1);
+    return a;
 }
 
 }  // namespace vp8

@@ -692,7 +692,7 @@ static int ent_alloc(vp8hip_ctx *c) {
     e.cap_chunks = e.cap_bools / 256 + 2 * ENT_MAX_PARTITIONS;
     e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 8 * ENT_MAX_PARTITIONS);
     HIPCHK(c, hipMalloc(&e.offs, (nslots + 1) * 4));
-    HIPCHK(c, hipMalloc(&e.tile_sum, (nslots / 1024 + 8) * 4));
+    HIPCHK(c, hipMalloc(&e.tile_sum, (nslots / 256 + 8) * 4));   // the frame path sums per 256 slots
     HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
     HIPCHK(c, hipMalloc(&e.maps, ent_maps_entries(e.cap_chunks) * 4));
     HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
@@ -819,42 +819,52 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     if (rc) return rc;
     if ((rc = hdr_alloc(c))) return rc;
     hipStream_t s = c->stream;
-    {   // count_probs + num_div_denom, the default-probability fallback (vp8enc.cpp:58-76), encode_coefficients (:77-81)
-        Timed t(c, VP8HIP_K_ENT_COUNT);
-        const uint8_t *defaults = hdr_default_coeff_probs();   // the fallback rides along in num_div_denom's kernel
-        launch_ent_count(s, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw, c->mbh, P, defaults);
-        if (!defaults) launch_default_probs(s, c->ent_probs, c->ent_denom0);
-    }
-    c->ent_counted_partitions = P;
-    {
-        Timed t(c, VP8HIP_K_ENT_ENCODE);
-        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, P, false);   // bool strings only
-    }
-    HdrFrame f;
-    f.is_key = p->is_key ? 1 : 0;
-    f.is_golden = p->is_golden ? 1 : 0;
-    f.is_altref = p->is_altref ? 1 : 0;
-    f.loop_filter_type = p->loop_filter_type;
-    f.sharpness = p->loop_filter_sharpness;
-    f.partitions_log2 = P == 8 ? 3 : (P == 4 ? 2 : (P == 2 ? 1 : 0));
-    const bool intra_info = p->is_key || p->use_intra_info;
-    {   // encode_header (:84)
-        Timed t(c, VP8HIP_K_HDR_ENCODE);
-        launch_hdr_encode(s, c->out, (!p->is_key && p->use_intra_info) ? c->intra_is_inter : nullptr, intra_info ? c->intra_modes : nullptr, f,
-                          c->d_sd, reinterpret_cast<const int32_t *>(c->d_stats + 4), c->ent_probs, c->ent_denom0, c->hdr, c->hdr_partial,
-                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh, false);
-        launch_bool_code2(s, c->ent, P, c->hdr, 1);   // the coefficient partitions and the first partition through the coder together
-    }
-    HIPCHK(c, hipGetLastError());
-    // gather_frame (encIO.h:1-30) on the device, then ONE read-back through pinned memory: the frame size and the
-    // first FRAME_FIRST_COPY bytes travel together; only a frame larger than that needs a second copy.
-    if (!c->h_frame) {
+    if (!c->h_frame) {   // the finished frame: device copy + pinned host copy
         c->h_frame_cap = (size_t)c->hdr.cap_words * 4 + (size_t)c->ent.cap_words * 4 + 64;
         HIPCHK(c, hipHostMalloc(&c->h_frame, c->h_frame_cap));
         HIPCHK(c, hipMalloc(&c->d_frame, c->h_frame_cap));
     }
+    FrameEntropy e;
+    e.o = c->out;
+    e.flags = c->ent_flags;
+    e.third = c->ent_third;
+    e.counts = c->ent_counts;
+    e.probs = c->ent_probs;
+    e.denom0 = c->ent_denom0;
+    e.coef = &c->ent;
+    e.hdr = &c->hdr;
+    e.hdr_partial = c->hdr_partial;
+    e.hdr_info = c->hdr_info;
+    e.hdr_sym = c->hdr_sym;
+    const bool intra_info = p->is_key || p->use_intra_info;
+    e.is_inter = (!p->is_key && p->use_intra_info) ? c->intra_is_inter : nullptr;
+    e.modes = intra_info ? c->intra_modes : nullptr;
+    e.f.is_key = p->is_key ? 1 : 0;
+    e.f.is_golden = p->is_golden ? 1 : 0;
+    e.f.is_altref = p->is_altref ? 1 : 0;
+    e.f.loop_filter_type = p->loop_filter_type;
+    e.f.sharpness = p->loop_filter_sharpness;
+    e.f.partitions_log2 = P == 8 ? 3 : (P == 4 ? 2 : (P == 2 ? 1 : 0));
+    e.d_sd = c->d_sd;
+    e.strength = reinterpret_cast<const int32_t *>(c->d_stats + 4);
+    e.mbw = c->mbw;
+    e.mbh = c->mbh;
+    e.P = P;
     const size_t head = p->is_key ? 10 : 3;
-    launch_frame_gather(s, c->ent, c->hdr, P, (uint32_t)head, (uint32_t)(c->h_frame_cap - 16), c->d_frame);
+    {   // count_probs + num_div_denom + the default-probability fallback (vp8enc.cpp:58-76), bools per block and per macroblock header
+        Timed t(c, VP8HIP_K_ENT_COUNT);
+        launch_fe_count(s, e);
+    }
+    c->ent_counted_partitions = P;
+    {   // encode_header's bools (:84) and encode_coefficients' (:77-81)
+        Timed t(c, VP8HIP_K_HDR_ENCODE);
+        launch_fe_emit(s, e);
+    }
+    {   // the boolean coder on both strings; its last kernel is gather_frame (encIO.h:1-30).  Then ONE read-back through
+        // pinned memory: the frame size and the first FRAME_FIRST_COPY bytes travel together; only a larger frame needs a second copy
+        Timed t(c, VP8HIP_K_ENT_ENCODE);
+        launch_frame_code(s, c->ent, P, c->hdr, (uint32_t)head, (uint32_t)(c->h_frame_cap - 16), c->d_frame);
+    }
     HIPCHK(c, hipGetLastError());
     const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));

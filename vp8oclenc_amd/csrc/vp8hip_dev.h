@@ -101,10 +101,10 @@ void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n
 // the coder on bool strings laid out per eb.plan (accumulators cleared by the emit kernel); eb.maps holds
 // cap_chunks chunk maps followed by the super-chunk maps (ent_maps_entries)
 void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P);
-void launch_bool_code2(hipStream_t s, const EntBuffers &a, int Pa, const EntBuffers &b, int Pb);   // two jobs in the same four launches
+// the coder on the coefficient partitions and the first partition at once, its last kernel laying the finished frame
+// out (gather_frame): frame[0] = frame size (0 = overflow), frame[1] = first-partition size, frame bytes from frame + 16
+void launch_frame_code(hipStream_t s, const EntBuffers &coef, int P, const EntBuffers &hdr, uint32_t head, uint32_t capacity, uint8_t *frame);
 inline size_t ent_maps_entries(uint32_t cap_chunks) { return ((size_t)cap_chunks + cap_chunks / 8 + 2 * ENT_MAX_PARTITIONS) * 128; }
-// gather_frame on the device: out[0] = frame size (0 = overflow), out[1] = first-partition size, frame bytes from out + 16
-void launch_frame_gather(hipStream_t s, const EntBuffers &coef, const EntBuffers &hdr, int P, uint32_t head, uint32_t capacity, uint8_t *out);
 
 // first partition on the device (kernels_hdr.hip): encode_header, src/entropy_host.cpp:709-1256
 struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* < 0: the device's */, partitions_log2; };
@@ -114,6 +114,23 @@ constexpr int HDR_STAT_WORDS = 84;   // per-workgroup partial sums of k_hdr_coun
 void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, const int32_t *modes, const HdrFrame &f, const SegData *d_sd,
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
                        uint8_t *sym, uint32_t *info, int mbw, int mbh, bool code = true);
+
+// the frame path of the entropy stage (kernels_entropy_stage.hip): the same steps sharing launches
+struct FrameEntropy {
+    MBOut o;
+    uint8_t *flags, *third;
+    uint32_t *counts, *probs, *denom0;
+    const EntBuffers *coef, *hdr;    // coef->offs receives bools per slot, coef->tile_sum the sums per 256 slots
+    uint32_t *hdr_partial, *hdr_info;
+    uint8_t *hdr_sym;
+    const int32_t *is_inter, *modes;
+    HdrFrame f;
+    const SegData *d_sd;
+    const int32_t *strength;
+    int mbw, mbh, P;
+};
+void launch_fe_count(hipStream_t s, const FrameEntropy &e);   // counts, probabilities, layout of the coefficient partitions
+void launch_fe_emit(hipStream_t s, const FrameEntropy &e);    // frame header + both bool strings; then launch_frame_code
 
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
