@@ -39,6 +39,8 @@ typedef struct {
     int32_t host_bitstream;  /* vp8drv_get_frame: 0 = the whole entropy stage on the device (vp8hip_encode_frame);
                                 1 = first partition on the host (vp8bs_encode_header) after downloading what it reads,
                                 the way the reference does it -- kept as the cross-check */
+    int32_t overlap_filter;  /* 1: loop filter on its own stream, side by side with the frame's entropy stage
+                                (vp8hip_filter_overlap); for a single video coded frame after frame.  Default 0 */
 } vp8drv_config;
 
 void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0 */

@@ -2,7 +2,7 @@
 // vp8drv, either one host thread per chunk (blocking vp8drv_get_frame) or ONE host thread for all of them
 // (vp8drv_get_frame_begin / _end).  Frames come from a raw I420 file (scripts/native/run_frame_bench.sh writes one
 // from the synthetic sequence the Python benches use).
-//   frame_bench <i420 file> <W> <H> <streams> <frames> <partitions> <mode: threads|pipeline> <bitstream: 0|1> [check_ssim]
+//   frame_bench <i420 file> <W> <H> <streams> <frames> <partitions> <mode: threads|pipeline> <bitstream: 0|1> [check_ssim] [overlap_filter]
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
     const char *path = argv[1];
     const int W = atoi(argv[2]), H = atoi(argv[3]), S = atoi(argv[4]), N = atoi(argv[5]), P = atoi(argv[6]);
     const bool pipeline = !strcmp(argv[7], "pipeline"), emit = atoi(argv[8]) != 0;
-    const int check = argc > 9 ? atoi(argv[9]) : 0;
+    const int check = argc > 9 ? atoi(argv[9]) : 0, overlap = argc > 10 ? atoi(argv[10]) : 0;
     const size_t ysz = (size_t)W * H, csz = ysz / 4, fsz = ysz + 2 * csz;
     FILE *f = fopen(path, "rb");
     if (!f) { perror(path); return 1; }
@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
     cfg.gop_size = 1 << 30;
     cfg.num_partitions = P;
     cfg.check_ssim = check;
+    cfg.overlap_filter = overlap;
     std::vector<vp8drv *> d(S);
     for (int k = 0; k < S; ++k) CK(vp8drv_create(&d[k], W, H, 0, &cfg));
     const size_t cap = (size_t)(W / 16) * (H / 16) * 900 + 65536;

@@ -17,4 +17,4 @@ print("coded size", s.W, s.H)
 PY
 HH=$(( (H + 15) / 16 * 16 ))
 if [ $# -eq 0 ]; then set -- "16 60 8 threads 0" "16 60 8 threads 1" "16 60 8 pipeline 0" "16 60 8 pipeline 1"; fi
-for cfg in "$@"; do set -- $cfg; /tmp/frame_bench /tmp/frames.i420 $W $HH $1 $2 $3 $4 $5 ${6:-0}; done
+for cfg in "$@"; do set -- $cfg; /tmp/frame_bench /tmp/frames.i420 $W $HH $1 $2 $3 $4 $5 ${6:-0} ${7:-0}; done

@@ -202,3 +202,26 @@ def test_get_frame_in_two_halves_across_chunks_equals_get_frame():
     host.close()
     for d in drvs:
         d.close()
+
+
+def test_loop_filter_on_its_own_stream_changes_nothing():
+    """overlap_filter: the filter runs beside the frame's entropy stage; frames and reconstructions stay the same, with and
+    without check_SSIM's fallback, across key frames."""
+    W, H = 320, 192
+    a, b = SynthSequence(W, H, seed=71), SynthSequence(W, H, seed=72)
+    frames = [a.frame(t) for t in range(5)] + [b.frame(t) for t in range(4)]
+    outs = []
+    for overlap in (0, 1):
+        d = api.NativeDriver(W, H, num_partitions=2, check_ssim=1, gop_size=6, qi_min=40, qi_max=100, ssim_target=0.9, overlap_filter=overlap)
+        got = []
+        for y, u, v in frames:
+            d.encode_frame_host(y, u, v)
+            f = d.get_frame()
+            rec = d.hip.download_last()
+            got.append((f, [p.copy() for p in rec]))
+        outs.append(got)
+        d.close()
+    for t, ((f0, r0), (f1, r1)) in enumerate(zip(*outs)):
+        assert f0 == f1, t
+        for p0, p1 in zip(r0, r1):
+            assert np.array_equal(p0, p1), t

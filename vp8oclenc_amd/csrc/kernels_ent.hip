@@ -505,7 +505,7 @@ __device__ __forceinline__ void chunk_slice(const Plan *plan, int P, uint32_t ch
 
 // one step of the coder's range recursion (write_bool, :82-105): returns the shift count
 __device__ __forceinline__ int range_step(uint32_t &r, uint32_t prob, uint32_t bit, uint32_t &split) {
-    split = 1u + (((r - 1u) * prob) >> 8);
+    split = 1u + (__umul24(r - 1u, prob) >> 8);   // both below 256: the full-rate 24-bit multiply
     r = bit ? r - split : split;
     const int s = __clz((int)r) - 24;
     r <<= s;
@@ -555,7 +555,7 @@ __device__ __forceinline__ bool super_slice(const Plan *plan, int P, uint32_t su
 // the eight chunk maps into the super-chunk's map, which is what the serial walk steps through.
 __global__ __launch_bounds__(1024) void k_ent_maps(CodeJobs jobs) {
     const CodeJob &J = jobs.j[blockIdx.y];
-    __shared__ uint16_t s_b[SUP][CHUNK];
+    __shared__ __attribute__((aligned(16))) uint16_t s_b[SUP][CHUNK];
     __shared__ uint32_t s_m[SUP][128];
     const int tid = threadIdx.x, w = tid >> 7, l = tid & 127;
     const Plan *plan = J.plan;
@@ -573,7 +573,18 @@ __global__ __launch_bounds__(1024) void k_ent_maps(CodeJobs jobs) {
         __syncthreads();
         if (w < nc) {
             uint32_t r = 128u + l, S = 0, split;
-            for (int i = 0; i < n; ++i) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(&s_b[w][0]);   // eight bools per LDS read, the next read in flight
+            int i = 0;                                                          // while these eight are stepped through
+            for (; i + 8 <= n; i += 8) {
+                const uint4 q = row[i >> 3];
+                const uint32_t e8[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t e = (e8[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                    S += range_step(r, e & 255u, e >> 8, split);
+                }
+            }
+            for (; i < n; ++i) {
                 const uint32_t e = s_b[w][i];
                 S += range_step(r, e & 255u, e >> 8, split);
             }

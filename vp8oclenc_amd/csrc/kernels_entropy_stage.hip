@@ -117,7 +117,7 @@ void launch_fe_emit(hipStream_t s, const FrameEntropy &e) {
     const int mbs = e.mbw * e.mbh, nblocks = mbs * 25;
     const hdr::Params hp = make_hdr_params(e.o, e.is_inter, e.modes, e.f, e.d_sd, e.strength, e.probs, e.denom0, h, e.mbw, e.mbh);
     const int nb_hdr = (mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
-    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, hp, e.hdr_partial, nb_hdr, h.offs, h.bools, e.hdr_sym, h.plan, e.hdr_info);
+    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, hp, e.hdr_partial, h.offs, h.bools, e.hdr_sym, h.plan, e.hdr_info);
     fe::EmitArgs a;
     a.coeffs = e.o.coeffs; a.nzc = e.o.nz; a.parts = e.o.parts;
     a.third_ctx = e.third;

@@ -25,7 +25,8 @@ namespace hdr {
 
 using namespace vp8hdr;
 
-constexpr int HDR_MB_PER_WG = 64;            // macroblocks per workgroup of 256 threads (one per quad of lanes)
+constexpr int HDR_MB_PER_WG = 16;            // macroblocks per workgroup of 256 threads (one per sixteen lanes)
+constexpr int HDR_LANES_PER_MB = 256 / HDR_MB_PER_WG;
 constexpr int NSTAT = 2 * MV_PROBS * 2 + 8;   // mv num/den + {seg0..3, coded (nz != 0), ref last, ref golden, replaced}
 enum { ST_SEG = 76, ST_CODED = 80, ST_LAST = 81, ST_GF = 82, ST_REPLACED = 83 };
 
@@ -77,10 +78,10 @@ __device__ __forceinline__ void hdr_count_body(int vb, const Params &a, uint32_t
     for (int i = threadIdx.x; i < NSTAT; i += 256) s_stat[i] = 0;
     __syncthreads();
     // Every macroblock takes its own path through the header template, so the lanes of a wavefront serialise; with one
-    // macroblock per FOUR lanes a wavefront walks 16 paths instead of 64 and the frame spreads over four times as
-    // many SIMDs (104 -> ~30 us at 1080p).
-    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x >> 2);
-    if ((threadIdx.x & 3) == 0 && mb < a.mbs) {
+    // macroblock per SIXTEEN lanes a wavefront walks 4 paths instead of 64 and the frame spreads over sixteen times as
+    // many wavefronts (104 us with one per lane, 47 us with one per four lanes at 1080p).
+    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x / HDR_LANES_PER_MB);
+    if ((threadIdx.x % HDR_LANES_PER_MB) == 0 && mb < a.mbs) {
         CountSink s;
         s.stat = s_stat;
         mb_header(a.v, mb, a.key != 0, k_kf_bmode_probs, s);
@@ -95,7 +96,9 @@ __device__ __forceinline__ void hdr_count_body(int vb, const Params &a, uint32_t
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NSTAT; i += 256) partial[vb * NSTAT + i] = s_stat[i];
+    // the frame's totals: one row of NSTAT words, zero at rest (k_hdr_frame clears it after reading)
+    for (int i = threadIdx.x; i < NSTAT; i += 256)
+        if (s_stat[i]) atomicAdd(&partial[i], s_stat[i]);
 }
 __global__ __launch_bounds__(256) void k_hdr_count(Params a, uint32_t *cnt, uint32_t *partial) { hdr_count_body(blockIdx.x, a, cnt, partial); }
 
@@ -119,9 +122,10 @@ struct Lane {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // frame header (encode_header :735-1061).  One workgroup.  cnt: bools per macroblock in, their exclusive prefix sums out.
-__global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *partial, int nparts, uint32_t *cnt, uint16_t *bools,
+__global__ __launch_bounds__(256) void k_hdr_frame(Params a, uint32_t *partial, uint32_t *cnt, uint16_t *bools,
                                                    uint8_t *sym_out, EntPlan *plan, uint32_t *info) {
     __shared__ uint32_t s_tot[NSTAT];
+    __shared__ int32_t s_sd[4 * SD_INTS];   // the segment data, read many times by the one lane that writes the frame-level bools
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_n1, s_total;
     __shared__ uint8_t s_sym[64];
@@ -148,13 +152,16 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *par
         if (t == 255) s_total = s_scan[255];
         __syncthreads();
     }
-    for (int i = t; i < NSTAT; i += 256) s_tot[i] = 0;
-    __syncthreads();
-    for (int i = t; i < nparts * NSTAT; i += 256) atomicAdd(&s_tot[i % NSTAT], partial[i]);   // coalesced reads, LDS adds
+    for (int i = t; i < NSTAT; i += 256) {
+        s_tot[i] = partial[i];
+        partial[i] = 0;   // zero at rest, for the next frame's k_hdr_count
+    }
+    for (int i = t; i < 4 * SD_INTS; i += 256) s_sd[i] = a.sd->v[i];
     __syncthreads();
     const int mbs = a.mbs;
     const bool key = a.key != 0;
-    const int32_t *sd = a.sd->v;
+    const int32_t *sd = s_sd;
+    const int sharpness = a.sharpness >= 0 ? a.sharpness : a.strength[1];
     const int replaced = key ? 0 : (int)s_tot[ST_REPLACED];
     if (t == 0) {
         // ---- the probability table of this frame (what the macroblock headers refer to symbolically) ----
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, const uint32_t *par
         }
         w.flag(a.loop_filter_type);
         w.literal(sd[SD_LOOP_FILTER_LEVEL], 6);
-        w.literal(a.sharpness >= 0 ? a.sharpness : a.strength[1], 3);
+        w.literal(sharpness, 3);
         w.flag(0);
         w.literal(a.partitions_log2, 2);
         w.literal(sd[SD_Y_AC_I], 7);
@@ -297,8 +304,8 @@ __device__ __forceinline__ void hdr_emit_body(int vb, int nvb, const Params &a, 
     __shared__ uint8_t s_sym[64];
     if (threadIdx.x < 64) s_sym[threadIdx.x] = sym[threadIdx.x];
     __syncthreads();
-    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x >> 2);
-    if ((threadIdx.x & 3) != 0 || mb >= a.mbs || plan->overflow) return;
+    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x / HDR_LANES_PER_MB);
+    if ((threadIdx.x % HDR_LANES_PER_MB) != 0 || mb >= a.mbs || plan->overflow) return;
     EmitSink s{bools + info[0] + offs[mb], s_sym};
     mb_header(a.v, mb, a.key != 0, k_kf_bmode_probs, s);
 }
@@ -341,7 +348,7 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
     const hdr::Params a = make_hdr_params(o, is_inter, modes, f, d_sd, strength, probs, denom0, eb, mbw, mbh);
     const int nwg = (a.mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
     hipLaunchKernelGGL(hdr::k_hdr_count, dim3(nwg), dim3(256), 0, s, a, eb.offs, partial);
-    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, nwg, eb.offs, eb.bools, sym, eb.plan, info);
+    hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, eb.offs, eb.bools, sym, eb.plan, info);
     hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
                        reinterpret_cast<unsigned long long *>(eb.acc));
     if (code) launch_bool_code(s, eb, 1);

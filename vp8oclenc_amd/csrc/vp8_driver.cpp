@@ -41,6 +41,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->display_width = 0;
     c->display_height = 0;
     c->host_bitstream = 0;
+    c->overlap_filter = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -54,6 +55,7 @@ int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const
         delete d;
         return rc;
     }
+    if (cfg->overlap_filter) vp8hip_filter_overlap(d->hip, 1);
     d->W = width;
     d->H = height;
     d->mbs = (width / 16) * (height / 16);

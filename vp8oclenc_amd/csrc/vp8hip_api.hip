@@ -60,6 +60,11 @@ struct vp8hip_ctx {
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
+    // loop filter on a stream of its own (vp8hip_filter_overlap): the entropy stage of the same frame reads nothing the
+    // filter writes, so the two run side by side; every other entry point joins the filter first (join_lf)
+    hipStream_t lf_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
+    bool lf_overlap = false, lf_pending = false;
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
     vp8hip_header_params frame_params{};
     int frame_partitions = 0;
@@ -208,6 +213,27 @@ int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMem
 
 extern "C" {
 
+// work enqueued on the context's stream from here on sees the filtered reconstruction
+static int join_lf(vp8hip_ctx *c) {
+    if (!c->lf_pending) return VP8HIP_OK;
+    c->lf_pending = false;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
+    return VP8HIP_OK;
+}
+#define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
+
+int vp8hip_filter_overlap(vp8hip_ctx *c, int on) {
+    if (!c) return VP8HIP_ERR_ARG;
+    JOIN_LF(c);
+    if (on && !c->lf_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->lf_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming));
+    }
+    c->lf_overlap = on != 0;
+    return VP8HIP_OK;
+}
+
 int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, int device_ordinal) {
     if (!out || width < 16 || height < 16 || (width % 16) || (height % 16) || width > 8192 || height > 8192)
         return VP8HIP_ERR_ARG;
@@ -299,6 +325,12 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
 void vp8hip_destroy(vp8hip_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->lf_stream) {
+        hipStreamSynchronize(c->lf_stream);
+        hipStreamDestroy(c->lf_stream);
+        hipEventDestroy(c->ev_fork);
+        hipEventDestroy(c->ev_lf);
+    }
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->ev_created)
         for (int i = 0; i < MAX_EVENTS; ++i) hipEventDestroy(c->ev[i]);
@@ -369,6 +401,7 @@ static void next_current(vp8hip_ctx *c) {
 }
 
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
     int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice);
@@ -379,12 +412,14 @@ int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, con
 }
 
 int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
     return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice);
 }
 
 int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
+    JOIN_LF(c);
     if (!c || !reductor || !sharpness) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     launch_lf_strength(c->stream, c->cur, c->d_stats + 8, c->d_stats);
@@ -407,6 +442,7 @@ int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpn
 }
 
 int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
+    JOIN_LF(c);
     if (!c || !Udiff || !Vdiff) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     *Udiff = *Vdiff = 0;
@@ -423,6 +459,7 @@ int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
 }
 
 int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     int rc = make_last(c, y, u, v, hipMemcpyHostToDevice);
     if (rc) return rc;
@@ -431,11 +468,13 @@ int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const 
 }
 
 int vp8hip_set_last_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     return make_last(c, y, u, v, hipMemcpyDeviceToDevice);
 }
 
 int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
+    JOIN_LF(c);
     if (!c || !sd) return VP8HIP_ERR_ARG;
     // staged through a ring of pinned slots so the call neither keeps the caller's pointer nor stalls
     // the stream (176 bytes per frame; 16 slots cover any realistic number of frames in flight)
@@ -446,6 +485,7 @@ int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
 }
 
 int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4], int qi_min) {
+    JOIN_LF(c);
     if (!c || !refqi) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, c->d_sd, reinterpret_cast<int32_t *>(c->d_stats + 4),
@@ -466,6 +506,7 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
 }
 
 int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
@@ -537,6 +578,7 @@ int vp8hip_download_results(vp8hip_ctx *c, const vp8hip_results *r) {
 }
 
 int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->ent_counted_partitions = 0;
     hipStream_t s = c->stream;
@@ -549,6 +591,7 @@ int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *p
 }
 
 int vp8hip_upload_recon(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     if (c->recon < 0 || c->recon == c->slot[0] || c->recon == c->slot[1] || c->recon == c->slot[2]) {
         c->recon = -1;
@@ -572,6 +615,7 @@ static int claim_recon(vp8hip_ctx *c) {
 }
 
 int vp8hip_intra_transform(vp8hip_ctx *c) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     int rc = claim_recon(c);
@@ -588,6 +632,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
 }
 
 int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *min_ssim) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (!c->recon_ready || c->recon < 0 || c->cur_count == 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
@@ -620,6 +665,7 @@ int vp8hip_download_intra(vp8hip_ctx *c, int32_t *modes, int32_t *is_inter) {
 }
 
 int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->ent_counted_partitions = 0;
     hipStream_t s = c->stream;
@@ -635,16 +681,26 @@ int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
 }
 
 int vp8hip_loop_filter(vp8hip_ctx *c) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
     Frame &f = c->frames[c->recon].f;
-    {
-        Timed t(c, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
-    }
-    {
-        Timed t(c, VP8HIP_K_BORDER);
-        launch_border(c->stream, f);
+    if (c->lf_overlap && !c->prof_mask) {   // (the per-kernel timers bracket launches on the context's stream only)
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));
+        launch_loop_filter3(c->lf_stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
+        launch_border(c->lf_stream, f);
+        HIPCHK(c, hipEventRecord(c->ev_lf, c->lf_stream));
+        c->lf_pending = true;
+    } else {
+        {
+            Timed t(c, VP8HIP_K_LOOP_FILTER);
+            launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
+        }
+        {
+            Timed t(c, VP8HIP_K_BORDER);
+            launch_border(c->stream, f);
+        }
     }
     // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
     c->frames[c->recon].pyramid_valid = false;
@@ -762,7 +818,8 @@ static int hdr_alloc(vp8hip_ctx *c) {
     HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
     HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
     HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
-    HIPCHK(c, hipMalloc(&c->hdr_partial, ((n + 63) / 64) * HDR_STAT_WORDS * 4));   // one row per workgroup of k_hdr_count (64 macroblocks)
+    HIPCHK(c, hipMalloc(&c->hdr_partial, HDR_STAT_WORDS * 4));   // the census of k_hdr_count: zero at rest (k_hdr_frame clears it)
+    HIPCHK(c, hipMemsetAsync(c->hdr_partial, 0, HDR_STAT_WORDS * 4, c->stream));
     HIPCHK(c, hipMalloc(&c->hdr_info, 16));
     HIPCHK(c, hipMalloc(&c->hdr_sym, 64));
     return VP8HIP_OK;
@@ -940,6 +997,7 @@ static int check_device_timeout(vp8hip_ctx *c) {
 }
 
 int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     const Frame &f = c->frames[c->slot[0]].f;
@@ -952,6 +1010,7 @@ int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
 }
 
 int vp8hip_synchronize(vp8hip_ctx *c) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_device_timeout(c);
@@ -975,6 +1034,7 @@ const char *vp8hip_status_string(int status) {
 }
 
 int vp8hip_profile_enable(vp8hip_ctx *c, uint32_t mask) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     int rc = prof_collect(c);
     c->prof_mask = mask;
@@ -995,6 +1055,7 @@ int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
 }
 
 int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst, size_t bytes) {
+    JOIN_LF(c);
     if (!c || !dst) return VP8HIP_ERR_ARG;
     hipStream_t s = c->stream;
     switch (what) {
@@ -1042,6 +1103,7 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
 // block `block`, 26 x {8 rows x 8 predicted pixels, cost, valid} as 26 x 18 dwords
 // test tap (not in the public header): weight_opt of n caller-supplied 4x4 difference blocks
 int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
+    JOIN_LF(c);
     if (!c || !d || !out || n <= 0) return VP8HIP_ERR_ARG;
     int32_t *dd = nullptr, *dout = nullptr;
     HIPCHK(c, hipMalloc(&dd, (size_t)n * 64));
@@ -1058,6 +1120,7 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
 // test hook (not in the public header): while on, the loop filter's inter-band counters are published from a wrong
 // base, so every band but the first runs into its bounded wait -> VP8HIP_ERR_TIMEOUT at the next synchronize
 int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->lf_stall_test = on ? 1 : 0;
     return VP8HIP_OK;
@@ -1066,6 +1129,7 @@ int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
 // test hook (not in the public header): MB_SSIM as an inter frame would have left it, so vp8hip_check_ssim can be
 // driven from stored inter-frame results (the golden vectors of tests/golden/intra)
 int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
+    JOIN_LF(c);
     if (!c || !ssim) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipMemcpyAsync(c->out.ssim, ssim, (size_t)c->mbs * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1077,6 +1141,7 @@ int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
 int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const int32_t *nz, const int32_t *ref, const int32_t *parts,
                                       const int16_t *vectors, const int32_t *is_inter, const int32_t *modes, const uint32_t *probs,
                                       const uint32_t *denom, const int32_t *sd) {
+    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     hipStream_t s = c->stream;
     const size_t n = c->mbs;
@@ -1096,6 +1161,7 @@ int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const i
 }
 
 int vp8hip_debug_search2_block(vp8hip_ctx *c, int ref, int block, void *out) {
+    JOIN_LF(c);
     if (!c || !out || ref < 0 || ref > 2 || c->slot[ref] < 0) return VP8HIP_ERR_ARG;
     RefSet refs;
     for (int r = 0; r < 3; ++r) {
