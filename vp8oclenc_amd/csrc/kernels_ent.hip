@@ -551,14 +551,20 @@ __device__ __forceinline__ bool super_slice(const Plan *plan, int P, uint32_t su
     return false;
 }
 
-// A workgroup takes a super-chunk: 128 lanes per chunk run it from each possible start range, then 128 lanes compose
-// the eight chunk maps into the super-chunk's map, which is what the serial walk steps through.
-__global__ __launch_bounds__(1024) void k_ent_maps(CodeJobs jobs) {
+// A workgroup takes a super-chunk: one wave per chunk runs it from each possible start range -- two per lane, two
+// independent dependency chains that the scheduler interleaves (a lone chain leaves every other issue slot of its
+// SIMD empty) -- then 128 lanes compose the eight chunk maps into the super-chunk's map, which is what the serial walk
+// steps through.
+constexpr int MAPS_THREADS = SUP * 64;
+__global__ __launch_bounds__(MAPS_THREADS) void k_ent_maps(CodeJobs jobs) {
     const CodeJob &J = jobs.j[blockIdx.y];
     __shared__ __attribute__((aligned(16))) uint16_t s_b[SUP][CHUNK];
     __shared__ uint32_t s_m[SUP][128];
-    const int tid = threadIdx.x, w = tid >> 7, l = tid & 127;
-    const Plan *plan = J.plan;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    __shared__ Plan s_plan;   // consulted several times per super-chunk: from LDS, not through chains of dependent global loads
+    for (int i = tid; i < (int)(sizeof(Plan) / 4); i += MAPS_THREADS) reinterpret_cast<uint32_t *>(&s_plan)[i] = reinterpret_cast<const uint32_t *>(J.plan)[i];
+    __syncthreads();
+    const Plan *plan = &s_plan;
     for (uint32_t sup = blockIdx.x;; sup += gridDim.x) {
         int p, nc;
         uint32_t c0;
@@ -568,29 +574,33 @@ __global__ __launch_bounds__(1024) void k_ent_maps(CodeJobs jobs) {
         if (w < nc) {
             const uint32_t b0 = plan->bool_base[p] + (c0 + w - plan->chunk_base[p]) * CHUNK, end = plan->bool_base[p] + plan->nbools[p];
             n = (int)(end - b0 < (uint32_t)CHUNK ? end - b0 : (uint32_t)CHUNK);
-            for (int i = l; i < n; i += 128) s_b[w][i] = J.bools[b0 + i];
+            for (int i = l; i < n; i += 64) s_b[w][i] = J.bools[b0 + i];
         }
         __syncthreads();
         if (w < nc) {
-            uint32_t r = 128u + l, S = 0, split;
-            const uint4 *row = reinterpret_cast<const uint4 *>(&s_b[w][0]);   // eight bools per LDS read, the next read in flight
-            int i = 0;                                                          // while these eight are stepped through
+            uint32_t r0 = 128u + l, r1 = 192u + l, S0 = 0, S1 = 0, split;
+            const uint4 *row = reinterpret_cast<const uint4 *>(&s_b[w][0]);   // eight bools per LDS read
+            int i = 0;
             for (; i + 8 <= n; i += 8) {
                 const uint4 q = row[i >> 3];
                 const uint32_t e8[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t e = (e8[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                    S += range_step(r, e & 255u, e >> 8, split);
+                    S0 += range_step(r0, e & 255u, e >> 8, split);
+                    S1 += range_step(r1, e & 255u, e >> 8, split);
                 }
             }
             for (; i < n; ++i) {
                 const uint32_t e = s_b[w][i];
-                S += range_step(r, e & 255u, e >> 8, split);
+                S0 += range_step(r0, e & 255u, e >> 8, split);
+                S1 += range_step(r1, e & 255u, e >> 8, split);
             }
-            const uint32_t e = r | (S << 8);
-            J.maps[(size_t)(c0 + w) * 128 + l] = e;
-            s_m[w][l] = e;
+            const uint32_t e0 = r0 | (S0 << 8), e1 = r1 | (S1 << 8);
+            J.maps[(size_t)(c0 + w) * 128 + l] = e0;
+            J.maps[(size_t)(c0 + w) * 128 + 64 + l] = e1;
+            s_m[w][l] = e0;
+            s_m[w][64 + l] = e1;
         }
         __syncthreads();
         if (tid < 128) {
@@ -840,7 +850,7 @@ static ent::CodeJob code_job(const EntBuffers &eb, int P) {
 }
 static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs) {
     const int maxP = jobs.j[0].P > jobs.j[njobs - 1].P ? jobs.j[0].P : jobs.j[njobs - 1].P;
-    hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(1024), 0, s, jobs);
+    hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(ent::MAPS_THREADS), 0, s, jobs);
     hipLaunchKernelGGL(ent::k_ent_walk, dim3(maxP, njobs), dim3(256), 0, s, jobs);
     hipLaunchKernelGGL(ent::k_ent_encode, dim3(512, njobs), dim3(256), 0, s, jobs);
     hipLaunchKernelGGL(ent::k_ent_finish, dim3(maxP, njobs), dim3(64 * ent::FIN_WAVES), 0, s, jobs);
