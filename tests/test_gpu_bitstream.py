@@ -225,3 +225,12 @@ def test_loop_filter_on_its_own_stream_changes_nothing():
         assert f0 == f1, t
         for p0, p1 in zip(r0, r1):
             assert np.array_equal(p0, p1), t
+
+
+def test_frames_beyond_a_million_blocks():
+    """7680x4320 = 3.24 million 4x4 block slots: the frame path's prefix sums have no size limit (the step-by-step
+    vp8hip_encode_coefficients keeps its 1 Mi one); key frame + inter frame, 8 partitions, byte-exact."""
+    W, H = 7680, 4320
+    s = SynthSequence(W, H, seed=5)
+    stream, st, _ = run_sequence(W, H, [s.frame(t) for t in range(2)], P=8)
+    assert st.key_frames == 1 and st.inter_frames == 1 and len(stream[0]) > 1 << 20

@@ -932,8 +932,7 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
     if (!c || !p) return VP8HIP_ERR_ARG;
     const int P = num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
-    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;
-    if (c->frame_pending) return VP8HIP_ERR_STATE;
+    if (c->frame_pending) return VP8HIP_ERR_STATE;   // (no size limit here: the frame path's prefix sums take any number of blocks)
     const int rc = frame_enqueue(c, P, p);
     if (rc) return rc;
     c->frame_params = *p;

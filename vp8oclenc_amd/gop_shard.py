@@ -73,6 +73,7 @@ class NativeEncoder:
     def __init__(self, width: int, height: int, device: int = 0, **cfg):
         from . import api
         cfg.setdefault("gop_size", 1 << 30)          # the chunk starts with its key frame; no other forced one inside
+        cfg.setdefault("overlap_filter", 1)          # one chunk at a time per GPU here: loop filter beside the entropy stage
         self.drv = api.NativeDriver(width, height, device=device, **cfg)
 
     def encode(self, y, u, v) -> bytes:
