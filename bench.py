@@ -248,7 +248,9 @@ def main():
         traffic, traffic_src = pmc_traffic(dominant, W, H)
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k)}
+                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k),
+                "note": "longest kernel per launch; none of this path's kernels is HBM-bound (integer search / transform / a "
+                        "serial filter chain): the binding resource is VALU issue, reported as issue_roofline.path"}
         extra = {}
         for k, (ms, n) in prof.items():
             if k == dominant or n == 0:
