@@ -908,15 +908,25 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     e.mbh = c->mbh;
     e.P = P;
     const size_t head = p->is_key ? 10 : 3;
+    static const bool stepwise = [] { const char *v = getenv("VP8HIP_ENT_STEPWISE"); return v && v[0] && v[0] != '0'; }();
+    if (stepwise && c->mbs * 25 <= 1024 * 1024) {   // A/B switch (the step-by-step scan stops at 2^20 blocks): the bool strings by the step-by-step kernels (15 launches instead of 5), then the same coder
+        const uint8_t *defaults = hdr_default_coeff_probs();
+        launch_ent_count(s, c->out, c->ent_flags, c->ent_third, c->ent_counts, c->ent_probs, c->ent_denom0, c->mbw, c->mbh, P, defaults);
+        if (!defaults) launch_default_probs(s, c->ent_probs, c->ent_denom0);
+        launch_ent_encode(s, c->out, c->ent_third, c->ent_probs, c->ent, c->mbw, c->mbh, P, false);
+        launch_hdr_encode(s, c->out, e.is_inter, e.modes, e.f, c->d_sd, e.strength, c->ent_probs, c->ent_denom0, c->hdr, c->hdr_partial,
+                          c->hdr_sym, c->hdr_info, c->mbw, c->mbh, false);
+    } else {
     {   // count_probs + num_div_denom + the default-probability fallback (vp8enc.cpp:58-76), bools per block and per macroblock header
         Timed t(c, VP8HIP_K_ENT_COUNT);
         launch_fe_count(s, e);
     }
-    c->ent_counted_partitions = P;
     {   // encode_header's bools (:84) and encode_coefficients' (:77-81)
         Timed t(c, VP8HIP_K_HDR_ENCODE);
         launch_fe_emit(s, e);
     }
+    }
+    c->ent_counted_partitions = P;
     {   // the boolean coder on both strings; its last kernel is gather_frame (encIO.h:1-30).  Then ONE read-back through
         // pinned memory: the frame size and the first FRAME_FIRST_COPY bytes travel together; only a larger frame needs a second copy
         Timed t(c, VP8HIP_K_ENT_ENCODE);
