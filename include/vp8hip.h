@@ -192,8 +192,8 @@ int vp8hip_encode_header(vp8hip_ctx *ctx, const vp8hip_header_params *params, ui
 /* entropy_encode() + gather_frame() (vp8enc.cpp:48-94, encIO.h:1-30) in one call and entirely on the device:
  * count_probs, num_div_denom, the default-probability fallback, encode_coefficients, encode_header, then the frame
  * is assembled in `out` -- first partition, the sizes of all coefficient partitions but the last, the partitions.
- * Nine kernel launches and ONE read-back through pinned memory (frame size and bytes together; a frame above 192 KiB
- * takes a second copy) instead of the 21 launches and eight blocking transfers of the step-by-step calls; any frame
+ * Nine kernel launches, the last of which writes the finished frame into pinned host memory itself (no copy command),
+ * instead of the 21 launches and eight blocking transfers of the step-by-step calls; any frame
  * size (the step-by-step vp8hip_encode_coefficients stops at 2^20 4x4 blocks).  params->partitions_log2 is ignored (derived from num_partitions).  *size = bytes of the finished frame:
  * what the reference hands to write_output_file(). */
 int vp8hip_encode_frame(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params, uint8_t *out, size_t capacity,
