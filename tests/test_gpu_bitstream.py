@@ -234,3 +234,26 @@ def test_frames_beyond_a_million_blocks():
     s = SynthSequence(W, H, seed=5)
     stream, st, _ = run_sequence(W, H, [s.frame(t) for t in range(2)], P=8)
     assert st.key_frames == 1 and st.inter_frames == 1 and len(stream[0]) > 1 << 20
+
+
+def test_entropy_stage_variants_emit_the_same_bytes():
+    """The A/B switches of the frame path (step-by-step bool-string kernels, device buffer + copy instead of writing into
+    pinned host memory) are read once per process: run each in its own interpreter and compare the stream's hash."""
+    import subprocess
+    import sys
+    prog = (
+        "import hashlib, sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from vp8oclenc_amd import api\n"
+        "from vp8oclenc_amd.synth import SynthSequence\n"
+        "s = SynthSequence(320, 192, seed=81); d = api.NativeDriver(320, 192, num_partitions=4, check_ssim=1, gop_size=4)\n"
+        "h = hashlib.sha256()\n"
+        "for t in range(7):\n"
+        "    d.encode_frame_host(*s.frame(t)); h.update(d.get_frame())\n"
+        "print(h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for extra in ({}, {"VP8HIP_ENT_STEPWISE": "1"}, {"VP8HIP_FRAME_ZEROCOPY": "0"}, {"VP8HIP_ENT_STEPWISE": "1", "VP8HIP_FRAME_ZEROCOPY": "0"}):
+        out = subprocess.run([sys.executable, "-c", prog], cwd=root, env={**os.environ, **extra}, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert len(set(digests)) == 1, digests
