@@ -505,11 +505,20 @@ __device__ __forceinline__ void chunk_slice(const Plan *plan, int P, uint32_t ch
 
 // one step of the coder's range recursion (write_bool, :82-105): returns the shift count
 __device__ __forceinline__ int range_step(uint32_t &r, uint32_t prob, uint32_t bit, uint32_t &split) {
-    split = 1u + (__umul24(r - 1u, prob) >> 8);   // both below 256: the full-rate 24-bit multiply
+    // 1 + ((r - 1) * prob >> 8) = (r * prob + 256 - prob) >> 8: one 24-bit multiply-add (both factors below 256) and a shift
+    split = (__umul24(r, prob) + (256u - prob)) >> 8;
     r = bit ? r - split : split;
-    const int s = __clz((int)r) - 24;
-    r <<= s;
-    return s;
+    const int z = __builtin_clz(r);   // r >= 1: split >= 1 and split < r
+    r = (r << z) >> 24;               // renormalised to 128..255
+    return z - 24;
+}
+// the same with the leading-zero count handed back raw: a caller that only sums shifts subtracts 24 per bool at the end
+__device__ __forceinline__ int range_step_z(uint32_t &r, uint32_t prob, uint32_t bias /* 256 - prob */, uint32_t bit) {
+    const uint32_t split = (__umul24(r, prob) + bias) >> 8;
+    r = bit ? r - split : split;
+    const int z = __builtin_clz(r);
+    r = (r << z) >> 24;
+    return z;
 }
 
 // One or two coder jobs per launch (the coefficient partitions and the first partition of a frame go through the coder
@@ -578,24 +587,28 @@ __global__ __launch_bounds__(MAPS_THREADS) void k_ent_maps(CodeJobs jobs) {
         }
         __syncthreads();
         if (w < nc) {
-            uint32_t r0 = 128u + l, r1 = 192u + l, S0 = 0, S1 = 0, split;
+            // every lane steps through the SAME bools: probability, its bias and the bit are wave-uniform and live in scalar
+            // registers (readfirstlane), which leaves seven vector instructions per bool and chain
+            uint32_t r0 = 128u + l, r1 = 192u + l, Z0 = 0, Z1 = 0;
             const uint4 *row = reinterpret_cast<const uint4 *>(&s_b[w][0]);   // eight bools per LDS read
             int i = 0;
             for (; i + 8 <= n; i += 8) {
                 const uint4 q = row[i >> 3];
-                const uint32_t e8[4] = {q.x, q.y, q.z, q.w};
+                const uint32_t e8[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const uint32_t e = (e8[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                    S0 += range_step(r0, e & 255u, e >> 8, split);
-                    S1 += range_step(r1, e & 255u, e >> 8, split);
+                    const uint32_t e = (e8[k >> 1] >> (16 * (k & 1))) & 0xffffu, pr = e & 255u, bias = 256u - pr, bit = e >> 8;
+                    Z0 += range_step_z(r0, pr, bias, bit);
+                    Z1 += range_step_z(r1, pr, bias, bit);
                 }
             }
             for (; i < n; ++i) {
-                const uint32_t e = s_b[w][i];
-                S0 += range_step(r0, e & 255u, e >> 8, split);
-                S1 += range_step(r1, e & 255u, e >> 8, split);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_b[w][i]), pr = e & 255u, bias = 256u - pr, bit = e >> 8;
+                Z0 += range_step_z(r0, pr, bias, bit);
+                Z1 += range_step_z(r1, pr, bias, bit);
             }
+            const uint32_t S0 = Z0 - 24u * (uint32_t)n, S1 = Z1 - 24u * (uint32_t)n;
             const uint32_t e0 = r0 | (S0 << 8), e1 = r1 | (S1 << 8);
             J.maps[(size_t)(c0 + w) * 128 + l] = e0;
             J.maps[(size_t)(c0 + w) * 128 + 64 + l] = e1;
@@ -686,20 +699,27 @@ __global__ __launch_bounds__(256) void k_ent_encode(CodeJobs jobs) {
         uint32_t r = st.x, W = st.y, split;
         const int lo = j * ENC_SUBLEN < n ? j * ENC_SUBLEN : n, hi = lo + ENC_SUBLEN < n ? lo + ENC_SUBLEN : n;
         const uint16_t *src = bools + b0;
-        for (int i0 = 0; i0 < lo; i0 += 16) {           // lo is a multiple of 16 (or n: then the tail guard below ends it)
-            uint32_t e[16];
+        // sixteen bools per batch, the NEXT batch's loads issued before this batch is stepped through (the lane's bools are
+        // contiguous through both phases; the buffer has slack behind its last bool): a lane waits for memory once, not
+        // once per batch -- the kernel is a handful of workgroups and nothing else hides that latency
+        uint32_t e[16], nx[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) e[k] = src[i0 + k];   // the buffer has slack behind the last bool
+        for (int k = 0; k < 16; ++k) e[k] = src[k];
+        int i0 = 0;
+        for (; i0 < lo; i0 += 16) {                     // lo is a multiple of 16 (or n: then the guard below ends it)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nx[k] = src[i0 + 16 + k];
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (i0 + k < lo) W += range_step(r, e[k] & 255u, e[k] >> 8, split);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) e[k] = nx[k];
         }
         uint32_t widx = W >> 5;
         unsigned long long cur = 0, nxt = 0;   // sums for output words widx and widx+1
-        for (int i0 = lo; i0 < hi; i0 += 16) {
-            uint32_t e[16];
+        for (; i0 < hi; i0 += 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) e[k] = src[i0 + k];
+            for (int k = 0; k < 16; ++k) nx[k] = src[i0 + 16 + k];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (i0 + k >= hi) continue;
@@ -716,6 +736,8 @@ __global__ __launch_bounds__(256) void k_ent_encode(CodeJobs jobs) {
                     cur = nxt; nxt = 0; ++widx;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) e[k] = nx[k];
         }
         if (cur) atomicAdd(&out[widx], cur);
         if (nxt) atomicAdd(&out[widx + 1], nxt);
