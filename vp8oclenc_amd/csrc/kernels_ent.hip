@@ -672,11 +672,11 @@ __global__ __launch_bounds__(256) void k_ent_walk(CodeJobs jobs) {
     }
 }
 
-// Four lanes per chunk: lane j first replays bools [0, 64j) of its chunk for the range and bit position only
-// (cheap), then codes bools [64j, 64j+64) into the accumulators.  Bools come straight from HBM/L2, sixteen loads
+// Eight lanes per chunk: lane j first replays bools [0, 32j) of its chunk for the range and bit position only
+// (cheap), then codes bools [32j, 32j+32) into the accumulators.  Bools come straight from HBM/L2, sixteen loads
 // issued back to back per batch (a version that staged chunks through LDS row by row serialised on load latency:
 // 141 us per 1080p frame).
-constexpr int ENC_SUB = 4, ENC_SUBLEN = CHUNK / ENC_SUB, ENC_CHUNKS = 64;   // chunks per workgroup of 256
+constexpr int ENC_SUB = 8, ENC_SUBLEN = CHUNK / ENC_SUB, ENC_CHUNKS = 256 / ENC_SUB;   // lanes per chunk, bools each codes, chunks per workgroup of 256
 __global__ __launch_bounds__(256) void k_ent_encode(CodeJobs jobs) {
     const CodeJob &J = jobs.j[blockIdx.y];
     __shared__ Plan s_plan;   // the plan is consulted per chunk: from LDS, not through a chain of dependent global loads
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_ent_encode(CodeJobs jobs) {
     unsigned long long *acc = J.acc;
     const int j = threadIdx.x & (ENC_SUB - 1);
     for (uint32_t c0 = blockIdx.x * ENC_CHUNKS; c0 < plan->total_chunks; c0 += gridDim.x * ENC_CHUNKS) {
-        const uint32_t chunk = c0 + (threadIdx.x >> 2);
+        const uint32_t chunk = c0 + (threadIdx.x / ENC_SUB);
         if (chunk >= plan->total_chunks) continue;
         int p, n;
         uint32_t b0;
