@@ -227,6 +227,8 @@ def main():
     enqueue_s = time.perf_counter() - t0      # host time to issue everything (diagnostic: host- vs GPU-bound)
     barrier()
     elapsed = time.perf_counter() - t0
+    for st in streams:
+        st.enc.synchronize()   # raises if a bounded device-side wait (loop filter / intra wavefronts) expired: no number then
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
