@@ -5,6 +5,7 @@
 // times, and the pixels are already in HBM -- so they are reductions on the device copy of the current frame.
 // No same-address atomics: every workgroup writes one partial sum, the consumer adds them up (a first version
 // with one atomicAdd per wave onto two words cost 0.1 ms per frame).
+#include <cstdlib>
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -27,7 +28,7 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *s_red) {   /
 // partial[2b] = sum of Y, partial[2b+1] = sum over interior pixels of (p - (8 neighbours)/8)^2 for the rows of
 // workgroup b.  Both are the reference's `int` accumulators, kept modulo 2^32 (order-independent), which is what
 // their overflow does.  A thread owns four adjacent columns and slides a three-row window down its rows.
-__global__ __launch_bounds__(256) void k_lf_strength(Plane y, uint32_t *partial) {
+__device__ __forceinline__ void lf_strength_body(const Plane &y, uint32_t *partial) {
     __shared__ uint32_t s_red[4];
     const int r0 = blockIdx.x * ROWS_PER_BLOCK;
     uint32_t s = 0, d = 0;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void k_lf_strength(Plane y, uint32_t *partial)
     d = block_sum(d, s_red);
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = d; }
 }
+__global__ __launch_bounds__(256) void k_lf_strength(Plane y, uint32_t *partial) { lf_strength_body(y, partial); }
 
 // partial[2b + plane] = sum |a - b| over the rows of workgroup b (8 chroma rows, four pixels per load)
 __global__ __launch_bounds__(256) void k_chroma_sad(Plane au, Plane av, Plane bu, Plane bv, uint32_t *partial) {
@@ -94,10 +96,11 @@ __global__ __launch_bounds__(256) void k_fold(const uint32_t *partial, int nbloc
 
 // get_loopfilter_strength's closing arithmetic (vp8enc.cpp:100-103,119-123) + prepare_segments_data
 // (vp8enc.cpp:129-221) on the device: the frame loop then needs no host round trip for its parameters
-__global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, int nblocks, uint32_t *stats, SegData *sd,
-                                                       int32_t *strength_out, int n, int ni, int is_key, int q0, int q1, int q2,
-                                                       int q3, int qi_min) {
+struct SegArgs { int n, ni, is_key, q0, q1, q2, q3, qi_min; };
+__device__ __forceinline__ void auto_segments_body(const uint32_t *partial, int nblocks, uint32_t *stats, SegData *sd,
+                                                   int32_t *strength_out, const SegArgs &g) {
     __shared__ uint32_t s_red[4];
+    const int n = g.n, ni = g.ni, is_key = g.is_key, q0 = g.q0, q1 = g.q1, q2 = g.q2, q3 = g.q3, qi_min = g.qi_min;
     uint32_t sum, dev;
     fold(partial, nblocks, s_red, sum, dev);
     if (threadIdx.x != 0) return;
@@ -142,18 +145,43 @@ __global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, 
         s[SD_HEV_THRESHOLD] = hev;
     }
 }
+__global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, int nblocks, uint32_t *stats, SegData *sd,
+                                                       int32_t *strength_out, SegArgs g) {
+    auto_segments_body(partial, nblocks, stats, sd, strength_out, g);
+}
+// the scan and its closing arithmetic in ONE launch: the workgroup that finishes last (a counter that is zero at rest) folds
+// the partial sums of all of them
+__global__ __launch_bounds__(256) void k_strength_segments(Plane y, uint32_t *partial, uint32_t *done, uint32_t *stats, SegData *sd,
+                                                           int32_t *strength_out, SegArgs g) {
+    __shared__ uint32_t s_last;
+    lf_strength_body(y, partial);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *done = 0;
+    auto_segments_body(partial, (int)gridDim.x, stats, sd, strength_out, g);
+}
 
 }  // namespace
 
-size_t rc_partial_words() { return 2 * MAX_PARTIALS; }
+size_t rc_partial_words() { return 2 * MAX_PARTIALS + 4; }   // + the completion counter of k_strength_segments (zero at rest)
 
 void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats, SegData *sd, int32_t *strength_out,
                           int is_key, const int32_t refqi[4], int qi_min) {
+    static const bool split = [] { const char *v = getenv("VP8HIP_SPLIT_SEGMENTS"); return v && v[0] && v[0] != '0'; }();   // A/B
     const Plane &y = cur.Y[0];
     const int nb = (y.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_lf_strength, dim3(nb), dim3(256), 0, s, y, partial);
-    hipLaunchKernelGGL(k_auto_segments, dim3(1), dim3(256), 0, s, partial, nb, stats, sd, strength_out, y.w * y.h,
-                       (y.h - 1) * (y.w - 1), is_key, refqi[0], refqi[1], refqi[2], refqi[3], qi_min);
+    const SegArgs g{y.w * y.h, (y.h - 1) * (y.w - 1), is_key, refqi[0], refqi[1], refqi[2], refqi[3], qi_min};
+    if (!split) {
+        hipLaunchKernelGGL(k_strength_segments, dim3(nb), dim3(256), 0, s, y, partial, partial + 2 * MAX_PARTIALS, stats, sd, strength_out, g);
+    } else {
+        hipLaunchKernelGGL(k_lf_strength, dim3(nb), dim3(256), 0, s, y, partial);
+        hipLaunchKernelGGL(k_auto_segments, dim3(1), dim3(256), 0, s, partial, nb, stats, sd, strength_out, g);
+    }
 }
 
 void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats) {

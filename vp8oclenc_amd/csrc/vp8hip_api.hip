@@ -273,6 +273,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     cur = carve_frame(cur, width, height, &c->cur);
     carve_frame(cur, width, height, &c->cur_prev);
     CR(hipMalloc(&c->d_stats, (8 + rc_partial_words()) * sizeof(uint32_t)));   // [0..3] sums, [4] reductor, [5] sharpness, [8..] partials
+    CR(hipMemsetAsync(c->d_stats, 0, (8 + rc_partial_words()) * sizeof(uint32_t), c->stream));   // (holds a completion counter that is zero at rest)
     for (int r = 0; r < 3; ++r) {
         CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
         CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
