@@ -1,41 +1,53 @@
 #!/usr/bin/env python3
 """bench.py -- macroblocks/s of the inter-frame path (ME + DCT + loop filter) on N MI355X.
 
-One "step" = one inter frame through the whole hot path behind the C ABI (vp8hip_set_current_device,
-vp8hip_set_segments, vp8hip_inter_transform, vp8hip_loop_filter) on synthetic 1080p YUV420 that is
-already resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL for the barrier and
-the max-over-ranks time only); every rank encodes its own GOP chunk -- GOPs are independent units
-(SURVEY.md section 8e), so there is no data-path collective and scaling is weak.
+Workload = BASELINE.json configs[2]: 1920x1080 YUV420, LAST+GOLDEN+ALTREF, loop filter on the GPU, synthetic frames
+resident in HBM, through the native frame loop behind the C ABI (vp8drv_encode_frame_device: segment data on the
+device, vp8hip_inter_transform, vp8hip_loop_filter).  A rank keeps G independent closed-GOP chunks in flight
+(GOPs are the unit the path shards by); one "step" = ONE INTER FRAME ON EACH OF THE G CHUNKS, so
+--steps K times K*G frames per GPU.  Before anything is timed every chunk is rolled forward into GOP steady state
+(>= 2*altref_range + 2 frames, chunk phases staggered), so the timed frames carry the real reference mix
+(2.8 references per frame on average); the run fails if they do not.
 
-Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time
-  cpu_baseline -- the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload
+N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the environment; started plainly with
+--gpus N > 1 (or --spawn) this process starts the N rank processes itself, before it touches the GPU.  RCCL carries
+the barrier and the max-over-ranks time only -- there is no data-path collective, scaling is weak.
+
+Prints ONE JSON line on rank 0 with, besides the contract's fields,
+  roofline       the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time, vs 8 TB/s
+  issue_roofline the resource that does bound the path: VALU issue CYCLES (per-opcode cost x PMC instruction counts)
+  single_stream  one chunk, frame after frame (what configs[2] literally is): MB/s and ms/frame      (N = 1 only)
+  other_configs  720p LAST-only (configs[1]), 4K 3-ref (configs[3]), 1080p SSIM target 0.93           (N = 1 only)
+  with_bitstream the same frames with finished VP8 frames delivered to host memory                     (N = 1 only)
+  cpu_baseline   the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload (N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
 # queue serialise.  The workload is many independent GOP chunks, one stream each: give the runtime 24 queues
 # (measured on MI355X: 4 -> 27, 8 -> 32, 16 -> 36, 24 -> 40 M MB/s with 16 chunks in flight; 32 and more are slower).
-# Must be set before the first HIP call of the process.
+# Must be set before the first HIP call of the process; vp8hip_create warns on stderr when a host forgot it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+ALTREF_RANGE = 5
+PREROLL = 2 * ALTREF_RANGE + 2
 
-# ALGORITHMIC bytes per launch of each kernel, as a function of the frame
-# geometry: mbs macroblocks, b8 = 4*mbs 8x8 blocks, nrefs enabled references.
+
 def algorithmic_bytes(kernel: str, W: int, H: int, nrefs: float) -> float:
+    """ALGORITHMIC bytes per launch: mbs macroblocks, b8 = 4*mbs 8x8 blocks, nrefs references."""
     mbs = (W // 16) * (H // 16)
     b8 = 4 * mbs
     if kernel.startswith("search1_l"):
@@ -48,201 +60,217 @@ def algorithmic_bytes(kernel: str, W: int, H: int, nrefs: float) -> float:
         return (384 + 384 + 16 + 8 + 800 + 384 + 20) * mbs  # cur + ref + MVs/ref/parts in; coeffs + recon + ids out
     if kernel == "loop_filter":
         return (384 * 2 + 8) * mbs             # recon read + written in place, mask + segment id
-    if kernel == "downsample":
-        return 0.0
     return 0.0
+
+
+def _profile_json(name: str):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel: str, W: int, H: int):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json; FETCH_SIZE and
-    WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot
-    run the profiler on itself, so this is the last measured value for the same geometry, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        e = t.get(f"{W}x{H}", {}).get(kernel)
-        if e:
-            return int(e["hbm_bytes_per_launch"]), t.get("source", "profiles/pmc_traffic.json")
-    except (OSError, ValueError, KeyError):
-        pass
-    return None, None
-
-
-def pmc_valu(W: int, H: int, nrefs: float):
-    """wave64 VALU instructions per launch of every kernel (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_valu.json) and
-    the measured chip-wide issue rate of this instruction mix (scripts/ubench/valu_peak.hip), or (None, None)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_valu.json")) as f:
-            t = json.load(f)
-        g = t[f"{W}x{H}"]
-        per = {k: (e["per_ref"] * nrefs if "per_ref" in e else e["fixed"]) for k, e in g.items()}
-        return per, t
-    except (OSError, ValueError, KeyError):
-        return None, None
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on
+    itself, so this is the last measured value for the same geometry, or None."""
+    t = _profile_json("pmc_traffic.json")
+    e = (t or {}).get(f"{W}x{H}", {}).get(kernel)
+    return (int(e["hbm_bytes_per_launch"]), t.get("source", "profiles/pmc_traffic.json")) if e else (None, None)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1920)
-    ap.add_argument("--warmup", type=int, default=480)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps; one step = one inter frame on each GOP chunk")
+    ap.add_argument("--warmup", type=int, default=30, help="untimed steps after the GOP pre-roll")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct-frames", type=int, default=8)
     ap.add_argument("--gops-per-gpu", type=int, default=16, help="independent GOP chunks in flight per GPU (1 = one stream)")
+    ap.add_argument("--refs", choices=["all", "last"], default="all", help="last = LAST only (BASELINE configs[1]: use_golden = use_altref = 0)")
     ap.add_argument("--ssim-target", type=float, default=-1.0, help="SSIM_target (reference default -1 = single LQ pass; 0.93 = the 4-pass path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--host-params", action="store_true",
-                    help="take the per-frame segment data from the host mirror (precomputed, untimed) instead of "
-                         "computing loop-filter strength and segment data on the device inside every step")
-    ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents (adds overhead)")
-    ap.add_argument("--bitstream", action="store_true",
-                    help="additionally measure the rate with complete VP8 frames delivered to the host (vp8drv_get_frame)")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip single_stream / other_configs / with_bitstream")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents in the timed region (adds packets)")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1 (the N > 1 launch path)")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no torchrun around it starts its own ranks.  Nothing here touches HIP.
+def spawn_ranks(args) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VP8_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Leg:
+    """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
+
+    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed):
+        from vp8oclenc_amd.synth import SynthSequence
+        self.torch, self.api = torch, api
+        seq = SynthSequence(W0, H0, seed=seed)
+        self.W, self.H = seq.W, seq.H
+        self.mbs = (self.W // 16) * (self.H // 16)
+        self.G, self.nd, self.refs = G, nd, refs
+        self.host_frames = [seq.frame(t) for t in range(nd)]
+        self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in self.host_frames]
+        self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
+        self.drv, self.t = [], []
+        for k in range(G):
+            d = api.NativeDriver(self.W, self.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
+                                 ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0)
+            t = (k * 3) % nd                                   # chunks start at different frames of the sequence
+            assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
+            self.drv.append(d)
+            self.t.append(t + 1)
+        self.frames = self.refsum = 0
+        # GOP steady state, untimed and independent of --warmup: every chunk past two altref periods, phases staggered so
+        # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames
+        for k in range(G):
+            for _ in range(PREROLL + k % ALTREF_RANGE):
+                self.step_one(k)
+        torch.cuda.synchronize()
+        self.frames = self.refsum = 0
+
+    def step_one(self, k):
+        d = self.drv[k]
+        d.encode_frame_device(*self.ptrs[self.t[k] % self.nd])
+        self.t[k] += 1
+        st = d.stats()
+        self.frames += 1
+        self.refsum += 1 + st.last_use_golden + st.last_use_altref
+
+    def step(self):
+        for k in range(self.G):
+            self.step_one(k)
+
+    def profile(self, kernels):
+        for d in self.drv:
+            d.hip.profile_enable(kernels)
+
+    def profile_read(self):
+        prof = {}
+        for d in self.drv:
+            for k, (ms, n) in d.hip.profile_read().items():
+                pm, pn = prof.get(k, (0.0, 0))
+                prof[k] = (pm + ms, pn + n)
+        return prof
+
+    def run(self, steps, barrier=None):
+        """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
+        sync = barrier or self.torch.cuda.synchronize
+        self.frames = self.refsum = 0
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        enq = time.perf_counter() - t0
+        sync()
+        el = time.perf_counter() - t0
+        for d in self.drv:
+            d.hip.synchronize()   # raises if a bounded device-side wait (loop filter / intra wavefronts) expired: no number then
+        return el, enq, self.refsum / max(self.frames, 1)
+
+    def close(self):
+        for d in self.drv:
+            d.close()
+        self.drv = []
+        self.dev_frames = []
+
+
+def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1):
+    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed)
+    for _ in range(warm):
+        leg.step()
+    el, enq, nrefs = leg.run(steps)
+    frames = steps * G
+    out = {"workload": f"{W0}x{H0}, {'LAST+GOLDEN+ALTREF' if refs == 'all' else 'LAST only'}, SSIM target {ssim_target}, {G} GOP chunk(s) in flight",
+           "value": round(leg.mbs * frames / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / frames * 1e3, 4),
+           "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs}
+    leg.close()
+    return out
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(spawn_ranks(args))      # before `import torch`: the launcher never initialises the GPU
     import torch
     from vp8oclenc_amd import api
-    from vp8oclenc_amd.synth import SynthSequence
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 or os.environ.get("VP8_BENCH_FORCE_DIST"):   # the variable exercises the RCCL path with one rank (1-GPU boxes)
+    if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-
-    # ---- workload: BASELINE.json configs[2] geometry.  Every rank encodes `gops_per_gpu` independent GOP
-    # chunks concurrently, one C-ABI context (= one HIP stream) each: closed GOPs are the unit the path
-    # shards by (SURVEY 8e), across GPUs and, on a 256-CU part whose loop filter is a latency-bound
-    # wavefront on a handful of CUs, also inside one GPU.
-    seq = SynthSequence(args.width, args.height, seed=1 + rank)
-    W, H = seq.W, seq.H
-    mbs = (W // 16) * (H // 16)
-    nd = max(2, args.distinct_frames)
-    G = max(1, args.gops_per_gpu)
-    host_frames = [seq.frame(t) for t in range(nd)]
-    dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in host_frames]
-    lastqi, altrefqi = api.quantizer_ladders(0, 48)        # reference defaults, init.h:1548-1603
-    seg_last, seg_alt = [], []
-    for y, _, _ in host_frames:                             # host parameter producers, outside the timed path
-        red, sharp = api.loopfilter_strength(y)
-        seg_last.append(api.prepare_segments_data(False, lastqi, 0, red, sharp))
-        seg_alt.append(api.prepare_segments_data(False, altrefqi, 0, red, sharp))
-    ref_hist = {"frames": 0, "refs": 0}
-
-    class GopStream:
-        """One closed GOP: its own context/stream, frame-type state machine and position in the sequence."""
-
-        def __init__(self, k: int):
-            self.enc = api.Vp8Hip(W, H, args.ssim_target, device=local)
-            self.gop = api.Gop(gop_size=1 << 30, altref_range=5)   # key frame only at the start of the chunk
-            self.t = (k * 3) % nd                                   # chunks start at different frames
-            self.gop.next()
-            self.gop.key_coded()                                    # key frame: coded by the host (out of scope)
-            y, u, v = dev_frames[self.t % nd]
-            self.enc.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-            self.gop.frame_done()
-            self.t += 1
-
-        def step(self):
-            g = self.gop.next()
-            i = self.t % nd
-            y, u, v = dev_frames[i]
-            self.enc.set_current_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-            if args.host_params:   # segment data precomputed by the host mirror, outside the timed region
-                self.enc.set_segments(seg_alt[i] if g.current_is_altref else seg_last[i])
-            else:                  # get_loopfilter_strength + prepare_segments_data on the device, inside the step
-                self.enc.auto_segments(False, altrefqi if g.current_is_altref else lastqi, 0)
-            ug, ua = self.gop.inter_flags()
-            self.enc.inter_transform(g.prev_is_golden, g.prev_is_altref, ug, ua)
-            self.enc.loop_filter()
-            self.gop.frame_done()
-            self.t += 1
-            ref_hist["frames"] += 1
-            ref_hist["refs"] += 1 + ug + ua
-
-    class NativeGopStream:
-        """The same, through the native frame loop (vp8_driver.cpp): one C call per frame, parameters on the device."""
-
-        def __init__(self, k: int):
-            self.drv = api.NativeDriver(W, H, device=local, gop_size=1 << 30, altref_range=5, qi_min=0, qi_max=48,
-                                        ssim_target=args.ssim_target, device_params=1, check_ssim=0)
-            self.enc = self.drv.hip
-            self.t = (k * 3) % nd
-            y, u, v = dev_frames[self.t % nd]
-            assert self.drv.encode_frame_device(y.data_ptr(), u.data_ptr(), v.data_ptr())   # frame 0 of the chunk: key
-            self.t += 1
-            self.ptrs = [tuple(p.data_ptr() for p in f) for f in dev_frames]
-
-        def step(self):
-            self.drv.encode_frame_device(*self.ptrs[self.t % nd])
-            self.t += 1
-            st = self.drv.stats()
-            ref_hist["frames"] += 1
-            ref_hist["refs"] += 1 + st.last_use_golden + st.last_use_altref
-
-    native = not args.host_params
-    streams = [(NativeGopStream if native else GopStream)(k) for k in range(G)]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup, with every kernel timed once to find the dominant one -----------------------------
-    nwarm = max(args.warmup, 1)
-    streams[0].enc.profile_enable(api.K_NAMES)
-    for i in range(nwarm):
-        streams[i % G].step()
-    torch.cuda.synchronize()
-    warm = streams[0].enc.profile_read()
-    n0 = len(range(0, nwarm, G))
-    per_frame = {k: ms / max(n0, 1) for k, (ms, n) in warm.items()}
-    dominant = max((k for k in per_frame if algorithmic_bytes(k, W, H, 1) > 0), key=lambda k: per_frame[k])
-    # every timed kernel costs two event packets per launch: with several chunks in flight only the dominant kernel (the
-    # roofline object) is timed in the timed region -- per-kernel durations are stretched by the other chunks there anyway;
-    # a one-chunk run (--gops-per-gpu 1) or VP8_BENCH_TIMED=hot also times the three hot kernels of the issue-rate table
-    timed_kernels = api.K_NAMES if args.profile_all else (sorted({dominant, "search1_l0", "search2", "mb"})
-                                                          if os.environ.get("VP8_BENCH_TIMED", "hot" if G == 1 else "dominant") == "hot" else [dominant])
-    for st in streams:
-        st.enc.profile_enable(timed_kernels)
-    ref_hist.update(frames=0, refs=0)
+    G = max(1, args.gops_per_gpu)
+    nd = max(2, args.distinct_frames)
+    leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank)
+    W, H, mbs = leg.W, leg.H, leg.mbs
 
-    # ---- timed region --------------------------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        streams[i % G].step()
-    enqueue_s = time.perf_counter() - t0      # host time to issue everything (diagnostic: host- vs GPU-bound)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for st in streams:
-        st.enc.synchronize()   # raises if a bounded device-side wait (loop filter / intra wavefronts) expired: no number then
+    # ---- warmup; every kernel of chunk 0 timed to find the dominant one --------------------------------------
+    leg.drv[0].hip.profile_enable(api.K_NAMES)
+    for _ in range(max(args.warmup, 1)):
+        leg.step()
+    torch.cuda.synchronize()
+    warm = leg.drv[0].hip.profile_read()
+    per_launch = {k: ms / n for k, (ms, n) in warm.items() if n}
+    dominant = max((k for k in per_launch if algorithmic_bytes(k, W, H, 1) > 0), key=lambda k: per_launch[k])
+    # each timed kernel costs two event packets per launch (timing four kernels on every chunk cost 6 % of the headline in
+    # a same-box A/B): the timed region times only the roofline kernel, on every chunk; the other kernels' launch times
+    # come from the warm-up steps of chunk 0 above (same steady state, fifteen other chunks in flight)
+    timed = api.K_NAMES if args.profile_all else [dominant]
+    leg.profile(timed)
+
+    # ---- timed region: exactly --steps steps, barrier + synchronize on both sides, max over ranks -------------
+    elapsed, enqueue_s, nrefs_avg = leg.run(args.steps, barrier)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    prof = {}
-    for st in streams:
-        for k, (ms, n) in st.enc.profile_read().items():
-            pm, pn = prof.get(k, (0.0, 0))
-            prof[k] = (pm + ms, pn + n)
-    nrefs_avg = ref_hist["refs"] / max(ref_hist["frames"], 1)
+    prof = leg.profile_read()
+    frames_per_gpu = args.steps * G
+    if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:
+        raise SystemExit(f"bench.py: the timed frames averaged {nrefs_avg:.2f} references per frame; LAST+GOLDEN+ALTREF in GOP "
+                         "steady state is 2.8 -- this would not be BASELINE configs[2]")
 
     out = None
     if rank == 0:
-        value = mbs * args.steps * world / elapsed
+        value = mbs * frames_per_gpu * world / elapsed
+        ms_frame = elapsed / frames_per_gpu * 1e3
         ms_k, n_k = prof[dominant]
         avg_ms = ms_k / max(n_k, 1)
         abytes = algorithmic_bytes(dominant, W, H, nrefs_avg)
@@ -251,121 +279,151 @@ def main():
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k),
-                "note": "longest kernel per launch; none of this path's kernels is HBM-bound (integer search / transform / a "
-                        "serial filter chain): the binding resource is VALU issue, reported as issue_roofline.path"}
-        extra = {}
-        for k, (ms, n) in prof.items():
+                "note": "longest kernel per launch, hipEvents on its own stream over the timed region, all chunks.  None of this "
+                        "path's kernels is HBM-bound (integer search / transform / a serial filter chain): the binding resource is "
+                        "VALU issue, see issue_roofline"}
+        others = {}
+        for k, (ms, n) in {**warm, **prof}.items():
             if k == dominant or n == 0:
                 continue
             b = algorithmic_bytes(k, W, H, nrefs_avg)
             a = b / (ms / n * 1e-3) / 1e9 if b else None
-            extra[k] = {"avg_launch_ms": round(ms / n, 5), "achieved_GBs": None if a is None else round(a, 3),
-                        "frac": None if a is None else round(a / HBM_PEAK_GBS, 6)}
-        # the resource that actually bounds the path: integer VALU issue.  Instructions per
-        # launch from the committed PMC pass, durations measured live, peak from the committed micro-benchmark.
-        issue = None
-        insts, vt = pmc_valu(W, H, nrefs_avg)
-        if insts:
-            peak = vt["peak_mix_winstr_per_ns"]
-            path_keys = ["search2", "search1_l0", "search1_l1", "search1_l2", "search1_l3", "search1_l4", "mb", "loop_filter",
-                         "downsample", "pack", "border"] + ([] if args.host_params else ["lf_strength"])
-            per_frame_insts = sum(insts[k] for k in path_keys)
-            path_rate = per_frame_insts / (elapsed / (args.steps * world) * 1e9)
-            issue = {"bound": "valu_issue", "unit": "wave64-instr/ns", "peak": peak, "peak_source": vt["peak_source"],
-                     "path": {"instructions_per_frame": int(per_frame_insts), "achieved": round(path_rate, 1), "frac": round(path_rate / peak, 4)},
-                     "instructions_source": vt["source"], "kernels": {}}
-            for k in ("search2", "search1_l0", "mb"):
-                if k in prof and prof[k][1]:
-                    r = insts[k] / (prof[k][0] / prof[k][1] * 1e6)
-                    issue["kernels"][k] = {"instructions_per_launch": int(insts[k]), "avg_launch_ms": round(prof[k][0] / prof[k][1], 5),
-                                           "achieved": round(r, 1), "frac": round(r / peak, 4)}
+            others[k] = {"avg_launch_ms": round(ms / n, 5), "algorithmic_bytes_per_launch": int(b), "achieved_GBs": None if a is None else round(a, 3),
+                         "frac": None if a is None else round(a / HBM_PEAK_GBS, 6)}
         out = {
             "metric": "macroblocks/sec inter-frame (ME+DCT+loopfilter), 1080p", "value": round(value, 1),
             "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, LAST+GOLDEN+ALTREF "
-                                   f"(avg {nrefs_avg:.2f} refs/frame), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
-                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": lastqi,
-                       "altref_range": 5, "frames_per_gpu": args.steps, "gops_per_gpu": G,
-                       "segment_params": "host mirror, precomputed" if args.host_params else "device, inside the step",
-                       "frame_loop": "python over the C ABI" if args.host_params else "native (vp8_driver.cpp), one call per frame",
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))},
+            "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, {'LAST+GOLDEN+ALTREF' if args.refs == 'all' else 'LAST only'} "
+                                   f"(avg {nrefs_avg:.2f} refs/frame, GOP steady state), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
+                       "step": f"one inter frame on each of the {G} GOP chunks = {G} frames per GPU",
+                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": list(api.quantizer_ladders(0, 48)[0]),
+                       "altref_range": ALTREF_RANGE, "preroll_frames_per_chunk": f"{PREROLL}..{PREROLL + ALTREF_RANGE - 1}", "frames_per_gpu": frames_per_gpu,
+                       "gops_per_gpu": G, "refs_per_frame": round(nrefs_avg, 3), "ms_per_frame": round(ms_frame, 5),
+                       "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
-            "issue_roofline": issue,
-            "kernels_ms_per_frame_warmup": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
-            "other_kernels": extra,
-            "fps": round(args.steps * world / elapsed, 2),
-            "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),
+            "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}),
+            "kernels_ms_per_launch_warmup": {k: round(v, 5) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
+            "other_kernels": others,
+            "fps": round(frames_per_gpu * world / elapsed, 2),
+            "timed_region_s": round(elapsed, 4),
+            "host_enqueue_ms_per_frame": round(enqueue_s / frames_per_gpu * 1e3, 4),
         }
-    # ---- optional: the same frames with complete VP8 frames delivered to host memory (vp8drv_get_frame: the whole
-    # entropy stage on the device), one host thread per GOP chunk.  Reported next to the headline value, never as it.
-    if args.bitstream and native:
-        import threading
-        nb = max(16, args.steps // G)
-        nbytes = [0] * G
-
-        def worker(k):
-            st = streams[k]
-            for _ in range(nb):
-                st.drv.encode_frame_device(*st.ptrs[st.t % nd])
-                st.t += 1
-                nbytes[k] += len(st.drv.get_frame())
-
-        for st in streams:   # untimed: the entropy stage allocates its scratch on first use
-            st.enc.profile_enable([])   # the per-kernel HIP events of the headline leg are read already; each one is a packet more
-            for _ in range(2):
-                st.drv.encode_frame_device(*st.ptrs[st.t % nd])
-                st.t += 1
-                st.drv.get_frame()
-        barrier()
-        tb = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(k,)) for k in range(G)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        barrier()
-        eb = time.perf_counter() - tb
-        if dist is not None:
-            tt = torch.tensor([eb], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            eb = float(tt.item())
-        if rank == 0:
-            out["with_bitstream"] = {"value": round(mbs * nb * G * world / eb, 1), "unit": "macroblocks/s", "fps": round(nb * G * world / eb, 1),
-                                     "frames": nb * G * world, "host_threads_per_gpu": G, "avg_frame_bytes": int(sum(nbytes) / (nb * G)),
-                                     "what": "native frame loop + vp8drv_get_frame: coefficient partitions and first partition coded on the "
-                                             "device, finished frames in host memory (byte-identical to the reference's output)"}
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) -------
+    leg.profile([])
+    # ---- side legs, rank 0 at N = 1 only: they are reported next to the headline value, never as it ------------
+    if rank == 0 and world == 1 and not args.no_side_legs:
+        out["with_bitstream"] = bitstream_leg(torch, leg, max(16, args.steps))
+    host_frames = leg.host_frames
+    leg.close()
+    if rank == 0 and world == 1 and not args.no_side_legs:
+        s1 = max(200, args.steps)
+        out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
+        out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
+        out["other_configs"] = {
+            "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local),
+            "4k_3refs": side_leg(torch, api, 3840, 2160, G, "all", -1.0, max(10, args.steps // 4), 3, local),
+            "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local),
+        }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(args, host_frames, seg_last, W, H, mbs)
+        out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
     if rank == 0:
         print(json.dumps(out))
-    for st in streams:
-        (st.drv if native else st.enc).close()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, host_frames, seg_last, W, H, mbs):
+def issue_roofline(W, H, nrefs, ms_frame, prof):
+    """VALU issue CYCLES per frame against the chip's capacity (256 CUs x 4 SIMDs x 2.4 GHz SIMD-cycles per second).
+    profiles/pmc_valu.json: wave64 instructions per launch by opcode class from the committed rocprofv3 --pmc pass and the
+    disassembly, and the measured issue cost of each class (scripts/ubench/valu_rates.hip).  Two peaks are quoted: the
+    guide's 2 cycles per wave64 VALU instruction (1 229 wave-instr/ns chip-wide) and what this instruction mix can reach
+    at its measured per-opcode costs."""
+    t = _profile_json("pmc_valu.json")
+    g = (t or {}).get(f"{W}x{H}")
+    if not g or "cycle_model" not in (t or {}):
+        return None
+    cm = t["cycle_model"]
+    simd_cycles_per_ns = cm["simds"] * cm["clock_ghz"]
+    path_keys = [k for k in g if k != "_meta"]
+    insts = {k: (g[k]["per_ref"] * nrefs if "per_ref" in g[k] else g[k]["fixed"]) for k in path_keys}
+    cycles = {k: (g[k].get("cycles_per_ref", 0) * nrefs if "per_ref" in g[k] else g[k].get("cycles_fixed", 0)) for k in path_keys}
+    tot_i, tot_c = sum(insts.values()), sum(cycles.values())
+    ns = ms_frame * 1e6
+    out = {"bound": "valu_issue", "unit": "SIMD issue cycles", "peak_simd_cycles_per_ns": simd_cycles_per_ns,
+           "path": {"instructions_per_frame": int(tot_i), "issue_cycles_per_frame": int(tot_c),
+                    "frac_of_issue_cycles": round(tot_c / (ns * simd_cycles_per_ns), 4),
+                    "wave_instr_per_ns": round(tot_i / ns, 1), "frac_of_2cycle_peak": round(tot_i * 2 / (ns * simd_cycles_per_ns), 4)},
+           "source": t.get("source"), "cost_source": cm.get("source"), "kernels": {}}
+    for k in ("search2", "search1_l0", "mb"):
+        if k in prof and prof[k][1] and k in insts:
+            kns = prof[k][0] / prof[k][1] * 1e6
+            out["kernels"][k] = {"instructions_per_launch": int(insts[k]), "issue_cycles_per_launch": int(cycles[k]),
+                                 "avg_launch_ms": round(kns * 1e-6, 5), "frac_of_issue_cycles": round(cycles[k] / (kns * simd_cycles_per_ns), 4),
+                                 "frac_of_2cycle_peak": round(insts[k] * 2 / (kns * simd_cycles_per_ns), 4),
+                                 "note": "launch time measured with all chunks in flight: other chunks' waves share the SIMDs"}
+    return out
+
+
+def bitstream_leg(torch, leg, nb):
+    """the same chunks with finished VP8 frames delivered to host memory (vp8drv_get_frame: the whole entropy stage on the
+    device), one host thread per GOP chunk"""
+    import threading
+    G = leg.G
+    nbytes = [0] * G
+
+    def worker(k):
+        d = leg.drv[k]
+        for _ in range(nb):
+            d.encode_frame_device(*leg.ptrs[leg.t[k] % leg.nd])
+            leg.t[k] += 1
+            nbytes[k] += len(d.get_frame())
+
+    for k in range(G):   # untimed: the entropy stage allocates its scratch on first use
+        for _ in range(2):
+            leg.drv[k].encode_frame_device(*leg.ptrs[leg.t[k] % leg.nd])
+            leg.t[k] += 1
+            leg.drv[k].get_frame()
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    eb = time.perf_counter() - tb
+    return {"value": round(leg.mbs * nb * G / eb, 1), "unit": "macroblocks/s", "fps": round(nb * G / eb, 1), "frames": nb * G,
+            "host_threads_per_gpu": G, "avg_frame_bytes": int(sum(nbytes) / (nb * G)),
+            "what": "native frame loop + vp8drv_get_frame: coefficient partitions and first partition coded on the device, finished "
+                    "frames in host memory (byte-identical to the reference's output)"}
+
+
+def cpu_baseline(args, api, host_frames, W, H, mbs):
     """Times oracle/vp8_oracle.c (the checker; OpenMP over blocks/MBs) on the host cores: kind 'port'."""
     # all host cores this process may run on (libgomp reads the variable when liboracle.so is loaded)
     os.environ["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle_lib import Oracle
+    lastqi, _ = api.quantizer_ladders(0, 48)        # reference defaults, init.h:1548-1603
+    segs = []
+    for y, _, _ in host_frames:                     # host parameter producers, outside the timed loop
+        red, sharp = api.loopfilter_strength(y)
+        segs.append(api.prepare_segments_data(False, lastqi, 0, red, sharp))
     ora = Oracle(W, H, args.ssim_target)
     threads = int(Oracle.lib().vp8o_num_threads())
     ora.upload_last(*host_frames[0])
-    ora.set_segments(seg_last[1])
+    ora.set_segments(segs[1])
     # warm once with LAST only (sets golden = altref = LAST like the frame after a key frame), then time
     ora.upload_current(*host_frames[1])
     ora.inter_transform(1, 1, 0, 0)
     ora.loop_filter()
     n, t0 = 0, time.perf_counter()
     while True:
-        f = host_frames[(2 + n) % len(host_frames)]
-        ora.set_segments(seg_last[(2 + n) % len(host_frames)])
-        ora.upload_current(*f)
+        i = (2 + n) % len(host_frames)
+        ora.set_segments(segs[i])
+        ora.upload_current(*host_frames[i])
         ora.inter_transform(0, 0, 1, 1)
         ora.loop_filter()
         n += 1

@@ -41,9 +41,12 @@ typedef struct {
                                 the way the reference does it -- kept as the cross-check */
     int32_t overlap_filter;  /* 1: loop filter on its own stream, side by side with the frame's entropy stage
                                 (vp8hip_filter_overlap); for a single video coded frame after frame.  Default 0 */
+    int32_t ref_mask;        /* which of the two optional references inter frames may search besides LAST: bit 0 GOLDEN,
+                                bit 1 ALTREF, ANDed onto the reference's own rule (inter_part.h:103-104).  Default 3 (= the
+                                reference); 0 = LAST only (BASELINE configs[1]) */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);

@@ -11,7 +11,13 @@
 # casts that narrowing implied -- 4 lines of luma_search_1step (src/GPU_kernels.cl:495,499,500,556)
 # and integer literals inside the loop-filter section (src/CPU_kernels.cl:829-1439).
 #
-# What this is NOT: the reference host program (vp8enc.cpp) builds here but cannot run (the
+# Second build (below, "gfx950"): the same two sed outputs compiled by AMD's OpenCL C compiler FOR THE MI355X, with the
+# vendor's own built-in library, into code objects oracle/_ref/ref_{gpu,cpu}_kernels_gfx950.co, plus the OpenCL host
+# oracle/ref_cl_driver.c -> oracle/_ref/libvp8ref_cl.so.  That pair runs the reference's kernels on the GPU box with the
+# vendor's built-ins (one exception forced by the hardware: MI355X has no image unit, see ref_image_as_buffer.cl) (scripts/gen_golden_gfx950.py makes tests/golden/gfx950/*.npz from it; tests/test_gpu_refcl.py
+# compares live).  Build options = the reference's own clBuildProgram options (src/init.h:181-186,337-342).
+#
+# What the x86 build is NOT: the reference host program (vp8enc.cpp) builds here but cannot run (the
 # OpenCL platform has 0 devices), so the kernels are driven by oracle/ref_driver.c, and the
 # OpenCL C built-ins they import come from oracle/ref_shim.cl (spec semantics, no encoder logic).
 set -e
@@ -49,6 +55,16 @@ $CL -x cl -cl-std=CL1.2 -cl-no-stdinc -target x86_64-unknown-linux-gnu -O2 -w -f
 $CL $CFLAGS -c "$HERE/ref_driver.c" -o "$TMP/driver.o"
 $CL -target x86_64-unknown-linux-gnu -shared -o "$OUT/libvp8ref.so" "$TMP/gpu.o" "$TMP/cpu.o" "$TMP/shim.o" "$TMP/driver.o"
 echo "built $OUT/libvp8ref.so"
+
+# gfx950: vendor compiler + vendor built-ins (links opencl.bc/ocml.bc/ockl.bc from /opt/rocm/amdgcn/bitcode), no shim.
+GFXFLAGS="-x cl -cl-std=CL1.0 -target amdgcn-amd-amdhsa -mcpu=gfx950 -Xclang -finclude-default-header -O3 -w"
+$CL $GFXFLAGS "$TMP/gpu.cl" -o "$OUT/ref_gpu_kernels_gfx950.co"
+# the MI355X has no image hardware (CL_DEVICE_IMAGE_SUPPORT = 0): for the two kernels that sample an image2d_t, a second
+# build in which the texel fetch reads a buffer (ref_image_as_buffer.cl says exactly what is replaced)
+$CL $GFXFLAGS -include "$HERE/ref_image_as_buffer.cl" "$TMP/gpu.cl" -o "$OUT/ref_gpu_kernels_imgbuf_gfx950.co"
+$CL $GFXFLAGS -DLOOP_FILTER "$TMP/cpu.cl" -o "$OUT/ref_cpu_kernels_gfx950.co"
+${CC:-gcc} -O2 -fPIC -shared -std=gnu99 -Wall -I/opt/rocm/include "$HERE/ref_cl_driver.c" -o "$OUT/libvp8ref_cl.so" -lOpenCL -ldl
+echo "built $OUT/ref_gpu_kernels_gfx950.co $OUT/ref_gpu_kernels_imgbuf_gfx950.co $OUT/ref_cpu_kernels_gfx950.co $OUT/libvp8ref_cl.so"
 
 # The reference's HOST intra path (src/intra_part.h, check_SSIM in src/vp8enc.cpp): the translation unit is
 # compiled from where it lies, main() renamed, driven by oracle/ref_host_driver.cpp.  It needs the OpenCL headers

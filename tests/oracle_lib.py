@@ -17,6 +17,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8ref.so")
 REF_HOST_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8refhost.so")
+REF_CL_SO = os.path.join(ORACLE_DIR, "_ref", "libvp8ref_cl.so")   # the reference's kernels on gfx950 through OpenCL (ref_cl_driver.c)
 
 SD_INTS = 11
 
@@ -253,6 +254,26 @@ def ref_stages() -> Stages | None:
     if not os.path.exists(REF_SO):
         return None
     return Stages(C.CDLL(REF_SO), "ref_")
+
+
+def ref_cl_stages() -> Stages | None:
+    """The reference's own kernels compiled by AMD's OpenCL compiler for gfx950 and run on the GPU through the vendor's
+    OpenCL runtime (oracle/ref_cl_driver.c + the code objects oracle/build_ref.sh leaves in oracle/_ref), or None where
+    the build is absent or there is no OpenCL GPU device (this container)."""
+    if not (os.path.exists(REF_CL_SO) and os.path.exists(os.path.join(ORACLE_DIR, "_ref", "ref_gpu_kernels_gfx950.co"))):
+        return None
+    try:
+        lib = C.CDLL(REF_CL_SO)
+    except OSError:
+        return None
+    lib.ref_cl_init.restype = ci
+    if lib.ref_cl_init() != 0:
+        return None
+    lib.ref_cl_device_name.restype = C.c_char_p
+    st = Stages(lib, "ref_")
+    st.device_name = lib.ref_cl_device_name().decode()
+    st.image_support = int(lib.ref_cl_image_support())   # 0 on MI355X: see oracle/ref_image_as_buffer.cl
+    return st
 
 
 class Intra:

@@ -6,7 +6,19 @@ outputs of every stage can be compared.  Test infrastructure.
 """
 from __future__ import annotations
 
+import ast
+import json
+
 import numpy as np
+
+
+def load_meta(z) -> dict:
+    """the one-line description stored with a golden fixture: JSON (gfx950 fixtures) or a dict literal (x86 fixtures)"""
+    text = str(z["meta"])
+    try:
+        return json.loads(text)
+    except ValueError:
+        return ast.literal_eval(text)
 
 
 def default_segments(qi=(12, 24, 36, 48), lf_levels=(6, 10, 14, 20), sharp=0, inter=True) -> np.ndarray:

@@ -15,7 +15,8 @@ from vp8oclenc_amd.synth import SynthSequence
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "entropy", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "entropy", "*.npz"))) + \
+    sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "gfx950", "e_*.npz")))   # the same kernels run on an MI355X
 
 
 def device_with(coeffs, parts, mbw, mbh):

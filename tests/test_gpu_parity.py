@@ -393,13 +393,17 @@ def test_parameter_scans_on_device_match_host_mirror():
 import glob as _glob
 import os as _os
 
-_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz")))
+# tests/golden/*.npz: the reference's kernels compiled for x86; tests/golden/gfx950/c*.npz: the same kernels compiled by AMD's
+# OpenCL compiler and run ON AN MI355X with the vendor's built-in library (scripts/gen_golden_gfx950.py)
+_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz"))) + \
+    sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "gfx950", "c*.npz")))
 
 
 @pytest.mark.parametrize("path", _GOLDEN, ids=[_os.path.basename(p)[:-4] for p in _GOLDEN])
 def test_golden_vectors(path):
+    from pipeline import load_meta
     z = np.load(path)
-    meta = eval(str(z["meta"]))
+    meta = load_meta(z)
     cur = tuple(np.ascontiguousarray(z[f"in_cur_{p}"]) for p in "YUV")
     refs = [tuple(np.ascontiguousarray(z[f"in_ref{r}_{p}"]) for p in "YUV") for r in range(3)]
     flags = (meta["use_golden"], meta["use_altref"])

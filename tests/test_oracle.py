@@ -1,6 +1,8 @@
 """The CPU restatement (oracle/vp8_oracle.c) against
-  (1) the committed golden vectors, which were produced by the reference's own kernels
-      (scripts/gen_golden.py, oracle/_ref) -- runs everywhere, no GPU, no /root/reference;
+  (1) the committed golden vectors, which were produced by the reference's own kernels -- tests/golden/gfx950/c*.npz by
+      the kernels compiled with AMD's OpenCL compiler and RUN ON THE MI355X with the vendor's built-in library
+      (scripts/gen_golden_gfx950.py, oracle/ref_cl_driver.c), tests/golden/*.npz by the same kernels compiled for x86
+      (scripts/gen_golden.py) -- runs everywhere, no GPU, no /root/reference;
   (2) the reference's own kernels executed live, stage by stage (only where oracle/_ref was built).
 Bit-exact for every integer output; MB_SSIM (float in the reference) within 1e-4.
 """
@@ -11,16 +13,17 @@ import numpy as np
 import pytest
 
 from oracle_lib import Oracle
-from pipeline import default_segments, run_inter_frame
+from pipeline import default_segments, load_meta, run_inter_frame
 from vp8oclenc_amd.synth import SynthSequence, noise_frames
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN_GFX950 = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "gfx950", "c*.npz")))
 SSIM_TOL = 1e-4
 
 
 def load_case(path):
     z = np.load(path)
-    meta = eval(str(z["meta"]))  # a dict literal written by scripts/gen_golden.py
+    meta = load_meta(z)
     cur = tuple(np.ascontiguousarray(z[f"in_cur_{p}"]) for p in "YUV")
     refs = [tuple(np.ascontiguousarray(z[f"in_ref{r}_{p}"]) for p in "YUV") for r in range(3)]
     return z, meta, cur, refs
@@ -45,6 +48,36 @@ def diff_against_golden(out: dict, z) -> list:
 
 def test_golden_fixtures_present():
     assert len(GOLDEN) >= 5
+    assert len(GOLDEN_GFX950) >= 8
+
+
+@pytest.mark.parametrize("path", GOLDEN_GFX950, ids=[os.path.basename(p)[:-4] for p in GOLDEN_GFX950])
+def test_restatement_matches_reference_kernels_run_on_gfx950(path, oracle_stages):
+    """The pin: outputs of the reference's kernels executed on an MI355X (vendor compiler, vendor built-ins)."""
+    z, meta, cur, refs = load_case(path)
+    assert "gfx950" in meta["device"]
+    out = run_inter_frame(oracle_stages, cur, refs, z["segments"], meta["use_golden"], meta["use_altref"],
+                          meta["ssim_target"])
+    bad = diff_against_golden(out, z)
+    assert not bad, f"{os.path.basename(path)}: restatement differs from the reference kernels run on gfx950: {bad}"
+
+
+def test_gfx950_report_says_what_the_fixtures_pin():
+    """report.json of the generating run: every integer output identical between the gfx950 run, the x86 build of the same
+    kernels (oracle/ref_shim.cl built-ins) and the restatement; MB_SSIM (float, fused mad on the GPU) within 1e-6."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "gfx950", "report.json")) as f:
+        rep = json.load(f)
+    assert "gfx950" in rep["device"] and rep["CL_DEVICE_IMAGE_SUPPORT"] == 0
+    assert len(rep["cases"]) >= 8
+    for name, c in rep["cases"].items():
+        for who in ("restatement_vs_gfx950", "x86_shim_build_vs_gfx950"):
+            d = dict(c[who])
+            ssim = d.pop("MB_SSIM", None)
+            assert not d, (name, who, d)
+            assert ssim is None or ssim["max_abs_diff"] < 1e-6, (name, who, ssim)
+    for name, e in rep["entropy"].items():
+        assert e["restatement_vs_gfx950"] == [], name
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])

@@ -41,6 +41,9 @@ class Vp8HipError(RuntimeError):
     pass
 
 
+ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
+
+
 class _Results(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs",
                                           "MB_segment_id", "MB_SSIM", "recon_Y", "recon_U", "recon_V")]
@@ -202,7 +205,7 @@ class DrvConfig(C.Structure):
     _fields_ = [("gop_size", C.c_int32), ("altref_range", C.c_int32), ("qi_min", C.c_int32), ("qi_max", C.c_int32),
                 ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32),
                 ("num_partitions", C.c_int32), ("display_width", C.c_int32), ("display_height", C.c_int32),
-                ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32)]
+                ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32), ("ref_mask", C.c_int32)]
 
 
 class DrvStats(C.Structure):
@@ -257,14 +260,26 @@ class NativeDriver:
     def get_frame(self) -> bytes:
         """The frame just coded as the reference's entropy_encode() + gather_frame() emit it (vp8drv_get_frame)."""
         self.lib.vp8drv_get_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
-        cap = self.hip.mbs * 900 + 65536
-        if getattr(self, "_frame_buf", None) is None or len(self._frame_buf) < cap:
-            self._frame_buf = np.zeros(cap, np.uint8)
         n = C.c_size_t(0)
-        rc = self.lib.vp8drv_get_frame(self.h, self._frame_buf.ctypes.data, cap, C.byref(n))
+        while True:
+            buf = self._frame_buffer()
+            rc = self.lib.vp8drv_get_frame(self.h, buf.ctypes.data, len(buf), C.byref(n))
+            if rc == ERR_OVERFLOW and len(buf) < self._frame_cap_max():   # the frame is still there: a larger buffer, same call
+                self._frame_buf = np.zeros(min(2 * len(buf), self._frame_cap_max()), np.uint8)
+                continue
+            break
         if rc != 0:
             raise Vp8HipError(f"vp8drv_get_frame: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return self._frame_buf[:n.value].tobytes()
+
+    def _frame_cap_max(self) -> int:
+        # the most a frame can be: 304 bools per 4x4 block at one byte each is far above it; the device scratch bound
+        return self.hip.mbs * 25 * 304 // 4 + (1 << 20)
+
+    def _frame_buffer(self):
+        if getattr(self, "_frame_buf", None) is None:
+            self._frame_buf = np.zeros(self.hip.mbs * 900 + 65536, np.uint8)
+        return self._frame_buf
 
     def get_frame_begin(self) -> None:
         """Enqueue the entropy stage of the frame just coded and return (vp8drv_get_frame_begin); get_frame_end collects."""
@@ -275,11 +290,14 @@ class NativeDriver:
 
     def get_frame_end(self) -> bytes:
         self.lib.vp8drv_get_frame_end.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
-        cap = self.hip.mbs * 900 + 65536
-        if getattr(self, "_frame_buf", None) is None or len(self._frame_buf) < cap:
-            self._frame_buf = np.zeros(cap, np.uint8)
         n = C.c_size_t(0)
-        rc = self.lib.vp8drv_get_frame_end(self.h, self._frame_buf.ctypes.data, cap, C.byref(n))
+        while True:
+            buf = self._frame_buffer()
+            rc = self.lib.vp8drv_get_frame_end(self.h, buf.ctypes.data, len(buf), C.byref(n))
+            if rc == ERR_OVERFLOW and len(buf) < self._frame_cap_max():
+                self._frame_buf = np.zeros(min(2 * len(buf), self._frame_cap_max()), np.uint8)
+                continue
+            break
         if rc != 0:
             raise Vp8HipError(f"vp8drv_get_frame_end: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return self._frame_buf[:n.value].tobytes()

@@ -42,6 +42,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->display_height = 0;
     c->host_bitstream = 0;
     c->overlap_filter = 0;
+    c->ref_mask = 3;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -125,6 +126,8 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     DRV_CHK(segments(d, host_y, false, refqi));
     int32_t use_golden = 0, use_altref = 0;
     vp8host_gop_inter_flags(&d->gop, &use_golden, &use_altref);                  // inter_part.h:103-104
+    use_golden &= d->cfg.ref_mask & 1;
+    use_altref &= (d->cfg.ref_mask >> 1) & 1;
     DRV_CHK(vp8hip_inter_transform(d->hip, d->gop.prev_is_golden, d->gop.prev_is_altref, use_golden, use_altref));
     d->st.last_use_golden = use_golden;
     d->st.last_use_altref = use_altref;

@@ -220,9 +220,13 @@ static int join_lf(vp8hip_ctx *c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
     return VP8HIP_OK;
 }
+// HIP's current device is per host thread: a context may be driven from a thread other than its creator's, or two contexts
+// on two GPUs from one thread -- every entry point that may allocate or use the null stream selects the context's device.
+#define USE_DEVICE(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
 #define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
 
 int vp8hip_filter_overlap(vp8hip_ctx *c, int on) {
+    USE_DEVICE(c);
     if (!c) return VP8HIP_ERR_ARG;
     JOIN_LF(c);
     if (on && !c->lf_stream) {
@@ -402,6 +406,7 @@ static void next_current(vp8hip_ctx *c) {
 }
 
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
@@ -413,6 +418,7 @@ int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, con
 }
 
 int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
@@ -420,6 +426,7 @@ int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const
 }
 
 int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !reductor || !sharpness) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
@@ -443,6 +450,7 @@ int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpn
 }
 
 int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !Udiff || !Vdiff) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
@@ -460,6 +468,7 @@ int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
 }
 
 int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     int rc = make_last(c, y, u, v, hipMemcpyHostToDevice);
@@ -469,12 +478,14 @@ int vp8hip_upload_last(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const 
 }
 
 int vp8hip_set_last_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     return make_last(c, y, u, v, hipMemcpyDeviceToDevice);
 }
 
 int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !sd) return VP8HIP_ERR_ARG;
     // staged through a ring of pinned slots so the call neither keeps the caller's pointer nor stalls
@@ -486,6 +497,7 @@ int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
 }
 
 int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4], int qi_min) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !refqi) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
@@ -496,6 +508,7 @@ int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4]
 }
 
 int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *reductor, int32_t *sharpness) {
+    USE_DEVICE(c);
     if (!c || !sd) return VP8HIP_ERR_ARG;
     int32_t rs[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(sd, c->d_sd, sizeof(SegData), hipMemcpyDeviceToHost, c->stream));
@@ -507,6 +520,7 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
 }
 
 int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
@@ -559,6 +573,7 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
 }
 
 int vp8hip_download_results(vp8hip_ctx *c, const vp8hip_results *r) {
+    USE_DEVICE(c);
     if (!c || !r) return VP8HIP_ERR_ARG;
     if (!c->recon_ready && (r->recon_Y || r->recon_U || r->recon_V)) return VP8HIP_ERR_STATE;
     hipStream_t s = c->stream;
@@ -579,6 +594,7 @@ int vp8hip_download_results(vp8hip_ctx *c, const vp8hip_results *r) {
 }
 
 int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *parts, const int32_t *seg) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->ent_counted_partitions = 0;
@@ -592,6 +608,7 @@ int vp8hip_upload_mb_data(vp8hip_ctx *c, const int16_t *coeffs, const int32_t *p
 }
 
 int vp8hip_upload_recon(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     if (c->recon < 0 || c->recon == c->slot[0] || c->recon == c->slot[1] || c->recon == c->slot[2]) {
@@ -616,6 +633,7 @@ static int claim_recon(vp8hip_ctx *c) {
 }
 
 int vp8hip_intra_transform(vp8hip_ctx *c) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
@@ -633,6 +651,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
 }
 
 int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *min_ssim) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (!c->recon_ready || c->recon < 0 || c->cur_count == 0) return VP8HIP_ERR_STATE;
@@ -658,6 +677,7 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
 }
 
 int vp8hip_download_intra(vp8hip_ctx *c, int32_t *modes, int32_t *is_inter) {
+    USE_DEVICE(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (modes) HIPCHK(c, hipMemcpyAsync(modes, c->intra_modes, (size_t)c->mbs * 64, hipMemcpyDeviceToHost, c->stream));
     if (is_inter) HIPCHK(c, hipMemcpyAsync(is_inter, c->intra_is_inter, (size_t)c->mbs * 4, hipMemcpyDeviceToHost, c->stream));
@@ -666,6 +686,7 @@ int vp8hip_download_intra(vp8hip_ctx *c, int32_t *modes, int32_t *is_inter) {
 }
 
 int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->ent_counted_partitions = 0;
@@ -682,6 +703,7 @@ int vp8hip_prepare_filter_mask(vp8hip_ctx *c, int32_t *nz_out) {
 }
 
 int vp8hip_loop_filter(vp8hip_ctx *c) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
@@ -713,6 +735,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
 }
 
 int vp8hip_count_probs(vp8hip_ctx *c, int num_partitions, uint32_t *new_probs, uint32_t *new_probs_denom) {
+    USE_DEVICE(c);
     if (!c || !new_probs || !new_probs_denom) return VP8HIP_ERR_ARG;
     if (num_partitions != 1 && num_partitions != 2 && num_partitions != 4 && num_partitions != 8) return VP8HIP_ERR_ARG;
     {
@@ -742,7 +765,8 @@ static void ent_free(vp8hip_ctx *c) {
 }
 
 static int ent_alloc(vp8hip_ctx *c) {
-    if (c->ent.bools) return VP8HIP_OK;
+    if (c->ent.plan) return VP8HIP_OK;   // the last allocation below: set only when all of them succeeded
+    if (c->ent.offs) ent_free(c);        // a partial allocation left by an earlier failure
     EntBuffers &e = c->ent;
     const size_t nslots = (size_t)c->mbs * 25;
     e.cap_bools = (uint32_t)(nslots * (size_t)c->ent_bools_per_block);
@@ -762,16 +786,19 @@ static int ent_alloc(vp8hip_ctx *c) {
 
 // A frame denser than the scratch was sized for (64 bools per 4x4 block to begin with): double it, up to the 304 bools a
 // block can produce at most, so that no frame is ever refused for the device's sake.  false = already at the maximum.
-static bool ent_grow(vp8hip_ctx *c) {
-    if (c->ent_bools_per_block >= 304) return false;
+static int ent_grow(vp8hip_ctx *c) {
+    if (c->ent_bools_per_block >= 304) return VP8HIP_ERR_OVERFLOW;
     hipStreamSynchronize(c->stream);
     ent_free(c);
     c->ent_bools_per_block = c->ent_bools_per_block * 2 > 304 ? 304 : c->ent_bools_per_block * 2;
-    return ent_alloc(c) == VP8HIP_OK;
+    const int rc = ent_alloc(c);       // VP8HIP_ERR_HIP (e.g. out of memory) is reported as such, not as an overflow
+    if (rc) ent_free(c);
+    return rc;
 }
 
 int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int num_partitions, int partition_step,
                                uint8_t *partitions, int32_t *partition_sizes) {
+    USE_DEVICE(c);
     if (!c || !coeff_probs || !partitions || !partition_sizes || partition_step < 4) return VP8HIP_ERR_ARG;
     if (num_partitions != 1 && num_partitions != 2 && num_partitions != 4 && num_partitions != 8) return VP8HIP_ERR_ARG;
     if (c->ent_counted_partitions != num_partitions) return VP8HIP_ERR_STATE;   // needs vp8hip_count_probs first
@@ -790,7 +817,7 @@ int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int n
         HIPCHK(c, hipMemcpyAsync(&plan, c->ent.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (!plan.overflow) break;
-        if (!ent_grow(c)) return VP8HIP_ERR_OVERFLOW;   // denser than the scratch: enlarge it and code the frame again
+        if ((rc = ent_grow(c)) != VP8HIP_OK) return rc;   // denser than the scratch: enlarge it and code the frame again
     }
     for (int p = 0; p < num_partitions; ++p)
         if (plan.nbytes[p] > (uint32_t)partition_step) return VP8HIP_ERR_OVERFLOW;
@@ -827,6 +854,7 @@ static int hdr_alloc(vp8hip_ctx *c) {
 }
 
 int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
+    USE_DEVICE(c);
     if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
     if (c->ent_counted_partitions == 0) return VP8HIP_ERR_STATE;    // the coefficient probabilities of this frame: vp8hip_count_probs first
     const size_t head = p->is_key ? 10 : 3;
@@ -853,6 +881,7 @@ int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *
     HIPCHK(c, hipMemcpyAsync(&plan, c->hdr.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (plan.overflow || head + plan.nbytes[0] > capacity) return VP8HIP_ERR_OVERFLOW;
+    if (plan.nbytes[0] >= (1u << 19)) return VP8HIP_ERR_OVERFLOW;   // the frame tag has 19 bits for the first partition's size
     HIPCHK(c, hipMemcpyAsync(out + head, c->hdr.bytes, plan.nbytes[0], hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     // frame tag (entropy_host.cpp:1214-1247): key/inter bit, version 0, show_frame, size of the first partition
@@ -949,6 +978,7 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
 }
 
 int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p) {
+    USE_DEVICE(c);
     if (!c || !p) return VP8HIP_ERR_ARG;
     const int P = num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
@@ -962,6 +992,7 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
 }
 
 int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t *size) {
+    USE_DEVICE(c);
     if (!c || !out || !size) return VP8HIP_ERR_ARG;
     if (!c->frame_pending) return VP8HIP_ERR_STATE;
     c->frame_pending = false;
@@ -973,11 +1004,16 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
         n = *reinterpret_cast<const uint32_t *>(c->h_frame);
         if (n) break;
         // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
-        if (!ent_grow(c)) return VP8HIP_ERR_OVERFLOW;
-        const int rc = frame_enqueue(c, c->frame_partitions, p);
+        int rc = ent_grow(c);
+        if (rc) return rc;
+        rc = frame_enqueue(c, c->frame_partitions, p);
         if (rc) return rc;
     }
-    if (n > capacity) return VP8HIP_ERR_OVERFLOW;
+    if (n > capacity) {
+        c->frame_pending = true;   // the coded frame stays in h_frame: the caller may come back with a larger buffer
+        return VP8HIP_ERR_OVERFLOW;
+    }
+    if (reinterpret_cast<const uint32_t *>(c->h_frame)[1] >= (1u << 19)) return VP8HIP_ERR_OVERFLOW;   // 19-bit size field of the frame tag
     const size_t head = p->is_key ? 10 : 3;
     const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     if (16 + n > first && !frame_zero_copy()) {
@@ -1001,6 +1037,7 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
 }
 
 int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
+    USE_DEVICE(c);
     if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
     const int rc = vp8hip_encode_frame_begin(c, num_partitions, p);
     return rc ? rc : vp8hip_encode_frame_end(c, out, capacity, size);
@@ -1016,6 +1053,7 @@ static int check_device_timeout(vp8hip_ctx *c) {
 }
 
 int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
@@ -1029,6 +1067,7 @@ int vp8hip_download_last(vp8hip_ctx *c, uint8_t *y, uint8_t *u, uint8_t *v) {
 }
 
 int vp8hip_synchronize(vp8hip_ctx *c) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1053,6 +1092,7 @@ const char *vp8hip_status_string(int status) {
 }
 
 int vp8hip_profile_enable(vp8hip_ctx *c, uint32_t mask) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     int rc = prof_collect(c);
@@ -1061,6 +1101,7 @@ int vp8hip_profile_enable(vp8hip_ctx *c, uint32_t mask) {
 }
 
 int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
+    USE_DEVICE(c);
     if (!c) return VP8HIP_ERR_ARG;
     int rc = prof_collect(c);
     if (rc) return rc;
@@ -1074,6 +1115,7 @@ int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
 }
 
 int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst, size_t bytes) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !dst) return VP8HIP_ERR_ARG;
     hipStream_t s = c->stream;
@@ -1122,6 +1164,7 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
 // block `block`, 26 x {8 rows x 8 predicted pixels, cost, valid} as 26 x 18 dwords
 // test tap (not in the public header): weight_opt of n caller-supplied 4x4 difference blocks
 int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !d || !out || n <= 0) return VP8HIP_ERR_ARG;
     int32_t *dd = nullptr, *dout = nullptr;
@@ -1139,6 +1182,7 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
 // test hook (not in the public header): while on, the loop filter's inter-band counters are published from a wrong
 // base, so every band but the first runs into its bounded wait -> VP8HIP_ERR_TIMEOUT at the next synchronize
 int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     c->lf_stall_test = on ? 1 : 0;
@@ -1148,6 +1192,7 @@ int vp8hip_debug_lf_stall(vp8hip_ctx *c, int on) {
 // test hook (not in the public header): MB_SSIM as an inter frame would have left it, so vp8hip_check_ssim can be
 // driven from stored inter-frame results (the golden vectors of tests/golden/intra)
 int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !ssim) return VP8HIP_ERR_ARG;
     HIPCHK(c, hipMemcpyAsync(c->out.ssim, ssim, (size_t)c->mbs * 4, hipMemcpyHostToDevice, c->stream));
@@ -1160,6 +1205,7 @@ int vp8hip_debug_upload_ssim(vp8hip_ctx *c, const float *ssim) {
 int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const int32_t *nz, const int32_t *ref, const int32_t *parts,
                                       const int16_t *vectors, const int32_t *is_inter, const int32_t *modes, const uint32_t *probs,
                                       const uint32_t *denom, const int32_t *sd) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     hipStream_t s = c->stream;
@@ -1180,6 +1226,7 @@ int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const i
 }
 
 int vp8hip_debug_search2_block(vp8hip_ctx *c, int ref, int block, void *out) {
+    USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !out || ref < 0 || ref > 2 || c->slot[ref] < 0) return VP8HIP_ERR_ARG;
     RefSet refs;
