@@ -213,6 +213,12 @@ int vp8hip_synchronize(vp8hip_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller) */
 void *vp8hip_stream(vp8hip_ctx *ctx);
 int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
+/* Hardware queues the HIP runtime of this process multiplexes its streams onto: GPU_MAX_HW_QUEUES as exported when the
+ * process started (default 4).  Contexts whose streams share a queue serialise; a host that keeps many GOP chunks in
+ * flight exports GPU_MAX_HW_QUEUES=24 before its first HIP call -- vp8hip_create prints one line to
+ * stderr when a process holds more contexts than queues (VP8HIP_QUIET=1 silences it).  No reference counterpart: the
+ * reference has one in-order OpenCL queue per reference frame (init.h:210-228). */
+int vp8hip_hw_queues(void);
 const char *vp8hip_status_string(int status);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

@@ -51,6 +51,15 @@ int vp8o_num_threads(void) {
 #endif
 }
 
+/* tests at 1080p / 4K raise the team size after the library was loaded (OMP_NUM_THREADS is read once, at load) */
+void vp8o_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ---- weight_opt, src/GPU_kernels.cl:85-190 ------------------------------------------------
  * Column pass keeps the reference's quirk: b1 is discarded, rows 1 and 3 use the raw r2. */
 int vp8o_weight(const int d[16]) {

@@ -154,6 +154,7 @@ const int16_t *vp8o_debug_net(const vp8o_ctx *c, int ref, int which /*1 or 2*/);
 const int32_t *vp8o_debug_bdiff(const vp8o_ctx *c, int ref);
 const uint8_t *vp8o_debug_pyramid(const vp8o_ctx *c, int ref /*0..2, 3 = current*/, int level /*0..4 = 1x..1/16*/);
 int vp8o_num_threads(void);
+void vp8o_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

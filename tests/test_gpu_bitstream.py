@@ -228,12 +228,31 @@ def test_loop_filter_on_its_own_stream_changes_nothing():
 
 
 def test_frames_beyond_a_million_blocks():
-    """7680x4320 = 3.24 million 4x4 block slots: the frame path's prefix sums have no size limit (the step-by-step
-    vp8hip_encode_coefficients keeps its 1 Mi one); key frame + inter frame, 8 partitions, byte-exact."""
-    W, H = 7680, 4320
+    """4096x2736 = 1.09 million 4x4 block slots: the frame path's prefix sums have no size limit (the step-by-step
+    vp8hip_encode_coefficients keeps its 1 Mi one); key frame + inter frame, 8 partitions, byte-exact.  (The format
+    itself stops a little further on: the frame tag holds the first partition's size in 19 bits, see the next test.)"""
+    W, H = 4096, 2736
     s = SynthSequence(W, H, seed=5)
     stream, st, _ = run_sequence(W, H, [s.frame(t) for t in range(2)], P=8)
-    assert st.key_frames == 1 and st.inter_frames == 1 and len(stream[0]) > 1 << 20
+    assert st.key_frames == 1 and st.inter_frames == 1 and len(stream[0]) > 1 << 19
+
+
+def test_first_partition_beyond_the_frame_tag_is_an_error():
+    """A 7680x4320 key frame codes 129 600 x 16 sub-block modes: its first partition passes 512 KiB, which the frame tag's
+    19-bit size field cannot say (RFC 6386 9.1).  The reference writes the truncated size and the frame cannot be decoded;
+    here the call fails with VP8HIP_ERR_OVERFLOW instead of returning such a frame."""
+    W, H = 7680, 4320
+    s = SynthSequence(W, H, seed=5)
+    d = api.NativeDriver(W, H, num_partitions=8)
+    assert d.encode_frame_host(*s.frame(0))
+    try:
+        frame = d.get_frame()
+    except api.Vp8HipError as e:
+        assert "(-7)" in str(e)
+    else:   # content whose key frame happens to fit: then the tag must tell the truth
+        first = (frame[0] | frame[1] << 8 | frame[2] << 16) >> 5
+        assert first < (1 << 19) and len(frame) > first
+    d.close()
 
 
 def test_entropy_stage_variants_emit_the_same_bytes():

@@ -1,0 +1,161 @@
+"""The long parity runs, inside `pytest -m gpu` so that the driver's round-end run sees them (they used to live in
+scripts/): BASELINE configs[2] as a 1080p GOP through the native frame loop with finished frames out, configs[3]
+(4K) with all three references, one seed of the randomised end-to-end run, the launcher of bench.py and the RCCL
+branch of the GOP-sharded gather.  Everything bit-exact against the CPU oracle loop + the reference's own
+encode_header (oracle/_ref -> tests/bitstream_cases.expected_frame)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from pipeline import default_segments
+from vp8oclenc_amd import api
+from vp8oclenc_amd.driver import InterPathDriver
+from vp8oclenc_amd.synth import SynthSequence
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _all_host_cores_for_the_oracle():
+    # the oracle is OpenMP code: at 1080p / 4K it needs the box's cores (the other test modules run it on 8 threads)
+    lib = Oracle.lib()
+    before = lib.vp8o_num_threads()
+    lib.vp8o_set_num_threads(min(64, len(os.sched_getaffinity(0))))
+    yield
+    lib.vp8o_set_num_threads(before)
+
+
+def _expected_frame():
+    from bitstream_cases import expected_frame
+    return expected_frame
+
+
+def test_1080p_gop_three_references_native_loop_frames_out():
+    """BASELINE configs[2]: 1920x1080, LAST+GOLDEN+ALTREF, loop filter on the GPU -- 30 frames of one GOP (key frame, golden,
+    altref every 5) through vp8drv_*; every finished frame and every filtered reconstruction against the oracle loop."""
+    expected_frame = _expected_frame()   # first partition by the reference's own encode_header where oracle/_ref travelled
+    s = SynthSequence(1920, 1080, seed=11)
+    W, H = s.W, s.H
+    P = 8
+    drv = api.NativeDriver(W, H, gop_size=150, num_partitions=P, check_ssim=1)
+    ora = Oracle(W, H, -1.0)
+    do = InterPathDriver(ora, W, H, gop_size=150)
+    seen = set()
+    for t in range(30):
+        y, u, v = s.frame(t)
+        was_key = drv.encode_frame_host(y, u, v)
+        got = drv.get_frame()
+        out = do.encode_frame(y, u, v)
+        assert was_key == (out is None), f"frame {t}: key decision differs"
+        exp = expected_frame(W, H, do.last_key if out is None else out, out is None, P)
+        assert got == exp, f"frame {t}: {len(got)} vs {len(exp)} bytes"
+        for p_, q_ in zip(drv.hip.download_last(), ora.download_last()):
+            assert np.array_equal(p_, q_), f"frame {t}: filtered reconstruction differs"
+        st = drv.stats()
+        if not was_key:
+            seen.add((st.last_use_golden, st.last_use_altref))
+    assert (1, 1) in seen and (0, 0) in seen          # frames with three references and with LAST only both occurred
+    assert drv.stats().key_frames == 1
+    drv.close()
+    ora.close()
+
+
+def test_4k_three_references_frame_pair():
+    """BASELINE configs[3] geometry with LAST + GOLDEN + ALTREF: every stage tap against the oracle."""
+    from test_gpu_parity import _compare, _frames, _one_frame
+    f = _frames(3840, 2160, 19)
+    frames = [f[2], f[0], f[1], f[3]]
+    h, o = _one_frame(3840, 2160, frames, default_segments(), (1, 1), -1.0)
+    _compare(h, o, [k for k in o if k in h], "4K 3 refs")
+    assert len(np.unique(h["MB_reference_frame"])) >= 2
+
+
+def test_fuzz_one_seed():
+    """scripts/fuzz_parity.py, 12 cases of one seed: random geometry / quantizers / SSIM target / GOP / partitions / content."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--cases", "12", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="8"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "all identical" in r.stdout
+
+
+def _bench(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-side-legs",
+                        "--cpu-seconds", "0", *extra], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "bench.py must print exactly ONE JSON line:\n" + r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`bench.py --gpus N` without torchrun starts N rank processes itself (the parent never touches the GPU) and the
+    ranks form an RCCL group; exercised here with N = 1 (--spawn) against the plain single-process run."""
+    a = _bench()
+    b = _bench("--spawn")
+    assert a["config"]["launcher"] == "single process" and b["config"]["launcher"] == "self-spawned ranks"
+    for d in (a, b):
+        assert d["n_gpus"] == 1 and d["config"]["refs_per_frame"] >= 2.7 and d["config"]["frames_per_gpu"] == 320
+        assert d["roofline"]["launches"] == 320
+    assert abs(a["value"] - b["value"]) / a["value"] < 0.10, (a["value"], b["value"])
+
+
+def test_bench_last_only_config():
+    d = _bench("--refs", "last", "--width", "1280", "--height", "720")
+    assert d["config"]["refs_per_frame"] == 1.0 and d["config"]["macroblocks_per_frame"] == 3600
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import torch, torch.distributed as dist
+    from vp8oclenc_amd import gop_shard
+    from vp8oclenc_amd.synth import SynthSequence
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    seq = SynthSequence(96, 64, seed=5)
+    mine = gop_shard.encode_chunks_frames(lambda: gop_shard.NativeEncoder(seq.W, seq.H, device=0), seq, gop_shard.gop_chunks(6, 3))
+    plain = gop_shard.gather_frames(mine, 6)
+    coll = gop_shard.gather_frames(mine, 6, dist, force_collective=True)     # all_gather of the lengths over RCCL
+    assert coll == plain and all(len(f) > 3 for f in coll)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rccl gather ok", sum(len(f) for f in coll))
+""")
+
+
+def test_gather_frames_over_rccl(tmp_path):
+    """The collective branch of gop_shard.gather_frames on the nccl (= RCCL) backend, one rank (a 1-GPU box); the two-rank
+    exchange itself is covered over gloo in tests/test_gop_shard.py."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_two_contexts_on_two_devices_from_worker_threads():
+    """entry points select the context's device themselves (HIP's current device is per thread)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import threading
+    s = SynthSequence(128, 96, seed=3)
+    drv = [api.NativeDriver(s.W, s.H, device=d, gop_size=150) for d in (0, 1)]
+    out = [[], []]
+
+    def work(i):
+        for t in range(4):
+            drv[i].encode_frame_host(*s.frame(t))
+            out[i].append(drv[i].get_frame())
+
+    th = [threading.Thread(target=work, args=(i,)) for i in (0, 1)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert out[0] == out[1] and len(out[0]) == 4

@@ -200,17 +200,22 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
         uint32_t c[4], q0[4], q1[4];
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)(sy + y) * a.cur.stride + sx);
+            c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)(sy + y) * a.cur.stride + sx) ^ 0x80808080u;
             const uint2 q = ld_u64(rp + (ptrdiff_t)(sy + y) * a.ref[r].stride + sx);
-            q0[y] = q.x; q1[y] = q.y;
+            q0[y] = q.x ^ 0x80808080u; q1[y] = q.y ^ 0x80808080u;
         }
+        // rows -> columns (byte r = row r), pixels biased: the form weight_cols_pre wants.  Candidate dx = i reads
+        // columns i..i+3 of the eight: no byte alignment per candidate, and the current block's share of the metric
+        // (16 dot4) is computed once for the five of them.
+        uint32_t cc[4], col[8];
+        transpose4x4(c, cc);
+        transpose4x4(q0, col);
+        transpose4x4(q1, col + 4);
+        int pre[16];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            uint32_t p[4];
+        for (int k = 0; k < 4; ++k) weight_pre_column(cc[k], pre + 4 * k);
 #pragma unroll
-            for (int y = 0; y < 4; ++y) p[y] = i == 0 ? q0[y] : (i == 4 ? q1[y] : __builtin_amdgcn_alignbyte(q1[y], q0[y], i));
-            acc[i] += weight_quads(c, p);
-        }
+        for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
     }
     const int pen_scale = a.pixel_rate < 4 ? 32 : 0;
     const int pen_y = iabs(iabs(py - cy) - v0y);
@@ -276,10 +281,24 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
 __global__ __launch_bounds__(256) void k_weight_tap(const int32_t *d, int n, int32_t *out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int v[16];
+    // the production form (weight_cols_pre) on a (current, prediction) byte pair with current - prediction = d:
+    // columns as dwords, biased by -128
+    uint32_t cc[4], pp[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = d[i * 16 + k];
-    out[i] = weight4x4(v);
+    for (int c = 0; c < 4; ++c) {
+        cc[c] = pp[c] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = d[i * 16 + 4 * r + c];
+            const uint32_t cb = (uint32_t)(v > 0 ? v : 0) ^ 0x80u, pb = (uint32_t)(v > 0 ? 0 : -v) ^ 0x80u;
+            cc[c] |= cb << (8 * r);
+            pp[c] |= pb << (8 * r);
+        }
+    }
+    int pre[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) weight_pre_column(cc[c], pre + 4 * c);
+    out[i] = weight_cols_pre(pre, pp);
 }
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out) {
     hipLaunchKernelGGL(k_weight_tap, dim3((n + 255) / 256), dim3(256), 0, s, d, n, out);

@@ -12,7 +12,9 @@
 //   * Vertical pass: lane k = candidate (dx,dy); a column is one ds_read_b128 and the six taps run down its
 //     bytes: 2.5 dot4 per sample with 7-tap pre-shifted constants (K_V7; the 7th slot absorbs the one-row
 //     offset between dy<0 and dy>=0), v_ashr_pk_u8_i32 saturates two samples at a time.
-//   * The current block and the zero-MV block are transposed through LDS so the metric sees columns too.
+//   * The current block and the zero-MV block are transposed through LDS so the metric sees columns too; the current
+//     block's share of the metric's column pass is computed once per block into LDS (weight_pre_column) and every
+//     candidate adds its own with one dot4 per quantity (weight_cols_pre, vp8hip_dev.h).
 // First version (32-bit multiply-adds, row-major H array; git history): 0.156 ms per 1080p frame, this one 0.091.
 #include "vp8hip_dev.h"
 
@@ -79,20 +81,11 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 // form with the bias in an SGPR instead of v_mov + v_dot4c
 __device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
 
-// weight of the 4x4 block whose COLUMNS are the byte quads c[k] (current) and p[k] (candidate)
-__device__ __forceinline__ int weight_cols(const uint32_t c[4], const uint32_t p[4]) {
-    int d[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[4 * r + k] = byte_of(c[k], r) - byte_of(p[k], r);
-    return weight4x4(d);
-}
-
 __global__ __launch_bounds__(256) void k_search2(S2Args a) {
     __shared__ uint32_t s_win[8][72];
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
-    __shared__ uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half]
+    __shared__ uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
+    __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
     const int r = a.refmap[blockIdx.y];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int b = imin(blockIdx.x * 8 + g, a.nblk - 1);
@@ -115,7 +108,7 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
         const int sel = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
         const uint8_t *base = sel ? rf.p : a.cur.p;
         const int stride = sel ? rf.stride : a.cur.stride;
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)(cy + row) * stride + cx + 4 * half);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)(cy + row) * stride + cx + 4 * half) ^ 0x80808080u;
         uint8_t *cz = reinterpret_cast<uint8_t *>(s_cz[g]) + sel * 64 + half * 32 + row;
 #pragma unroll
         for (int j = 0; j < 4; ++j) cz[j * 8] = (uint8_t)(v >> (8 * j));
@@ -161,6 +154,14 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
         for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * 20] << (8 * rr);
         s_HT[g][2 * HT_XC + c * 4 + rg] = v;
     }
+    {   // the current block's share of the metric (vp8hip_dev.h, weight_pre_column): 16 columns x 4 quantities, two per lane.
+        // Order = the order the cost loop below walks the 4x4 blocks: q = (m*2 + n)*4 + j  <->  column 4n+j, row half m
+        const int q = lane & 15, m = q >> 3, n = (q >> 2) & 1, j = q & 3;
+        const uint32_t ccol = s_cz[g][(4 * n + j) * 2 + m];
+        int *pre = &s_pre[g][q * 4 + (lane >> 4) * 2];
+        pre[0] = dot4s(ccol, lane < 16 ? K_W_R0 : K_W_X, 0);
+        pre[1] = dot4s(ccol, lane < 16 ? K_W_R2 : K_W_Y, 0);
+    }
     __syncthreads();
 
     // ---- vertical pass + cost ----------------------------------------------------------------------
@@ -190,11 +191,11 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
                 if (si >= 2) acc = dot4(h[m + 2], t[tb + 2], acc);
                 s[i] = acc;
             }
-            P[c][0] = pack4(ashr7_pk_u8(s[0], s[1]), ashr7_pk_u8(s[2], s[3]));
-            P[c][1] = pack4(ashr7_pk_u8(s[4], s[5]), ashr7_pk_u8(s[6], s[7]));
-            if (yc == 2) {   // whole-pel dy: rows 3..10 of the column, un-biased
-                P[c][0] = __builtin_amdgcn_alignbyte(h[1], h[0], 3) ^ 0x80808080u;
-                P[c][1] = __builtin_amdgcn_alignbyte(h[2], h[1], 3) ^ 0x80808080u;
+            P[c][0] = pack4(ashr7_pk_u8(s[0], s[1]), ashr7_pk_u8(s[2], s[3])) ^ 0x80808080u;   // biased, like everything the metric reads
+            P[c][1] = pack4(ashr7_pk_u8(s[4], s[5]), ashr7_pk_u8(s[6], s[7])) ^ 0x80808080u;
+            if (yc == 2) {   // whole-pel dy: rows 3..10 of the column
+                P[c][0] = __builtin_amdgcn_alignbyte(h[1], h[0], 3);
+                P[c][1] = __builtin_amdgcn_alignbyte(h[2], h[1], 3);
             }
         }
     } else {  // zero MV: whole-pel, both passes are the identity
@@ -206,16 +207,21 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            uint32_t cc[4], pp[4];
+            int pre[16];
+            uint32_t pp[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cc[j] = s_cz[g][(4 * n + j) * 2 + m]; pp[j] = P[4 * n + j][m]; }
-            diff += weight_cols(cc, pp);
+            for (int j = 0; j < 4; ++j) {
+                const int4 v = *reinterpret_cast<const int4 *>(&s_pre[g][((m * 2 + n) * 4 + j) * 4]);
+                pre[4 * j] = v.x; pre[4 * j + 1] = v.y; pre[4 * j + 2] = v.z; pre[4 * j + 3] = v.w;
+                pp[j] = P[4 * n + j][m];
+            }
+            diff += weight_cols_pre(pre, pp);
         }
     if (k < 25) diff += (iabs(dx) + iabs(dy)) * 32;  // :1176-1178
     if (a.dbg && live && b == a.dbg_block) {
         if (k < 26) {
             uint32_t *d = a.dbg + k * 18;
-            for (int c = 0; c < 8; ++c) { d[2 * c] = P[c][0]; d[2 * c + 1] = P[c][1]; }
+            for (int c = 0; c < 8; ++c) { d[2 * c] = P[c][0] ^ 0x80808080u; d[2 * c + 1] = P[c][1] ^ 0x80808080u; }
             d[16] = (uint32_t)diff;
             d[17] = valid;
         }

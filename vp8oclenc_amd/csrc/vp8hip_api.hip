@@ -6,9 +6,11 @@
 // clEnqueueCopyBuffer + three clEnqueueCopyImage of inter_part.h:35-50,72-83), the vector nets,
 // the per-macroblock outputs, and one in-order HIP stream.
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 
 #include "../../include/vp8hip.h"
@@ -66,6 +68,7 @@ struct vp8hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     bool lf_overlap = false, lf_pending = false;
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
+    bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
     int frame_partitions = 0;
     int ent_bools_per_block = 64;   // what that scratch is sized for; doubled (up to 304, the maximum) when a frame needs more
@@ -211,6 +214,8 @@ int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMem
 
 }  // namespace
 
+static std::atomic<int> g_live_contexts{0};
+
 extern "C" {
 
 // work enqueued on the context's stream from here on sees the filtered reconstruction
@@ -324,11 +329,29 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipStreamSynchronize(c->stream));
 #undef CR
     *out = c;
+    c->counted = true;
+    // Contexts overlap only if their streams sit on different hardware queues, and the HIP runtime multiplexes all streams
+    // of a process onto GPU_MAX_HW_QUEUES queues (default 4), read once at its first call: nothing the library can set.
+    // A host that keeps more contexts than queues gets a one-line note (VP8HIP_QUIET=1 silences it).
+    static std::atomic<bool> warned{false};
+    const int n = ++g_live_contexts;
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? atoi(q) : 4;
+    if (n > queues && !getenv("VP8HIP_QUIET") && !warned.exchange(true))
+        fprintf(stderr, "vp8hip: %d contexts in this process but GPU_MAX_HW_QUEUES=%d hardware queues: their streams will share queues and "
+                        "serialise (measured on MI355X with 16 contexts: 27 M MB/s at 4 queues, 40 M at 24).  Export GPU_MAX_HW_QUEUES=24 "
+                        "before the process makes its first HIP call.\n", n, queues);
     return VP8HIP_OK;
+}
+
+int vp8hip_hw_queues(void) {   // what the runtime was told when the process started (the default is 4)
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    return q ? atoi(q) : 4;
 }
 
 void vp8hip_destroy(vp8hip_ctx *c) {
     if (!c) return;
+    if (c->counted) --g_live_contexts;
     hipSetDevice(c->device);
     if (c->lf_stream) {
         hipStreamSynchronize(c->lf_stream);

@@ -199,23 +199,57 @@ __device__ __forceinline__ uint32_t abs_acc(s16x2 v, uint32_t acc) {
     return __builtin_amdgcn_sad_u16(as_u32(v) ^ 0x80008000u, 0x80008000u, acc);
 }
 
-// Column pass in 32-bit, row pass on PAIRS of rows in packed 16-bit (v_pk_*): every intermediate fits
-// int16 for 8-bit pixel differences (|R| <= 8160, |a1|,|b1| <= 16320, |a1 +- b1 + 7| <= 32647), so
-// the arithmetic is the same integers as the 32-bit form.  The kernels that use this are bound by
-// VALU issue (measured), so fewer instructions per 4x4 block is the whole game.
-__device__ __forceinline__ int weight4x4(const int d[16]) {
+// ---- the form the search kernels use --------------------------------------------------------------------------
+// Issue cost on gfx950 (scripts/ubench/valu_cost.hip, profiles/valu_cost.json): only plain VOP1/VOP2 add / sub / logic /
+// right shifts issue in ~2.3 SIMD cycles; every SDWA, VOP3 and VOP3P instruction (perm, sad, dot2, dot4, v_pk_*,
+// even v_lshlrev_b32) costs ~4.2.  So the metric is organised to need the FEWEST instructions, whatever their kind:
+//   * a 4x4 block arrives as four COLUMN dwords (byte r = row r), pixels biased by -128 (signed bytes);
+//   * the column pass is linear in the pixels except for two rounding shifts, and the current block is the same for
+//     every candidate: its share is computed once per column (weight_pre_column: four dot4) and each candidate only adds
+//     the prediction's share with ONE v_dot4_i32_i8 per quantity, the accumulator input carrying the current block's:
+//         R0 = 8(r0+r1-r2+r3), R2 = 8(r0-r1+r2+r3), X = 16 r2, Y = 32 (r0-r3)        (r = current - prediction)
+//   * the two rotations take (X, Y) as one packed pair: scaled by 16 so that ">> 12" becomes "the high half":
+//         R1 = (2217 r2 + 5352*8 (r0-r3) + 14500) >> 12 = (2217 X + 21408 Y + 16*14500) >> 16,
+//         R3 = (2217*8 (r0-r3) - 5352 r2 + 7500) >> 12 = (8868 Y - 5352 X + 16*7500) >> 16
+//     (|X| <= 4080, |Y| <= 8160, sums < 2^28: exact);
+//   * row pass on PAIRS of rows in packed 16-bit (every intermediate fits int16 for 8-bit pixel differences:
+//     |R| <= 8160, |a1|,|b1| <= 16320, |a1 +- b1 + 7| <= 32647), |a|+|b| of a pair = xor + one v_sad_u16.
+// 9 instructions per column instead of 4 byte subtractions + 13: the device metric is pinned on 200k random and on the
+// extreme difference blocks by test_block_match_metric_device_vs_oracle through k_weight_tap.
+constexpr uint32_t pk8s(int a, int b, int c, int d) {
+    return (uint32_t)(a & 255) | ((uint32_t)(b & 255) << 8) | ((uint32_t)(c & 255) << 16) | ((uint32_t)(d & 255) << 24);
+}
+constexpr uint32_t K_W_R0 = pk8s(8, 8, -8, 8), K_W_R2 = pk8s(8, -8, 8, 8), K_W_X = pk8s(0, 0, 16, 0), K_W_Y = pk8s(32, 0, 0, -32);
+constexpr uint32_t K_W_R0N = pk8s(-8, -8, 8, -8), K_W_R2N = pk8s(-8, 8, -8, -8), K_W_XN = pk8s(0, 0, -16, 0), K_W_YN = pk8s(-32, 0, 0, 32);
+constexpr uint32_t K_ROT16_A = 2217u | (21408u << 16);                       // (X, Y) . (2217, 21408)
+constexpr uint32_t K_ROT16_B = (uint32_t)(-5352 & 0xffff) | (8868u << 16);   // (X, Y) . (-5352, 8868)
+// clamp (int32 saturation, never reached: |sums| < 2^15) selects the three-address VOP3P form; without it hipcc emits the
+// two-address v_dot4c plus a v_mov per use to keep the accumulator input alive
+__device__ __forceinline__ int dot4s(uint32_t a, uint32_t k, int c) { return __builtin_amdgcn_sdot4((int)a, (int)k, c, true); }
+
+// the current block's share of one column (ccol = its four rows as biased bytes): {R0, R2, X, Y} parts
+__device__ __forceinline__ void weight_pre_column(uint32_t ccol, int pre[4]) {
+    pre[0] = dot4s(ccol, K_W_R0, 0);
+    pre[1] = dot4s(ccol, K_W_R2, 0);
+    pre[2] = dot4s(ccol, K_W_X, 0);
+    pre[3] = dot4s(ccol, K_W_Y, 0);
+}
+
+// weight of (current - prediction) for one 4x4 block: pre = weight_pre_column of the four current columns,
+// p = the four prediction columns as biased bytes
+__device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t p[4]) {
     s16x2 A[4], B[4];   // A[c] = (R0[c], R1[c]) = rows 0,1 of the column-pass output, B[c] = rows 2,3
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int r0 = d[c], r1 = d[4 + c], r2 = d[8 + c], r3 = d[12 + c];
-        const int s03 = r0 + r3, d12 = r1 - r2;
-        const int R0 = (s03 + d12) * 8;        // a + c1 with a = (r0+r3)<<3, c1 = (r1-r2)<<3
-        const int R2 = (s03 - d12) * 8;
-        const uint32_t xy = pk16(r2, (r0 - r3) * 8);   // (raw r2, d): the reference's quirk
-        const int R1 = dot2(xy, K_ROT_A, 14500) >> 12;
-        const int R3 = dot2(xy, K_ROT_B, 7500) >> 12;
-        A[c] = as_s16x2(pk16(R0, R1));
-        B[c] = as_s16x2(pk16(R2, R3));
+        const int R0 = dot4s(p[c], K_W_R0N, pre[4 * c + 0]);
+        const int R2 = dot4s(p[c], K_W_R2N, pre[4 * c + 1]);
+        const int X = dot4s(p[c], K_W_XN, pre[4 * c + 2]);
+        const int Y = dot4s(p[c], K_W_YN, pre[4 * c + 3]);
+        const uint32_t xy = pk16(X, Y);
+        const int t1 = dot2(xy, K_ROT16_A, 16 * 14500);
+        const int t3 = dot2(xy, K_ROT16_B, 16 * 7500);
+        A[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1, (uint32_t)R0, 0x07060100u));   // (low half of R0, high half of t1)
+        B[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3, (uint32_t)R2, 0x07060100u));
     }
     uint32_t acc = 0;
     int o00 = 0;
@@ -231,12 +265,13 @@ __device__ __forceinline__ int weight4x4(const int d[16]) {
         const int t1l = dot2(xy_lo, K_ROT_A, 12000), t1h = dot2(xy_hi, K_ROT_A, 12000);
         const int t3l = dot2(xy_lo, K_ROT_B, 51000), t3h = dot2(xy_hi, K_ROT_B, 51000);
         // (x >> 16) of both rows = the high halves, packed
-        s16x2 o1 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1h, (uint32_t)t1l, 0x07060302u));
+        const s16x2 o1 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1h, (uint32_t)t1l, 0x07060302u));
         const s16x2 o3 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3h, (uint32_t)t3l, 0x07060302u));
-        const u16x2 nz = __builtin_bit_cast(u16x2, d1 | (s16x2{0, 0} - d1)) >> u16x2{15, 15};   // d1 != 0
-        o1 = o1 + __builtin_bit_cast(s16x2, nz);
+        // |o1 + (d1 != 0)| per half: the +1 rides in the subtrahend of the absolute difference.  Plain 32-bit logic on
+        // the packed pair (as a 16-bit vector compare hipcc scalarises it into two v_cmp and two v_cndmask per pair)
+        const uint32_t nz = ((as_u32(d1) | as_u32(s16x2{0, 0} - d1)) >> 15) & 0x00010001u;   // d1 != 0, per half
         acc = abs_acc(o0, acc);
-        acc = abs_acc(o1, acc);
+        acc = __builtin_amdgcn_sad_u16(as_u32(o1) ^ 0x80008000u, 0x80008000u - nz, acc);
         acc = abs_acc(o2, acc);
         acc = abs_acc(o3, acc);
         if (h == 0) o00 = o0.x;
@@ -245,14 +280,16 @@ __device__ __forceinline__ int weight4x4(const int d[16]) {
     return (int)acc - (a00 - (a00 >> 2));   // DC counts a quarter (DC_UNSIGNIFICANCE, :83,:183)
 }
 
-// weight of the 4x4 block whose rows are the byte quads c[r] (current) and p[r] (candidate)
-__device__ __forceinline__ int weight_quads(const uint32_t c[4], const uint32_t p[4]) {
-    int d[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[4 * r + k] = byte_of(c[r], k) - byte_of(p[r], k);
-    return weight4x4(d);
+// 4x4 byte transpose: rows r[0..3] (byte k = column k) -> columns (byte r = row r); eight v_perm
+__device__ __forceinline__ void transpose4x4(const uint32_t r[4], uint32_t c[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u);   // r0.b0 r1.b0 r0.b1 r1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);   // r0.b2 r1.b2 r0.b3 r1.b3
+    const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u);
+    const uint32_t t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    c[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    c[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    c[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    c[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
 // VP8 six-tap filters by 1/8-pel phase, src/GPU_kernels.cl:563-572

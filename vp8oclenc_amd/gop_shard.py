@@ -95,33 +95,52 @@ def encode_chunks_frames(make_encoder, sequence, chunks) -> dict[int, bytes]:
     return frames
 
 
-def gather_frames(local: dict[int, bytes], total_frames: int, dist=None) -> list[bytes]:
-    """Every rank's frames in frame order on every rank (lengths, then one padded byte matrix: two all_gathers)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_frames(local: dict[int, bytes], total_frames: int, dist=None, dst: int = 0, force_collective: bool = False):
+    """The sequence's frames in frame order on rank `dst` (None on the other ranks).
+
+    Each rank sends only the frames it owns: one small all_gather of the per-frame lengths (-1 = not mine), then every
+    rank's frames, concatenated, go to `dst` point to point -- `dst` holds the sequence once, the others hold nothing
+    they did not code.  (A padded frames x max-length byte matrix all_gathered to every rank, the first version, cost
+    world * total_frames * max_len bytes per rank: key frames set max_len.)
+    force_collective: take the collective path even with one rank, so that a 1-GPU box exercises the RCCL branch."""
+    collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+    if not collective:
         assert len(local) == total_frames
         return [local[t] for t in range(total_frames)]
     import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     lens = torch.full((total_frames,), -1, dtype=torch.int64)
     for t, b in local.items():
         lens[t] = len(b)
     lens = lens.to(dev)
-    all_lens = [torch.empty_like(lens) for _ in range(dist.get_world_size())]
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
     all_lens = torch.stack(all_lens).cpu()
     assert ((all_lens >= 0).sum(dim=0) == 1).all(), "every frame must be encoded by exactly one rank"
-    width = int(all_lens.max())
-    mine = torch.zeros((total_frames, width), dtype=torch.uint8)
-    for t, b in local.items():
-        mine[t, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
-    mine = mine.to(dev)
-    bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(bufs, mine)
-    owner = all_lens.argmax(dim=0)
-    out = []
-    for t in range(total_frames):
-        r = int(owner[t])
-        out.append(bufs[r][t, :int(all_lens[r, t])].cpu().numpy().tobytes())
+    mine = sorted(local)
+    blob = b"".join(local[t] for t in mine)
+    if rank != dst:
+        if blob:
+            dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst=dst)
+        return None
+    out: list = [None] * total_frames
+    for r in range(world):
+        owned = [t for t in range(total_frames) if all_lens[r, t] >= 0]
+        total = int(sum(int(all_lens[r, t]) for t in owned))
+        if r == rank:
+            data = blob
+        elif total:
+            buf = torch.empty(total, dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=r)
+            data = buf.cpu().numpy().tobytes()
+        else:
+            data = b""
+        off = 0
+        for t in owned:
+            n = int(all_lens[r, t])
+            out[t] = data[off:off + n]
+            off += n
     return out
 
 
