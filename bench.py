@@ -123,7 +123,7 @@ def spawn_ranks(args) -> int:
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
-    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed):
+    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0):
         from vp8oclenc_amd.synth import SynthSequence
         self.torch, self.api = torch, api
         seq = SynthSequence(W0, H0, seed=seed)
@@ -136,7 +136,8 @@ class Leg:
         self.drv, self.t = [], []
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
-                                 ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0)
+                                 ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
+                                 overlap_filter=overlap_filter)
             t = (k * 3) % nd                                   # chunks start at different frames of the sequence
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
             self.drv.append(d)
@@ -197,7 +198,8 @@ class Leg:
 
 
 def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1):
-    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed)
+    # one chunk = one video coded frame after frame: the loop filter on its own stream, GOLDEN/ALTREF searched beside it
+    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0)
     for _ in range(warm):
         leg.step()
     el, enq, nrefs = leg.run(steps)

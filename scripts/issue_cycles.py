@@ -49,15 +49,22 @@ def cost_of(mn: str, operands: str):
     return C_SLOW, "slow", ""
 
 
-LOOP_TRIPS = {"k_search1": 4}    # kernels whose one backward branch is a loop with a known trip count (4 sub-blocks)
+LOOP_TRIPS = {"k_search1<loop>": 4}    # kernel name -> trip count of its one backward branch (the four 4x4 sub-blocks)
+
+
+def short_name(mangled: str) -> str:
+    m = re.search(r"(k_[a-z0-9_]+)", mangled)
+    name = m.group(1) if m else mangled
+    if name == "k_search1":      # template <bool SPLIT>
+        name += "<split>" if "ILb1E" in mangled else "<loop>"
+    return name
 
 
 def kernels_of(asm_text: str):
     """yield (mangled name, [(mnemonic, operands)]) for every kernel (functions that end in s_endpgm); the body of a loop
     listed in LOOP_TRIPS is repeated trip-count times, so the stream is the dynamic one"""
     for name, body in _kernels_static(asm_text):
-        short = re.search(r"(k_[a-z0-9_]+)", name)
-        trips = LOOP_TRIPS.get(short.group(1) if short else "", 1)
+        trips = LOOP_TRIPS.get(short_name(name), 1)
         if trips > 1:
             labels = {ops: i for i, (mn, ops) in enumerate(body) if mn == "<label>"}
             for i, (mn, ops) in enumerate(body):
@@ -124,8 +131,7 @@ def main():
     out = {}
     for f in a.files:
         for name, body in kernels_of(compile_asm(f)):
-            short = re.search(r"(k_[a-z0-9_]+)", name)
-            short = short.group(1) if short else name
+            short = short_name(name)
             n, cyc, by, avoidable = price(body)
             out[short] = {"file": f, "static_valu": n, "static_cycles": round(cyc, 1), "cycles_per_instr": round(cyc / max(n, 1), 3),
                           "fast_opcodes_made_slow_by_an_sgpr_source": int(sum(avoidable.values()))}

@@ -3,6 +3,8 @@
 // Behaviour follows the reference kernels cited at each kernel (paths under the reference's src/);
 // the parallel decomposition is new: one 32-lane half-wave per 8x8 block with one search
 // candidate per lane, the winner found with a wave-level packed (cost,index) minimum.
+#include <stdlib.h>
+
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -153,18 +155,55 @@ struct Search1Args {
     int pbw, pbh;   // block grid of the coarser level (whose cells of src[] were written this frame)
 };
 
-// Mapping: five lanes per 8x8 block, lane j = candidate row dy = j-2; the lane loads its eight
-// 12-byte reference rows once and walks the five dx candidates over them in registers (the window
-// bytes are shared by the five candidates of a row).  12 blocks per wave (60 of 64 lanes busy).
-constexpr int S1_BLOCKS_PER_WAVE = 12;
-constexpr int S1_BLOCKS_PER_WG = 4 * S1_BLOCKS_PER_WAVE;
+// Two mappings of the same work:
+//   SPLIT = false: five lanes per 8x8 block, lane j = candidate row dy = j-2, a loop over the four 4x4 sub-blocks;
+//                  12 blocks per wave.  Fewest instructions (the per-block preamble is paid once): the throughput form.
+//   SPLIT = true:  twenty lanes per block = (sub-block sb) x (dy); the four sub-block costs of a candidate meet in two
+//                  shuffles; 3 blocks per wave.  The same arithmetic in four times as many waves, each a quarter as long
+//                  (the preamble is paid per sub-block: +29 % instructions): the latency form.  On the coarse levels,
+//                  which have a few hundred blocks, a launch lasts as long as ONE wave: 12 us per level with the loop,
+//                  5-6 us split (single video, frame after frame: 73 -> 45 us of a 540 us frame for the five levels).
+// In either, a lane loads the 8-byte reference rows of a sub-block at its dy once and walks the five dx candidates over
+// them in registers (the window bytes are shared by the five candidates of a row).
+template <bool SPLIT>
+struct S1Map {
+    static constexpr int LANES_PER_BLOCK = SPLIT ? 20 : 5;
+    static constexpr int BLOCKS_PER_WAVE = SPLIT ? 3 : 12;
+    static constexpr int BLOCKS_PER_WG = 4 * BLOCKS_PER_WAVE;
+};
 
+// cost of the five dx candidates of one 4x4 sub-block (sx, sy) for this lane's dy row, added to acc[]
+__device__ __forceinline__ void s1_subblock(const uint8_t *cp, int cstride, const uint8_t *rp, int rstride, int acc[5]) {
+    uint32_t c[4], q0[4], q1[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)y * cstride) ^ 0x80808080u;
+        const uint2 q = ld_u64(rp + (ptrdiff_t)y * rstride);
+        q0[y] = q.x ^ 0x80808080u; q1[y] = q.y ^ 0x80808080u;
+    }
+    // rows -> columns (byte r = row r), pixels biased: the form weight_cols_pre wants.  Candidate dx = i reads
+    // columns i..i+3 of the eight: no byte alignment per candidate, and the current block's share of the metric
+    // (16 dot4) is computed once for the five of them.
+    uint32_t cc[4], col[8];
+    transpose4x4(c, cc);
+    transpose4x4(q0, col);
+    transpose4x4(q1, col + 4);
+    int pre[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) weight_pre_column(cc[k], pre + 4 * k);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
+    using M = S1Map<SPLIT>;
     const int r = a.refmap[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane / 5, j = lane - 5 * grp;
-    const int b_raw = (blockIdx.x * 4 + wave) * S1_BLOCKS_PER_WAVE + grp;
-    const bool live = grp < S1_BLOCKS_PER_WAVE && b_raw < a.nblk;
+    const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
+    const int sb0 = sub / 5, j = sub - 5 * sb0;       // SPLIT: this lane's sub-block; otherwise sb0 = 0
+    const int b_raw = (blockIdx.x * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
+    const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
     const int b = live ? b_raw : a.nblk - 1;
     const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
     // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
@@ -188,34 +227,22 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
 
     const uint8_t *cp = a.cur.p + (ptrdiff_t)cy * a.cur.stride + cx;
     const uint8_t *rp = a.ref[r].p + (ptrdiff_t)ly * a.ref[r].stride + lx;
-    // One 4x4 sub-block at a time (loop NOT unrolled): 4 current dwords + 4 x 8 reference bytes feed
-    // the five dx candidates, whose costs accumulate in acc[].  Measured on MI355X
-    // (scripts/ubench/valu_rates.hip): one wave issues a VALU instruction every ~5.5 cycles whatever
-    // the instruction, and throughput scales linearly to >= 4 waves per SIMD -- so the register
-    // footprint (waves per SIMD), not the instruction mix, decides the speed of this kernel.
     int acc[5] = {0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int sb = 0; sb < 4; ++sb) {
-        const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
-        uint32_t c[4], q0[4], q1[4];
+    if (SPLIT) {
+        const int sx = (sb0 >> 1) * 4, sy = (sb0 & 1) * 4;   // sub-block order (0,0),(0,+4 rows),(+4 cols,0),(+4,+4), :456-458
+        s1_subblock(cp + (ptrdiff_t)sy * a.cur.stride + sx, a.cur.stride, rp + (ptrdiff_t)sy * a.ref[r].stride + sx, a.ref[r].stride, acc);
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)(sy + y) * a.cur.stride + sx) ^ 0x80808080u;
-            const uint2 q = ld_u64(rp + (ptrdiff_t)(sy + y) * a.ref[r].stride + sx);
-            q0[y] = q.x ^ 0x80808080u; q1[y] = q.y ^ 0x80808080u;
+        for (int i = 0; i < 5; ++i) {   // lanes sub, sub+5, sub+10, sub+15 of the block: the sums land on sb0 = 0
+            acc[i] += __shfl(acc[i], lane + 10, 64);
+            acc[i] += __shfl(acc[i], lane + 5, 64);
         }
-        // rows -> columns (byte r = row r), pixels biased: the form weight_cols_pre wants.  Candidate dx = i reads
-        // columns i..i+3 of the eight: no byte alignment per candidate, and the current block's share of the metric
-        // (16 dot4) is computed once for the five of them.
-        uint32_t cc[4], col[8];
-        transpose4x4(c, cc);
-        transpose4x4(q0, col);
-        transpose4x4(q1, col + 4);
-        int pre[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) weight_pre_column(cc[k], pre + 4 * k);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
+    } else {
+        // one sub-block at a time (loop NOT unrolled: the register footprint decides how many waves a SIMD holds)
+#pragma unroll 1
+        for (int sb = 0; sb < 4; ++sb) {
+            const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
+            s1_subblock(cp + (ptrdiff_t)sy * a.cur.stride + sx, a.cur.stride, rp + (ptrdiff_t)sy * a.ref[r].stride + sx, a.ref[r].stride, acc);
+        }
     }
     const int pen_scale = a.pixel_rate < 4 ? 32 : 0;
     const int pen_y = iabs(iabs(py - cy) - v0y);
@@ -229,13 +256,14 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
         const uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)(j * 5 + i) : 0xffffffffu;
         best = key < best ? key : best;
     }
-    // minimum over the five lanes of the block: (cost << 8 | dxy) = the reference's first strict minimum
+    // minimum over the five dy lanes of the block (its sb = 0 lanes hold the full sums): (cost << 8 | dxy) = the
+    // reference's first strict minimum
 #pragma unroll
     for (int off = 1; off <= 4; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl((int)best, lane + off, 64);
         if (j + off < 5 && o < best) best = o;
     }
-    if (j == 0 && live) {
+    if (sub == 0 && live) {
         int bx, by;  // best position minus block position
         if (best != 0xffffffffu) {
             const int k = best & 0xff;
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
 }
 
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx,
-                    int net_width) {
+                    int net_width, bool latency) {
     Search1Args a;
     a.cur = cur.Y[level];
     int n = 0;
@@ -274,7 +302,12 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
     a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
     if (a.nblk <= 0 || n == 0) return;
-    hipLaunchKernelGGL(k_search1, dim3((a.nblk + S1_BLOCKS_PER_WG - 1) / S1_BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    // fewer waves than the chip has SIMDs: the launch is as long as one wave whatever else runs -> the short-wave form.
+    // VP8HIP_S1_SPLIT=0/1 forces one form (same-box A/B runs)
+    static const int forced = [] { const char *v = getenv("VP8HIP_S1_SPLIT"); return v && v[0] ? (v[0] == '1' ? 1 : 0) : -1; }();
+    const bool split = forced >= 0 ? forced == 1 : (latency || (size_t)a.nblk * n < (size_t)12 * 1024);
+    if (split) hipLaunchKernelGGL(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
 }
 
 // test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)

@@ -50,7 +50,9 @@ struct vp8hip_ctx {
 
     NetSet nets{};
     MBOut out{};
-    SegData *d_sd = nullptr;
+    SegData *d_sd = nullptr;        // the segment data in force (one of d_sd2)
+    SegData *d_sd2[2] = {nullptr, nullptr};
+    const SegData *lf_sd = nullptr; // what the loop filter in flight on lf_stream reads: the next frame's data go to the other buffer
     SegData *h_sd_ring = nullptr;   // pinned staging for vp8hip_set_segments
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
@@ -218,6 +220,13 @@ static std::atomic<int> g_live_contexts{0};
 
 extern "C" {
 
+// New segment data while the previous frame's loop filter is still in flight on lf_stream (it reads its own frame's data):
+// they go to the other buffer.  Consumers on the context's stream are ordered behind the write anyway.
+static SegData *sd_for_writing(vp8hip_ctx *c) {
+    if (c->lf_pending && c->lf_sd == c->d_sd) c->d_sd = c->d_sd == c->d_sd2[0] ? c->d_sd2[1] : c->d_sd2[0];
+    return c->d_sd;
+}
+
 // work enqueued on the context's stream from here on sees the filtered reconstruction
 static int join_lf(vp8hip_ctx *c) {
     if (!c->lf_pending) return VP8HIP_OK;
@@ -297,7 +306,9 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->out.vec, (size_t)c->mbs * 16));
     CR(hipMalloc(&c->out.coeffs, (size_t)c->mbs * 800));
     CR(hipMalloc(&c->out.first_lf0, 64));
-    CR(hipMalloc(&c->d_sd, sizeof(SegData)));
+    CR(hipMalloc(&c->d_sd2[0], 2 * sizeof(SegData)));
+    c->d_sd2[1] = c->d_sd2[0] + 1;
+    c->d_sd = c->d_sd2[0];
     CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
     CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
     CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
@@ -322,7 +333,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMemsetAsync(c->out.ssim, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.vec, 0, (size_t)c->mbs * 16, c->stream));
     CR(hipMemsetAsync(c->out.coeffs, 0, (size_t)c->mbs * 800, c->stream));
-    CR(hipMemsetAsync(c->d_sd, 0, sizeof(SegData), c->stream));
+    CR(hipMemsetAsync(c->d_sd2[0], 0, 2 * sizeof(SegData), c->stream));
     for (int i = 0; i < MAX_EVENTS; ++i) CR(hipEventCreate(&c->ev[i]));
     c->ev_created = true;
     c->recon = 0;
@@ -377,7 +388,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->out.vec);
     hipFree(c->out.coeffs);
     hipFree(c->out.first_lf0);
-    hipFree(c->d_sd);
+    hipFree(c->d_sd2[0]);
     if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
     if (c->h_frame) hipHostFree(c->h_frame);
     hipFree(c->d_frame);
@@ -430,7 +441,6 @@ static void next_current(vp8hip_ctx *c) {
 
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
     int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice);
@@ -442,7 +452,6 @@ int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, con
 
 int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const void *v) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
     return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice);
@@ -450,7 +459,6 @@ int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const
 
 int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !reductor || !sharpness) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     launch_lf_strength(c->stream, c->cur, c->d_stats + 8, c->d_stats);
@@ -474,7 +482,6 @@ int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpn
 
 int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !Udiff || !Vdiff) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
     *Udiff = *Vdiff = 0;
@@ -509,22 +516,20 @@ int vp8hip_set_last_device(vp8hip_ctx *c, const void *y, const void *u, const vo
 
 int vp8hip_set_segments(vp8hip_ctx *c, const int32_t sd[VP8HIP_SD_INTS]) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !sd) return VP8HIP_ERR_ARG;
     // staged through a ring of pinned slots so the call neither keeps the caller's pointer nor stalls
     // the stream (176 bytes per frame; 16 slots cover any realistic number of frames in flight)
     SegData *slot = c->h_sd_ring + (c->sd_ring_pos++ & 15);
     memcpy(slot, sd, sizeof(SegData));
-    HIPCHK(c, hipMemcpyAsync(c->d_sd, slot, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sd_for_writing(c), slot, sizeof(SegData), hipMemcpyHostToDevice, c->stream));
     return VP8HIP_OK;
 }
 
 int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4], int qi_min) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c || !refqi) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
-    launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, c->d_sd, reinterpret_cast<int32_t *>(c->d_stats + 4),
+    launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, sd_for_writing(c), reinterpret_cast<int32_t *>(c->d_stats + 4),
                          is_key_frame ? 1 : 0, refqi, qi_min);
     HIPCHK(c, hipGetLastError());
     return VP8HIP_OK;
@@ -544,7 +549,6 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
 
 int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
     USE_DEVICE(c);
-    JOIN_LF(c);
     if (!c) return VP8HIP_ERR_ARG;
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
@@ -558,8 +562,42 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         c->recon = pick_free_frame(c);
         if (c->recon < 0) return VP8HIP_ERR_STATE;
     }
-    // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
     FrameSurf &last = c->frames[c->slot[0]];
+    RefSet refs;
+    refs.use[0] = 1;
+    refs.use[1] = use_golden ? 1 : 0;
+    refs.use[2] = use_altref ? 1 : 0;
+    for (int r = 0; r < 3; ++r) refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
+    const int net_width = c->mbw * 2;
+    // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
+    // references in `which` (the reference runs the three references on three queues, inter_part.h:122-135)
+    auto search = [&](const RefSet &which) {
+        int src = 0;
+        for (int l = 4; l >= 0; --l) {
+            Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
+            // one video coded frame after frame (filter on its own stream): nothing else fills the chip, short waves pay
+            launch_search1(s, c->cur, which, c->nets, l, src, net_width, c->lf_overlap && l > 0);
+            src ^= 1;
+        }
+        Timed t(c, VP8HIP_K_SEARCH2);
+        launch_search2(s, c->cur, which, c->nets);
+    };
+    // While the previous frame's loop filter is still running on its own stream (vp8hip_filter_overlap): only LAST is
+    // what it writes.  GOLDEN and ALTREF -- never the frame being filtered: use_golden / use_altref exclude a reference
+    // that was refreshed by the previous frame, inter_part.h:103-104 -- are searched first, beside the filter; the filter
+    // is joined only then, and LAST follows.  A single video coded frame after frame is bound by the filter's dependency
+    // chain (0.36 ms of a 0.60 ms frame at 1080p); this takes 1.8 of the 2.8 reference searches out of the chain.
+    const bool split = c->lf_pending && (use_golden || use_altref) && (!use_golden || c->slot[1] != c->slot[0]) &&
+                       (!use_altref || c->slot[2] != c->slot[0]);
+    if (split) {
+        if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
+        c->cur_pyramid_valid = true;
+        RefSet others = refs;
+        others.use[0] = 0;
+        search(others);
+    }
+    JOIN_LF(c);
+    // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
     if (!last.pyramid_valid && !c->cur_pyramid_valid) {
         build_pyramid(c, &c->cur, &last.f);
     } else {
@@ -568,23 +606,12 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
     }
     last.pyramid_valid = true;
     c->cur_pyramid_valid = true;
-
-    RefSet refs;
-    refs.use[0] = 1;
-    refs.use[1] = use_golden ? 1 : 0;
-    refs.use[2] = use_altref ? 1 : 0;
-    for (int r = 0; r < 3; ++r) refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
-    const int net_width = c->mbw * 2;
-    // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854
-    int src = 0;
-    for (int l = 4; l >= 0; --l) {
-        Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
-        launch_search1(s, c->cur, refs, c->nets, l, src, net_width);
-        src ^= 1;
-    }
-    {
-        Timed t(c, VP8HIP_K_SEARCH2);
-        launch_search2(s, c->cur, refs, c->nets);
+    if (split) {
+        RefSet only_last = refs;
+        only_last.use[1] = only_last.use[2] = 0;
+        search(only_last);
+    } else {
+        search(refs);
     }
     {
         Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
@@ -738,6 +765,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         launch_border(c->lf_stream, f);
         HIPCHK(c, hipEventRecord(c->ev_lf, c->lf_stream));
         c->lf_pending = true;
+        c->lf_sd = c->d_sd;
     } else {
         {
             Timed t(c, VP8HIP_K_LOOP_FILTER);

@@ -55,7 +55,7 @@ void launch_border(hipStream_t s, const Frame &f);
 void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b);   // all four levels of one or two frames
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
-                    int src_idx, int net_width);
+                    int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
                     int dbg_block = -1);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
