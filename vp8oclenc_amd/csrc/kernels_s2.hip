@@ -45,6 +45,10 @@ static __device__ __constant__ const uint32_t K_V7[5][12] = {
 
 constexpr int HT_XC = 36;            // dwords per x case in the transposed H array: 8 columns x 16 B + 16 B bank skew
 constexpr int KBIAS = 128 * 128 + 64;  // undo the -128 pixel bias (taps sum to 128) + rounding
+constexpr int V_STRIDE = 20;           // dwords per candidate in the V array: 8 columns x 8 B + 16 B so that the b128 reads of 16 lanes miss each other's banks
+// Every LDS array of the kernel is indexed by the block's slot g, and the 32 lanes of a block sit in ONE wave: the stages
+// hand data over inside a wave, so a wave-level "my LDS writes have landed" is all the synchronisation there is
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 struct S2Args {
     Plane cur;
@@ -84,7 +88,8 @@ __device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __b
 __global__ __launch_bounds__(256) void k_search2(S2Args a) {
     __shared__ uint32_t s_win[8][72];
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
-    __shared__ uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
+    __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
+    __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
     __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
     const int r = a.refmap[blockIdx.y];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) cz[j * 8] = (uint8_t)(v >> (8 * j));
     }
-    __syncthreads();
+    lds_fence();
 
     // ---- horizontal pass -------------------------------------------------------------------------
     if (lane < 28) {
@@ -162,26 +167,24 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
         pre[0] = dot4s(ccol, lane < 16 ? K_W_R0 : K_W_X, 0);
         pre[1] = dot4s(ccol, lane < 16 ? K_W_R2 : K_W_Y, 0);
     }
-    __syncthreads();
+    lds_fence();
 
-    // ---- vertical pass + cost ----------------------------------------------------------------------
-    const int k = lane;
-    const int dx = k % 5 - 2, dy = k / 5 - 2;
-    int qx = (int16_t)(cx * 4 + v0x + dx), qy = (int16_t)(cy * 4 + v0y + dy);
-    if (k == 25) { qx = cx * 4; qy = cy * 4; }
-    const bool valid = live && k < 26 && qx >= 0 && qx <= a.w * 4 - 32 && qy >= 0 && qy <= a.h * 4 - 32;
-    uint32_t P[8][2];
-    if (k < 25) {
-        const int xc = k % 5, yc = k / 5;
+    // ---- vertical pass -------------------------------------------------------------------------------
+    // Producer: the 25 candidates need, per fractional x case and column, the column filtered by four vertical filters
+    // (dy = -2, -1, +1, +2; dy = 0 is a copy).  One candidate per lane computing its own 8x8 (the first version) keeps
+    // 25 of 32 lanes busy and filters the five dy = 0 predictions for nothing: 2048 sample slots for 1000 samples.
+    // Here lane = (column c = lane >> 2, filter f = lane & 3) walks the five x cases: 5 x 8 samples per lane, every lane
+    // busy, results to LDS; the f = 0 lanes also lay down the dy = 0 copies.
+    {
+        const int f = lane & 3, c = lane >> 2, ycf = f + (f >> 1);   // y case 0, 1, 3, 4
         uint32_t t[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) t[i] = K_V7[yc][i];
-        const uint4 *H = reinterpret_cast<const uint4 *>(s_HT[g] + xc * HT_XC);
+        for (int i = 0; i < 10; ++i) t[i] = K_V7[ycf][i];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint4 hv = H[c];
+        for (int xc = 0; xc < 5; ++xc) {
+            const uint4 hv = reinterpret_cast<const uint4 *>(s_HT[g] + xc * HT_XC)[c];
             const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w};
-            int s[8];
+            int sm[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = i >> 2, si = i & 3;
@@ -189,18 +192,38 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
                 int acc = dot4k(h[m], t[tb], KBIAS);
                 acc = dot4(h[m + 1], t[tb + 1], acc);
                 if (si >= 2) acc = dot4(h[m + 2], t[tb + 2], acc);
-                s[i] = acc;
+                sm[i] = acc;
             }
-            P[c][0] = pack4(ashr7_pk_u8(s[0], s[1]), ashr7_pk_u8(s[2], s[3])) ^ 0x80808080u;   // biased, like everything the metric reads
-            P[c][1] = pack4(ashr7_pk_u8(s[4], s[5]), ashr7_pk_u8(s[6], s[7])) ^ 0x80808080u;
-            if (yc == 2) {   // whole-pel dy: rows 3..10 of the column
-                P[c][0] = __builtin_amdgcn_alignbyte(h[1], h[0], 3);
-                P[c][1] = __builtin_amdgcn_alignbyte(h[2], h[1], 3);
+            uint2 v;   // biased, like everything the metric reads
+            v.x = pack4(ashr7_pk_u8(sm[0], sm[1]), ashr7_pk_u8(sm[2], sm[3])) ^ 0x80808080u;
+            v.y = pack4(ashr7_pk_u8(sm[4], sm[5]), ashr7_pk_u8(sm[6], sm[7])) ^ 0x80808080u;
+            *reinterpret_cast<uint2 *>(&s_V[g][(ycf * 5 + xc) * V_STRIDE + c * 2]) = v;
+            if (f == 0) {   // whole-pel dy: rows 3..10 of the column
+                uint2 w;
+                w.x = __builtin_amdgcn_alignbyte(h[1], h[0], 3);
+                w.y = __builtin_amdgcn_alignbyte(h[2], h[1], 3);
+                *reinterpret_cast<uint2 *>(&s_V[g][(2 * 5 + xc) * V_STRIDE + c * 2]) = w;
             }
         }
-    } else {  // zero MV: whole-pel, both passes are the identity
+    }
+    lds_fence();
+
+    // ---- cost: lane = candidate --------------------------------------------------------------------
+    const int k = lane;
+    const int dx = k % 5 - 2, dy = k / 5 - 2;
+    int qx = (int16_t)(cx * 4 + v0x + dx), qy = (int16_t)(cy * 4 + v0y + dy);
+    if (k == 25) { qx = cx * 4; qy = cy * 4; }
+    const bool valid = live && k < 26 && qx >= 0 && qx <= a.w * 4 - 32 && qy >= 0 && qy <= a.h * 4 - 32;
+    uint32_t P[8][2];
+    {
+        // candidates 0..24: their prediction from the producer; lane 25 (zero MV: whole-pel, both passes are the identity)
+        // and the idle lanes read the zero-MV block
+        const uint32_t *src = k < 25 ? &s_V[g][k * V_STRIDE] : &s_cz[g][16];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { P[c][0] = s_cz[g][16 + 2 * c]; P[c][1] = s_cz[g][17 + 2 * c]; }
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + 4 * c4);
+            P[2 * c4][0] = v.x; P[2 * c4][1] = v.y; P[2 * c4 + 1][0] = v.z; P[2 * c4 + 1][1] = v.w;
+        }
     }
     int diff = 0;
 #pragma unroll
