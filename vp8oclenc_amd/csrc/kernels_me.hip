@@ -153,6 +153,7 @@ struct Search1Args {
     int refmap[3];
     int net_width, w, h, pixel_rate, rate_shift, nblk, bw;
     int pbw, pbh;   // block grid of the coarser level (whose cells of src[] were written this frame)
+    uint32_t bw_inv;   // ceil(2^32 / bw)
 };
 
 // Two mappings of the same work:
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
     const int b_raw = (blockIdx.x * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
     const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
     const int b = live ? b_raw : a.nblk - 1;
-    const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
+    const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
+    const int cx = bx * 8, cy = by * 8;
     // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
     // coarser level's block grid are read but never written; reading them as 0 here is the same thing
     // without the extra kernel.  vector / pixel_rate truncates toward zero (:495-500).
@@ -299,6 +301,7 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.rate_shift = level;
     a.bw = a.w / 8;
     a.nblk = (a.w / 8) * (a.h / 8);
+    a.bw_inv = a.bw > 0 ? (uint32_t)(((1ull << 32) + a.bw - 1) / a.bw) : 0;
     a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
     a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
     if (a.nblk <= 0 || n == 0) return;

@@ -58,6 +58,7 @@ struct S2Args {
     int32_t *bdiff[3];
     int refmap[3];
     int w, h, nblk, bw;
+    uint32_t bw_inv;   // ceil(2^32 / bw)
     uint32_t *dbg;   // test tap: per-candidate prediction (column-major) and cost of block dbg_block, or nullptr
     int dbg_block;
 };
@@ -86,16 +87,17 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 __device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
 
 __global__ __launch_bounds__(256) void k_search2(S2Args a) {
-    __shared__ uint32_t s_win[8][72];
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
+    uint32_t(*s_win)[25 * V_STRIDE] = s_V;   // the staged window (72 dwords) is dead once the horizontal pass has read it: same bytes
     __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
     const int r = a.refmap[blockIdx.y];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int b = imin(blockIdx.x * 8 + g, a.nblk - 1);
     const bool live = blockIdx.x * 8 + g < a.nblk;
-    const int cx = (b % a.bw) * 8, cy = (b / a.bw) * 8;
+    const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
+    const int cx = bx * 8, cy = by * 8;
     const uint32_t nv = reinterpret_cast<const uint32_t *>(a.net_in[r])[b];
     const int nx = (int16_t)(nv & 0xffffu), ny = (int16_t)(nv >> 16);
     const int v0x = (int16_t)(nx * 4), v0y = (int16_t)(ny * 4);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
             d[17] = valid;
         }
         for (int i = lane; i < 5 * HT_XC; i += 32) a.dbg[468 + i] = s_HT[g][i];
-        for (int i = lane; i < 72; i += 32) a.dbg[648 + i] = s_win[g][i];
+        // (the staged window is gone by now: its bytes hold vertical pass results; a.dbg[648..719] stay as the caller left them)
         if (lane == 0) { a.dbg[730] = (uint32_t)Lx; a.dbg[731] = (uint32_t)Ly; a.dbg[732] = (uint32_t)o; }
     }
     uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
@@ -286,6 +288,7 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.w = a.cur.w;
     a.h = a.cur.h;
     a.bw = a.w / 8;
+    a.bw_inv = (uint32_t)(((1ull << 32) + a.bw - 1) / a.bw);
     a.nblk = a.w * a.h / 64;
     a.dbg = dbg;
     a.dbg_block = dbg_block;
