@@ -175,6 +175,15 @@ class Leg:
                 prof[k] = (pm + ms, pn + n)
         return prof
 
+    def clock_read(self):
+        """the loop filter by the kernel's own clock, all chunks: (ms, launches) since the last call"""
+        tot, n = 0.0, 0
+        for d in self.drv:
+            ms, k = d.hip.profile_read_clock()
+            tot += ms
+            n += k
+        return tot, n
+
     def run(self, steps, barrier=None):
         """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
         sync = barrier or self.torch.cuda.synchronize
@@ -256,6 +265,7 @@ def main():
     # come from the warm-up steps of chunk 0 above (same steady state, fifteen other chunks in flight)
     timed = api.K_NAMES if args.profile_all else [dominant]
     leg.profile(timed)
+    leg.clock_read()   # restart the in-kernel clock sums
 
     # ---- timed region: exactly --steps steps, barrier + synchronize on both sides, max over ranks -------------
     elapsed, enqueue_s, nrefs_avg = leg.run(args.steps, barrier)
@@ -264,6 +274,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = leg.profile_read()
+    clk_ms, clk_n = leg.clock_read()
     frames_per_gpu = args.steps * G
     if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:
         raise SystemExit(f"bench.py: the timed frames averaged {nrefs_avg:.2f} references per frame; LAST+GOLDEN+ALTREF in GOP "
@@ -281,9 +292,17 @@ def main():
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k),
-                "note": "longest kernel per launch, hipEvents on its own stream over the timed region, all chunks.  None of this "
-                        "path's kernels is HBM-bound (integer search / transform / a serial filter chain): the binding resource is "
-                        "VALU issue, see issue_roofline"}
+                "note": "longest kernel per launch; achieved = algorithmic bytes / avg_launch_ms, HIP events of its own stream over the "
+                        "timed region, all chunks.  With 16 streams on the part those events also count the time a packet waits for its "
+                        "queue (a one-chunk run and a run under rocprofv3 do not show it): kernel_clock gives the same launches by the "
+                        "kernel's own clock, which is what the rocprofv3 kernel trace under profiles/ shows.  None of this path's kernels "
+                        "is HBM-bound (integer search / transform / a serial filter chain): the binding resource is VALU issue, see "
+                        "issue_roofline"}
+        if dominant == "loop_filter" and clk_n:
+            kms = clk_ms / clk_n
+            roof["kernel_clock"] = {"avg_launch_ms": round(kms, 5), "launches": int(clk_n), "achieved": round(abytes / (kms * 1e-3) / 1e9, 3),
+                                    "frac": round(abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                    "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row"}
         others = {}
         for k, (ms, n) in {**warm, **prof}.items():
             if k == dominant or n == 0:

@@ -247,6 +247,10 @@ typedef enum {
 int vp8hip_profile_enable(vp8hip_ctx *ctx, uint32_t mask);
 /* blocks until the stream is idle; total_ms[id] / launches[id] since the last read (arrays of VP8HIP_K_COUNT) */
 int vp8hip_profile_read(vp8hip_ctx *ctx, double *total_ms, int64_t *launches);
+/* The loop filter's duration by the kernel's own clock (s_memrealtime: start of its first band to the end of its last row),
+ * summed since the last call.  With many contexts in flight the HIP events of vp8hip_profile_read also count the time a
+ * packet waits for its queue to be scheduled; this figure does not, and it is what a rocprofv3 kernel trace shows. */
+int vp8hip_profile_read_clock(vp8hip_ctx *ctx, double *loop_filter_ms, int64_t *loop_filter_launches);
 
 /* stage outputs of the last vp8hip_inter_transform, for parity tests */
 typedef enum {

@@ -21,7 +21,7 @@ DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CO
 
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
-    "vp8hip_hw_queues",
+    "vp8hip_hw_queues", "vp8hip_profile_read_clock",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
@@ -518,6 +518,13 @@ class Vp8Hip:
         n = (C.c_int64 * K_COUNT)()
         self._chk(self.lib.vp8hip_profile_read(self.h, ms, n), "profile_read")
         return {K_NAMES[i]: (ms[i], n[i]) for i in range(K_COUNT) if n[i]}
+
+    def profile_read_clock(self):
+        """(ms, launches) of the loop filter by the kernel's own clock since the last call (vp8hip_profile_read_clock)"""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self.lib.vp8hip_profile_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        self._chk(self.lib.vp8hip_profile_read_clock(self.h, C.byref(ms), C.byref(n)), "profile_read_clock")
+        return ms.value, n.value
 
     def debug(self, what: int, ref: int = 0, level: int = 0) -> np.ndarray:
         if what in (DBG_NET1, DBG_NET2):

@@ -176,6 +176,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 8) sh.flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) { sh.first_lf0 = 0x7fffffff; sh.abort = 0; }
+    // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
+    // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
+    // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches}
+    if (band == 0 && threadIdx.x == 0) __hip_atomic_store(clk, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int mbw = a.mbw, mbh = a.mbh;
     const int band_row0 = band * ROWS;
@@ -452,6 +457,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
         o[0] = st_wait; o[1] = st_p1; o[2] = st_p2; o[3] = st_wb;
     }
 #endif
+    if (gr == mbh && l32 == 0) {   // the frame's last row: this wave is the last to finish real work
+        const unsigned long long t0 = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(clk + 1, __builtin_amdgcn_s_memrealtime() - t0);
+        atomicAdd(clk + 2, 1ull);
+    }
 }
 
 }  // namespace lf3
@@ -476,7 +486,7 @@ void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, cons
     a.gbase = (int)(n * (unsigned)(mbw + 2));
     a.err = progress + LF_ERR_WORD;
     a.stall_test = stall_test;
-    hipLaunchKernelGGL(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
+    VP8_LAUNCH(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
 }
 
 }  // namespace vp8

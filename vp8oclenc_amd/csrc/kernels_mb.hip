@@ -488,7 +488,7 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
     a.nets = nets;
     a.use_golden = refs.use[1];
     a.use_altref = refs.use[2];
-    hipLaunchKernelGGL(k_mb, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+    VP8_LAUNCH(k_mb, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k_border(Plane py, Plane pu, Plane pv) {
 
 void launch_border(hipStream_t s, const Frame &f) {
     dim3 grid(f.Y[0].h + 2 * EXT, 3);
-    hipLaunchKernelGGL(k_border, grid, dim3(64), 0, s, f.Y[0], f.U, f.V);
+    VP8_LAUNCH(k_border, grid, dim3(64), 0, s, f.Y[0], f.U, f.V);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -98,7 +98,7 @@ void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b) {
     PyrArgs p;
     p.f[0] = *a;
     p.f[1] = b ? *b : *a;
-    hipLaunchKernelGGL(k_pyramid, dim3((a->Y[0].w + 63) / 64, (a->Y[0].h + 63) / 64, b ? 2 : 1), dim3(256), 0, s, p);
+    VP8_LAUNCH(k_pyramid, dim3((a->Y[0].w + 63) / 64, (a->Y[0].h + 63) / 64, b ? 2 : 1), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_pack(Plane py, Plane pu, Plane pv, cons
 
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
-    hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, f.Y[0], f.U, f.V, (const uint8_t *)y,
+    VP8_LAUNCH(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, f.Y[0], f.U, f.V, (const uint8_t *)y,
                        (const uint8_t *)u, (const uint8_t *)v);
 }
 
@@ -309,8 +309,8 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     // VP8HIP_S1_SPLIT=0/1 forces one form (same-box A/B runs)
     static const int forced = [] { const char *v = getenv("VP8HIP_S1_SPLIT"); return v && v[0] ? (v[0] == '1' ? 1 : 0) : -1; }();
     const bool split = forced >= 0 ? forced == 1 : (latency || (size_t)a.nblk * n < (size_t)12 * 1024);
-    if (split) hipLaunchKernelGGL(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    if (split) VP8_LAUNCH(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    else VP8_LAUNCH(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
 }
 
 // test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)

@@ -292,7 +292,7 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.nblk = a.w * a.h / 64;
     a.dbg = dbg;
     a.dbg_block = dbg_block;
-    hipLaunchKernelGGL(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
+    VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
 }
 
 }  // namespace vp8

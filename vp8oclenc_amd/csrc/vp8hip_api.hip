@@ -93,6 +93,10 @@ struct vp8hip_ctx {
     int64_t prof_n[VP8HIP_K_COUNT] = {0};
 };
 
+namespace vp8 {
+thread_local LaunchTiming tl_timing;
+}
+
 namespace {
 
 #define HIPCHK(c, call)                                  \
@@ -136,18 +140,37 @@ uint8_t *carve_frame(uint8_t *cursor, int W, int H, Frame *f) {
 }
 
 // ---- per-kernel event timing --------------------------------------------------------------------
+// Stages that are ONE kernel launch get their two events recorded by the dispatch itself (VP8_LAUNCH, vp8hip_dev.h): the
+// kernel's own begin and end.  Stages made of several launches (entropy stage, intra) are bracketed with hipEventRecord.
+constexpr uint32_t SINGLE_LAUNCH_STAGES = (1u << VP8HIP_K_PACK) | (1u << VP8HIP_K_DOWNSAMPLE) | (1u << VP8HIP_K_SEARCH1_L4) | (1u << VP8HIP_K_SEARCH1_L3) |
+                                          (1u << VP8HIP_K_SEARCH1_L2) | (1u << VP8HIP_K_SEARCH1_L1) | (1u << VP8HIP_K_SEARCH1_L0) | (1u << VP8HIP_K_SEARCH2) |
+                                          (1u << VP8HIP_K_MB) | (1u << VP8HIP_K_LOOP_FILTER) | (1u << VP8HIP_K_BORDER);
 struct Timed {
     vp8hip_ctx *c;
     int slot = -1;
+    bool by_dispatch = false;
     Timed(vp8hip_ctx *ctx, int kernel) : c(ctx) {
         if (!(c->prof_mask & (1u << kernel)) || c->ev_used + 2 > MAX_EVENTS) return;
         slot = c->ev_used;
         c->ev_kernel[slot / 2] = kernel;
         c->ev_used += 2;
-        hipEventRecord(c->ev[slot], c->stream);
+        by_dispatch = (SINGLE_LAUNCH_STAGES >> kernel) & 1u;
+        if (by_dispatch) {
+            tl_timing.start = c->ev[slot];
+            tl_timing.stop = c->ev[slot + 1];
+            tl_timing.launches = 0;
+        } else {
+            hipEventRecord(c->ev[slot], c->stream);
+        }
     }
     ~Timed() {
-        if (slot >= 0) hipEventRecord(c->ev[slot + 1], c->stream);
+        if (slot < 0) return;
+        if (by_dispatch) {
+            if (tl_timing.launches == 0) c->ev_used -= 2;   // nothing was launched (a pyramid level without a block): give the slot back
+            tl_timing = LaunchTiming{};
+        } else {
+            hipEventRecord(c->ev[slot + 1], c->stream);
+        }
     }
 };
 
@@ -1162,6 +1185,20 @@ int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
         c->prof_ms[k] = 0;
         c->prof_n[k] = 0;
     }
+    return VP8HIP_OK;
+}
+
+int vp8hip_profile_read_clock(vp8hip_ctx *c, double *loop_filter_ms, int64_t *loop_filter_launches) {
+    USE_DEVICE(c);
+    if (!c || !loop_filter_ms || !loop_filter_launches) return VP8HIP_ERR_ARG;
+    JOIN_LF(c);
+    unsigned long long clk[3] = {0, 0, 0};
+    int32_t *base = c->d_progress + LF_ERR_WORD + 4;
+    HIPCHK(c, hipMemcpyAsync(clk, base, sizeof(clk), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(base + 2, 0, 16, c->stream));   // sum and count restart; the start stamp is rewritten by every launch
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *loop_filter_ms = (double)clk[1] * 1e-5;   // 100 MHz ticks
+    *loop_filter_launches = (int64_t)clk[2];
     return VP8HIP_OK;
 }
 
