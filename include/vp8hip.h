@@ -219,6 +219,22 @@ int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
  * stderr when a process holds more contexts than queues (VP8HIP_QUIET=1 silences it).  No reference counterpart: the
  * reference has one in-order OpenCL queue per reference frame (init.h:210-228). */
 int vp8hip_hw_queues(void);
+
+/* ---- one frame's reference searches on different devices (reference: the three searches of a frame run
+ * on three command queues and share only the current frame, inter_part.h:122-135, 201-236) --------------------------------
+ * Every device holds a context with the same frames.  Per inter frame each calls vp8hip_inter_search with the references
+ * it is to search (search_mask: bit 0 LAST, bit 1 GOLDEN, bit 2 ALTREF; the use_* flags are the frame's, as for
+ * vp8hip_inter_transform), hands its vectors and costs over -- vp8hip_export_search / vp8hip_import_search copy one
+ * reference's quarter-pel vector net (short2 per 8x8 block) and cost net (int per 8x8 block) to / from DEVICE memory of the
+ * caller, e.g. the buffers of an RCCL all_gather -- and the device that has all of them calls vp8hip_inter_finish
+ * (select_reference ... SSIM, filter mask: what vp8hip_inter_transform does after its searches), then the loop filter;
+ * vp8hip_export_last copies the filtered reconstruction (tight planes) to device memory for the broadcast that makes it
+ * the other devices' LAST (vp8hip_set_last_device there).  All asynchronous on the context's stream (vp8hip_stream). */
+int vp8hip_inter_search(vp8hip_ctx *ctx, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref, int search_mask);
+int vp8hip_inter_finish(vp8hip_ctx *ctx, int use_golden, int use_altref);
+int vp8hip_export_search(vp8hip_ctx *ctx, int ref, void *d_vectors, void *d_costs);
+int vp8hip_import_search(vp8hip_ctx *ctx, int ref, const void *d_vectors, const void *d_costs);
+int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
 const char *vp8hip_status_string(int status);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

@@ -21,7 +21,8 @@ DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CO
 
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
-    "vp8hip_hw_queues", "vp8hip_profile_read_clock",
+    "vp8hip_hw_queues", "vp8hip_profile_read_clock", "vp8hip_inter_search", "vp8hip_inter_finish", "vp8hip_export_search",
+    "vp8hip_import_search", "vp8hip_export_last",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",

@@ -570,12 +570,10 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
     return VP8HIP_OK;
 }
 
-int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
-    USE_DEVICE(c);
-    if (!c) return VP8HIP_ERR_ARG;
+// reference rotation + the reconstruction surface of the new frame: the head of every inter frame
+static int inter_begin(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
-    hipStream_t s = c->stream;
     // reference rotation, inter_part.h:35-50,72-83: golden/altref := the frame that is LAST now
     if (prev_is_golden) c->slot[1] = c->slot[0];
     if (prev_is_altref) c->slot[2] = c->slot[0];
@@ -585,26 +583,53 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         c->recon = pick_free_frame(c);
         if (c->recon < 0) return VP8HIP_ERR_STATE;
     }
-    FrameSurf &last = c->frames[c->slot[0]];
+    return VP8HIP_OK;
+}
+
+static RefSet ref_set(const vp8hip_ctx *c, int use_last, int use_golden, int use_altref) {
     RefSet refs;
-    refs.use[0] = 1;
+    refs.use[0] = use_last ? 1 : 0;
     refs.use[1] = use_golden ? 1 : 0;
     refs.use[2] = use_altref ? 1 : 0;
     for (int r = 0; r < 3; ++r) refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
+    return refs;
+}
+
+// hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
+// references in `which` (the reference runs the three references on three queues, inter_part.h:122-135)
+static void search_refs(vp8hip_ctx *c, const RefSet &which) {
+    hipStream_t s = c->stream;
     const int net_width = c->mbw * 2;
-    // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
-    // references in `which` (the reference runs the three references on three queues, inter_part.h:122-135)
-    auto search = [&](const RefSet &which) {
-        int src = 0;
-        for (int l = 4; l >= 0; --l) {
-            Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
-            // one video coded frame after frame (filter on its own stream): nothing else fills the chip, short waves pay
-            launch_search1(s, c->cur, which, c->nets, l, src, net_width, c->lf_overlap && l > 0);
-            src ^= 1;
-        }
-        Timed t(c, VP8HIP_K_SEARCH2);
-        launch_search2(s, c->cur, which, c->nets);
-    };
+    int src = 0;
+    for (int l = 4; l >= 0; --l) {
+        Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
+        // one video coded frame after frame (filter on its own stream): nothing else fills the chip, short waves pay
+        launch_search1(s, c->cur, which, c->nets, l, src, net_width, c->lf_overlap && l > 0);
+        src ^= 1;
+    }
+    Timed t(c, VP8HIP_K_SEARCH2);
+    launch_search2(s, c->cur, which, c->nets);
+}
+
+// prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
+static void pyramids(vp8hip_ctx *c) {
+    FrameSurf &last = c->frames[c->slot[0]];
+    if (!last.pyramid_valid && !c->cur_pyramid_valid) {
+        build_pyramid(c, &c->cur, &last.f);
+    } else {
+        if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
+        if (!last.pyramid_valid) build_pyramid(c, &last.f, nullptr);
+    }
+    last.pyramid_valid = true;
+    c->cur_pyramid_valid = true;
+}
+
+int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    int rc = inter_begin(c, prev_is_golden, prev_is_altref, use_golden, use_altref);
+    if (rc) return rc;
+    const RefSet refs = ref_set(c, 1, use_golden, use_altref);
     // While the previous frame's loop filter is still running on its own stream (vp8hip_filter_overlap): only LAST is
     // what it writes.  GOLDEN and ALTREF -- never the frame being filtered: use_golden / use_altref exclude a reference
     // that was refreshed by the previous frame, inter_part.h:103-104 -- are searched first, beside the filter; the filter
@@ -615,33 +640,78 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
     if (split) {
         if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
         c->cur_pyramid_valid = true;
-        RefSet others = refs;
-        others.use[0] = 0;
-        search(others);
+        search_refs(c, ref_set(c, 0, use_golden, use_altref));
     }
     JOIN_LF(c);
-    // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
-    if (!last.pyramid_valid && !c->cur_pyramid_valid) {
-        build_pyramid(c, &c->cur, &last.f);
-    } else {
-        if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
-        if (!last.pyramid_valid) build_pyramid(c, &last.f, nullptr);
-    }
-    last.pyramid_valid = true;
-    c->cur_pyramid_valid = true;
-    if (split) {
-        RefSet only_last = refs;
-        only_last.use[1] = only_last.use[2] = 0;
-        search(only_last);
-    } else {
-        search(refs);
-    }
+    pyramids(c);
+    search_refs(c, split ? ref_set(c, 1, 0, 0) : refs);
     {
         Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
-        launch_mb(s, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
+        launch_mb(c->stream, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+// ---- one frame's reference searches on different devices --------------------------------------------
+// The reference runs the LAST / GOLDEN / ALTREF searches of a frame on three command queues (inter_part.h:122-135,
+// 201-236): they share nothing but the current frame.  Split over devices, each searches the references in its mask,
+// the vectors and costs travel (8 bytes per 8x8 block and reference) and the device that finishes the frame needs all of them.
+int vp8hip_inter_search(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref, int search_mask) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    JOIN_LF(c);
+    int rc = inter_begin(c, prev_is_golden, prev_is_altref, use_golden, use_altref);
+    if (rc) return rc;
+    pyramids(c);
+    const int m = search_mask & (1 | (use_golden ? 2 : 0) | (use_altref ? 4 : 0));
+    if (m) search_refs(c, ref_set(c, m & 1, m & 2, m & 4));
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_inter_finish(vp8hip_ctx *c, int use_golden, int use_altref) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->slot[0] < 0 || c->recon < 0) return VP8HIP_ERR_STATE;
+    JOIN_LF(c);
+    {
+        Timed t(c, VP8HIP_K_MB);
+        launch_mb(c->stream, c->cur, ref_set(c, 1, use_golden, use_altref), c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target,
+                  c->mbw, c->mbh);
+    }
+    c->recon_ready = true;
+    HIPCHK(c, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_export_search(vp8hip_ctx *c, int ref, void *d_vectors, void *d_costs) {
+    USE_DEVICE(c);
+    if (!c || ref < 0 || ref > 2 || !d_vectors || !d_costs) return VP8HIP_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(d_vectors, c->nets.net[ref][0], (size_t)c->b8 * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_costs, c->nets.bdiff[ref], (size_t)c->b8 * 4, hipMemcpyDeviceToDevice, c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_import_search(vp8hip_ctx *c, int ref, const void *d_vectors, const void *d_costs) {
+    USE_DEVICE(c);
+    if (!c || ref < 0 || ref > 2 || !d_vectors || !d_costs) return VP8HIP_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->nets.net[ref][0], d_vectors, (size_t)c->b8 * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->nets.bdiff[ref], d_costs, (size_t)c->b8 * 4, hipMemcpyDeviceToDevice, c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_export_last(vp8hip_ctx *c, void *d_y, void *d_u, void *d_v) {
+    USE_DEVICE(c);
+    if (!c || !d_y || !d_u || !d_v) return VP8HIP_ERR_ARG;
+    JOIN_LF(c);
+    if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
+    const Frame &f = c->frames[c->slot[0]].f;
+    const Plane *pl[3] = {&f.Y[0], &f.U, &f.V};
+    void *dst[3] = {d_y, d_u, d_v};
+    for (int i = 0; i < 3; ++i)
+        HIPCHK(c, hipMemcpy2DAsync(dst[i], pl[i]->w, pl[i]->p, pl[i]->stride, pl[i]->w, pl[i]->h, hipMemcpyDeviceToDevice, c->stream));
     return VP8HIP_OK;
 }
 

@@ -1,0 +1,166 @@
+"""One GOP split BY REFERENCE over the ranks of a process group -- SURVEY.md section 8e(i), north_star's "RCCL broadcast
+of reconstructed reference frames".
+
+The reference runs the LAST / GOLDEN / ALTREF searches of a frame on three command queues (inter_part.h:122-135,
+201-236): they share nothing but the current frame.  Here each of up to three ranks (one per GPU) searches the
+references it owns (reference r belongs to rank r mod world), the quarter-pel vector nets and cost nets -- 8 bytes per
+8x8 block and reference, 261 KB at 1080p -- meet in one all_gather (RCCL over xGMI on the GPUs), rank 0 finishes the frame
+(select_reference ... SSIM, filter mask, loop filter) and broadcasts the filtered reconstruction (1.5 * W * H bytes,
+3.1 MB at 1080p), which becomes every rank's LAST.  The frame-type state machine runs identically on every rank, so the
+GOLDEN / ALTREF rotation needs no message.
+
+This is the only data-path collective of the package; GOP-level sharding (gop_shard.py) needs none and scales better
+-- a 3 MB exchange per 0.5 ms frame is latency-bound -- so this path is for ONE live stream that must be coded faster
+than one GPU codes it.  The loop is InterPathDriver's (driver.py) without check_SSIM.
+
+A backend is an encoder context with the C ABI's method names (vp8oclenc_amd.api.Vp8Hip through HipRefBackend below; the
+CPU oracle through tests/refshard_cpu.py) plus four exchanges in torch tensors on the backend's device:
+    export_search(ref) -> int32 [2, b8]   (vectors, costs)      import_search(ref, tensor)
+    export_last()      -> uint8 [W*H*3/2] (Y, U, V tight)       import_last(tensor)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import api
+
+
+class HipRefBackend(api.Vp8Hip):
+    """Vp8Hip + the device-memory exchanges of include/vp8hip.h (vp8hip_inter_search ... vp8hip_export_last)."""
+
+    def __init__(self, width: int, height: int, ssim_target: float = -1.0, device: int = 0):
+        super().__init__(width, height, ssim_target, device)
+        import ctypes as C
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        vp = C.c_void_p
+        self.lib.vp8hip_inter_search.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.vp8hip_inter_finish.argtypes = [vp, C.c_int, C.c_int]
+        self.lib.vp8hip_export_search.argtypes = [vp, C.c_int, vp, vp]
+        self.lib.vp8hip_import_search.argtypes = [vp, C.c_int, vp, vp]
+        self.lib.vp8hip_export_last.argtypes = [vp, vp, vp, vp]
+
+    def inter_search(self, prev_is_golden, prev_is_altref, use_golden, use_altref, mask):
+        self._chk(self.lib.vp8hip_inter_search(self.h, int(prev_is_golden), int(prev_is_altref), int(use_golden), int(use_altref), int(mask)), "inter_search")
+
+    def inter_finish(self, use_golden, use_altref):
+        self._chk(self.lib.vp8hip_inter_finish(self.h, int(use_golden), int(use_altref)), "inter_finish")
+
+    def export_search(self, ref: int):
+        t = self.torch.empty((2, self.b8), dtype=self.torch.int32, device=self.dev)
+        self._chk(self.lib.vp8hip_export_search(self.h, ref, t[0].data_ptr(), t[1].data_ptr()), "export_search")
+        self.synchronize()          # the copies ran on the context's stream; the collective runs on torch's
+        return t
+
+    def import_search(self, ref: int, t):
+        t = t.contiguous()
+        self.torch.cuda.current_stream(self.dev).synchronize()
+        self._chk(self.lib.vp8hip_import_search(self.h, ref, t[0].data_ptr(), t[1].data_ptr()), "import_search")
+        self.synchronize()          # t may be freed by the caller
+
+    def _plane_split(self, t):
+        n = self.W * self.H
+        return t[:n], t[n:n + n // 4], t[n + n // 4:]
+
+    def export_last(self):
+        t = self.torch.empty(self.W * self.H * 3 // 2, dtype=self.torch.uint8, device=self.dev)
+        y, u, v = self._plane_split(t)
+        self._chk(self.lib.vp8hip_export_last(self.h, y.data_ptr(), u.data_ptr(), v.data_ptr()), "export_last")
+        self.synchronize()
+        return t
+
+    def import_last(self, t):
+        self.torch.cuda.current_stream(self.dev).synchronize()
+        y, u, v = self._plane_split(t.contiguous())
+        self.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
+        self.synchronize()
+
+
+class RefShardDriver:
+    """The reference's frame loop with a frame's reference searches spread over the ranks of `dist` (None = one process).
+
+    encode_frame returns the frame's outputs on rank 0 ({"key": True} for a key frame) and None on the other ranks."""
+
+    def __init__(self, backend, dist, width: int, height: int, gop_size: int = 150, altref_range: int = 5, qi_min: int = 0,
+                 qi_max: int = 48, force_collective: bool = False, download: bool = True, loopback: bool = False):
+        self.be, self.dist = backend, dist
+        self.W, self.H = width, height
+        self.gop = api.Gop(gop_size, altref_range)
+        self.qi_min = min(qi_min, qi_max)
+        self.lastqi, self.altrefqi = api.quantizer_ladders(qi_min, qi_max)
+        self.collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+        self.rank = dist.get_rank() if self.collective else 0
+        self.world = dist.get_world_size() if self.collective else 1
+        self.download = download
+        self.loopback = loopback     # also import what this rank itself exported (a one-rank run then walks every exchange)
+        self.bytes_gathered = self.bytes_broadcast = 0
+
+    def owner(self, ref: int) -> int:
+        return ref % self.world
+
+    def _segments(self, y, is_key: bool, is_altref: bool):
+        reductor, sharp = api.loopfilter_strength(y)
+        return api.prepare_segments_data(is_key, self.altrefqi if is_altref else self.lastqi, self.qi_min, reductor, sharp)
+
+    def _share_last(self):
+        """rank 0's filtered reconstruction becomes every rank's LAST (broadcast; RCCL on the GPUs)"""
+        if not self.collective:
+            return
+        if self.rank == 0:
+            t = self.be.export_last()
+        else:
+            import torch
+            t = torch.empty(self.W * self.H * 3 // 2, dtype=torch.uint8, device=self.be.dev)
+        self.dist.broadcast(t, src=0)
+        self.bytes_broadcast += t.numel()
+        if self.rank != 0 or self.loopback:
+            self.be.import_last(t)
+
+    def _share_search(self, used):
+        """every used reference's vectors and costs from its owner to every rank (one all_gather)"""
+        if not self.collective:
+            return
+        import torch
+        mine = torch.zeros((3, 2, self.be.b8), dtype=torch.int32, device=self.be.dev)
+        for r in used:
+            if self.owner(r) == self.rank:
+                mine[r] = self.be.export_search(r)
+        allv = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine)
+        self.bytes_gathered += self.world * mine.numel() * 4
+        for r in used:
+            if self.owner(r) != self.rank or self.loopback:
+                self.be.import_search(r, allv[self.owner(r)][r])
+
+    def encode_frame(self, y: np.ndarray, u: np.ndarray, v: np.ndarray):
+        g = self.gop.next()
+        self.be.upload_current(y, u, v)
+        if g.current_is_key:
+            if self.rank == 0:       # key frames are one raster-order wavefront: one device codes them
+                self.be.set_segments(self._segments(y, True, True))
+                self.be.intra_transform()
+                self.be.prepare_filter_mask(want_nz=False)
+                self.be.loop_filter()
+            self.gop.key_coded()
+            self._share_last()
+            self.gop.frame_done()
+            return {"key": True} if self.rank == 0 else None
+        sd = self._segments(y, False, bool(g.current_is_altref))
+        self.be.set_segments(sd)
+        use_golden, use_altref = self.gop.inter_flags()
+        used = [0] + ([1] if use_golden else []) + ([2] if use_altref else [])
+        mask = sum(1 << r for r in used if self.owner(r) == self.rank)
+        self.be.inter_search(g.prev_is_golden, g.prev_is_altref, use_golden, use_altref, mask)
+        self._share_search(used)
+        out = None
+        if self.rank == 0:
+            self.be.inter_finish(use_golden, use_altref)
+            out = {"key": False, "segments": sd, "use_golden": use_golden, "use_altref": use_altref}
+            if self.download:
+                out.update(self.be.download_results(recon=True))
+            self.be.prepare_filter_mask(want_nz=False)
+            self.be.loop_filter()
+        self._share_last()
+        self.gop.frame_done()
+        return out
