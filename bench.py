@@ -176,13 +176,14 @@ class Leg:
         return prof
 
     def clock_read(self):
-        """the loop filter by the kernel's own clock, all chunks: (ms, launches) since the last call"""
-        tot, n = 0.0, 0
+        """the loop filter by the kernel's own clock, all chunks: (ms, launches, shader clock GHz) since the last call"""
+        tot, n, ghz = 0.0, 0, 0.0
         for d in self.drv:
-            ms, k = d.hip.profile_read_clock()
+            ms, k, g = d.hip.profile_read_clock()
             tot += ms
             n += k
-        return tot, n
+            ghz += g * k
+        return tot, n, ghz / max(n, 1)
 
     def run(self, steps, barrier=None):
         """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
@@ -249,7 +250,8 @@ def main():
 
     G = max(1, args.gops_per_gpu)
     nd = max(2, args.distinct_frames)
-    leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank)
+    leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
+              overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")))   # experiment switch: every chunk's filter on a second stream
     W, H, mbs = leg.W, leg.H, leg.mbs
 
     # ---- warmup; every kernel of chunk 0 timed to find the dominant one --------------------------------------
@@ -274,7 +276,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = leg.profile_read()
-    clk_ms, clk_n = leg.clock_read()
+    clk_ms, clk_n, clk_ghz = leg.clock_read()
     frames_per_gpu = args.steps * G
     if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:
         raise SystemExit(f"bench.py: the timed frames averaged {nrefs_avg:.2f} references per frame; LAST+GOLDEN+ALTREF in GOP "
@@ -302,7 +304,8 @@ def main():
             kms = clk_ms / clk_n
             roof["kernel_clock"] = {"avg_launch_ms": round(kms, 5), "launches": int(clk_n), "achieved": round(abytes / (kms * 1e-3) / 1e9, 3),
                                     "frac": round(abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                    "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row"}
+                                    "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row",
+                                    "shader_clock_ghz": round(clk_ghz, 3)}
         others = {}
         for k, (ms, n) in {**warm, **prof}.items():
             if k == dominant or n == 0:
@@ -325,7 +328,7 @@ def main():
                        "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
-            "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}),
+            "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}, clk_ghz if clk_n else None),
             "kernels_ms_per_launch_warmup": {k: round(v, 5) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
             "other_kernels": others,
             "fps": round(frames_per_gpu * world / elapsed, 2),
@@ -355,7 +358,7 @@ def main():
         dist.destroy_process_group()
 
 
-def issue_roofline(W, H, nrefs, ms_frame, prof):
+def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):
     """VALU issue CYCLES per frame against the chip's capacity (256 CUs x 4 SIMDs x 2.4 GHz SIMD-cycles per second).
     profiles/pmc_valu.json: wave64 instructions per launch by opcode class from the committed rocprofv3 --pmc pass and the
     disassembly, and the measured issue cost of each class (scripts/ubench/valu_rates.hip).  Two peaks are quoted: the
@@ -375,7 +378,9 @@ def issue_roofline(W, H, nrefs, ms_frame, prof):
     out = {"bound": "valu_issue", "unit": "SIMD issue cycles", "peak_simd_cycles_per_ns": simd_cycles_per_ns,
            "path": {"instructions_per_frame": int(tot_i), "issue_cycles_per_frame": int(tot_c),
                     "frac_of_issue_cycles": round(tot_c / (ns * simd_cycles_per_ns), 4),
-                    "wave_instr_per_ns": round(tot_i / ns, 1), "frac_of_2cycle_peak": round(tot_i * 2 / (ns * simd_cycles_per_ns), 4)},
+                    "wave_instr_per_ns": round(tot_i / ns, 1), "frac_of_2cycle_peak": round(tot_i * 2 / (ns * simd_cycles_per_ns), 4),
+                    "shader_clock_held_ghz": None if not held_clock_ghz else round(held_clock_ghz, 3),
+                    "frac_of_issue_cycles_at_held_clock": None if not held_clock_ghz else round(tot_c / (ns * cm["simds"] * held_clock_ghz), 4)},
            "source": t.get("source"), "cost_source": cm.get("source"), "kernels": {}}
     for k in ("search2", "search1_l0", "mb"):
         if k in prof and prof[k][1] and k in insts:

@@ -266,7 +266,8 @@ int vp8hip_profile_read(vp8hip_ctx *ctx, double *total_ms, int64_t *launches);
 /* The loop filter's duration by the kernel's own clock (s_memrealtime: start of its first band to the end of its last row),
  * summed since the last call.  With many contexts in flight the HIP events of vp8hip_profile_read also count the time a
  * packet waits for its queue to be scheduled; this figure does not, and it is what a rocprofv3 kernel trace shows. */
-int vp8hip_profile_read_clock(vp8hip_ctx *ctx, double *loop_filter_ms, int64_t *loop_filter_launches);
+int vp8hip_profile_read_clock(vp8hip_ctx *ctx, double *loop_filter_ms, int64_t *loop_filter_launches, double *shader_clock_ghz /* may be NULL:
+    the shader clock those launches ran at (s_memtime cycles per s_memrealtime tick, averaged over the launches) */);
 
 /* stage outputs of the last vp8hip_inter_transform, for parity tests */
 typedef enum {

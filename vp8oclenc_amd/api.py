@@ -521,11 +521,11 @@ class Vp8Hip:
         return {K_NAMES[i]: (ms[i], n[i]) for i in range(K_COUNT) if n[i]}
 
     def profile_read_clock(self):
-        """(ms, launches) of the loop filter by the kernel's own clock since the last call (vp8hip_profile_read_clock)"""
-        ms, n = C.c_double(0), C.c_int64(0)
-        self.lib.vp8hip_profile_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-        self._chk(self.lib.vp8hip_profile_read_clock(self.h, C.byref(ms), C.byref(n)), "profile_read_clock")
-        return ms.value, n.value
+        """(ms, launches, shader clock GHz) of the loop filter by the kernel's own clock since the last call (vp8hip_profile_read_clock)"""
+        ms, n, ghz = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self.lib.vp8hip_profile_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        self._chk(self.lib.vp8hip_profile_read_clock(self.h, C.byref(ms), C.byref(n), C.byref(ghz)), "profile_read_clock")
+        return ms.value, n.value, ghz.value
 
     def debug(self, what: int, ref: int = 0, level: int = 0) -> np.ndarray:
         if what in (DBG_NET1, DBG_NET2):

@@ -26,6 +26,9 @@
 //   * One LDS poll per step (middle of the step) covers every dependency.
 // History (1080p, one frame): v1 one wave per row through HBM 1.9 ms; v2 (git history) banded, two-step lag,
 // writer wave 0.71 ms; this file 0.36 ms.
+#include <stdlib.h>
+#include <string.h>
+
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -179,8 +182,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
     // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
     // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
-    unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches}
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches, sum of shader-clock cycles}
     if (band == 0 && threadIdx.x == 0) __hip_atomic_store(clk, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long cyc0 = __builtin_amdgcn_s_memtime(), tick0 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     const int mbw = a.mbw, mbh = a.mbh;
     const int band_row0 = band * ROWS;
@@ -459,8 +463,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
 #endif
     if (gr == mbh && l32 == 0) {   // the frame's last row: this wave is the last to finish real work
         const unsigned long long t0 = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(clk + 1, __builtin_amdgcn_s_memrealtime() - t0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(clk + 1, t1 - t0);
         atomicAdd(clk + 2, 1ull);
+        // the shader clock this wave saw while it ran: s_memtime cycles per 100 MHz tick (MI355X_MICROARCH.md, DVFS (6))
+        atomicAdd(clk + 3, (__builtin_amdgcn_s_memtime() - cyc0) * 1000ull / (t1 - tick0 + 1));
     }
 }
 
@@ -486,6 +493,8 @@ void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, cons
     a.gbase = (int)(n * (unsigned)(mbw + 2));
     a.err = progress + LF_ERR_WORD;
     a.stall_test = stall_test;
+    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "lf") != nullptr; }();
+    if (skip) return;   // timing experiment only
     VP8_LAUNCH(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
 }
 

@@ -8,6 +8,9 @@
 // the kernel with predictor, residual and coefficients in registers: the predictor/residual planes
 // of the reference never exist in HBM.  Mapping: 32 lanes per macroblock, lane b < 24 owns 4x4
 // block b (0-15 Y raster, 16-19 U, 20-23 V) -- the block index of macroblock_coeffs_t.
+#include <stdlib.h>
+#include <string.h>
+
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -234,8 +237,7 @@ __device__ __forceinline__ float sum4(float acc, int lane) {   // (((c0 + c1) + 
 // be contracted (the reference's mad is a*b+c, unfused).
 // All LDS traffic of a macroblock stays inside its own 32 lanes = half of one wave, so program order is the
 // only synchronisation needed: there is no workgroup barrier in this kernel.
-__global__ __launch_bounds__(256) void k_mb(MBArgs a) {
-    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
+__device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int mb_raw = blockIdx.x * 8 + g;
     const bool live = mb_raw < a.mbs;
@@ -474,6 +476,18 @@ __global__ __launch_bounds__(256) void k_mb(MBArgs a) {
     }
 }
 
+// The body holds a macroblock's predictor, residual, coefficients and reconstruction in registers: 193 VGPRs, two waves per
+// SIMD -- and with the frame loads, the LDS tile and the float SSIM chains it is latency-bound at that occupancy (0.5 of its
+// issue cycles when alone; its waves also take the register file away from the search waves of other GOP chunks).  MINW is
+// the waves per SIMD the register allocator must make room for; what does not fit spills to scratch (L1/L2-resident).
+// Same-box A/B with 16 chunks (VP8HIP_MB_WAVES=2/3/4, scripts/ab.sh): 2 waves 48.7-49.6, 3 waves (168 VGPRs, 52 B of
+// scratch) 45.1-49.5, 4 waves (128 VGPRs, 204 B) 42.8-43.8 M MB/s -- spilling costs more than the occupancy returns.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_mb(MBArgs a) {
+    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
+    mb_body(a, s_t);
+}
+
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
     MBArgs a;
@@ -488,7 +502,12 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
     a.nets = nets;
     a.use_golden = refs.use[1];
     a.use_altref = refs.use[2];
-    VP8_LAUNCH(k_mb, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "mb") != nullptr; }();
+    if (skip) return;   // timing experiment only (what the frame costs without this kernel); never set in production
+    static const int minw = [] { const char *v = getenv("VP8HIP_MB_WAVES"); return v && v[0] >= '2' && v[0] <= '4' ? v[0] - '0' : 2; }();
+    if (minw == 4) VP8_LAUNCH(k_mb<4>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+    else if (minw == 3) VP8_LAUNCH(k_mb<3>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+    else VP8_LAUNCH(k_mb<2>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

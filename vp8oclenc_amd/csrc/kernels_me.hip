@@ -4,6 +4,7 @@
 // the parallel decomposition is new: one 32-lane half-wave per 8x8 block with one search
 // candidate per lane, the winner found with a wave-level packed (cost,index) minimum.
 #include <stdlib.h>
+#include <string.h>
 
 #include "vp8hip_dev.h"
 
@@ -305,6 +306,8 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
     a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
     if (a.nblk <= 0 || n == 0) return;
+    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s1") != nullptr; }();
+    if (skip) return;   // timing experiment only
     // fewer waves than the chip has SIMDs: the launch is as long as one wave whatever else runs -> the short-wave form.
     // VP8HIP_S1_SPLIT=0/1 forces one form (same-box A/B runs)
     static const int forced = [] { const char *v = getenv("VP8HIP_S1_SPLIT"); return v && v[0] ? (v[0] == '1' ? 1 : 0) : -1; }();

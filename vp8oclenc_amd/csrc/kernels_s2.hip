@@ -16,6 +16,9 @@
 //     block's share of the metric's column pass is computed once per block into LDS (weight_pre_column) and every
 //     candidate adds its own with one dot4 per quantity (weight_cols_pre, vp8hip_dev.h).
 // First version (32-bit multiply-adds, row-major H array; git history): 0.156 ms per 1080p frame, this one 0.091.
+#include <stdlib.h>
+#include <string.h>
+
 #include "vp8hip_dev.h"
 
 namespace vp8 {
@@ -292,6 +295,8 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.nblk = a.w * a.h / 64;
     a.dbg = dbg;
     a.dbg_block = dbg_block;
+    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s2") != nullptr; }();
+    if (skip) return;   // timing experiment only
     VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
 }
 

@@ -1258,17 +1258,18 @@ int vp8hip_profile_read(vp8hip_ctx *c, double *total_ms, int64_t *launches) {
     return VP8HIP_OK;
 }
 
-int vp8hip_profile_read_clock(vp8hip_ctx *c, double *loop_filter_ms, int64_t *loop_filter_launches) {
+int vp8hip_profile_read_clock(vp8hip_ctx *c, double *loop_filter_ms, int64_t *loop_filter_launches, double *shader_clock_ghz) {
     USE_DEVICE(c);
     if (!c || !loop_filter_ms || !loop_filter_launches) return VP8HIP_ERR_ARG;
     JOIN_LF(c);
-    unsigned long long clk[3] = {0, 0, 0};
+    unsigned long long clk[4] = {0, 0, 0, 0};
     int32_t *base = c->d_progress + LF_ERR_WORD + 4;
     HIPCHK(c, hipMemcpyAsync(clk, base, sizeof(clk), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemsetAsync(base + 2, 0, 16, c->stream));   // sum and count restart; the start stamp is rewritten by every launch
+    HIPCHK(c, hipMemsetAsync(base + 2, 0, 24, c->stream));   // sums and count restart; the start stamp is rewritten by every launch
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *loop_filter_ms = (double)clk[1] * 1e-5;   // 100 MHz ticks
     *loop_filter_launches = (int64_t)clk[2];
+    if (shader_clock_ghz) *shader_clock_ghz = clk[2] ? (double)clk[3] / (double)clk[2] * 1e-4 : 0.0;   // (cycles per tick x 1000) x 100 MHz
     return VP8HIP_OK;
 }
 
