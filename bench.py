@@ -88,7 +88,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--distinct-frames", type=int, default=8)
-    ap.add_argument("--gops-per-gpu", type=int, default=16, help="independent GOP chunks in flight per GPU (1 = one stream)")
+    ap.add_argument("--gops-per-gpu", type=int, default=32, help="independent GOP chunks in flight per GPU (1 = one stream)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VP8_BENCH_BATCH", "4")),
+                    help="GOP chunks per batched launch (1 = every chunk launches its own kernels on its own stream; up to 4)")
     ap.add_argument("--refs", choices=["all", "last"], default="all", help="last = LAST only (BASELINE configs[1]: use_golden = use_altref = 0)")
     ap.add_argument("--ssim-target", type=float, default=-1.0, help="SSIM_target (reference default -1 = single LQ pass; 0.93 = the 4-pass path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -123,7 +125,7 @@ def spawn_ranks(args) -> int:
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
-    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0):
+    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1):
         from vp8oclenc_amd.synth import SynthSequence
         self.torch, self.api = torch, api
         seq = SynthSequence(W0, H0, seed=seed)
@@ -150,6 +152,19 @@ class Leg:
                 self.step_one(k)
         torch.cuda.synchronize()
         self.frames = self.refsum = 0
+        # batched launches: groups of `batch` chunks advance together, one launch per stage for the group (vp8drv_batch_*)
+        self.batches = []
+        if batch > 1:
+            for k0 in range(0, G, batch):
+                self.batches.append((list(range(k0, min(k0 + batch, G))), api.NativeBatch(self.drv[k0:k0 + batch])))
+
+    def step_group(self, members, nb):
+        nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members])
+        for k in members:
+            self.t[k] += 1
+            st = self.drv[k].stats()
+            self.frames += 1
+            self.refsum += 1 + st.last_use_golden + st.last_use_altref
 
     def step_one(self, k):
         d = self.drv[k]
@@ -160,6 +175,10 @@ class Leg:
         self.refsum += 1 + st.last_use_golden + st.last_use_altref
 
     def step(self):
+        if self.batches:
+            for members, nb in self.batches:
+                self.step_group(members, nb)
+            return
         for k in range(self.G):
             self.step_one(k)
 
@@ -201,15 +220,18 @@ class Leg:
         return el, enq, self.refsum / max(self.frames, 1)
 
     def close(self):
+        for _, nb in self.batches:
+            nb.close()
+        self.batches = []
         for d in self.drv:
             d.close()
         self.drv = []
         self.dev_frames = []
 
 
-def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1):
+def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1):
     # one chunk = one video coded frame after frame: the loop filter on its own stream, GOLDEN/ALTREF searched beside it
-    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0)
+    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1)
     for _ in range(warm):
         leg.step()
     el, enq, nrefs = leg.run(steps)
@@ -249,9 +271,11 @@ def main():
         torch.cuda.synchronize()
 
     G = max(1, args.gops_per_gpu)
+    B = max(1, min(4, args.batch))
     nd = max(2, args.distinct_frames)
     leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
-              overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")))   # experiment switch: every chunk's filter on a second stream
+              overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")),   # experiment switch: every chunk's filter on a second stream
+              batch=B)
     W, H, mbs = leg.W, leg.H, leg.mbs
 
     # ---- warmup; every kernel of chunk 0 timed to find the dominant one --------------------------------------
@@ -288,12 +312,14 @@ def main():
         ms_frame = elapsed / frames_per_gpu * 1e3
         ms_k, n_k = prof[dominant]
         avg_ms = ms_k / max(n_k, 1)
-        abytes = algorithmic_bytes(dominant, W, H, nrefs_avg)
+        items = B if (B > 1 and G > 1) else 1       # a batched launch does the stage for B chunks
+        abytes = algorithmic_bytes(dominant, W, H, nrefs_avg) * items
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dominant, W, H)
+        traffic = None if traffic is None else traffic * items   # the PMC pass ran one chunk per launch
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "launches": int(n_k),
+                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "chunks_per_launch": items, "launches": int(n_k),
                 "note": "longest kernel per launch; achieved = algorithmic bytes / avg_launch_ms, HIP events of its own stream over the "
                         "timed region, all chunks.  With 16 streams on the part those events also count the time a packet waits for its "
                         "queue (a one-chunk run and a run under rocprofv3 do not show it): kernel_clock gives the same launches by the "
@@ -301,16 +327,17 @@ def main():
                         "is HBM-bound (integer search / transform / a serial filter chain): the binding resource is VALU issue, see "
                         "issue_roofline"}
         if dominant == "loop_filter" and clk_n:
-            kms = clk_ms / clk_n
-            roof["kernel_clock"] = {"avg_launch_ms": round(kms, 5), "launches": int(clk_n), "achieved": round(abytes / (kms * 1e-3) / 1e9, 3),
-                                    "frac": round(abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+            kms = clk_ms / clk_n             # every member of a batched launch stamps its own frame: this is per chunk
+            cb = abytes / items
+            roof["kernel_clock"] = {"avg_launch_ms": round(kms, 5), "launches": int(clk_n), "achieved": round(cb / (kms * 1e-3) / 1e9, 3),
+                                    "frac": round(cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                                     "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row",
                                     "shader_clock_ghz": round(clk_ghz, 3)}
         others = {}
         for k, (ms, n) in {**warm, **prof}.items():
             if k == dominant or n == 0:
                 continue
-            b = algorithmic_bytes(k, W, H, nrefs_avg)
+            b = algorithmic_bytes(k, W, H, nrefs_avg) * items
             a = b / (ms / n * 1e-3) / 1e9 if b else None
             others[k] = {"avg_launch_ms": round(ms / n, 5), "algorithmic_bytes_per_launch": int(b), "achieved_GBs": None if a is None else round(a, 3),
                          "frac": None if a is None else round(a / HBM_PEAK_GBS, 6)}
@@ -320,11 +347,13 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height} YUV420 inter frames, {'LAST+GOLDEN+ALTREF' if args.refs == 'all' else 'LAST only'} "
-                                   f"(avg {nrefs_avg:.2f} refs/frame, GOP steady state), loop filter on GPU, {G} GOP chunk(s) in flight per GPU",
+                                   f"(avg {nrefs_avg:.2f} refs/frame, GOP steady state), loop filter on GPU, {G} GOP chunk(s) in flight per GPU"
+                                   + (f", {B} chunks per batched launch ({(G + B - 1) // B} streams)" if B > 1 else ""),
                        "step": f"one inter frame on each of the {G} GOP chunks = {G} frames per GPU",
                        "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": list(api.quantizer_ladders(0, 48)[0]),
                        "altref_range": ALTREF_RANGE, "preroll_frames_per_chunk": f"{PREROLL}..{PREROLL + ALTREF_RANGE - 1}", "frames_per_gpu": frames_per_gpu,
-                       "gops_per_gpu": G, "refs_per_frame": round(nrefs_avg, 3), "ms_per_frame": round(ms_frame, 5),
+                       "gops_per_gpu": G, "chunks_per_batched_launch": B, "refs_per_frame": round(nrefs_avg, 3),
+                       "ms_per_frame": round(ms_frame, 5),
                        "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
@@ -346,9 +375,9 @@ def main():
         out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
         out["other_configs"] = {
-            "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local),
-            "4k_3refs": side_leg(torch, api, 3840, 2160, G, "all", -1.0, max(10, args.steps // 4), 3, local),
-            "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local),
+            "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local, batch=B),
+            "4k_3refs": side_leg(torch, api, 3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3, local, batch=B),
+            "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local, batch=B),
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
@@ -406,6 +435,14 @@ def bitstream_leg(torch, leg, nb):
             leg.t[k] += 1
             nbytes[k] += len(d.get_frame())
 
+    def group_worker(members, batch):     # batched launches: the group's frames in one call, then every member's bytes
+        for _ in range(nb):
+            leg.step_group(members, batch)
+            for k in members:
+                leg.drv[k].get_frame_begin()
+            for k in members:
+                nbytes[k] += len(leg.drv[k].get_frame_end())
+
     for k in range(G):   # untimed: the entropy stage allocates its scratch on first use
         for _ in range(2):
             leg.drv[k].encode_frame_device(*leg.ptrs[leg.t[k] % leg.nd])
@@ -413,7 +450,8 @@ def bitstream_leg(torch, leg, nb):
             leg.drv[k].get_frame()
     torch.cuda.synchronize()
     tb = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(G)]
+    th = ([threading.Thread(target=group_worker, args=(m, b)) for m, b in leg.batches] if leg.batches
+          else [threading.Thread(target=worker, args=(k,)) for k in range(G)])
     for t in th:
         t.start()
     for t in th:
@@ -421,7 +459,7 @@ def bitstream_leg(torch, leg, nb):
     torch.cuda.synchronize()
     eb = time.perf_counter() - tb
     return {"value": round(leg.mbs * nb * G / eb, 1), "unit": "macroblocks/s", "fps": round(nb * G / eb, 1), "frames": nb * G,
-            "host_threads_per_gpu": G, "avg_frame_bytes": int(sum(nbytes) / (nb * G)),
+            "host_threads_per_gpu": len(th), "avg_frame_bytes": int(sum(nbytes) / (nb * G)),
             "what": "native frame loop + vp8drv_get_frame: coefficient partitions and first partition coded on the device, finished "
                     "frames in host memory (byte-identical to the reference's output)"}
 

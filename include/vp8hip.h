@@ -215,8 +215,9 @@ void *vp8hip_stream(vp8hip_ctx *ctx);
 int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
 /* Hardware queues the HIP runtime of this process multiplexes its streams onto: GPU_MAX_HW_QUEUES as exported when the
  * process started (default 4).  Contexts whose streams share a queue serialise; a host that keeps many GOP chunks in
- * flight exports GPU_MAX_HW_QUEUES=24 before its first HIP call -- vp8hip_create prints one line to
- * stderr when a process holds more contexts than queues (VP8HIP_QUIET=1 silences it).  No reference counterpart: the
+ * flight exports GPU_MAX_HW_QUEUES=24 before its first HIP call, or advances them in batches
+ * (vp8hip_batch_create below) -- vp8hip_inter_transform prints one line to stderr when more contexts launch on streams of
+ * their own than there are queues (VP8HIP_QUIET=1 silences it).  No reference counterpart: the
  * reference has one in-order OpenCL queue per reference frame (init.h:210-228). */
 int vp8hip_hw_queues(void);
 
@@ -235,6 +236,24 @@ int vp8hip_inter_finish(vp8hip_ctx *ctx, int use_golden, int use_altref);
 int vp8hip_export_search(vp8hip_ctx *ctx, int ref, void *d_vectors, void *d_costs);
 int vp8hip_import_search(vp8hip_ctx *ctx, int ref, const void *d_vectors, const void *d_costs);
 int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
+
+/* ---- batched contexts: one launch per stage for up to four GOP chunks ---------------------------------------------------
+ * The MI355X runs four to five kernels at once however many streams offer work, so sixteen contexts
+ * that each launch their own kernels leave most of the part idle.  A batch groups up to VP8HIP_MAX_BATCH contexts of one
+ * geometry, SSIM target and device; its stage calls do for every member what the per-context call of the same name does,
+ * in ONE kernel launch per stage (same kernels, blockIdx.z = member), on one stream that the members share from then on --
+ * so a member's own calls (vp8hip_intra_transform for a chunk's key frame, vp8hip_encode_frame, downloads) stay ordered
+ * with the batched stages.  Arrays are indexed by member; `active` (may be NULL = all) leaves members out of a stage.
+ * No reference counterpart: the reference codes one video on one in-order queue set. */
+#define VP8HIP_MAX_BATCH 4
+typedef struct vp8hip_batch vp8hip_batch;
+int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n);
+void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream */
+int vp8hip_batch_set_current_device(vp8hip_batch *b, const void *const *y, const void *const *u, const void *const *v);
+int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min);
+int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
+                                 const int *use_golden, const int *use_altref);
+int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
 const char *vp8hip_status_string(int status);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

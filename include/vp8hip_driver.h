@@ -73,6 +73,18 @@ int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 int vp8drv_get_frame_begin(vp8drv *d);
 int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 
+/* Several GOP chunks advanced one frame at a time, every stage ONE launch for all of them (vp8hip_batch_* in vp8hip.h): what a
+ * host with many chunks in flight uses instead of one stream per chunk -- the part runs four to five kernels at once, so
+ * sixteen narrow launches queue where four wide ones fill it.  Members: up to VP8HIP_MAX_BATCH drivers of one geometry
+ * with device_params = 1, check_ssim = 0, overlap_filter = 0.  One call = vp8drv_encode_frame_device on every member
+ * (force_key / was_key indexed by member, either may be NULL); a member whose frame is a key frame takes its ordinary key-frame
+ * path on the shared stream.  vp8drv_get_frame[_begin/_end] per member afterwards, as usual. */
+typedef struct vp8drv_batch vp8drv_batch;
+int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n);
+void vp8drv_batch_destroy(vp8drv_batch *b);      /* the drivers stay */
+int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const void *const *y, const void *const *u, const void *const *v, const int *force_key,
+                                     int *was_key);
+
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {
     int32_t frame_number, inter_frames, key_frames;

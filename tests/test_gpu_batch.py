@@ -1,0 +1,51 @@
+"""Batched launches (vp8hip_batch_*, vp8drv_batch_*): four GOP chunks advanced together, one launch per stage, must produce
+exactly the frames each chunk produces on its own."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from vp8oclenc_amd import api
+from vp8oclenc_amd.synth import SynthSequence
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("W,H,n,frames,gop", [(320, 192, 4, 14, 6), (640, 352, 3, 8, 150), (1920, 1080, 2, 5, 150)])
+def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop):
+    import torch
+    seqs = [SynthSequence(W, H, seed=40 + i) for i in range(n)]
+    Wp, Hp = seqs[0].W, seqs[0].H
+    cfg = dict(gop_size=gop, altref_range=3, num_partitions=2, device_params=1, check_ssim=0)
+    # chunks start at different points of their GOPs (different frame types inside one batched launch): member i has
+    # already coded i frames on its own when the batch takes over
+    single = [api.NativeDriver(Wp, Hp, **cfg) for _ in range(n)]
+    batched = [api.NativeDriver(Wp, Hp, **cfg) for _ in range(n)]
+    dev = [[tuple(torch.from_numpy(p).cuda() for p in s.frame(t)) for t in range(frames + n)] for s in seqs]
+    ptr = [[tuple(p.data_ptr() for p in f) for f in d] for d in dev]
+    pos = [0] * n
+    for i in range(n):
+        for _ in range(i):
+            for drv in (single[i], batched[i]):
+                drv.encode_frame_device(*ptr[i][pos[i]])
+                drv.get_frame()
+            pos[i] += 1
+    nb = api.NativeBatch(batched)
+    keys_seen = 0
+    for t in range(frames):
+        keys = nb.encode_frame_device([ptr[i][pos[i]] for i in range(n)])
+        for i in range(n):
+            k = single[i].encode_frame_device(*ptr[i][pos[i]])
+            assert k == keys[i], (t, i)
+            keys_seen += int(k)
+            a, b = single[i].get_frame(), batched[i].get_frame()
+            assert a == b, f"frame {t} of chunk {i}: {len(a)} vs {len(b)} bytes"
+            for p_, q_ in zip(single[i].hip.download_last(), batched[i].hip.download_last()):
+                assert np.array_equal(p_, q_), (t, i)
+            sa, sb = single[i].stats(), batched[i].stats()
+            assert (sa.last_use_golden, sa.last_use_altref, sa.inter_frames, sa.key_frames) == (sb.last_use_golden, sb.last_use_altref, sb.inter_frames, sb.key_frames)
+            pos[i] += 1
+    assert keys_seen >= (1 if gop < frames else 0)
+    nb.close()
+    for d in single + batched:
+        d.close()

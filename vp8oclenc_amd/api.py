@@ -22,7 +22,9 @@ DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CO
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
     "vp8hip_hw_queues", "vp8hip_profile_read_clock", "vp8hip_inter_search", "vp8hip_inter_finish", "vp8hip_export_search",
-    "vp8hip_import_search", "vp8hip_export_last",
+    "vp8hip_import_search", "vp8hip_export_last", "vp8hip_batch_create", "vp8hip_batch_destroy", "vp8hip_batch_set_current_device",
+    "vp8hip_batch_auto_segments", "vp8hip_batch_inter_transform", "vp8hip_batch_loop_filter", "vp8drv_batch_create", "vp8drv_batch_destroy",
+    "vp8drv_batch_encode_frame_device",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
@@ -313,6 +315,49 @@ class NativeDriver:
         if getattr(self, "h", None):
             self.hip.close()
             self.lib.vp8drv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeBatch:
+    """Up to four NativeDrivers advanced one frame at a time with ONE launch per stage (vp8drv_batch_*, include/vp8hip_driver.h)."""
+
+    def __init__(self, drivers):
+        self.lib = load_library()
+        self.drivers = list(drivers)
+        n = len(self.drivers)
+        self.lib.vp8drv_batch_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
+        self.lib.vp8drv_batch_destroy.argtypes = [C.c_void_p]
+        self.lib.vp8drv_batch_destroy.restype = None
+        self.lib.vp8drv_batch_encode_frame_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        arr = (C.c_void_p * n)(*[d.h for d in self.drivers])
+        h = C.c_void_p()
+        rc = self.lib.vp8drv_batch_create(C.byref(h), arr, n)
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_batch_create: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        self.h = h
+        self.n = n
+        self._ptrs = [(C.c_void_p * n)() for _ in range(3)]
+        self._key = (C.c_int * n)()
+
+    def encode_frame_device(self, planes):
+        """planes[i] = (d_y, d_u, d_v) device pointers of member i's frame; returns the list of "was a key frame" flags"""
+        for i, (y, u, v) in enumerate(planes):
+            self._ptrs[0][i], self._ptrs[1][i], self._ptrs[2][i] = y, u, v
+        rc = self.lib.vp8drv_batch_encode_frame_device(self.h, self._ptrs[0], self._ptrs[1], self._ptrs[2], None, self._key)
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_batch_encode_frame_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return [bool(k) for k in self._key]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vp8drv_batch_destroy(self.h)
             self.h = None
 
     def __del__(self):

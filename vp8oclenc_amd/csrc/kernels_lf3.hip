@@ -173,7 +173,7 @@ constexpr int SPIN_LIMIT = 1 << 22;
         if (sh.abort) return;                                                       \
     }
 
-__global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
+__device__ __forceinline__ void loop_filter3_body(const Args &a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
     const int band = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -471,10 +471,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) {
     }
 }
 
+__global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) { loop_filter3_body(a); }
+__global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3_b(BatchOf<Args> b) { loop_filter3_body(b.item[blockIdx.z]); }
+
 }  // namespace lf3
 
-void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no, int stall_test) {
+static lf3::Args loop_filter3_args(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress, int mbw, int mbh,
+                                   unsigned launch_no, int stall_test) {
     lf3::Args a;
     a.Y = recon.Y[0];
     a.U = recon.U;
@@ -493,9 +496,27 @@ void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, cons
     a.gbase = (int)(n * (unsigned)(mbw + 2));
     a.err = progress + LF_ERR_WORD;
     a.stall_test = stall_test;
+    return a;
+}
+static bool lf_skip() {
     static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "lf") != nullptr; }();
-    if (skip) return;   // timing experiment only
+    return skip;   // timing experiment only
+}
+
+void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh, unsigned launch_no, int stall_test) {
+    const lf3::Args a = loop_filter3_args(s, recon, o, d_sd, progress, mbw, mbh, launch_no, stall_test);
+    if (lf_skip()) return;
     VP8_LAUNCH(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
+}
+
+void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
+                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n) {
+    BatchOf<lf3::Args> b;
+    b.n = n;
+    for (int i = 0; i < n; ++i) b.item[i] = loop_filter3_args(s, *recon[i], *o[i], d_sd[i], progress[i], mbw, mbh, launch_no[i], 0);
+    if (lf_skip()) return;
+    VP8_LAUNCH(lf3::k_loop_filter3_b, dim3(b.item[0].nbands, 1, n), dim3(lf3::NWAVES * 64), 0, s, b);
 }
 
 }  // namespace vp8

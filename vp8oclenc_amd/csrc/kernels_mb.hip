@@ -488,8 +488,13 @@ __global__ __launch_bounds__(256, MINW) void k_mb(MBArgs a) {
     mb_body(a, s_t);
 }
 
-void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
-               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
+__global__ __launch_bounds__(256, 2) void k_mb_b(BatchOf<MBArgs> b) {
+    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
+    mb_body(b.item[blockIdx.z], s_t);
+}
+
+static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon, const MBOut &o, const SegData *d_sd,
+                      float ssim_target, int mbw, int mbh) {
     MBArgs a;
     a.cur = cur;
     for (int r = 0; r < 3; ++r) a.ref[r] = refs.ref[r];
@@ -502,12 +507,31 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
     a.nets = nets;
     a.use_golden = refs.use[1];
     a.use_altref = refs.use[2];
+    return a;
+}
+static bool mb_skip() {
     static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "mb") != nullptr; }();
-    if (skip) return;   // timing experiment only (what the frame costs without this kernel); never set in production
+    return skip;   // timing experiment only (what the frame costs without this kernel); never set in production
+}
+
+void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
+               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
+    const MBArgs a = mb_args(cur, refs, nets, recon, o, d_sd, ssim_target, mbw, mbh);
+    if (mb_skip()) return;
     static const int minw = [] { const char *v = getenv("VP8HIP_MB_WAVES"); return v && v[0] >= '2' && v[0] <= '4' ? v[0] - '0' : 2; }();
     if (minw == 4) VP8_LAUNCH(k_mb<4>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
     else if (minw == 3) VP8_LAUNCH(k_mb<3>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
     else VP8_LAUNCH(k_mb<2>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+}
+
+void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
+                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n) {
+    static_assert(sizeof(BatchOf<MBArgs>) <= 4096, "the batch travels in the kernel arguments");
+    BatchOf<MBArgs> b;
+    b.n = n;
+    for (int i = 0; i < n; ++i) b.item[i] = mb_args(*cur[i], refs[i], *nets[i], *recon[i], *o[i], d_sd[i], ssim_target, mbw, mbh);
+    if (mb_skip()) return;
+    VP8_LAUNCH(k_mb_b, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------------------

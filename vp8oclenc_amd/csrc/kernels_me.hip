@@ -14,8 +14,9 @@ namespace vp8 {
 // Edge replication of a reference frame's Y/U/V planes (replaces the clamp-to-edge image sampler,
 // GPU_kernels.cl:562).  grid = (max rows + 2*EXT, 3 planes), block = 64.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_border(Plane py, Plane pu, Plane pv) {
-    const Plane pl = blockIdx.y == 0 ? py : (blockIdx.y == 1 ? pu : pv);
+struct BorderItem { Plane y, u, v; };
+__device__ __forceinline__ void border_body(const BorderItem &a) {
+    const Plane pl = blockIdx.y == 0 ? a.y : (blockIdx.y == 1 ? a.u : a.v);
     const int row = (int)blockIdx.x - EXT;
     if (row >= pl.h + EXT) return;
     uint8_t *dst = pl.p + (ptrdiff_t)row * pl.stride;
@@ -30,9 +31,18 @@ __global__ __launch_bounds__(64) void k_border(Plane py, Plane pu, Plane pv) {
     }
 }
 
+__global__ __launch_bounds__(64) void k_border(BorderItem a) { border_body(a); }
+__global__ __launch_bounds__(64) void k_border_b(BatchOf<BorderItem> b) { border_body(b.item[blockIdx.z]); }
+
 void launch_border(hipStream_t s, const Frame &f) {
     dim3 grid(f.Y[0].h + 2 * EXT, 3);
-    VP8_LAUNCH(k_border, grid, dim3(64), 0, s, f.Y[0], f.U, f.V);
+    VP8_LAUNCH(k_border, grid, dim3(64), 0, s, BorderItem{f.Y[0], f.U, f.V});
+}
+void launch_border_batch(hipStream_t s, const Frame *const *f, int n) {
+    BatchOf<BorderItem> b;
+    b.n = n;
+    for (int i = 0; i < n; ++i) b.item[i] = BorderItem{f[i]->Y[0], f[i]->U, f[i]->V};
+    VP8_LAUNCH(k_border_b, dim3(f[0]->Y[0].h + 2 * EXT, 3, n), dim3(64), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -42,7 +52,7 @@ void launch_border(hipStream_t s, const Frame &f) {
 // 4x4 tiles below it; every level is computed from the ROUNDED level above it, exactly like the
 // reference's cascade of launches.  grid = (ceil(W/64), ceil(H/64), surfaces), block = 256.
 // ------------------------------------------------------------------------------------------------
-struct PyrArgs { Frame f[2]; };
+struct PyrArgs { Frame f[2 * MAX_BATCH]; };   // blockIdx.z picks the surface: one or two of a context, or those of a batch
 
 __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     __shared__ uint8_t s2[16][16];
@@ -101,12 +111,20 @@ void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b) {
     p.f[1] = b ? *b : *a;
     VP8_LAUNCH(k_pyramid, dim3((a->Y[0].w + 63) / 64, (a->Y[0].h + 63) / 64, b ? 2 : 1), dim3(256), 0, s, p);
 }
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes) {
+    if (nframes <= 0) return;
+    PyrArgs p;
+    for (int i = 0; i < nframes; ++i) p.f[i] = *f[i];
+    VP8_LAUNCH(k_pyramid, dim3((f[0]->Y[0].w + 63) / 64, (f[0]->Y[0].h + 63) / 64, nframes), dim3(256), 0, s, p);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch (8 bytes per thread).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack(Plane py, Plane pu, Plane pv, const uint8_t *sy, const uint8_t *su,
-                                              const uint8_t *sv) {
+struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; };
+__device__ __forceinline__ void pack_body(const PackItem &a) {
+    const Plane &py = a.py, &pu = a.pu, &pv = a.pv;
+    const uint8_t *sy = a.sy, *su = a.su, *sv = a.sv;
     int i = blockIdx.x * 256 + threadIdx.x;
     const int ny = (py.w >> 3) * py.h, nc = (pu.w >> 3) * pu.h;
     const Plane *pl = &py;
@@ -123,10 +141,20 @@ __global__ __launch_bounds__(256) void k_pack(Plane py, Plane pu, Plane pv, cons
     *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
 }
 
+__global__ __launch_bounds__(256) void k_pack(PackItem a) { pack_body(a); }
+__global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b) { pack_body(b.item[blockIdx.z]); }
+
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
-    VP8_LAUNCH(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, f.Y[0], f.U, f.V, (const uint8_t *)y,
-                       (const uint8_t *)u, (const uint8_t *)v);
+    VP8_LAUNCH(k_pack, dim3((n + 255) / 256), dim3(256), 0, s,
+               PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v});
+}
+void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n) {
+    BatchOf<PackItem> b;
+    b.n = n;
+    for (int i = 0; i < n; ++i) b.item[i] = PackItem{f[i]->Y[0], f[i]->U, f[i]->V, (const uint8_t *)y[i], (const uint8_t *)u[i], (const uint8_t *)v[i]};
+    const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
+    VP8_LAUNCH(k_pack_b, dim3((units + 255) / 256, 1, n), dim3(256), 0, s, b);
 }
 
 // minimum of a packed key over the 32 lanes of a half-wave
@@ -152,6 +180,7 @@ struct Search1Args {
     const int16_t *src[3];
     int16_t *dst[3];
     int refmap[3];
+    int nrefs;      // enabled references of this context (a batched launch is sized for the largest of its contexts)
     int net_width, w, h, pixel_rate, rate_shift, nblk, bw;
     int pbw, pbh;   // block grid of the coarser level (whose cells of src[] were written this frame)
     uint32_t bw_inv;   // ceil(2^32 / bw)
@@ -198,8 +227,9 @@ __device__ __forceinline__ void s1_subblock(const uint8_t *cp, int cstride, cons
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_search1(Search1Args a) {
+__device__ __forceinline__ void search1_body(const Search1Args &a) {
     using M = S1Map<SPLIT>;
+    if ((int)blockIdx.y >= a.nrefs) return;
     const int r = a.refmap[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
@@ -283,8 +313,12 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) {
     }
 }
 
-void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx,
-                    int net_width, bool latency) {
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_search1(Search1Args a) { search1_body<SPLIT>(a); }
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z]); }
+
+static Search1Args search1_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx, int net_width) {
     Search1Args a;
     a.cur = cur.Y[level];
     int n = 0;
@@ -294,6 +328,7 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
         a.dst[r] = nets.net[r][src_idx ^ 1];
         if (refs.use[r]) a.refmap[n++] = r;
     }
+    a.nrefs = n;
     for (int i = n; i < 3; ++i) a.refmap[i] = 0;
     a.net_width = net_width;
     a.w = a.cur.w;
@@ -305,15 +340,47 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.bw_inv = a.bw > 0 ? (uint32_t)(((1ull << 32) + a.bw - 1) / a.bw) : 0;
     a.pbw = level < 4 ? cur.Y[level + 1].w / 8 : 0;
     a.pbh = level < 4 ? cur.Y[level + 1].h / 8 : 0;
-    if (a.nblk <= 0 || n == 0) return;
+    return a;
+}
+
+static bool search1_skip() {
     static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s1") != nullptr; }();
-    if (skip) return;   // timing experiment only
-    // fewer waves than the chip has SIMDs: the launch is as long as one wave whatever else runs -> the short-wave form.
-    // VP8HIP_S1_SPLIT=0/1 forces one form (same-box A/B runs)
+    return skip;   // timing experiment only
+}
+// fewer waves than the chip has SIMDs: the launch is as long as one wave whatever else runs -> the short-wave form.
+// VP8HIP_S1_SPLIT=0/1 forces one form (same-box A/B runs)
+static bool search1_split(size_t blocks_times_refs, bool latency) {
     static const int forced = [] { const char *v = getenv("VP8HIP_S1_SPLIT"); return v && v[0] ? (v[0] == '1' ? 1 : 0) : -1; }();
-    const bool split = forced >= 0 ? forced == 1 : (latency || (size_t)a.nblk * n < (size_t)12 * 1024);
-    if (split) VP8_LAUNCH(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
-    else VP8_LAUNCH(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    return forced >= 0 ? forced == 1 : (latency || blocks_times_refs < (size_t)12 * 1024);
+}
+
+void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx,
+                    int net_width, bool latency) {
+    const Search1Args a = search1_args(cur, refs, nets, level, src_idx, net_width);
+    const int n = a.nrefs;
+    if (a.nblk <= 0 || n == 0 || search1_skip()) return;
+    if (search1_split((size_t)a.nblk * n, latency))
+        VP8_LAUNCH(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    else
+        VP8_LAUNCH(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+}
+
+void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
+                          int net_width, int n) {
+    BatchOf<Search1Args> b;
+    b.n = n;
+    int maxrefs = 0, totrefs = 0;
+    for (int i = 0; i < n; ++i) {
+        b.item[i] = search1_args(*cur[i], refs[i], *nets[i], level, src_idx, net_width);
+        maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
+        totrefs += b.item[i].nrefs;
+    }
+    const int nblk = b.item[0].nblk;
+    if (nblk <= 0 || maxrefs == 0 || search1_skip()) return;
+    if (search1_split((size_t)nblk * totrefs, false))
+        VP8_LAUNCH(k_search1_b<true>, dim3((nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
+    else
+        VP8_LAUNCH(k_search1_b<false>, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
 }
 
 // test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)

@@ -151,8 +151,13 @@ __global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, 
 }
 // the scan and its closing arithmetic in ONE launch: the workgroup that finishes last (a counter that is zero at rest) folds
 // the partial sums of all of them
-__global__ __launch_bounds__(256) void k_strength_segments(Plane y, uint32_t *partial, uint32_t *done, uint32_t *stats, SegData *sd,
-                                                           int32_t *strength_out, SegArgs g) {
+struct StrengthItem { Plane y; uint32_t *partial, *done, *stats; SegData *sd; int32_t *strength_out; SegArgs g; };
+__device__ __forceinline__ void strength_segments_body(const StrengthItem &a) {
+    const Plane &y = a.y;
+    uint32_t *partial = a.partial, *done = a.done, *stats = a.stats;
+    SegData *sd = a.sd;
+    int32_t *strength_out = a.strength_out;
+    const SegArgs &g = a.g;
     __shared__ uint32_t s_last;
     lf_strength_body(y, partial);
     if (threadIdx.x == 0) {
@@ -165,6 +170,8 @@ __global__ __launch_bounds__(256) void k_strength_segments(Plane y, uint32_t *pa
     if (threadIdx.x == 0) *done = 0;
     auto_segments_body(partial, (int)gridDim.x, stats, sd, strength_out, g);
 }
+__global__ __launch_bounds__(256) void k_strength_segments(StrengthItem a) { strength_segments_body(a); }
+__global__ __launch_bounds__(256) void k_strength_segments_b(BatchOf<StrengthItem> b) { strength_segments_body(b.item[blockIdx.z]); }
 
 }  // namespace
 
@@ -177,11 +184,25 @@ void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, ui
     const int nb = (y.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     const SegArgs g{y.w * y.h, (y.h - 1) * (y.w - 1), is_key, refqi[0], refqi[1], refqi[2], refqi[3], qi_min};
     if (!split) {
-        hipLaunchKernelGGL(k_strength_segments, dim3(nb), dim3(256), 0, s, y, partial, partial + 2 * MAX_PARTIALS, stats, sd, strength_out, g);
+        hipLaunchKernelGGL(k_strength_segments, dim3(nb), dim3(256), 0, s, StrengthItem{y, partial, partial + 2 * MAX_PARTIALS, stats, sd, strength_out, g});
     } else {
         hipLaunchKernelGGL(k_lf_strength, dim3(nb), dim3(256), 0, s, y, partial);
         hipLaunchKernelGGL(k_auto_segments, dim3(1), dim3(256), 0, s, partial, nb, stats, sd, strength_out, g);
     }
+}
+
+void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
+                                int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n) {
+    BatchOf<StrengthItem> b;
+    b.n = n;
+    const Plane &y0 = cur[0]->Y[0];
+    const int nb = (y0.h + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    for (int i = 0; i < n; ++i) {
+        const Plane &y = cur[i]->Y[0];
+        const SegArgs g{y.w * y.h, (y.h - 1) * (y.w - 1), is_key[i], refqi[i][0], refqi[i][1], refqi[i][2], refqi[i][3], qi_min};
+        b.item[i] = StrengthItem{y, partial[i], partial[i] + 2 * MAX_PARTIALS, stats[i], sd[i], strength_out[i], g};
+    }
+    hipLaunchKernelGGL(k_strength_segments_b, dim3(nb, 1, n), dim3(256), 0, s, b);
 }
 
 void launch_lf_strength(hipStream_t s, const Frame &cur, uint32_t *partial, uint32_t *stats) {

@@ -60,6 +60,7 @@ struct S2Args {
     int16_t *net_out[3];
     int32_t *bdiff[3];
     int refmap[3];
+    int nrefs;       // enabled references of this context (a batched launch is sized for the largest of its contexts)
     int w, h, nblk, bw;
     uint32_t bw_inv;   // ceil(2^32 / bw)
     uint32_t *dbg;   // test tap: per-candidate prediction (column-major) and cost of block dbg_block, or nullptr
@@ -89,7 +90,8 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 // form with the bias in an SGPR instead of v_mov + v_dot4c
 __device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
 
-__global__ __launch_bounds__(256) void k_search2(S2Args a) {
+__device__ __forceinline__ void search2_body(const S2Args &a) {
+    if ((int)blockIdx.y >= a.nrefs) return;
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
@@ -274,9 +276,12 @@ __global__ __launch_bounds__(256) void k_search2(S2Args a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_search2(S2Args a) { search2_body(a); }
+__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) { search2_body(b.item[blockIdx.z]); }
+
 }  // namespace
 
-void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
+static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
     S2Args a;
     a.cur = cur.Y[0];
     int n = 0;
@@ -287,6 +292,7 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
         a.bdiff[r] = nets.bdiff[r];
         if (refs.use[r]) a.refmap[n++] = r;
     }
+    a.nrefs = n;
     for (int i = n; i < 3; ++i) a.refmap[i] = 0;
     a.w = a.cur.w;
     a.h = a.cur.h;
@@ -295,9 +301,29 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     a.nblk = a.w * a.h / 64;
     a.dbg = dbg;
     a.dbg_block = dbg_block;
+    return a;
+}
+static bool search2_skip() {
     static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s2") != nullptr; }();
-    if (skip) return;   // timing experiment only
-    VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, n), dim3(256), 0, s, a);
+    return skip;   // timing experiment only
+}
+
+void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
+    const S2Args a = search2_args(cur, refs, nets, dbg, dbg_block);
+    if (a.nrefs == 0 || search2_skip()) return;
+    VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
+}
+
+void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n) {
+    BatchOf<S2Args> b;
+    b.n = n;
+    int maxrefs = 0;
+    for (int i = 0; i < n; ++i) {
+        b.item[i] = search2_args(*cur[i], refs[i], *nets[i], nullptr, -1);
+        maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
+    }
+    if (maxrefs == 0 || search2_skip()) return;
+    VP8_LAUNCH(k_search2_b, dim3((b.item[0].nblk + 7) / 8, maxrefs, n), dim3(256), 0, s, b);
 }
 
 }  // namespace vp8

@@ -278,6 +278,98 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
     return frame_body(d, y, d->gop.current_is_key || force_key);
 }
 
+// ---- several GOP chunks one frame at a time, every stage one launch for all of them (vp8hip_batch_*) -----------------------
+struct vp8drv_batch {
+    int n = 0;
+    vp8drv *d[VP8HIP_MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
+    vp8hip_batch *hb = nullptr;
+};
+
+int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n) {
+    if (!out || !drv || n < 1 || n > VP8HIP_MAX_BATCH) return VP8HIP_ERR_ARG;
+    *out = nullptr;
+    vp8hip_ctx *ctx[VP8HIP_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        // the batched loop is the device-parameter loop without check_SSIM (what bench.py and a file-to-file transcode run)
+        if (!drv[i] || !drv[i]->cfg.device_params || drv[i]->cfg.check_ssim || drv[i]->cfg.overlap_filter) return VP8HIP_ERR_ARG;
+        ctx[i] = drv[i]->hip;
+    }
+    vp8drv_batch *b = new (std::nothrow) vp8drv_batch();
+    if (!b) return VP8HIP_ERR_ARG;
+    const int rc = vp8hip_batch_create(&b->hb, ctx, n);
+    if (rc != VP8HIP_OK) {
+        delete b;
+        return rc;
+    }
+    b->n = n;
+    for (int i = 0; i < n; ++i) b->d[i] = drv[i];
+    *out = b;
+    return VP8HIP_OK;
+}
+
+void vp8drv_batch_destroy(vp8drv_batch *b) {
+    if (!b) return;
+    vp8hip_batch_destroy(b->hb);
+    delete b;
+}
+
+int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const void *const *y, const void *const *u, const void *const *v, const int *force_key,
+                                     int *was_key) {
+    if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
+    int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {0, 0, 0, 0};
+    int pg[VP8HIP_MAX_BATCH], pa[VP8HIP_MAX_BATCH], ug[VP8HIP_MAX_BATCH], ua[VP8HIP_MAX_BATCH];
+    int32_t refqi[VP8HIP_MAX_BATCH][4];
+    for (int i = 0; i < b->n; ++i) {
+        vp8drv *d = b->d[i];
+        vp8host_gop_next(&d->gop);
+        key[i] = d->gop.current_is_key || (force_key && force_key[i]);
+        active[i] = !key[i];
+        if (was_key) was_key[i] = key[i];
+    }
+    DRV_CHK(vp8hip_batch_set_current_device(b->hb, y, u, v));                    // vp8enc.cpp:386-388, all members in one launch
+    int n_inter = 0;
+    for (int i = 0; i < b->n; ++i) {
+        vp8drv *d = b->d[i];
+        if (key[i]) {   // a key frame is a raster-order wavefront of its own: the member's ordinary path, on the shared stream
+            const int rc = key_frame(d, nullptr);
+            if (rc < 0) return rc;
+            continue;
+        }
+        ++n_inter;
+        const int32_t *q = d->gop.current_is_altref ? d->altrefqi : d->lastqi;   // vp8enc.cpp:149-151
+        for (int k = 0; k < 4; ++k) refqi[i][k] = q[k];
+        int32_t g = 0, a = 0;
+        vp8host_gop_inter_flags(&d->gop, &g, &a);                               // inter_part.h:103-104
+        ug[i] = g & (d->cfg.ref_mask & 1);
+        ua[i] = a & ((d->cfg.ref_mask >> 1) & 1);
+        pg[i] = d->gop.prev_is_golden;
+        pa[i] = d->gop.prev_is_altref;
+        d->sharpness = -1;
+    }
+    if (!n_inter) return VP8HIP_OK;
+    DRV_CHK(vp8hip_batch_auto_segments(b->hb, active, zero, refqi, b->d[0]->qi_min));   // vp8enc.cpp:390, 419
+    DRV_CHK(vp8hip_batch_inter_transform(b->hb, active, pg, pa, ug, ua));
+    DRV_CHK(vp8hip_batch_loop_filter(b->hb, active));
+    for (int i = 0; i < b->n; ++i) {
+        if (key[i]) continue;
+        vp8drv *d = b->d[i];
+        d->st.last_use_golden = ug[i];
+        d->st.last_use_altref = ua[i];
+        d->st.last_prev_is_golden = pg[i];
+        d->st.last_prev_is_altref = pa[i];
+        d->st.last_was_altref = d->gop.current_is_altref;
+        d->checked = false;
+        d->replaced = 0;
+        vp8host_gop_frame_done(&d->gop);
+        d->st.inter_frames++;
+        d->st.frame_number = d->gop.frame_number;
+        d->have_frame = true;
+        d->last_key = false;
+        d->last_altref = d->st.last_was_altref != 0;
+    }
+    return VP8HIP_OK;
+}
+
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     if (!d || !out || !size) return VP8HIP_ERR_ARG;
     if (!d->have_frame) return VP8HIP_ERR_STATE;

@@ -34,7 +34,8 @@ struct vp8hip_ctx {
     int W = 0, H = 0, mbw = 0, mbh = 0, mbs = 0, b8 = 0;
     float ssim_target = -1.0f;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream in use: the context's own, or its batch's (vp8hip_batch_create)
+    hipStream_t own_stream = nullptr;   // the one vp8hip_create made
     int last_hip_error = 0;
 
     uint8_t *pixel_pool = nullptr;  // one allocation for every surface
@@ -239,7 +240,21 @@ int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMem
 
 }  // namespace
 
-static std::atomic<int> g_live_contexts{0};
+static std::atomic<int> g_live_contexts{0};   // contexts that launch on a stream of their own (members of a batch share one)
+
+// Contexts overlap only if their streams sit on different hardware queues, and the HIP runtime multiplexes all streams
+// of a process onto GPU_MAX_HW_QUEUES queues (default 4), read once at its first call: nothing the library can set.
+// A host that runs more contexts on streams of their own than there are queues gets a one-line note (VP8HIP_QUIET=1
+// silences it).
+static void note_queue_oversubscription() {
+    static std::atomic<bool> warned{false};
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? atoi(q) : 4, n = g_live_contexts.load();
+    if (n > queues && !getenv("VP8HIP_QUIET") && !warned.exchange(true))
+        fprintf(stderr, "vp8hip: %d contexts on streams of their own but GPU_MAX_HW_QUEUES=%d hardware queues: the streams will share queues and "
+                        "serialise (measured on MI355X with 16 contexts: 27 M MB/s at 4 queues, 40 M at 24).  Export GPU_MAX_HW_QUEUES=24 before "
+                        "the process makes its first HIP call, or advance the contexts in batches (vp8hip_batch_create).\n", n, queues);
+}
 
 extern "C" {
 
@@ -306,6 +321,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     } while (0)
     CR(hipSetDevice(device_ordinal));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = c->stream;
     const size_t fb = frame_bytes(width, height);
     CR(hipMalloc(&c->pixel_pool, fb * (NFRAMES + 2)));
     CR(hipMemsetAsync(c->pixel_pool, 0, fb * (NFRAMES + 2), c->stream));
@@ -364,17 +380,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
 #undef CR
     *out = c;
     c->counted = true;
-    // Contexts overlap only if their streams sit on different hardware queues, and the HIP runtime multiplexes all streams
-    // of a process onto GPU_MAX_HW_QUEUES queues (default 4), read once at its first call: nothing the library can set.
-    // A host that keeps more contexts than queues gets a one-line note (VP8HIP_QUIET=1 silences it).
-    static std::atomic<bool> warned{false};
-    const int n = ++g_live_contexts;
-    const char *q = getenv("GPU_MAX_HW_QUEUES");
-    const int queues = q ? atoi(q) : 4;
-    if (n > queues && !getenv("VP8HIP_QUIET") && !warned.exchange(true))
-        fprintf(stderr, "vp8hip: %d contexts in this process but GPU_MAX_HW_QUEUES=%d hardware queues: their streams will share queues and "
-                        "serialise (measured on MI355X with 16 contexts: 27 M MB/s at 4 queues, 40 M at 24).  Export GPU_MAX_HW_QUEUES=24 "
-                        "before the process makes its first HIP call.\n", n, queues);
+    ++g_live_contexts;
     return VP8HIP_OK;
 }
 
@@ -448,7 +454,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->hdr_partial);
     hipFree(c->hdr_info);
     hipFree(c->hdr_sym);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -627,6 +633,7 @@ static void pyramids(vp8hip_ctx *c) {
 int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
     USE_DEVICE(c);
     if (!c) return VP8HIP_ERR_ARG;
+    note_queue_oversubscription();
     int rc = inter_begin(c, prev_is_golden, prev_is_altref, use_golden, use_altref);
     if (rc) return rc;
     const RefSet refs = ref_set(c, 1, use_golden, use_altref);
@@ -712,6 +719,192 @@ int vp8hip_export_last(vp8hip_ctx *c, void *d_y, void *d_u, void *d_v) {
     void *dst[3] = {d_y, d_u, d_v};
     for (int i = 0; i < 3; ++i)
         HIPCHK(c, hipMemcpy2DAsync(dst[i], pl[i]->w, pl[i]->p, pl[i]->stride, pl[i]->w, pl[i]->h, hipMemcpyDeviceToDevice, c->stream));
+    return VP8HIP_OK;
+}
+
+// ---- batched contexts ---------------------------------------------------------------------------------------------------
+// Up to MAX_BATCH contexts of one geometry on one device advance one frame together: every stage is ONE launch for all of
+// them (vp8hip_dev.h, "batched launches").  The members share the batch's stream, so their own entry points (key frames,
+// the entropy stage, downloads) stay ordered with the batched stages.
+struct vp8hip_batch {
+    int n = 0;
+    vp8hip_ctx *c[MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;
+};
+
+int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
+    if (!out || !ctxs || n < 1 || n > MAX_BATCH) return VP8HIP_ERR_ARG;
+    *out = nullptr;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->device != ctxs[0]->device ||
+            ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap)
+            return VP8HIP_ERR_ARG;
+    vp8hip_batch *b = new (std::nothrow) vp8hip_batch();
+    if (!b) return VP8HIP_ERR_ARG;
+    USE_DEVICE(ctxs[0]);
+    b->n = n;
+    b->stream = ctxs[0]->own_stream;
+    for (int i = 0; i < n; ++i) {
+        hipStreamSynchronize(ctxs[i]->stream);
+        ctxs[i]->stream = b->stream;
+        b->c[i] = ctxs[i];
+    }
+    g_live_contexts -= n - 1;   // one stream for all of them now
+    *out = b;
+    return VP8HIP_OK;
+}
+
+void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay, each back on its own stream
+    if (!b) return;
+    hipSetDevice(b->c[0]->device);
+    hipStreamSynchronize(b->stream);
+    for (int i = 0; i < b->n; ++i) b->c[i]->stream = b->c[i]->own_stream;
+    g_live_contexts += b->n - 1;
+    delete b;
+}
+
+int vp8hip_batch_set_current_device(vp8hip_batch *b, const void *const *y, const void *const *u, const void *const *v) {
+    if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    const Frame *f[MAX_BATCH];
+    for (int i = 0; i < b->n; ++i) {
+        if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
+        next_current(b->c[i]);
+        f[i] = &b->c[i]->cur;
+    }
+    Timed t(c0, VP8HIP_K_PACK);
+    launch_pack_batch(b->stream, f, y, u, v, b->n);
+    HIPCHK(c0, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+// `active[i] == 0` leaves context i out of the stage (a chunk whose frame is a key frame goes through its own
+// vp8hip_intra_transform); active == NULL means all
+int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min) {
+    if (!b || !is_key_frame || !refqi) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    const Frame *cur[MAX_BATCH];
+    uint32_t *partial[MAX_BATCH], *stats[MAX_BATCH];
+    SegData *sd[MAX_BATCH];
+    int32_t *strength[MAX_BATCH];
+    int key[MAX_BATCH];
+    int32_t qi[MAX_BATCH][4];
+    int n = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        vp8hip_ctx *c = b->c[i];
+        if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+        cur[n] = &c->cur;
+        partial[n] = c->d_stats + 8;
+        stats[n] = c->d_stats;
+        sd[n] = sd_for_writing(c);
+        strength[n] = reinterpret_cast<int32_t *>(c->d_stats + 4);
+        key[n] = is_key_frame[i] ? 1 : 0;
+        for (int k = 0; k < 4; ++k) qi[n][k] = refqi[i][k];
+        ++n;
+    }
+    if (n) launch_auto_segments_batch(b->stream, cur, partial, stats, sd, strength, key, qi, qi_min, n);
+    HIPCHK(c0, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
+                                 const int *use_golden, const int *use_altref) {
+    if (!b || !prev_is_golden || !prev_is_altref || !use_golden || !use_altref) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    vp8hip_ctx *m[MAX_BATCH];
+    RefSet refs[MAX_BATCH];
+    const Frame *cur[MAX_BATCH], *recon[MAX_BATCH], *pyr[2 * MAX_BATCH];
+    const NetSet *nets[MAX_BATCH];
+    const MBOut *outs[MAX_BATCH];
+    const SegData *sds[MAX_BATCH];
+    int n = 0, npyr = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        vp8hip_ctx *c = b->c[i];
+        const int rc = inter_begin(c, prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
+        if (rc) return rc;
+        FrameSurf &last = c->frames[c->slot[0]];
+        if (!c->cur_pyramid_valid) pyr[npyr++] = &c->cur;
+        if (!last.pyramid_valid) pyr[npyr++] = &last.f;
+        last.pyramid_valid = true;
+        c->cur_pyramid_valid = true;
+        refs[n] = ref_set(c, 1, use_golden[i], use_altref[i]);
+        cur[n] = &c->cur;
+        recon[n] = &c->frames[c->recon].f;
+        nets[n] = &c->nets;
+        outs[n] = &c->out;
+        sds[n] = c->d_sd;
+        m[n++] = c;
+    }
+    if (!n) return VP8HIP_OK;
+    hipStream_t s = b->stream;
+    {
+        Timed t(c0, VP8HIP_K_DOWNSAMPLE);
+        launch_pyramid_batch(s, pyr, npyr);
+    }
+    const int net_width = c0->mbw * 2;
+    int src = 0;
+    for (int l = 4; l >= 0; --l) {
+        Timed t(c0, VP8HIP_K_SEARCH1_L4 + (4 - l));
+        launch_search1_batch(s, cur, refs, nets, l, src, net_width, n);
+        src ^= 1;
+    }
+    {
+        Timed t(c0, VP8HIP_K_SEARCH2);
+        launch_search2_batch(s, cur, refs, nets, n);
+    }
+    {
+        Timed t(c0, VP8HIP_K_MB);
+        launch_mb_batch(s, cur, refs, nets, recon, outs, sds, c0->ssim_target, c0->mbw, c0->mbh, n);
+    }
+    for (int i = 0; i < n; ++i) m[i]->recon_ready = true;
+    HIPCHK(c0, hipGetLastError());
+    return VP8HIP_OK;
+}
+
+int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
+    if (!b) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    vp8hip_ctx *m[MAX_BATCH];
+    const Frame *recon[MAX_BATCH];
+    const MBOut *outs[MAX_BATCH];
+    const SegData *sds[MAX_BATCH];
+    int32_t *prog[MAX_BATCH];
+    unsigned launch_no[MAX_BATCH];
+    int n = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        vp8hip_ctx *c = b->c[i];
+        if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
+        recon[n] = &c->frames[c->recon].f;
+        outs[n] = &c->out;
+        sds[n] = c->d_sd;
+        prog[n] = c->d_progress;
+        launch_no[n] = c->lf_launches++;
+        m[n++] = c;
+    }
+    if (!n) return VP8HIP_OK;
+    {
+        Timed t(c0, VP8HIP_K_LOOP_FILTER);
+        launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n);
+    }
+    {
+        Timed t(c0, VP8HIP_K_BORDER);
+        launch_border_batch(b->stream, recon, n);
+    }
+    for (int i = 0; i < n; ++i) {   // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
+        vp8hip_ctx *c = m[i];
+        c->frames[c->recon].pyramid_valid = false;
+        c->slot[0] = c->recon;
+        c->recon = -1;
+        c->recon_ready = false;
+    }
+    HIPCHK(c0, hipGetLastError());
     return VP8HIP_OK;
 }
 

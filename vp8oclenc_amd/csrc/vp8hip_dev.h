@@ -64,10 +64,33 @@ struct MBOut {
 
 struct SegData { int32_t v[4 * SD_INTS]; };
 
+// ---- batched launches -------------------------------------------------------------------------------------------------
+// Measured on MI355X (scripts/ubench/concurrency.hip, and the kernel trace of sixteen GOP chunks on sixteen streams): the
+// part runs FOUR TO FIVE kernels at once however many streams offer work, and with more than ~8 active streams the
+// hardware queues are time-sliced.  Sixteen chunks each launching its own narrow kernels therefore leave the chip with
+// one wide kernel at a time (loop filters of 9 workgroups hold two of the slots on average).  So the same kernels also
+// exist in a batched form: ONE launch does a stage for up to MAX_BATCH contexts of equal geometry (blockIdx.z = context),
+// the argument blocks of the single form travel as an array in the kernel arguments, and a few streams carry what sixteen did.
+constexpr int MAX_BATCH = 4;
+template <typename A> struct BatchOf { int n; A item[MAX_BATCH]; };
+
 // ---- launchers (kernels_*.hip) ---------------------------------------------------------------
 void launch_border(hipStream_t s, const Frame &f);
 void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b);   // all four levels of one or two frames
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v);
+// batched forms: n <= MAX_BATCH contexts (pyramid: nframes <= 2 * MAX_BATCH surfaces)
+void launch_border_batch(hipStream_t s, const Frame *const *f, int n);
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes);
+void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n);
+void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
+                          int net_width, int n);
+void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n);
+void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
+                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n);
+void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
+                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n);
+void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
+                                int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
                     int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
