@@ -145,22 +145,29 @@ class Leg:
             self.drv.append(d)
             self.t.append(t + 1)
         self.frames = self.refsum = 0
-        # GOP steady state, untimed and independent of --warmup: every chunk past two altref periods, phases staggered so
-        # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames
-        for k in range(G):
-            for _ in range(PREROLL + k % ALTREF_RANGE):
-                self.step_one(k)
-        torch.cuda.synchronize()
-        self.frames = self.refsum = 0
         # batched launches: groups of `batch` chunks advance together, one launch per stage for the group (vp8drv_batch_*)
         self.batches = []
         if batch > 1:
             for k0 in range(0, G, batch):
                 self.batches.append((list(range(k0, min(k0 + batch, G))), api.NativeBatch(self.drv[k0:k0 + batch])))
+        # GOP steady state, untimed and independent of --warmup: every chunk past two altref periods, phases staggered so
+        # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames
+        if self.batches:
+            for members, nb in self.batches:
+                for r in range(PREROLL + ALTREF_RANGE - 1):
+                    self.step_group(members, nb, [r < PREROLL + k % ALTREF_RANGE for k in members])
+        else:
+            for k in range(G):
+                for _ in range(PREROLL + k % ALTREF_RANGE):
+                    self.step_one(k)
+        torch.cuda.synchronize()
+        self.frames = self.refsum = 0
 
-    def step_group(self, members, nb):
-        nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members])
-        for k in members:
+    def step_group(self, members, nb, on=None):
+        nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members], on)
+        for i, k in enumerate(members):
+            if on is not None and not on[i]:
+                continue
             self.t[k] += 1
             st = self.drv[k].stats()
             self.frames += 1
@@ -326,13 +333,16 @@ def main():
                         "kernel's own clock, which is what the rocprofv3 kernel trace under profiles/ shows.  None of this path's kernels "
                         "is HBM-bound (integer search / transform / a serial filter chain): the binding resource is VALU issue, see "
                         "issue_roofline"}
-        if dominant == "loop_filter" and clk_n:
+        lf_clock = None
+        if clk_n:
             kms = clk_ms / clk_n             # every member of a batched launch stamps its own frame: this is per chunk
-            cb = abytes / items
-            roof["kernel_clock"] = {"avg_launch_ms": round(kms, 5), "launches": int(clk_n), "achieved": round(cb / (kms * 1e-3) / 1e9, 3),
-                                    "frac": round(cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                    "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row",
-                                    "shader_clock_ghz": round(clk_ghz, 3)}
+            cb = algorithmic_bytes("loop_filter", W, H, nrefs_avg)
+            lf_clock = {"kernel": "loop_filter", "avg_ms_per_chunk": round(kms, 5), "frames": int(clk_n), "achieved": round(cb / (kms * 1e-3) / 1e9, 3),
+                        "frac": round(cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                        "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row",
+                        "shader_clock_ghz": round(clk_ghz, 3)}
+            if dominant == "loop_filter":
+                roof["kernel_clock"] = lf_clock
         others = {}
         for k, (ms, n) in {**warm, **prof}.items():
             if k == dominant or n == 0:
@@ -357,6 +367,7 @@ def main():
                        "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
+            "loop_filter_by_its_own_clock": lf_clock,
             "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}, clk_ghz if clk_n else None),
             "kernels_ms_per_launch_warmup": {k: round(v, 5) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
             "other_kernels": others,

@@ -249,7 +249,7 @@ int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
 typedef struct vp8hip_batch vp8hip_batch;
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n);
 void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream */
-int vp8hip_batch_set_current_device(vp8hip_batch *b, const void *const *y, const void *const *u, const void *const *v);
+int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v);
 int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min);
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);

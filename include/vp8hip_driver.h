@@ -82,8 +82,8 @@ int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size)
 typedef struct vp8drv_batch vp8drv_batch;
 int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n);
 void vp8drv_batch_destroy(vp8drv_batch *b);      /* the drivers stay */
-int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const void *const *y, const void *const *u, const void *const *v, const int *force_key,
-                                     int *was_key);
+int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL = all; 0 = this member sits the call out */,
+                                     const void *const *y, const void *const *u, const void *const *v, const int *force_key, int *was_key);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "16 1 24" "24 3 24" "32 4 24" "36 4 24" "40 4 24" "48 4 24" "30 3 24" "36 3 24" "32 4 8" "32 4 12" "24 3 8" "16 1 24"; do set -- $cfg; GPU_MAX_HW_QUEUES=$3 python3 bench.py --steps 60 --warmup 10 --gops-per-gpu $1 --batch $2 --no-side-legs --cpu-seconds 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('chunks $1 batch $2 queues $3', round(d['value']/1e6,2), d['config']['ms_per_frame'])"; done
+for i in 1 2 3 4 5 6 7 8; do python3 bench.py --steps 20 --warmup 5 --no-side-legs --cpu-seconds 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('run $i', round(d['value']/1e6,2), d['config']['ms_per_frame'], d['roofline']['kernel'])"; done

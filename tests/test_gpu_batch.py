@@ -33,8 +33,14 @@ def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop):
     nb = api.NativeBatch(batched)
     keys_seen = 0
     for t in range(frames):
-        keys = nb.encode_frame_device([ptr[i][pos[i]] for i in range(n)])
+        on = [True] * n
+        if t == 2:           # one call in which the odd members sit out
+            on = [i % 2 == 0 for i in range(n)]
+        keys = nb.encode_frame_device([ptr[i][pos[i]] for i in range(n)], on)
         for i in range(n):
+            if not on[i]:
+                assert not keys[i]
+                continue
             k = single[i].encode_frame_device(*ptr[i][pos[i]])
             assert k == keys[i], (t, i)
             keys_seen += int(k)

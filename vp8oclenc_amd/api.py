@@ -334,8 +334,8 @@ class NativeBatch:
         self.lib.vp8drv_batch_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
         self.lib.vp8drv_batch_destroy.argtypes = [C.c_void_p]
         self.lib.vp8drv_batch_destroy.restype = None
-        self.lib.vp8drv_batch_encode_frame_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.lib.vp8drv_batch_encode_frame_device.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                              C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         arr = (C.c_void_p * n)(*[d.h for d in self.drivers])
         h = C.c_void_p()
         rc = self.lib.vp8drv_batch_create(C.byref(h), arr, n)
@@ -345,12 +345,17 @@ class NativeBatch:
         self.n = n
         self._ptrs = [(C.c_void_p * n)() for _ in range(3)]
         self._key = (C.c_int * n)()
+        self._members = (C.c_int * n)()
 
-    def encode_frame_device(self, planes):
-        """planes[i] = (d_y, d_u, d_v) device pointers of member i's frame; returns the list of "was a key frame" flags"""
-        for i, (y, u, v) in enumerate(planes):
-            self._ptrs[0][i], self._ptrs[1][i], self._ptrs[2][i] = y, u, v
-        rc = self.lib.vp8drv_batch_encode_frame_device(self.h, self._ptrs[0], self._ptrs[1], self._ptrs[2], None, self._key)
+    def encode_frame_device(self, planes, members=None):
+        """planes[i] = (d_y, d_u, d_v) device pointers of member i's frame (None for a member that sits this call out, or
+        members[i] false); returns the list of "was a key frame" flags"""
+        for i, p in enumerate(planes):
+            on = p is not None and (members is None or members[i])
+            self._members[i] = 1 if on else 0
+            if on:
+                self._ptrs[0][i], self._ptrs[1][i], self._ptrs[2][i] = p
+        rc = self.lib.vp8drv_batch_encode_frame_device(self.h, self._members, self._ptrs[0], self._ptrs[1], self._ptrs[2], None, self._key)
         if rc < 0:
             raise Vp8HipError(f"vp8drv_batch_encode_frame_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return [bool(k) for k in self._key]

@@ -313,23 +313,27 @@ void vp8drv_batch_destroy(vp8drv_batch *b) {
     delete b;
 }
 
-int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const void *const *y, const void *const *u, const void *const *v, const int *force_key,
-                                     int *was_key) {
+int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
+                                     const int *force_key, int *was_key) {
     if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
     int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {0, 0, 0, 0};
     int pg[VP8HIP_MAX_BATCH], pa[VP8HIP_MAX_BATCH], ug[VP8HIP_MAX_BATCH], ua[VP8HIP_MAX_BATCH];
     int32_t refqi[VP8HIP_MAX_BATCH][4];
     for (int i = 0; i < b->n; ++i) {
         vp8drv *d = b->d[i];
+        key[i] = active[i] = 0;
+        if (was_key) was_key[i] = 0;
+        if (members && !members[i]) continue;      // this member sits the call out
         vp8host_gop_next(&d->gop);
         key[i] = d->gop.current_is_key || (force_key && force_key[i]);
         active[i] = !key[i];
         if (was_key) was_key[i] = key[i];
     }
-    DRV_CHK(vp8hip_batch_set_current_device(b->hb, y, u, v));                    // vp8enc.cpp:386-388, all members in one launch
+    DRV_CHK(vp8hip_batch_set_current_device(b->hb, members, y, u, v));          // vp8enc.cpp:386-388, all members in one launch
     int n_inter = 0;
     for (int i = 0; i < b->n; ++i) {
         vp8drv *d = b->d[i];
+        if (members && !members[i]) continue;
         if (key[i]) {   // a key frame is a raster-order wavefront of its own: the member's ordinary path, on the shared stream
             const int rc = key_frame(d, nullptr);
             if (rc < 0) return rc;
@@ -351,7 +355,7 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const void *const *y, cons
     DRV_CHK(vp8hip_batch_inter_transform(b->hb, active, pg, pa, ug, ua));
     DRV_CHK(vp8hip_batch_loop_filter(b->hb, active));
     for (int i = 0; i < b->n; ++i) {
-        if (key[i]) continue;
+        if (!active[i]) continue;
         vp8drv *d = b->d[i];
         d->st.last_use_golden = ug[i];
         d->st.last_use_altref = ua[i];
