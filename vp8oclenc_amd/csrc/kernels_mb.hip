@@ -285,7 +285,11 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const Plane &rp = plane == 0 ? rfm.Y[0] : (plane == 1 ? rfm.U : rfm.V);
     const int tile_off = plane == 0 ? 0 : (plane == 1 ? 256 : 320);
 
-    int pred[16], res[16], curp[16];
+    // The predictor stays packed (four dwords of bytes) and the current block lives in the LDS tile: a pass re-forms the
+    // residual from them, and everything a pass produces (coefficients, block 24, reconstruction) is stored as the pass
+    // produces it -- the last pass to run is the one that counts, GPU_kernels.cl:1391 -- so that none of the 16-entry
+    // arrays stays alive across the float SSIM section (193 VGPRs and two waves per SIMD before; see k_mb below).
+    uint32_t predw[4] = {0, 0, 0, 0};
     if (blk) {
         // prepare_predictors_and_residual, :1285-1344: vector of the block's 8x8 quadrant
         const int quad = plane == 0 ? (by >> 1) * 2 + (bx >> 1) : by * 2 + bx;
@@ -295,15 +299,12 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
         const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;  // >= 0 for every in-frame vector
         const int dx = (fxp & gm) * (plane == 0 ? 2 : 1), dy = (fyp & gm) * (plane == 0 ? 2 : 1);
         const int ix = iclamp(fxp >> gsh, 2 - EXT, rp.w + EXT - 7), iy = iclamp(fyp >> gsh, 2 - EXT, rp.h + EXT - 7);
+        int pred[16];
         predict4x4(rp, ix, iy, dx, dy, pred);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            predw[r] = (uint32_t)pred[4 * r] | ((uint32_t)pred[4 * r + 1] << 8) | ((uint32_t)pred[4 * r + 2] << 16) | ((uint32_t)pred[4 * r + 3] << 24);
             const uint32_t cw = *reinterpret_cast<const uint32_t *>(cp.p + (ptrdiff_t)(posy + r) * cp.stride + posx);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                curp[4 * r + c] = byte_of(cw, c);
-                res[4 * r + c] = curp[4 * r + c] - pred[4 * r + c];
-            }
             *reinterpret_cast<uint32_t *>(&s_t[g].cur[tile_off + (by * 4 + r) * msz + bx * 4]) = cw;
         }
     }
@@ -343,11 +344,7 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
 
     float ssim = -2.0f;  // pack_8x8_into_16x16, :1352
     int seg_final = a.o.seg[mb];
-    int coef[16];
-    int q24[16];
-    int recp[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { coef[k] = 0; q24[k] = 0; recp[k] = 0; }
+    int nz_blk = 0;            // this lane's share of prepare_filter_mask's count, from the last pass that ran
     bool any_pass = false;
 
     for (int seg = 3; seg >= 0; --seg) {        // inter_part.h:329
@@ -366,15 +363,26 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
             dc_q = imin(k_dc_q[qi(SD[SD_UV_DC_IDELTA] + i)], 132);
             ac_q = k_ac_q[qi(SD[SD_UV_AC_IDELTA] + i)];
         }
+        int coef[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) coef[k] = 0;
         if (blk) {
+            int res[16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_t[g].cur[tile_off + (by * 4 + r) * msz + bx * 4]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) res[4 * r + c] = byte_of(cw, c) - byte_of(predw[r], c);
+            }
             fdct4x4(res, coef);
             const TDiv ddc = tdiv_make(dc_q), dac = tdiv_make(ac_q);
             coef[0] = tdiv(coef[0], ddc);        // truncating, :1478-1481
 #pragma unroll
             for (int k = 1; k < 16; ++k) coef[k] = tdiv(coef[k], dac);
         }
+        nz_blk = 0;
         if (parts == 0) {                        // wht4x4_iwht4x4, :1498-1543 (all lanes: shuffles)
-            int X[16];
+            int X[16], q24[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) X[k] = (int16_t)__shfl(coef[0], k, 32);
             const int y2dc = k_dc_q[qi(SD[SD_Y2_DC_IDELTA] + i)] * 2;
@@ -386,8 +394,18 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
                 for (int k = 1; k < 16; ++k) nd = (lane == k) ? X[k] : nd;
                 coef[0] = (int16_t)nd;           // stored as short, :1537
             }
+            if (lane == 24) {                    // block 24 and its share of the non-zero count (CPU_kernels.cl:800-819)
+                if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + 24) * 16, q24);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) nz_blk += iabs((int16_t)q24[k]);
+            }
         }
         if (blk) {                               // idct4x4, :1545-1608
+            if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + lane) * 16, coef);
+            // prepare_filter_mask, CPU_kernels.cl:800-819
+#pragma unroll
+            for (int k = 1; k < 16; ++k) nz_blk += iabs((int16_t)coef[k]);
+            if (plane != 0 || parts != 0) nz_blk += iabs((int16_t)coef[0]);
             int L[16];
             L[0] = __mul24((int16_t)coef[0], dc_q);
 #pragma unroll
@@ -397,11 +415,9 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
             for (int r = 0; r < 4; ++r) {
                 uint32_t w = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    recp[4 * r + c] = sat8(L[4 * r + c] + pred[4 * r + c]);
-                    w |= (uint32_t)recp[4 * r + c] << (8 * c);
-                }
+                for (int c = 0; c < 4; ++c) w |= (uint32_t)sat8(L[4 * r + c] + byte_of(predw[r], c)) << (8 * c);
                 *reinterpret_cast<uint32_t *>(&s_t[g].rec[tile_off + (by * 4 + r) * msz + bx * 4]) = w;
+                if (live) *reinterpret_cast<uint32_t *>(rc.p + (ptrdiff_t)(posy + r) * rc.stride + posx) = w;
             }
         }
         }
@@ -445,25 +461,7 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     }
 
     // ---- results -------------------------------------------------------------------------------
-    int nz = 0;
-    if (blk && any_pass) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t w = (uint32_t)recp[4 * r] | ((uint32_t)recp[4 * r + 1] << 8) | ((uint32_t)recp[4 * r + 2] << 16) |
-                               ((uint32_t)recp[4 * r + 3] << 24);
-            if (live) *reinterpret_cast<uint32_t *>(rc.p + (ptrdiff_t)(posy + r) * rc.stride + posx) = w;
-        }
-        if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + lane) * 16, coef);
-        // prepare_filter_mask, CPU_kernels.cl:800-819
-#pragma unroll
-        for (int k = 1; k < 16; ++k) nz += iabs((int16_t)coef[k]);
-        if (plane != 0 || parts != 0) nz += iabs((int16_t)coef[0]);
-    }
-    if (any_pass && parts == 0 && lane == 24) {
-        if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + 24) * 16, q24);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) nz += iabs((int16_t)q24[k]);
-    }
+    int nz = any_pass ? nz_blk : 0;
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) nz += __shfl_xor(nz, m, 32);
     if (lane == 0 && live) {

@@ -343,6 +343,11 @@ static Search1Args search1_args(const Frame &cur, const RefSet &refs, const NetS
     return a;
 }
 
+int persistent_workgroups() {
+    static const int n = [] { const char *v = getenv("VP8HIP_PERSIST"); return v && v[0] ? atoi(v) : 0; }();
+    return n;
+}
+
 static bool search1_skip() {
     static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s1") != nullptr; }();
     return skip;   // timing experiment only

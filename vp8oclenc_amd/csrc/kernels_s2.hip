@@ -90,17 +90,17 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 // form with the bias in an SGPR instead of v_mov + v_dot4c
 __device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
 
-__device__ __forceinline__ void search2_body(const S2Args &a) {
-    if ((int)blockIdx.y >= a.nrefs) return;
+__device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_idx) {
+    if (ref_idx >= a.nrefs) return;
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
     uint32_t(*s_win)[25 * V_STRIDE] = s_V;   // the staged window (72 dwords) is dead once the horizontal pass has read it: same bytes
     __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
-    const int r = a.refmap[blockIdx.y];
+    const int r = a.refmap[ref_idx];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const int b = imin(blockIdx.x * 8 + g, a.nblk - 1);
-    const bool live = blockIdx.x * 8 + g < a.nblk;
+    const int b = imin(wg_x * 8 + g, a.nblk - 1);
+    const bool live = wg_x * 8 + g < a.nblk;
     const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
     const int cx = bx * 8, cy = by * 8;
     const uint32_t nv = reinterpret_cast<const uint32_t *>(a.net_in[r])[b];
@@ -276,8 +276,21 @@ __device__ __forceinline__ void search2_body(const S2Args &a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_search2(S2Args a) { search2_body(a); }
-__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) { search2_body(b.item[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_search2(S2Args a) { search2_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) { search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y); }
+// Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
+// block group) space with a stride.  A command-processor pipe stays busy with a launch until its last workgroup is
+// placed -- for a grid of tens of thousands of workgroups on a full chip that is the kernel's whole duration, and the
+// pipe's other queues wait (the kernel trace of eight busy streams shows 3.6 kernels running and every stream idle half of
+// the time, ~0.26 ms between a kernel's end and its successor's start).  A grid that fits is placed at once.
+__global__ __launch_bounds__(256) void k_search2_p(BatchOf<S2Args> b, int nbx, int maxrefs, int total) {
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int item = w / (nbx * maxrefs), rem = w - item * (nbx * maxrefs);
+        const int ref_idx = rem / nbx, wg_x = rem - ref_idx * nbx;
+        search2_body(b.item[item], wg_x, ref_idx);
+        lds_fence();   // the next round reuses this workgroup's LDS: every read of this round has returned
+    }
+}
 
 }  // namespace
 
@@ -323,7 +336,13 @@ void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
     }
     if (maxrefs == 0 || search2_skip()) return;
-    VP8_LAUNCH(k_search2_b, dim3((b.item[0].nblk + 7) / 8, maxrefs, n), dim3(256), 0, s, b);
+    const int nbx = (b.item[0].nblk + 7) / 8;
+    const int persist = persistent_workgroups();
+    if (persist > 0 && nbx * maxrefs * n > persist) {
+        VP8_LAUNCH(k_search2_p, dim3(persist), dim3(256), 0, s, b, nbx, maxrefs, nbx * maxrefs * n);
+        return;
+    }
+    VP8_LAUNCH(k_search2_b, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
 }
 
 }  // namespace vp8

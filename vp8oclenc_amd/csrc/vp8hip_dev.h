@@ -73,6 +73,8 @@ struct SegData { int32_t v[4 * SD_INTS]; };
 // the argument blocks of the single form travel as an array in the kernel arguments, and a few streams carry what sixteen did.
 constexpr int MAX_BATCH = 4;
 template <typename A> struct BatchOf { int n; A item[MAX_BATCH]; };
+// workgroups of a persistent launch (0 = launch the full grid); VP8HIP_PERSIST overrides (same-box A/B runs)
+int persistent_workgroups();
 
 // ---- launchers (kernels_*.hip) ---------------------------------------------------------------
 void launch_border(hipStream_t s, const Frame &f);
