@@ -36,36 +36,71 @@ __device__ __forceinline__ int tdiv(int x, const TDiv &d) {
 // `construct`, GPU_kernels.cl:574-774: separable six-tap on a 4x4 block at integer position (ix,iy)
 // with 1/8-pel phases (fx,fy).  Of the nine horizontally filtered lines the first six are saturated
 // to u8, the last three are narrowed with a plain (uchar) cast (wrap mod 256) -- :702-708,727-733,752-758.
-__device__ __forceinline__ void predict4x4(const Plane &rf, int ix, int iy, int fx, int fy, int out[16]) {
-    int H[9][4];
-    int f[6];
-    load_taps(fx, f);
+//
+// Both passes on v_dot4_i32_i8 (the 32-bit multiply-add form of the first version was a third of the kernel's issue
+// cycles): pixels as signed bytes p-128 (every tap set sums to 128: sum p*f = sum (p-128)*f + 128*128), taps pre-shifted
+// into the four byte positions a 4-sample row needs (the block is loaded from its own address, so output c starts at byte
+// c of the line).  The horizontal results are packed per line, transposed (3 x eight v_perm) into columns whose bytes
+// run down the six vertical taps, and the four output columns are transposed back into the rows the transform reads.
+// Phase 0 (whole-pel: tap 128 does not fit a signed byte) selects the unfiltered bytes instead, per line / per column.
+constexpr uint32_t pk8t(int a, int b, int c, int d) {
+    return (uint32_t)(a & 255) | ((uint32_t)(b & 255) << 8) | ((uint32_t)(c & 255) << 16) | ((uint32_t)(d & 255) << 24);
+}
+// six taps f0..f5 placed at byte offset c = 0..3: entries [2c], [2c+1] and, for c = 3, [8]
+#define P6(f0, f1, f2, f3, f4, f5)                                                                          \
+    {pk8t(f0, f1, f2, f3), pk8t(f4, f5, 0, 0), pk8t(0, f0, f1, f2), pk8t(f3, f4, f5, 0), pk8t(0, 0, f0, f1),  \
+     pk8t(f2, f3, f4, f5), pk8t(0, 0, 0, f0),  pk8t(f1, f2, f3, f4), pk8t(f5, 0, 0, 0),  0, 0, 0}
+static __device__ __constant__ const uint32_t K_P6[8][12] = {   // 1/8-pel phases 0..7, GPU_kernels.cl:563-572 (phase 0 never used)
+    P6(0, 0, 0, 0, 0, 0),       P6(0, -6, 123, 12, -1, 0), P6(2, -11, 108, 36, -8, 1), P6(0, -9, 93, 50, -6, 0),
+    P6(3, -16, 77, 77, -16, 3), P6(0, -6, 50, 93, -9, 0),  P6(1, -8, 36, 108, -11, 2), P6(0, -1, 12, 123, -6, 0)};
+constexpr int KB6 = 128 * 128 + 64;   // undo the -128 pixel bias + rounding
+__device__ __forceinline__ int d4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
+__device__ __forceinline__ int d4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+// four 6-tap sums of a 12-byte line (three dwords of biased bytes), outputs c = 0..3 start at byte c
+__device__ __forceinline__ void six_tap4(uint32_t w0, uint32_t w1, uint32_t w2, const uint32_t t[9], int s[4]) {
+    s[0] = d4(w1, t[1], d4k(w0, t[0], KB6));
+    s[1] = d4(w1, t[3], d4k(w0, t[2], KB6));
+    s[2] = d4(w1, t[5], d4k(w0, t[4], KB6));
+    s[3] = d4(w2, t[8], d4(w1, t[7], d4k(w0, t[6], KB6)));
+}
+__device__ __forceinline__ uint32_t pack_sat4(const int s[4]) {   // sat8(s >> 7) of four sums, byte c = sum c
+    const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(s[0], s[1], 7), hi = __builtin_amdgcn_ashr_pk_u8_i32(s[2], s[3], 7);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+// rows out[r] (byte c = column c) of the 4x4 predictor
+__device__ __forceinline__ void predict4x4(const Plane &rf, int ix, int iy, int fx, int fy, uint32_t out[4]) {
+    uint32_t tx[9], ty[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { tx[i] = K_P6[fx][i]; ty[i] = K_P6[fy][i]; }
+    uint32_t Hb[9];   // horizontally filtered lines, four biased bytes each
 #pragma unroll
     for (int L = 0; L < 9; ++L) {
         const uint8_t *p = rf.p + (ptrdiff_t)(iy - 2 + L) * rf.stride + (ix - 2);
-        const uint32_t w0 = ld_u32(p), w1 = ld_u32(p + 4), w2 = ld_u32(p + 8);
-        int bb[9];
+        const uint32_t w0 = ld_u32(p) ^ 0x80808080u, w1 = ld_u32(p + 4) ^ 0x80808080u, w2 = ld_u32(p + 8) ^ 0x80808080u;
+        int sm[4];
+        six_tap4(w0, w1, w2, tx, sm);
+        uint32_t h;
+        if (L < 6) {
+            h = pack_sat4(sm);                    // saturated lines, :600-680
+        } else {                                  // the last three: C division toward zero, then a plain (uchar) cast, :702-758
+            h = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) bb[i] = byte_of(i < 4 ? w0 : (i < 8 ? w1 : w2), i & 3);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int s = 64;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) s += bb[c + t] * f[t];
-            const int v = div128(s);
-            H[L][c] = (L < 6) ? sat8(v) : (v & 0xff);
+            for (int c = 0; c < 4; ++c) h |= (uint32_t)(div128(sm[c]) & 0xff) << (8 * c);
         }
+        h ^= 0x80808080u;
+        Hb[L] = fx == 0 ? __builtin_amdgcn_alignbyte(w1, w0, 2) : h;   // whole-pel x: bytes 2..5 of the line as they are
     }
-    load_taps(fy, f);
+    uint32_t ca[4], cb[4], oc[4];   // columns: rows 0-3, rows 4-7 (row 8 comes from Hb[8])
+    transpose4x4(Hb, ca);
+    transpose4x4(Hb + 4, cb);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int s = 64;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) s += H[i + t][c] * f[t];
-            out[4 * i + c] = sat8_shr7(s);
-        }
+    for (int c = 0; c < 4; ++c) {
+        int sm[4];
+        six_tap4(ca[c], cb[c], Hb[8] >> (8 * c), ty, sm);   // only byte 0 of the third dword meets a non-zero tap
+        const uint32_t v = pack_sat4(sm);
+        oc[c] = fy == 0 ? (__builtin_amdgcn_alignbyte(cb[c], ca[c], 2) ^ 0x80808080u) : v;   // whole-pel y: rows 2..5 of the column
+    }
+    transpose4x4(oc, out);
 }
 
 // dct4x4, GPU_kernels.cl:1417-1476: libvpx fdct constants, vertical pass first
@@ -299,11 +334,9 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
         const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;  // >= 0 for every in-frame vector
         const int dx = (fxp & gm) * (plane == 0 ? 2 : 1), dy = (fyp & gm) * (plane == 0 ? 2 : 1);
         const int ix = iclamp(fxp >> gsh, 2 - EXT, rp.w + EXT - 7), iy = iclamp(fyp >> gsh, 2 - EXT, rp.h + EXT - 7);
-        int pred[16];
-        predict4x4(rp, ix, iy, dx, dy, pred);
+        predict4x4(rp, ix, iy, dx, dy, predw);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            predw[r] = (uint32_t)pred[4 * r] | ((uint32_t)pred[4 * r + 1] << 8) | ((uint32_t)pred[4 * r + 2] << 16) | ((uint32_t)pred[4 * r + 3] << 24);
             const uint32_t cw = *reinterpret_cast<const uint32_t *>(cp.p + (ptrdiff_t)(posy + r) * cp.stride + posx);
             *reinterpret_cast<uint32_t *>(&s_t[g].cur[tile_off + (by * 4 + r) * msz + bx * 4]) = cw;
         }
