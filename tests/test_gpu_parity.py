@@ -320,8 +320,6 @@ def test_loop_filter_alone_on_band_and_ring_edge_geometries(W, H):
     """The banded loop filter on random reconstructions / masks / segments: one macroblock column (narrower than
     the strip ring), one macroblock row, heights that end exactly on a band, the flush row alone in a band,
     more bands than fit one wave of workgroups; three launches each (hand-off races show up as differences)."""
-    import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import lf_check
     assert lf_check.run(W, H, seed=W + H, reps=2)
 

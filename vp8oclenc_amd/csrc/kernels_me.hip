@@ -1,8 +1,10 @@
 // kernels_me.hip -- motion estimation side of the inter-frame path for gfx950:
-//   edge replication, pyramid, hierarchical full-pel search, quarter-pel search, reference choice.
-// Behaviour follows the reference kernels cited at each kernel (paths under the reference's src/);
-// the parallel decomposition is new: one 32-lane half-wave per 8x8 block with one search
-// candidate per lane, the winner found with a wave-level packed (cost,index) minimum.
+//   packing of a new frame into its padded surface, edge replication, pyramid, hierarchical full-pel search
+//   (the quarter-pel search is kernels_s2.hip, the reference choice is inside k_mb).
+// Behaviour follows the reference kernels cited at each kernel (paths under the reference's src/); the parallel
+// decomposition is new (k_search1: a lane per candidate row of an 8x8 block walking five candidates over
+// transposed columns, the winner by a shuffle minimum of packed (cost, index) keys).  Every kernel has a single
+// and a batched form (blockIdx.z = context, vp8hip_dev.h).
 #include <stdlib.h>
 #include <string.h>
 
@@ -155,16 +157,6 @@ void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *
     for (int i = 0; i < n; ++i) b.item[i] = PackItem{f[i]->Y[0], f[i]->U, f[i]->V, (const uint8_t *)y[i], (const uint8_t *)u[i], (const uint8_t *)v[i]};
     const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
     VP8_LAUNCH(k_pack_b, dim3((units + 255) / 256, 1, n), dim3(256), 0, s, b);
-}
-
-// minimum of a packed key over the 32 lanes of a half-wave
-__device__ __forceinline__ uint32_t halfwave_min(uint32_t key) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)key, m, 32);
-        key = o < key ? o : key;
-    }
-    return key;
 }
 
 // ------------------------------------------------------------------------------------------------
