@@ -254,6 +254,11 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(spawn_ranks(args))      # before `import torch`: the launcher never initialises the GPU
+    # stdout carries ONE line, the JSON: native libraries (RCCL prints its version banner there) and anything else that
+    # writes to file descriptor 1 during the run go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     from vp8oclenc_amd import api
 
@@ -392,10 +397,12 @@ def main():
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):
