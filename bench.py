@@ -456,8 +456,11 @@ def bitstream_leg(torch, leg, nb):
     def group_worker(members, batch):     # batched launches: the group's frames in one call, then every member's bytes
         for _ in range(nb):
             leg.step_group(members, batch)
-            for k in members:
-                leg.drv[k].get_frame_begin()
+            if os.environ.get("VP8_BENCH_ENT_BATCH", "1") != "0":
+                batch.get_frames_begin()
+            else:
+                for k in members:
+                    leg.drv[k].get_frame_begin()
             for k in members:
                 nbytes[k] += len(leg.drv[k].get_frame_end())
 

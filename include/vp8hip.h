@@ -254,6 +254,9 @@ int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);
 int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
+/* vp8hip_encode_frame_begin for the active members in the same nine launches (params[i] = member i's header parameters;
+ * every member is then between _begin and _end: take each frame with vp8hip_encode_frame_end) */
+int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_partitions, const vp8hip_header_params *params);
 const char *vp8hip_status_string(int status);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

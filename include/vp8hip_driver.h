@@ -84,6 +84,9 @@ int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n);
 void vp8drv_batch_destroy(vp8drv_batch *b);      /* the drivers stay */
 int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL = all; 0 = this member sits the call out */,
                                      const void *const *y, const void *const *u, const void *const *v, const int *force_key, int *was_key);
+/* vp8drv_get_frame_begin for the members' frames in one set of launches (src/vp8enc.cpp:48-94 for up to four chunks at
+ * once); then vp8drv_get_frame_end on every member */
+int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

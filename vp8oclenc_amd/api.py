@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "vp8hip_hw_queues", "vp8hip_profile_read_clock", "vp8hip_inter_search", "vp8hip_inter_finish", "vp8hip_export_search",
     "vp8hip_import_search", "vp8hip_export_last", "vp8hip_batch_create", "vp8hip_batch_destroy", "vp8hip_batch_set_current_device",
     "vp8hip_batch_auto_segments", "vp8hip_batch_inter_transform", "vp8hip_batch_loop_filter", "vp8drv_batch_create", "vp8drv_batch_destroy",
-    "vp8drv_batch_encode_frame_device",
+    "vp8drv_batch_encode_frame_device", "vp8hip_batch_encode_frame_begin", "vp8drv_batch_get_frame_begin",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
@@ -359,6 +359,16 @@ class NativeBatch:
         if rc < 0:
             raise Vp8HipError(f"vp8drv_batch_encode_frame_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return [bool(k) for k in self._key]
+
+    def get_frames_begin(self, members=None) -> None:
+        """The entropy stage of the members' frames in one set of launches (vp8drv_batch_get_frame_begin); every member's
+        driver then takes its frame with get_frame_end()."""
+        for i in range(self.n):
+            self._members[i] = 1 if (members is None or members[i]) else 0
+        self.lib.vp8drv_batch_get_frame_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = self.lib.vp8drv_batch_get_frame_begin(self.h, self._members)
+        if rc != 0:
+            raise Vp8HipError(f"vp8drv_batch_get_frame_begin: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
 
     def close(self):
         if getattr(self, "h", None):

@@ -88,13 +88,20 @@ __device__ __forceinline__ int third_context(const uint8_t *flags, const int32_t
 // row (the reference's num and denom - 1 are the sums over the rows of a partition).  Histogram in LDS, written
 // out with plain stores and summed by k_ent_probs: no atomics in HBM.
 constexpr int CNT_SPLIT = 4;   // workgroups per macroblock row
-__global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
-                                                   const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw) {
+struct CountItem {
+    const int16_t *coeffs;
+    const int32_t *nzc, *parts;
+    const uint8_t *flags;
+    uint8_t *third_ctx;
+    uint32_t *counts;
+    int mbw;
+};
+__device__ __forceinline__ void count_body(int mb_row, int quarter, const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
+                                           const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw) {
     __shared__ uint32_t s_h[NCTX * 2];
     for (int i = threadIdx.x; i < NCTX * 2; i += 256) s_h[i] = 0;
     __syncthreads();
-    const int mb_row = blockIdx.x;
-    const int per = (mbw * 25 + CNT_SPLIT - 1) / CNT_SPLIT, i0 = blockIdx.y * per;
+    const int per = (mbw * 25 + CNT_SPLIT - 1) / CNT_SPLIT, i0 = quarter * per;
     const int i1 = i0 + per < mbw * 25 ? i0 + per : mbw * 25;
     for (int item = i0 + threadIdx.x; item < i1; item += 256) {
         const int mb_col = item / 25, b = item % 25;
@@ -134,8 +141,16 @@ __global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const 
         }
     }
     __syncthreads();
-    uint32_t *dst = counts + (size_t)(mb_row * CNT_SPLIT + blockIdx.y) * NCTX * 2;
+    uint32_t *dst = counts + (size_t)(mb_row * CNT_SPLIT + quarter) * NCTX * 2;
     for (int i = threadIdx.x; i < NCTX * 2; i += 256) dst[i] = s_h[i];
+}
+__global__ __launch_bounds__(256) void k_ent_count(const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
+                                                   const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw) {
+    count_body(blockIdx.x, blockIdx.y, coeffs, nzc, parts, flags, third_ctx, counts, mbw);
+}
+__global__ __launch_bounds__(256) void k_ent_count_b(BatchOf<CountItem> b) {   // blockIdx.z = member of the batch
+    const CountItem &a = b.item[blockIdx.z];
+    count_body(blockIdx.x, blockIdx.y, a.coeffs, a.nzc, a.parts, a.flags, a.third_ctx, a.counts, a.mbw);
 }
 
 // num_div_denom (:764-778) + the denominators of partition 0 that the host inspects (vp8enc.cpp:69-76):
@@ -533,10 +548,11 @@ struct CodeJob {
     int32_t *sizes;
     int P;
 };
+// Frames of a batch (vp8hip_batch_encode_frame_begin) are job pairs 2m, 2m + 1 of the same launches.
 struct CodeJobs {
-    CodeJob j[2];
-    uint8_t *frame;            // not null: j[0] = coefficient partitions, j[1] = first partition, and k_ent_finish lays the
-    uint32_t head, capacity;   // finished frame out at frame + 16 (gather_frame, src/encIO.h:1-30); see k_ent_finish
+    CodeJob j[2 * MAX_BATCH];
+    uint8_t *frame[MAX_BATCH];                       // [m] not null: j[2m] = coefficient partitions, j[2m + 1] = first partition, and
+    uint32_t head[MAX_BATCH], capacity[MAX_BATCH];   // k_ent_finish lays the finished frame out at frame[m] + 16 (gather_frame, src/encIO.h:1-30)
 };
 
 constexpr int SUP = 8;   // chunks per super-chunk (never across a partition boundary)
@@ -758,27 +774,30 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void k_ent_finish(CodeJobs jobs) {
     const uint32_t nb = plan->nbytes[p], nw = (nb + 3) / 4;
     const unsigned long long *in = J.acc + plan->word_base[p];
     uint8_t *out = J.bytes + (size_t)plan->word_base[p] * 4;
-    if (jobs.frame) {
+    const int m = blockIdx.y >> 1, side = blockIdx.y & 1;
+    uint8_t *const frame = jobs.frame[m];
+    if (frame) {
         // gather_frame on the fly: `head` bytes left for the host, first partition, the 3-byte sizes of all coefficient
         // partitions but the last, the partitions.  frame[0] = frame size (0 = a coder overflowed its scratch or the
         // frame does not fit), frame[1] = size of the first partition; the sizes are known since k_ent_walk.
-        const Plan *pc = jobs.j[0].plan, *ph = jobs.j[1].plan;
-        const int P = jobs.j[0].P;
-        const uint32_t table = jobs.head + ph->nbytes[0];
-        uint32_t o = table + 3u * (uint32_t)(P - 1), mine = jobs.head;
+        const Plan *pc = jobs.j[2 * m].plan, *ph = jobs.j[2 * m + 1].plan;
+        const int P = jobs.j[2 * m].P;
+        const uint32_t head = jobs.head[m];
+        const uint32_t table = head + ph->nbytes[0];
+        uint32_t o = table + 3u * (uint32_t)(P - 1), mine = head;
         for (int q = 0; q < P; ++q) {
-            if (blockIdx.y == 0 && q == p) mine = o;
+            if (side == 0 && q == p) mine = o;
             o += pc->nbytes[q];
         }
-        const bool ok = !(pc->overflow || ph->overflow || o > jobs.capacity);
-        if (blockIdx.y == 1 && threadIdx.x == 0) {
-            reinterpret_cast<uint32_t *>(jobs.frame)[0] = ok ? o : 0u;
-            reinterpret_cast<uint32_t *>(jobs.frame)[1] = ph->nbytes[0];
+        const bool ok = !(pc->overflow || ph->overflow || o > jobs.capacity[m]);
+        if (side == 1 && threadIdx.x == 0) {
+            reinterpret_cast<uint32_t *>(frame)[0] = ok ? o : 0u;
+            reinterpret_cast<uint32_t *>(frame)[1] = ph->nbytes[0];
         }
         if (!ok) return;
-        if (blockIdx.y == 1 && threadIdx.x < 3u * (uint32_t)(P - 1))
-            jobs.frame[16 + table + threadIdx.x] = (uint8_t)(pc->nbytes[threadIdx.x / 3] >> (8 * (threadIdx.x % 3)));
-        out = jobs.frame + 16 + mine;
+        if (side == 1 && threadIdx.x < 3u * (uint32_t)(P - 1))
+            frame[16 + table + threadIdx.x] = (uint8_t)(pc->nbytes[threadIdx.x / 3] >> (8 * (threadIdx.x % 3)));
+        out = frame + 16 + mine;
     }
     uint32_t C = 0;   // carry into the least significant word of the step
     int par = 0;
@@ -871,7 +890,8 @@ static ent::CodeJob code_job(const EntBuffers &eb, int P) {
     return j;
 }
 static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs) {
-    const int maxP = jobs.j[0].P > jobs.j[njobs - 1].P ? jobs.j[0].P : jobs.j[njobs - 1].P;
+    int maxP = 1;
+    for (int i = 0; i < njobs; ++i) maxP = jobs.j[i].P > maxP ? jobs.j[i].P : maxP;
     hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(ent::MAPS_THREADS), 0, s, jobs);
     hipLaunchKernelGGL(ent::k_ent_walk, dim3(maxP, njobs), dim3(256), 0, s, jobs);
     hipLaunchKernelGGL(ent::k_ent_encode, dim3(512, njobs), dim3(256), 0, s, jobs);
@@ -886,10 +906,21 @@ void launch_frame_code(hipStream_t s, const EntBuffers &coef, int P, const EntBu
     ent::CodeJobs jobs{};
     jobs.j[0] = code_job(coef, P);
     jobs.j[1] = code_job(hdr, 1);
-    jobs.frame = frame;
-    jobs.head = head;
-    jobs.capacity = capacity;
+    jobs.frame[0] = frame;
+    jobs.head[0] = head;
+    jobs.capacity[0] = capacity;
     bool_code(s, jobs, 2);
+}
+void launch_frame_code_batch(hipStream_t s, const FrameEntropy *e, const FrameOut *fo, int n) {
+    ent::CodeJobs jobs{};
+    for (int m = 0; m < n; ++m) {
+        jobs.j[2 * m] = code_job(*e[m].coef, e[m].P);
+        jobs.j[2 * m + 1] = code_job(*e[m].hdr, 1);
+        jobs.frame[m] = fo[m].frame;
+        jobs.head[m] = fo[m].head;
+        jobs.capacity[m] = fo[m].capacity;
+    }
+    bool_code(s, jobs, 2 * n);
 }
 
 static ent::Geom make_geom(const EntBuffers &eb, int mbw, int mbh, int P) {

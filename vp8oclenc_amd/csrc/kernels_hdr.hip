@@ -122,8 +122,8 @@ struct Lane {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // frame header (encode_header :735-1061).  One workgroup.  cnt: bools per macroblock in, their exclusive prefix sums out.
-__global__ __launch_bounds__(256) void k_hdr_frame(Params a, uint32_t *partial, uint32_t *cnt, uint16_t *bools,
-                                                   uint8_t *sym_out, EntPlan *plan, uint32_t *info) {
+__device__ __forceinline__ void hdr_frame_body(const Params &a, uint32_t *partial, uint32_t *cnt, uint16_t *bools,
+                                               uint8_t *sym_out, EntPlan *plan, uint32_t *info) {
     __shared__ uint32_t s_tot[NSTAT];
     __shared__ int32_t s_sd[4 * SD_INTS];   // the segment data, read many times by the one lane that writes the frame-level bools
     __shared__ uint32_t s_scan[256];
@@ -296,6 +296,22 @@ __global__ __launch_bounds__(256) void k_hdr_frame(Params a, uint32_t *partial, 
     }
     __syncthreads();
     if (t < 64) sym_out[t] = s_sym[t];
+}
+__global__ __launch_bounds__(256) void k_hdr_frame(Params a, uint32_t *partial, uint32_t *cnt, uint16_t *bools,
+                                                   uint8_t *sym_out, EntPlan *plan, uint32_t *info) {
+    hdr_frame_body(a, partial, cnt, bools, sym_out, plan, info);
+}
+struct FrameItem {
+    Params a;
+    uint32_t *partial, *cnt;
+    uint16_t *bools;
+    uint8_t *sym_out;
+    EntPlan *plan;
+    uint32_t *info;
+};
+__global__ __launch_bounds__(256) void k_hdr_frame_b(BatchOf<FrameItem> b) {   // one workgroup per member of the batch
+    const FrameItem &f = b.item[blockIdx.x];
+    hdr_frame_body(f.a, f.partial, f.cnt, f.bools, f.sym_out, f.plan, f.info);
 }
 
 __device__ __forceinline__ void hdr_emit_body(int vb, int nvb, const Params &a, const uint32_t *offs, const uint8_t *sym, const EntPlan *plan,

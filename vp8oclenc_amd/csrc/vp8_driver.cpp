@@ -391,6 +391,23 @@ int vp8drv_get_frame_begin(vp8drv *d) {
     return vp8hip_encode_frame_begin(d->hip, P, &hp);
 }
 
+// vp8drv_get_frame_begin for the members of a batch in one set of launches; every member then takes its frame with
+// vp8drv_get_frame_end
+int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members) {
+    if (!b) return VP8HIP_ERR_ARG;
+    vp8hip_header_params hp[VP8HIP_MAX_BATCH];
+    const int P = b->d[0]->cfg.num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    for (int i = 0; i < b->n; ++i) {
+        if (members && !members[i]) continue;
+        vp8drv *d = b->d[i];
+        if (d->cfg.num_partitions != P) return VP8HIP_ERR_ARG;
+        if (!d->have_frame || d->cfg.host_bitstream) return VP8HIP_ERR_STATE;
+        hp[i] = header_params(d);
+    }
+    return vp8hip_batch_encode_frame_begin(b->hb, members, P, hp);
+}
+
 int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     if (!d || !out || !size) return VP8HIP_ERR_ARG;
     return vp8hip_encode_frame_end(d->hip, out, capacity, size);

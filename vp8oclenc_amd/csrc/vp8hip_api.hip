@@ -1261,17 +1261,16 @@ static bool frame_zero_copy() {
 }
 // Everything of a frame's entropy stage up to the read-back, enqueued; nothing waits.
 static constexpr size_t FRAME_FIRST_COPY = 192 * 1024;
-static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
+// buffers + the description of one context's frame for the entropy stage's launchers
+static int frame_prepare(vp8hip_ctx *c, int P, const vp8hip_header_params *p, FrameEntropy &e, FrameOut &fo) {
     int rc = ent_alloc(c);
     if (rc) return rc;
     if ((rc = hdr_alloc(c))) return rc;
-    hipStream_t s = c->stream;
     if (!c->h_frame) {   // the finished frame: device copy + pinned host copy
         c->h_frame_cap = (size_t)c->hdr.cap_words * 4 + (size_t)c->ent.cap_words * 4 + 64;
         HIPCHK(c, hipHostMalloc(&c->h_frame, c->h_frame_cap));
         if (!frame_zero_copy()) HIPCHK(c, hipMalloc(&c->d_frame, c->h_frame_cap));
     }
-    FrameEntropy e;
     e.o = c->out;
     e.flags = c->ent_flags;
     e.third = c->ent_third;
@@ -1297,7 +1296,17 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     e.mbw = c->mbw;
     e.mbh = c->mbh;
     e.P = P;
-    const size_t head = p->is_key ? 10 : 3;
+    fo.frame = frame_zero_copy() ? c->h_frame : c->d_frame;
+    fo.head = p->is_key ? 10 : 3;
+    fo.capacity = (uint32_t)(c->h_frame_cap - 16);
+    return VP8HIP_OK;
+}
+static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
+    FrameEntropy e;
+    FrameOut fo;
+    const int rc = frame_prepare(c, P, p, e, fo);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
     static const bool stepwise = [] { const char *v = getenv("VP8HIP_ENT_STEPWISE"); return v && v[0] && v[0] != '0'; }();
     if (stepwise && c->mbs * 25 <= 1024 * 1024) {   // A/B switch (the step-by-step scan stops at 2^20 blocks): the bool strings by the step-by-step kernels (15 launches instead of 5), then the same coder
         const uint8_t *defaults = hdr_default_coeff_probs();
@@ -1321,7 +1330,7 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
         // buffer (or, VP8HIP_FRAME_ZEROCOPY=0, into device memory: then the frame size and the first FRAME_FIRST_COPY bytes travel
         // in one copy and only a larger frame needs a second one)
         Timed t(c, VP8HIP_K_ENT_ENCODE);
-        launch_frame_code(s, c->ent, P, c->hdr, (uint32_t)head, (uint32_t)(c->h_frame_cap - 16), frame_zero_copy() ? c->h_frame : c->d_frame);
+        launch_frame_code(s, c->ent, P, c->hdr, fo.head, fo.capacity, fo.frame);
     }
     HIPCHK(c, hipGetLastError());
     if (frame_zero_copy()) return VP8HIP_OK;   // the coder's last kernel wrote the frame into the pinned host buffer itself
@@ -1341,6 +1350,60 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
     c->frame_params = *p;
     c->frame_partitions = P;
     c->frame_pending = true;
+    return VP8HIP_OK;
+}
+
+// The entropy stage of the frames of a batch's members in the same nine launches (blockIdx.z = member; the coder takes the
+// members' bool strings as job pairs).  Every active member is then between _begin and _end: vp8hip_encode_frame_end
+// per member reads its frame back (and, should a frame have been denser than the coder's scratch, codes that one again
+// on its own).
+int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_partitions, const vp8hip_header_params *params) {
+    if (!b || !params) return VP8HIP_ERR_ARG;
+    const int P = num_partitions;
+    if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    FrameEntropy e[MAX_BATCH];
+    FrameOut fo[MAX_BATCH];
+    vp8hip_ctx *m[MAX_BATCH];
+    int n = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        if (b->c[i]->frame_pending) return VP8HIP_ERR_STATE;
+    }
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        vp8hip_ctx *c = b->c[i];
+        const int rc = frame_prepare(c, P, &params[i], e[n], fo[n]);
+        if (rc) return rc;
+        c->frame_params = params[i];
+        c->frame_partitions = P;
+        m[n++] = c;
+    }
+    if (!n) return VP8HIP_OK;
+    hipStream_t s = b->stream;
+    {
+        Timed t(c0, VP8HIP_K_ENT_COUNT);
+        launch_fe_count_batch(s, e, n);
+    }
+    {
+        Timed t(c0, VP8HIP_K_HDR_ENCODE);
+        launch_fe_emit_batch(s, e, n);
+    }
+    {
+        Timed t(c0, VP8HIP_K_ENT_ENCODE);
+        launch_frame_code_batch(s, e, fo, n);
+    }
+    HIPCHK(c0, hipGetLastError());
+    for (int i = 0; i < n; ++i) {
+        vp8hip_ctx *c = m[i];
+        c->ent_counted_partitions = P;
+        if (!frame_zero_copy()) {
+            const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
+            HIPCHK(c0, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
+        }
+        c->frame_pending = true;
+    }
     return VP8HIP_OK;
 }
 

@@ -170,6 +170,12 @@ struct FrameEntropy {
 };
 void launch_fe_count(hipStream_t s, const FrameEntropy &e);   // counts, probabilities, layout of the coefficient partitions
 void launch_fe_emit(hipStream_t s, const FrameEntropy &e);    // frame header + both bool strings; then launch_frame_code
+// the frames of up to MAX_BATCH contexts of one geometry in the same nine launches (blockIdx.z = member; the coder takes
+// the job pairs 2m, 2m + 1)
+struct FrameOut { uint8_t *frame; uint32_t head, capacity; };
+void launch_fe_count_batch(hipStream_t s, const FrameEntropy *e, int n);
+void launch_fe_emit_batch(hipStream_t s, const FrameEntropy *e, int n);
+void launch_frame_code_batch(hipStream_t s, const FrameEntropy *e, const FrameOut *fo, int n);
 
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
