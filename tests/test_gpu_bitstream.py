@@ -227,6 +227,39 @@ def test_loop_filter_on_its_own_stream_changes_nothing():
             assert np.array_equal(p0, p1), t
 
 
+@pytest.mark.parametrize("frames_out", [True, False])
+def test_overlap_three_references_device_frames(frames_out):
+    """overlap_filter on the path the single_stream leg of bench.py times: frames already in device memory, parameters scanned
+    on the device, LAST + GOLDEN + ALTREF.  The context trades streams at every filter (the next frame's pack, parameter scan
+    and GOLDEN / ALTREF searches run beside it, the LAST search behind it on the filter's own stream): same frames, same
+    reconstructions, with the entropy stage beside the filter or without one."""
+    import torch
+    W, H = 640, 352
+    s = SynthSequence(W, H, seed=73)
+    dev = [tuple(torch.from_numpy(p).cuda() for p in s.frame(t)) for t in range(16)]
+    outs = []
+    for overlap in (0, 1):
+        d = api.NativeDriver(s.W, s.H, num_partitions=4, check_ssim=0, gop_size=150, altref_range=3, device_params=1, overlap_filter=overlap)
+        got, refs = [], set()
+        for t, f in enumerate(dev):
+            d.encode_frame_device(*(p.data_ptr() for p in f))
+            st = d.stats()
+            refs.add((st.last_use_golden, st.last_use_altref))
+            if frames_out:
+                got.append(d.get_frame())
+            if t % 5 == 4 or not frames_out:
+                got.append([p.copy() for p in d.hip.download_last()])
+        assert (1, 1) in refs
+        outs.append(got)
+        d.close()
+    for t, (g0, g1) in enumerate(zip(*outs)):
+        if isinstance(g0, bytes):
+            assert g0 == g1, t
+        else:
+            for p0, p1 in zip(g0, g1):
+                assert np.array_equal(p0, p1), t
+
+
 def test_frames_beyond_a_million_blocks():
     """4096x2736 = 1.09 million 4x4 block slots: the frame path's prefix sums have no size limit (the step-by-step
     vp8hip_encode_coefficients keeps its 1 Mi one); key frame + inter frame, 8 partitions, byte-exact.  (The format

@@ -49,7 +49,7 @@ constexpr int TILE_BYTES = 3 * TILE_PLANE;
 constexpr int TILE_SLOTS = 2;          // a finished tile is drained to HBM at the top of the next step
 constexpr int BIAS = 256;
 
-enum { F_TOP = WORKERS, F_PUB, F_COUNT };   // flag[0..WORKERS-1] = 2*step + phase of each worker
+enum { F_TOP = WORKERS, F_PUB, F_ABORT = 7 };   // flag[0..WORKERS-1] = 2*step + phase of each worker
 
 __device__ __forceinline__ int ad(int a, int b) { return (int)__builtin_amdgcn_sad_u16((uint32_t)a, (uint32_t)b, 0u); }
 __device__ __forceinline__ int c128(int v) { return iclamp(v, -128, 127); }
@@ -150,11 +150,16 @@ struct Args {
 struct Shared {
     uint8_t strip[ROWS + 1][STRIP_BYTES];         // strip[r] = bottom rows of the MB row ABOVE local row r
     uint8_t tile[ROWS][TILE_SLOTS][TILE_BYTES];   // work tiles: this step's and the previous one's (being drained)
-    volatile int flag[8];                         // worker progress, F_TOP, F_PUB
+    int flag[8];                                  // worker progress, F_TOP, F_PUB; [F_ABORT]: a bounded wait expired somewhere in
+                                                  // this workgroup, everybody leaves.  Read and written through `flag` below.
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
-    volatile int abort;                           // a bounded wait expired somewhere in this workgroup: everybody leaves
 };
+// The flags are polled: the accesses must be volatile, and a volatile access through HIP's generic pointers stays a FLAT
+// instruction (the address-space inference pass leaves volatile accesses alone) -- a flat load that resolves to LDS takes the
+// vector-memory path, returns on vmcnt behind the wave's prefetch loads and block stores, and four of them one after the other
+// were the 450 cycles of every step's poll.  Through an LDS-qualified pointer they are ds_read / ds_write on lgkmcnt.
+typedef __attribute__((address_space(3))) volatile int lds_flag_t;
 
 constexpr int NWAVES = WORKERS + 2;         // workers + loader + publisher
 
@@ -166,19 +171,20 @@ constexpr int SPIN_LIMIT = 1 << 22;
 #define LF_WAIT(cond_unsatisfied, nap)                                              \
     {                                                                               \
         int spins_ = 0;                                                             \
-        while ((cond_unsatisfied) && !sh.abort) {                                   \
+        while ((cond_unsatisfied) && !flag[F_ABORT]) {                              \
             __builtin_amdgcn_s_sleep(nap);                                          \
-            if (++spins_ > SPIN_LIMIT / (nap)) { sh.abort = 1; *a.err = 1; }        \
+            if (++spins_ > SPIN_LIMIT / (nap)) { flag[F_ABORT] = 1; *a.err = 1; }   \
         }                                                                           \
-        if (sh.abort) return;                                                       \
+        if (flag[F_ABORT]) return;                                                  \
     }
 
 __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
     const int band = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x < 8) sh.flag[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { sh.first_lf0 = 0x7fffffff; sh.abort = 0; }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    lds_flag_t *const flag = (lds_flag_t *)sh.flag;
+    if (threadIdx.x < 8) flag[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
     // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
     // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
     // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
@@ -220,14 +226,14 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         const uint8_t *sp = sh.strip[ROWS] + pl * STRIP_PLANE + rr * SROW;
         for (int x = 0; x <= mbw; ++x) {
             const int done = 2 * (x + ROWS - 1) + 2;   // the last row has finished macroblock x
-            LF_WAIT(sh.flag[WORKERS - 1] < done, 3)
+            LF_WAIT(flag[WORKERS - 1] < done, 3)
             if (lane < 44) {
                 const uint32_t v = *reinterpret_cast<const uint32_t *>(sp + ((x * msz - 4 + 4 * j) & rmask));
                 st_sc1(reinterpret_cast<uint32_t *>(P.p + (ptrdiff_t)y * P.stride + x * msz - 4) + j, v);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
-                sh.flag[F_PUB] = x + 1;
+                flag[F_PUB] = x + 1;
                 __hip_atomic_store(&a.gprog[band], a.gbase + x + 1 - (a.stall_test ? (1 << 20) : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -257,7 +263,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         // row 0 has finished macroblock m (row 0: step == macroblock).
 #define DRAIN_TOP(m)                                                                                        \
     {                                                                                                       \
-        LF_WAIT(sh.flag[0] < 2 * (m) + 2, 8)                                                                 \
+        LF_WAIT(flag[0] < 2 * (m) + 2, 8)                                                                    \
         if (lane < 32) st_sc1(reinterpret_cast<uint32_t *>(gp + (m) * msz - 4),                             \
                               *reinterpret_cast<const uint32_t *>(sp + (((m) * msz - 4 + 4 * j) & rmask))); \
     }
@@ -270,7 +276,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             if (x >= RING_MB - 1) DRAIN_TOP(x - (RING_MB - 1))
             if (lane < 32) *reinterpret_cast<uint32_t *>(sp + ((x * msz + 4 * j) & rmask)) = ld_sc1(reinterpret_cast<const uint32_t *>(gp + x * msz));
             lds_fence();
-            if (lane == 0) sh.flag[F_TOP] = x + 1;
+            if (lane == 0) flag[F_TOP] = x + 1;
         }
         for (int m = imax(mbw - (RING_MB - 1), 0); m <= mbw; ++m) DRAIN_TOP(m)
         return;
@@ -395,7 +401,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             trow[0] = left4;   // flush column: only the carried four columns are meaningful
         }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-        if (lane == 0) sh.flag[wave] = 2 * S + 1;
+        if (lane == 0) flag[wave] = 2 * S + 1;
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p1 += st_t1 - st_t0; st_t0 = st_t1;
@@ -411,14 +417,18 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             const int need_top = imin(x_r0 + 1, mbw);
             // last wave: the publisher must have drained what the second row is about to overwrite in strip[ROWS]
             const int need_pub = (wave + 1 == WORKERS && publishes) ? S - (ROWS - 1) - (RING_MB - 2) : 0;
+            // Everything the poll compares is the same in all lanes; readfirstlane says so to the compiler, which otherwise
+            // builds the loop out of exec-mask bookkeeping (a third of the poll's instructions on the path of every step).
+            const int up = imax(wave - 1, 0), dn = imin(wave + 1, WORKERS - 1);
             for (int spins = 0;; ++spins) {
-                const int f_up = wave > 0 ? sh.flag[wave - 1] : need_up;
-                const int f_dn = wave + 1 < WORKERS ? sh.flag[wave + 1] : need_dn;
-                const int f_top = top_dep ? sh.flag[F_TOP] : need_top;
-                const int f_pub = sh.flag[F_PUB];
-                if (f_up >= need_up && f_dn >= need_dn && f_top >= need_top && f_pub >= need_pub) break;
-                if (spins > SPIN_LIMIT) { sh.abort = 1; *a.err = 1; }
-                if (sh.abort) return;
+                // (unconditional loads: five ds_read_b32 in flight at once)
+                const int f_up = flag[up], f_dn = flag[dn], f_top = flag[F_TOP], f_pub = flag[F_PUB], f_abort = flag[F_ABORT];
+                const bool ok = (wave == 0 || f_up >= need_up) && (wave + 1 == WORKERS || f_dn >= need_dn) && (!top_dep || f_top >= need_top) &&
+                                f_pub >= need_pub;
+                const int state = __builtin_amdgcn_readfirstlane(f_abort ? 2 : (ok ? 1 : 0));
+                if (state == 1) break;
+                if (state == 2) return;
+                if (spins > SPIN_LIMIT) { flag[F_ABORT] = 1; *a.err = 1; }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -449,7 +459,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             left4 = trow[nd];   // columns msz-4 .. msz-1 of this macroblock after both phases (next P1's left side)
         }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-        if (lane == 0) sh.flag[wave] = 2 * S + 2;
+        if (lane == 0) flag[wave] = 2 * S + 2;
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p2 += st_t1 - st_t0;

@@ -65,9 +65,13 @@ struct vp8hip_ctx {
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
     EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
-    // loop filter on a stream of its own (vp8hip_filter_overlap): the entropy stage of the same frame reads nothing the
-    // filter writes, so the two run side by side; every other entry point joins the filter first (join_lf)
-    hipStream_t lf_stream = nullptr;
+    // vp8hip_filter_overlap: the context has a second stream and the loop filter and whatever does not depend on it run side
+    // by side (the entropy stage of the same frame, the next frame's pack / parameter scan / GOLDEN + ALTREF searches).  The
+    // FILTER stays on the stream the frame was coded on and the context moves over (`stream` and `lf_stream` trade places
+    // in vp8hip_loop_filter and back in join_lf): a video's dependency chain -- LAST search, transform, filter, border, LAST
+    // search ... -- is then launches of ONE stream, and the two cross-stream hand-offs (12 us each on this part) are on the
+    // side work's path, which has 0.25 ms of slack.  Every entry point that needs the filtered frame joins first (join_lf).
+    hipStream_t lf_stream = nullptr;   // the stream `stream` is not
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     bool lf_overlap = false, lf_pending = false;
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
@@ -269,7 +273,12 @@ static SegData *sd_for_writing(vp8hip_ctx *c) {
 static int join_lf(vp8hip_ctx *c) {
     if (!c->lf_pending) return VP8HIP_OK;
     c->lf_pending = false;
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
+    // back to the stream the filter is on, behind it and behind everything that ran beside it
+    HIPCHK(c, hipEventRecord(c->ev_lf, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_lf, 0));
+    hipStream_t side = c->stream;
+    c->stream = c->lf_stream;
+    c->lf_stream = side;
     return VP8HIP_OK;
 }
 // HIP's current device is per host thread: a context may be driven from a thread other than its creator's, or two contexts
@@ -394,6 +403,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     if (c->counted) --g_live_contexts;
     hipSetDevice(c->device);
     if (c->lf_stream) {
+        (void)join_lf(c);   // `stream` is the one vp8hip_create made again
         hipStreamSynchronize(c->lf_stream);
         hipStreamDestroy(c->lf_stream);
         hipEventDestroy(c->ev_fork);
@@ -1061,11 +1071,13 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
     Frame &f = c->frames[c->recon].f;
     if (c->lf_overlap && !c->prof_mask) {   // (the per-kernel timers bracket launches on the context's stream only)
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));
-        launch_loop_filter3(c->lf_stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
-        launch_border(c->lf_stream, f);
-        HIPCHK(c, hipEventRecord(c->ev_lf, c->lf_stream));
+        hipStream_t chain = c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_fork, chain));
+        launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
+        launch_border(chain, f);
+        HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
+        c->stream = c->lf_stream;
+        c->lf_stream = chain;
         c->lf_pending = true;
         c->lf_sd = c->d_sd;
     } else {
