@@ -154,6 +154,7 @@ struct Shared {
                                                   // this workgroup, everybody leaves.  Read and written through `flag` below.
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
+    uint32_t sdp[4];                              // per segment: int_lim | mb_lim << 8 | b_lim << 16 | hev << 24 (all < 256)
 };
 // The flags are polled: the accesses must be volatile, and a volatile access through HIP's generic pointers stays a FLAT
 // instruction (the address-space inference pass leaves volatile accesses alone) -- a flat load that resolves to LDS takes the
@@ -185,6 +186,11 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     lds_flag_t *const flag = (lds_flag_t *)sh.flag;
     if (threadIdx.x < 8) flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
+    if (threadIdx.x < 4) {   // a table read per macroblock: selecting among four registers by a per-lane index compiles to branches
+        const int32_t *sd = a.sd->v + threadIdx.x * SD_INTS;
+        sh.sdp[threadIdx.x] = (uint32_t)(sd[SD_INTERIOR_LIMIT] & 0xff) | ((uint32_t)(sd[SD_MBEDGE_LIMIT] & 0xff) << 8) |
+                              ((uint32_t)(sd[SD_SUB_BEDGE_LIMIT] & 0xff) << 16) | ((uint32_t)(sd[SD_HEV_THRESHOLD] & 0xff) << 24);
+    }
     // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
     // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
     // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
@@ -318,15 +324,6 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     const bool has_top = gr > 0;
     const bool publishes = band + 1 < a.nbands;   // a next band exists: every row of this band is real
     const int first_lf0 = sh.first_lf0;
-    // segment parameters packed per segment: int_lim | mb_lim<<8 | b_lim<<16 | hev<<24 (all < 256)
-    uint32_t sdp[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int32_t *sd = a.sd->v + s * SD_INTS;
-        sdp[s] = (uint32_t)(sd[SD_INTERIOR_LIMIT] & 0xff) | ((uint32_t)(sd[SD_MBEDGE_LIMIT] & 0xff) << 8) |
-                 ((uint32_t)(sd[SD_SUB_BEDGE_LIMIT] & 0xff) << 16) | ((uint32_t)(sd[SD_HEV_THRESHOLD] & 0xff) << 24);
-    }
-
     // Prefetch of macroblock 0.  Every lane loads 16 bytes (chroma lanes use 8 of them; at the right frame edge
     // the rest is margin).  The loads stay inside a branch on purpose: hoisted to the top of the loop body, hipcc
     // parks an s_waitcnt vmcnt(0) right behind them (measured: +700 cycles per step).
@@ -351,17 +348,18 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         STAMP(st_t0);
         uint8_t *tile = sh.tile[r][S & 1];
         const int x = S - r;
-        const bool act = row_any && x >= 0 && x <= mbw;
-        const bool mbstep = act && row_real && x < mbw;    // a real macroblock (else: flush column / flush row)
+        // (`&`, not `&&`: one predicate, one exec mask -- short-circuit evaluation nests the regions)
+        const bool p1_on = row_real & (x >= 0) & (x <= mbw);   // a real macroblock or the flush column behind the last one
+        const bool mbstep = p1_on & (x < mbw);
         const int x0 = x * msz;
         const uint4 own = nxt;
         const int seg = nxt_seg, maskv = nxt_mask;
-        if (mbstep && x + 1 < mbw) {   // prefetch the next macroblock of this row
+        if (mbstep & (x + 1 < mbw)) {   // prefetch the next macroblock of this row
             nxt = *reinterpret_cast<const uint4 *>(pf_p + x0 + msz);
             nxt_seg = pf_seg[x + 1];
             nxt_mask = pf_mask[x + 1];
         }
-        if (drain_lane && x >= 1 && x <= mbw + 1) {   // the block of macroblock x-1 (or the flush column)
+        if (drain_lane & (x >= 1) & (x <= mbw + 1)) {   // the block of macroblock x-1 (or the flush column)
             const int c0 = ((x - 1) * msz - 4) & dr_col;
             const uint8_t *src = dr_src + ((S - 1) & 1) * dr_slot;
             uint32_t v[4];
@@ -371,37 +369,37 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             *reinterpret_cast<uint2 *>(g) = make_uint2(v[0], v[1]);
             if (pl == 0) *reinterpret_cast<uint2 *>(g + 2) = make_uint2(v[2], v[3]);
         }
-        const uint32_t sp = seg == 0 ? sdp[0] : (seg == 1 ? sdp[1] : (seg == 2 ? sdp[2] : sdp[3]));
+        const uint32_t sp = sh.sdp[seg & 3];
         Limits L;
         // an edge that does not apply gets interior limit -1: its mask can never be true
         const int int_lim = sp & 0xff;
         L.mb_delta = int_lim - ((sp >> 8) & 0xff) * 2 - 1;
         L.b_delta = int_lim - ((sp >> 16) & 0xff) * 2 - 1;
         L.hev_thr = sp >> 24;
-        const bool do_filter = mbstep && (gr * mbw + x) < first_lf0;
-        const bool en_in = do_filter && maskv != 0;
+        const bool do_filter = mbstep & ((gr * mbw + x) < first_lf0);
+        const bool en_in = do_filter & (maskv != 0);
         const int il4 = en_in ? int_lim : -1;
         const int il8 = en_in && pl == 0 ? int_lim : -1;
         uint32_t *trow = reinterpret_cast<uint32_t *>(tile + tile_lane);
         // ---- P1: vertical edges, lane = pixel row, in registers ---------------------------------
-        if (mbstep) {
+        // The flush column (x == mbw) takes the same path with every edge off: the filters are then the identity and the
+        // carried four columns land in the tile's first dword unchanged; the rest of its tile row is margin.
+        if (p1_on) {
             int t[20];
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] = ub(left4, k);
 #pragma unroll
             for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
-            filter_line(t, L, do_filter && x > 0 ? int_lim : -1, il4, il8);
+            filter_line(t, L, do_filter & (x > 0) ? int_lim : -1, il4, il8);
             const uint32_t d0 = pack4(t[0], t[1], t[2], t[3]);
             trow[0] = d0;
 #pragma unroll
             for (int j = 1; j < 5; ++j) trow[j] = pack4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
             // the row below reads columns x0-4..x0-1 of our bottom rows in P2 of this very step
             *reinterpret_cast<uint32_t *>(botw + ((x0 - 4) & botw_mask)) = d0;
-        } else if (act && row_real) {
-            trow[0] = left4;   // flush column: only the carried four columns are meaningful
         }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-        if (lane == 0) flag[wave] = 2 * S + 1;
+        flag[wave] = 2 * S + 1;   // (every lane, the same word: no exec mask to set up and restore)
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p1 += st_t1 - st_t0; st_t0 = st_t1;
@@ -448,7 +446,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);   // one wait for the twenty loads instead of one per use
 #pragma unroll
             for (int k = 0; k < 20; ++k) t[k] |= BIAS;
-            filter_line(t, L, do_filter && has_top ? int_lim : -1, il4, il8);
+            filter_line(t, L, do_filter & has_top ? int_lim : -1, il4, il8);
             // rows 1-3 of the strip above (row 0 of the frame: a scratch strip nobody reads)
             tp[1 * SROW] = (uint8_t)satb(t[1]); tp[2 * SROW] = (uint8_t)satb(t[2]); tp[3 * SROW] = (uint8_t)satb(t[3]);
             int s[16];
@@ -459,7 +457,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             left4 = trow[nd];   // columns msz-4 .. msz-1 of this macroblock after both phases (next P1's left side)
         }
         __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-        if (lane == 0) flag[wave] = 2 * S + 2;
+        flag[wave] = 2 * S + 2;
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p2 += st_t1 - st_t0;
