@@ -31,11 +31,14 @@ import subprocess
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
-# queue serialise.  The workload is many independent GOP chunks, one stream each: give the runtime 24 queues
-# (measured on MI355X: 4 -> 27, 8 -> 32, 16 -> 36, 24 -> 40 M MB/s with 16 chunks in flight; 32 and more are slower).
-# Must be set before the first HIP call of the process; vp8hip_create warns on stderr when a host forgot it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue
+# serialise; the workload is many independent GOP chunks.  But the part's hardware scheduler holds 24 queues of a process at
+# once: with more (the runtime keeps every queue it ever made, torch and RCCL bring their own) it rotates them and
+# CONTEXT-SWITCHES running waves -- the loop filter's waves change hardware slots mid-launch (`waves_context_switched` in the
+# JSON line) and one GOP coded frame after frame takes 0.51 instead of 0.445 ms per frame.  16 leaves room (measured, 32 chunks
+# in 8 batches: 4 -> 37, 8 -> 48, 12 -> 50, 16 -> 55, 20 -> 54, 24 -> 53 M MB/s).
+# Must be set before the first HIP call of the process; the library notes on stderr when a host's contexts outnumber the queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -204,11 +207,13 @@ class Leg:
     def clock_read(self):
         """the loop filter by the kernel's own clock, all chunks: (ms, launches, shader clock GHz) since the last call"""
         tot, n, ghz = 0.0, 0, 0.0
+        self.context_switches = 0
         for d in self.drv:
             ms, k, g = d.hip.profile_read_clock()
             tot += ms
             n += k
             ghz += g * k
+            self.context_switches += d.hip.profile_context_switches()
         return tot, n, ghz / max(n, 1)
 
     def run(self, steps, barrier=None):
@@ -241,11 +246,15 @@ def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4
     leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1)
     for _ in range(warm):
         leg.step()
+    leg.clock_read()
     el, enq, nrefs = leg.run(steps)
+    lf_ms, lf_n, ghz = leg.clock_read()
     frames = steps * G
     out = {"workload": f"{W0}x{H0}, {'LAST+GOLDEN+ALTREF' if refs == 'all' else 'LAST only'}, SSIM target {ssim_target}, {G} GOP chunk(s) in flight",
            "value": round(leg.mbs * frames / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / frames * 1e3, 4),
-           "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs}
+           "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs,
+           "loop_filter_ms_by_its_own_clock": round(lf_ms / max(lf_n, 1), 4), "shader_clock_ghz": round(ghz, 3),
+           "waves_context_switched": leg.context_switches}
     leg.close()
     return out
 
@@ -345,7 +354,8 @@ def main():
             lf_clock = {"kernel": "loop_filter", "avg_ms_per_chunk": round(kms, 5), "frames": int(clk_n), "achieved": round(cb / (kms * 1e-3) / 1e9, 3),
                         "frac": round(cb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                         "how": "s_memrealtime (100 MHz) at the start of the kernel's first band and at the end of its last row",
-                        "shader_clock_ghz": round(clk_ghz, 3)}
+                        "shader_clock_ghz": round(clk_ghz, 3),
+                        "waves_context_switched": leg.context_switches}   # launches whose last wave changed hardware slots: 0 unless the process's queues are oversubscribed
             if dominant == "loop_filter":
                 roof["kernel_clock"] = lf_clock
         others = {}

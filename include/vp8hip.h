@@ -290,6 +290,10 @@ int vp8hip_profile_read(vp8hip_ctx *ctx, double *total_ms, int64_t *launches);
  * packet waits for its queue to be scheduled; this figure does not, and it is what a rocprofv3 kernel trace shows. */
 int vp8hip_profile_read_clock(vp8hip_ctx *ctx, double *loop_filter_ms, int64_t *loop_filter_launches, double *shader_clock_ghz /* may be NULL:
     the shader clock those launches ran at (s_memtime cycles per s_memrealtime tick, averaged over the launches) */);
+/* Among the launches counted by the last vp8hip_profile_read_clock: how many had the wave that runs the frame's last row END on
+ * another hardware slot than it started on -- it was context-switched, which happens when the process holds more queues than
+ * the part's scheduler keeps resident (24 on MI355X: GPU_MAX_HW_QUEUES plus what torch / RCCL create).  0 when healthy. */
+int64_t vp8hip_profile_context_switches(const vp8hip_ctx *ctx);
 
 /* stage outputs of the last vp8hip_inter_transform, for parity tests */
 typedef enum {

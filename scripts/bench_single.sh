@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 for ov in 0 1; do VP8_BENCH_OVERLAP=$ov python3 - <<PY
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch
 import bench

@@ -7,7 +7,7 @@
 Without --yuv the synthetic sequence of the tests is used.  A raw I420 file must have the given width/height (multiples
 of 16: padding is the caller's job, as it is copy_with_padding's in the reference, encIO.h:141-196)."""
 import argparse, os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

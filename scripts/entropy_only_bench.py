@@ -1,7 +1,7 @@
 """Entropy stage alone (vp8drv_get_frame repeated on one encoded frame), S streams on S host threads: the stage's
 saturated device cost per frame, to set beside the inter path's 0.197 ms."""
 import argparse, os, sys, threading, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ".")
 import torch
 from vp8oclenc_amd import api

@@ -2,7 +2,7 @@
 """Whole-encoder timing: native frame loop + vp8drv_get_frame (complete VP8 frames out), one thread per GOP stream.
     python scripts/frame_bench.py [--streams N] [--frames K] [--width W --height H] [--partitions P]"""
 import argparse, os, sys, threading, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

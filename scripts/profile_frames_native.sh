@@ -2,7 +2,7 @@
 # one chunk (chain latency per kernel) and 16 chunks (what the default bench runs side by side)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=24
+export GPU_MAX_HW_QUEUES=16
 bash scripts/native/run_frame_bench.sh "1 60 8 threads 1" > /dev/null
 for S in 1 16; do
 rocprofv3 --kernel-trace --stats -d gpurun_out/r01k_native$S -o fr --output-format csv -- /tmp/frame_bench /tmp/frames.i420 1920 1088 $S 60 8 threads 1 > gpurun_out/r01k_native$S.txt 2>/dev/null

@@ -1,7 +1,7 @@
 """16 GOP chunks with finished frames delivered to the host (bench.py's with_bitstream leg alone): the workload of the
 frames-out kernel trace"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

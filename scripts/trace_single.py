@@ -1,6 +1,6 @@
 """one GOP chunk, frame after frame, loop filter on its own stream: the workload of the single-stream kernel trace"""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

@@ -194,9 +194,10 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
     // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
     // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
-    unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches, sum of shader-clock cycles}
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches, sum of shader-clock cycles per tick x 1000, launches left out of that sum, launches whose last wave changed slots}
     if (band == 0 && threadIdx.x == 0) __hip_atomic_store(clk, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long cyc0 = __builtin_amdgcn_s_memtime(), tick0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t hwid0 = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
     __syncthreads();
     const int mbw = a.mbw, mbh = a.mbh;
     const int band_row0 = band * ROWS;
@@ -475,7 +476,12 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         atomicAdd(clk + 1, t1 - t0);
         atomicAdd(clk + 2, 1ull);
         // the shader clock this wave saw while it ran: s_memtime cycles per 100 MHz tick (MI355X_MICROARCH.md, DVFS (6))
-        atomicAdd(clk + 3, (__builtin_amdgcn_s_memtime() - cyc0) * 1000ull / (t1 - tick0 + 1));
+        const unsigned long long ratio = (__builtin_amdgcn_s_memtime() - cyc0) * 1000ull / (t1 - tick0 + 1);
+        const uint32_t hwid1 = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        // a wave that was context-switched (the hardware scheduler rotating an oversubscribed set of queues) comes back on
+        // another slot, whose cycle counter is another one: such launches are counted, not averaged
+        if (ratio > 100000ull) atomicAdd(clk + 4, 1ull); else atomicAdd(clk + 3, ratio);
+        if (hwid1 != hwid0) atomicAdd(clk + 5, 1ull);
     }
 }
 

@@ -74,6 +74,7 @@ struct vp8hip_ctx {
     hipStream_t lf_stream = nullptr;   // the stream `stream` is not
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     bool lf_overlap = false, lf_pending = false;
+    int64_t lf_context_switches = 0;   // see vp8hip_profile_context_switches
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
     bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
@@ -256,8 +257,10 @@ static void note_queue_oversubscription() {
     const int queues = q ? atoi(q) : 4, n = g_live_contexts.load();
     if (n > queues && !getenv("VP8HIP_QUIET") && !warned.exchange(true))
         fprintf(stderr, "vp8hip: %d contexts on streams of their own but GPU_MAX_HW_QUEUES=%d hardware queues: the streams will share queues and "
-                        "serialise (measured on MI355X with 16 contexts: 27 M MB/s at 4 queues, 40 M at 24).  Export GPU_MAX_HW_QUEUES=24 before "
-                        "the process makes its first HIP call, or advance the contexts in batches (vp8hip_batch_create).\n", n, queues);
+                        "serialise (measured on MI355X with 32 contexts in 8 batches: 37 M MB/s at 4 queues, 55 M at 16).  Export "
+                        "GPU_MAX_HW_QUEUES=16 before the process makes its first HIP call -- not more: beyond 24 queues per process the "
+                        "hardware scheduler rotates them and context-switches running waves -- and advance the contexts in batches "
+                        "(vp8hip_batch_create).\n", n, queues);
 }
 
 extern "C" {
@@ -291,7 +294,13 @@ int vp8hip_filter_overlap(vp8hip_ctx *c, int on) {
     if (!c) return VP8HIP_ERR_ARG;
     JOIN_LF(c);
     if (on && !c->lf_stream) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->lf_stream, hipStreamNonBlocking));
+        // A priority class of its own: the runtime maps streams to a few hardware queues by its own bookkeeping, and the
+        // two streams of a context on ONE queue serialise the side work into the chain (0.57 instead of 0.45 ms per 1080p
+        // frame; seen after other contexts' streams had come and gone in the same process).  Queues are per priority, and
+        // the side work -- which has a quarter of a millisecond of slack -- is the one to yield.
+        int least = 0, greatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->lf_stream, hipStreamNonBlocking, least));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming));
     }
@@ -1546,16 +1555,23 @@ int vp8hip_profile_read_clock(vp8hip_ctx *c, double *loop_filter_ms, int64_t *lo
     USE_DEVICE(c);
     if (!c || !loop_filter_ms || !loop_filter_launches) return VP8HIP_ERR_ARG;
     JOIN_LF(c);
-    unsigned long long clk[4] = {0, 0, 0, 0};
+    unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
     int32_t *base = c->d_progress + LF_ERR_WORD + 4;
     HIPCHK(c, hipMemcpyAsync(clk, base, sizeof(clk), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemsetAsync(base + 2, 0, 24, c->stream));   // sums and count restart; the start stamp is rewritten by every launch
+    HIPCHK(c, hipMemsetAsync(base + 2, 0, 40, c->stream));   // sums and count restart; the start stamp is rewritten by every launch
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->lf_context_switches = (int64_t)clk[5];
+    if (getenv("VP8HIP_DEBUG_CLOCK")) fprintf(stderr, "lf clock: launches %llu anomalies %llu hw_id changed %llu\n", clk[2], clk[4], clk[5]);
     *loop_filter_ms = (double)clk[1] * 1e-5;   // 100 MHz ticks
     *loop_filter_launches = (int64_t)clk[2];
-    if (shader_clock_ghz) *shader_clock_ghz = clk[2] ? (double)clk[3] / (double)clk[2] * 1e-4 : 0.0;   // (cycles per tick x 1000) x 100 MHz
+    if (shader_clock_ghz) *shader_clock_ghz = clk[2] > clk[4] ? (double)clk[3] / (double)(clk[2] - clk[4]) * 1e-4 : 0.0;   // (cycles per tick x 1000) x 100 MHz
     return VP8HIP_OK;
 }
+
+// Launches (among those of the last vp8hip_profile_read_clock) in which the wave that runs the frame's last row ended on another
+// hardware slot than it started on: it was context-switched, i.e. the hardware scheduler is rotating an oversubscribed set of
+// queues (more than 24 per process on this part).  0 on a healthy configuration.
+int64_t vp8hip_profile_context_switches(const vp8hip_ctx *c) { return c ? c->lf_context_switches : 0; }
 
 int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst, size_t bytes) {
     USE_DEVICE(c);
