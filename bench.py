@@ -138,7 +138,7 @@ class Leg:
         self.host_frames = [seq.frame(t) for t in range(nd)]
         self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in self.host_frames]
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
-        self.drv, self.t = [], []
+        self.drv, self.t, self.batches = [], [], []
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
                                  ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
@@ -147,12 +147,14 @@ class Leg:
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
             self.drv.append(d)
             self.t.append(t + 1)
+            # batched launches: groups of `batch` chunks advance together, one launch per stage for the group (vp8drv_batch_*).
+            # A group is formed as soon as its members exist: their own streams go and the group gets a new one, so the
+            # process never holds more than batch + G / batch streams and every group ends up on a hardware queue of its own
+            # (the runtime hands a new stream the least used of its queues)
+            if batch > 1 and (len(self.drv) % batch == 0 or k == G - 1):
+                k0 = len(self.drv) - 1 - (len(self.drv) - 1) % batch
+                self.batches.append((list(range(k0, len(self.drv))), api.NativeBatch(self.drv[k0:])))
         self.frames = self.refsum = 0
-        # batched launches: groups of `batch` chunks advance together, one launch per stage for the group (vp8drv_batch_*)
-        self.batches = []
-        if batch > 1:
-            for k0 in range(0, G, batch):
-                self.batches.append((list(range(k0, min(k0 + batch, G))), api.NativeBatch(self.drv[k0:k0 + batch])))
         # GOP steady state, untimed and independent of --warmup: every chunk past two altref periods, phases staggered so
         # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames
         if self.batches:

@@ -762,18 +762,26 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     if (!b) return VP8HIP_ERR_ARG;
     USE_DEVICE(ctxs[0]);
     b->n = n;
-    b->stream = ctxs[0]->own_stream;
+    // Idle streams still take part in the runtime's stream -> hardware queue assignment: with 32 contexts' own streams
+    // alive, two of eight batch streams could land on one queue and serialise (a slow mode of 0.21 instead of 0.16 ms per
+    // frame in one run out of four).  The members' own streams go, the batch gets a new one -- batches made one after the
+    // other then sit on consecutive queues -- and vp8hip_batch_destroy gives every member a stream of its own again.
     for (int i = 0; i < n; ++i) {
         hipStreamSynchronize(ctxs[i]->stream);
+        if (ctxs[i]->own_stream) hipStreamDestroy(ctxs[i]->own_stream);
+        ctxs[i]->own_stream = nullptr;
+    }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+        for (int i = 0; i < n; ++i) {
+            hipStreamCreateWithFlags(&ctxs[i]->own_stream, hipStreamNonBlocking);
+            ctxs[i]->stream = ctxs[i]->own_stream;
+        }
+        delete b;
+        return VP8HIP_ERR_HIP;
+    }
+    for (int i = 0; i < n; ++i) {
         ctxs[i]->stream = b->stream;
         b->c[i] = ctxs[i];
-        // Idle streams still take part in the runtime's stream -> hardware queue assignment: with 32 contexts' own streams
-        // alive, two of eight batch streams could land on one queue and serialise (a slow mode of 0.21 instead of 0.16 ms per
-        // frame in one run out of four).  The members' own streams go; vp8hip_batch_destroy makes new ones.
-        if (i > 0 && ctxs[i]->own_stream) {
-            hipStreamDestroy(ctxs[i]->own_stream);
-            ctxs[i]->own_stream = nullptr;
-        }
     }
     g_live_contexts -= n - 1;   // one stream for all of them now
     *out = b;
@@ -784,6 +792,7 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay, each back o
     if (!b) return;
     hipSetDevice(b->c[0]->device);
     hipStreamSynchronize(b->stream);
+    hipStreamDestroy(b->stream);
     for (int i = 0; i < b->n; ++i) {
         if (!b->c[i]->own_stream) hipStreamCreateWithFlags(&b->c[i]->own_stream, hipStreamNonBlocking);
         b->c[i]->stream = b->c[i]->own_stream;
