@@ -252,7 +252,8 @@ def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4
     el, enq, nrefs = leg.run(steps)
     lf_ms, lf_n, ghz = leg.clock_read()
     frames = steps * G
-    out = {"workload": f"{W0}x{H0}, {'LAST+GOLDEN+ALTREF' if refs == 'all' else 'LAST only'}, SSIM target {ssim_target}, {G} GOP chunk(s) in flight",
+    out = {"workload": f"{W0}x{H0}, {'LAST+GOLDEN+ALTREF' if refs == 'all' else 'LAST only'}, SSIM target {ssim_target}, {G} GOP chunk(s) in flight"
+                       + (f" in batches of {batch}" if G > 1 and batch > 1 else ""),
            "value": round(leg.mbs * frames / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / frames * 1e3, 4),
            "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs,
            "loop_filter_ms_by_its_own_clock": round(lf_ms / max(lf_n, 1), 4), "shader_clock_ghz": round(ghz, 3),
@@ -403,8 +404,10 @@ def main():
         out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
         out["other_configs"] = {
-            "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local, batch=B),
-            "4k_3refs": side_leg(torch, api, 3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3, local, batch=B),
+            # chunks in flight and chunks per batch to suit the frame size (eight or more batches = streams; same-box sweeps in
+            # profiles/README.md: 720p 32 chunks in batches of 4 86.0, 48 -> 91.5; 4K 16 chunks in batches of 4 55.0, of 2 -> 59.7)
+            "720p_last_only": side_leg(torch, api, 1280, 720, G * 3 // 2 if B > 1 else G, "last", -1.0, max(20, args.steps // 2), 5, local, batch=B),
+            "4k_3refs": side_leg(torch, api, 3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3, local, batch=max(1, B // 2)),
             "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local, batch=B),
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

@@ -75,9 +75,9 @@ __device__ __forceinline__ void filter_mb_edge(EdgeRegs &e, const Limits &L, int
     int w = c128(e.p1 - e.q1);
     w = c128(w + (e.q0 - e.p0) * 3);
     w = mask ? w : 0;
-    int a = hev ? w : 0;
-    const int b = imin(a + 3, 127) >> 3;
-    a = imin(a + 4, 127) >> 3;
+    int a = imin(hev ? w : 0, 123);   // min(a + 4, 127) >> 3 and min(a + 3, 127) >> 3 are both 15 from 123 on: one min for the two
+    const int b = (a + 3) >> 3;
+    a = (a + 4) >> 3;
     e.q0 -= a; e.p0 += b;
     w = hev ? 0 : w;
     a = (w * 27 + 63) >> 7; e.q0 -= a; e.p0 += a;
@@ -89,10 +89,10 @@ __device__ __forceinline__ void filter_b_edge(EdgeRegs &e, const Limits &L, int 
     edge_masks(e, int_lim, L.b_delta, L.hev_thr, mask, hev);
     int a = c128(e.p1 - e.q1);
     a = hev ? a : 0;
-    a = c128(a + (e.q0 - e.p0) * 3);
+    a = iclamp(a + (e.q0 - e.p0) * 3, -128, 123);   // the clamp to 127 and the two min(.., 127) >> 3 behind it in one (see filter_mb_edge)
     a = mask ? a : 0;
-    const int b = imin(a + 3, 127) >> 3;
-    a = imin(a + 4, 127) >> 3;
+    const int b = (a + 3) >> 3;
+    a = (a + 4) >> 3;
     e.q0 -= a; e.p0 += b;
     a = (a + 1) >> 1;
     a = hev ? 0 : a;
@@ -154,7 +154,7 @@ struct Shared {
                                                   // this workgroup, everybody leaves.  Read and written through `flag` below.
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
-    uint32_t sdp[4];                              // per segment: int_lim | mb_lim << 8 | b_lim << 16 | hev << 24 (all < 256)
+    int4 lim[4];                                  // per segment: {interior limit, mb_delta, b_delta, hev threshold} (struct Limits)
 };
 // The flags are polled: the accesses must be volatile, and a volatile access through HIP's generic pointers stays a FLAT
 // instruction (the address-space inference pass leaves volatile accesses alone) -- a flat load that resolves to LDS takes the
@@ -188,8 +188,9 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
     if (threadIdx.x < 4) {   // a table read per macroblock: selecting among four registers by a per-lane index compiles to branches
         const int32_t *sd = a.sd->v + threadIdx.x * SD_INTS;
-        sh.sdp[threadIdx.x] = (uint32_t)(sd[SD_INTERIOR_LIMIT] & 0xff) | ((uint32_t)(sd[SD_MBEDGE_LIMIT] & 0xff) << 8) |
-                              ((uint32_t)(sd[SD_SUB_BEDGE_LIMIT] & 0xff) << 16) | ((uint32_t)(sd[SD_HEV_THRESHOLD] & 0xff) << 24);
+        const int il = sd[SD_INTERIOR_LIMIT] & 0xff;
+        sh.lim[threadIdx.x] = make_int4(il, il - (sd[SD_MBEDGE_LIMIT] & 0xff) * 2 - 1, il - (sd[SD_SUB_BEDGE_LIMIT] & 0xff) * 2 - 1,
+                                        sd[SD_HEV_THRESHOLD] & 0xff);
     }
     // The kernel's own clock (constant 100 MHz): band 0 stamps the start, the wave that runs the frame's last row (the
     // virtual flush row) adds end - start to an accumulator the host reads with the profile (vp8hip_profile_read_clock).
@@ -353,8 +354,15 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         const bool p1_on = row_real & (x >= 0) & (x <= mbw);   // a real macroblock or the flush column behind the last one
         const bool mbstep = p1_on & (x < mbw);
         const int x0 = x * msz;
-        const uint4 own = nxt;
+        // the prefetched macroblock is unpacked HERE, before the next prefetch is issued into the same registers: taking a
+        // copy of the sixteen bytes + segment + mask instead cost nine moves per step
+        int t[20];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? nxt.x : (k < 8 ? nxt.y : (k < 12 ? nxt.z : nxt.w)), k & 3);
         const int seg = nxt_seg, maskv = nxt_mask;
+        // (Under a predicate on purpose.  Unconditional loads from a clamped position would save the moves that keep the old
+        // registers alive for the lanes that do not load, but hipcc then waits for the loads it has just issued -- s_waitcnt
+        // vmcnt(4) and vmcnt(3) a few instructions further down: +9 % on the whole kernel.)
         if (mbstep & (x + 1 < mbw)) {   // prefetch the next macroblock of this row
             nxt = *reinterpret_cast<const uint4 *>(pf_p + x0 + msz);
             nxt_seg = pf_seg[x + 1];
@@ -370,13 +378,13 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
             *reinterpret_cast<uint2 *>(g) = make_uint2(v[0], v[1]);
             if (pl == 0) *reinterpret_cast<uint2 *>(g + 2) = make_uint2(v[2], v[3]);
         }
-        const uint32_t sp = sh.sdp[seg & 3];
+        const int4 lim = sh.lim[seg & 3];
         Limits L;
         // an edge that does not apply gets interior limit -1: its mask can never be true
-        const int int_lim = sp & 0xff;
-        L.mb_delta = int_lim - ((sp >> 8) & 0xff) * 2 - 1;
-        L.b_delta = int_lim - ((sp >> 16) & 0xff) * 2 - 1;
-        L.hev_thr = sp >> 24;
+        const int int_lim = lim.x;
+        L.mb_delta = lim.y;
+        L.b_delta = lim.z;
+        L.hev_thr = lim.w;
         const bool do_filter = mbstep & ((gr * mbw + x) < first_lf0);
         const bool en_in = do_filter & (maskv != 0);
         const int il4 = en_in ? int_lim : -1;
@@ -386,11 +394,8 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
         // The flush column (x == mbw) takes the same path with every edge off: the filters are then the identity and the
         // carried four columns land in the tile's first dword unchanged; the rest of its tile row is margin.
         if (p1_on) {
-            int t[20];
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] = ub(left4, k);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t[4 + k] = ub(k < 4 ? own.x : (k < 8 ? own.y : (k < 12 ? own.z : own.w)), k & 3);
             filter_line(t, L, do_filter & (x > 0) ? int_lim : -1, il4, il8);
             const uint32_t d0 = pack4(t[0], t[1], t[2], t[3]);
             trow[0] = d0;
