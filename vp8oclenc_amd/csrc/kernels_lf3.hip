@@ -433,7 +433,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
                 if (state == 1) break;
                 if (state == 2) return;
                 if (spins > SPIN_LIMIT) { flag[F_ABORT] = 1; *a.err = 1; }
-                __builtin_amdgcn_s_sleep(1);
+                if (spins < 32) asm volatile("s_nop 3"); else __builtin_amdgcn_s_sleep(1);   // the flag is usually a few hundred cycles away: a tight poll first, naps when it is not
             }
         }
         STAMP(st_t1);
