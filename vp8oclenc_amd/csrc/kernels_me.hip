@@ -17,34 +17,29 @@ namespace vp8 {
 // GPU_kernels.cl:562).  grid = (max rows + 2*EXT, 3 planes), block = 64.
 // ------------------------------------------------------------------------------------------------
 struct BorderItem { Plane y, u, v; };
-__device__ __forceinline__ void border_body(const BorderItem &a) {
-    const Plane pl = blockIdx.y == 0 ? a.y : (blockIdx.y == 1 ? a.u : a.v);
-    const int row = (int)blockIdx.x - EXT;
+// one row (-EXT .. h + EXT - 1) of one plane by the 64 lanes of a wave
+__device__ __forceinline__ void border_row(const Plane &pl, int row, int lane) {
     if (row >= pl.h + EXT) return;
     uint8_t *dst = pl.p + (ptrdiff_t)row * pl.stride;
     if (row >= 0 && row < pl.h) {
-        for (int t = threadIdx.x; t < 2 * EXT; t += 64) {
+        for (int t = lane; t < 2 * EXT; t += 64) {
             const int x = t < EXT ? t - EXT : pl.w + (t - EXT);
             dst[x] = dst[t < EXT ? 0 : pl.w - 1];
         }
     } else {
         const uint8_t *src = pl.p + (ptrdiff_t)iclamp(row, 0, pl.h - 1) * pl.stride;
-        for (int x = -EXT + (int)threadIdx.x; x < pl.w + EXT; x += 64) dst[x] = src[iclamp(x, 0, pl.w - 1)];
+        for (int x = -EXT + lane; x < pl.w + EXT; x += 64) dst[x] = src[iclamp(x, 0, pl.w - 1)];
     }
+}
+__device__ __forceinline__ void border_body(const BorderItem &a) {
+    border_row(blockIdx.y == 0 ? a.y : (blockIdx.y == 1 ? a.u : a.v), (int)blockIdx.x - EXT, threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void k_border(BorderItem a) { border_body(a); }
-__global__ __launch_bounds__(64) void k_border_b(BatchOf<BorderItem> b) { border_body(b.item[blockIdx.z]); }
 
 void launch_border(hipStream_t s, const Frame &f) {
     dim3 grid(f.Y[0].h + 2 * EXT, 3);
     VP8_LAUNCH(k_border, grid, dim3(64), 0, s, BorderItem{f.Y[0], f.U, f.V});
-}
-void launch_border_batch(hipStream_t s, const Frame *const *f, int n) {
-    BatchOf<BorderItem> b;
-    b.n = n;
-    for (int i = 0; i < n; ++i) b.item[i] = BorderItem{f[i]->Y[0], f[i]->U, f[i]->V};
-    VP8_LAUNCH(k_border_b, dim3(f[0]->Y[0].h + 2 * EXT, 3, n), dim3(64), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -54,7 +49,11 @@ void launch_border_batch(hipStream_t s, const Frame *const *f, int n) {
 // 4x4 tiles below it; every level is computed from the ROUNDED level above it, exactly like the
 // reference's cascade of launches.  grid = (ceil(W/64), ceil(H/64), surfaces), block = 256.
 // ------------------------------------------------------------------------------------------------
-struct PyrArgs { Frame f[2 * MAX_BATCH]; };   // blockIdx.z picks the surface: one or two of a context, or those of a batch
+// A surface that has just come out of the loop filter also needs its replicated edges before it serves as a reference; the
+// pyramid reads the interior only, so the two do not depend on each other and share the launch (bit z of border_mask: the rows
+// of workgroups behind the tiles do surface z's edges, a wave per row of a plane) -- one link less in every frame's chain.
+struct PyrArgs { Frame f[2 * MAX_BATCH]; uint32_t border_mask; };   // blockIdx.z picks the surface: one or two of a context, or those of a batch
+static int border_jobs(const Frame &f) { return (f.Y[0].h + 2 * EXT) + 2 * (f.U.h + 2 * EXT); }
 
 __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     __shared__ uint8_t s2[16][16];
@@ -62,6 +61,16 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     const Frame &f = a.f[blockIdx.z];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const Plane &P0 = f.Y[0];
+    const int tiles_y = (P0.h + 63) / 64;
+    if ((int)blockIdx.y >= tiles_y) {
+        if (!((a.border_mask >> blockIdx.z) & 1)) return;
+        int job = (((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x) * 4 + (t >> 6);
+        const int ny = P0.h + 2 * EXT, nc = f.U.h + 2 * EXT;
+        if (job < ny) border_row(P0, job - EXT, t & 63);
+        else if (job < ny + nc) border_row(f.U, job - ny - EXT, t & 63);
+        else if (job < ny + 2 * nc) border_row(f.V, job - ny - nc - EXT, t & 63);
+        return;
+    }
     // 4x4 source pixels -> 2x2 of level 1 -> 1 of level 2
     const int sx = imin(blockIdx.x * 64 + 4 * tx, P0.w - 4), sy0 = blockIdx.y * 64 + 4 * ty;
     uint32_t r[4];
@@ -107,17 +116,24 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     }
 }
 
-void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b) {
+static dim3 pyramid_grid(const Frame &f, int nframes, uint32_t border_mask) {
+    const int gx = (f.Y[0].w + 63) / 64, gy = (f.Y[0].h + 63) / 64;
+    const int extra = border_mask ? ((border_jobs(f) + 3) / 4 + gx - 1) / gx : 0;
+    return dim3(gx, gy + extra, nframes);
+}
+void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t border_mask) {
     PyrArgs p;
     p.f[0] = *a;
     p.f[1] = b ? *b : *a;
-    VP8_LAUNCH(k_pyramid, dim3((a->Y[0].w + 63) / 64, (a->Y[0].h + 63) / 64, b ? 2 : 1), dim3(256), 0, s, p);
+    p.border_mask = border_mask;
+    VP8_LAUNCH(k_pyramid, pyramid_grid(*a, b ? 2 : 1, border_mask), dim3(256), 0, s, p);
 }
-void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes) {
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask) {
     if (nframes <= 0) return;
     PyrArgs p;
     for (int i = 0; i < nframes; ++i) p.f[i] = *f[i];
-    VP8_LAUNCH(k_pyramid, dim3((f[0]->Y[0].w + 63) / 64, (f[0]->Y[0].h + 63) / 64, nframes), dim3(256), 0, s, p);
+    p.border_mask = border_mask;
+    VP8_LAUNCH(k_pyramid, pyramid_grid(*f[0], nframes, border_mask), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ constexpr int MAX_EVENTS = 4096;
 struct FrameSurf {
     Frame f;
     bool pyramid_valid = false;
+    bool border_valid = true;    // false: fresh out of the loop filter, replicated edges still to be made (with its pyramid)
 };
 
 }  // namespace
@@ -223,10 +224,10 @@ int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, cons
     return copy_in(c, f.V, v, kind);
 }
 
-void build_pyramid(vp8hip_ctx *c, Frame *a, Frame *b) {
+void build_pyramid(vp8hip_ctx *c, Frame *a, Frame *b, uint32_t border_mask = 0) {
     // cascade: every level from the rounded previous level (inter_part.h:11-33), one launch
     Timed t(c, VP8HIP_K_DOWNSAMPLE);
-    launch_pyramid(c->stream, a, b);
+    launch_pyramid(c->stream, a, b, border_mask);
 }
 
 int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
@@ -239,6 +240,7 @@ int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMem
         launch_border(c->stream, c->frames[idx].f);
     }
     c->frames[idx].pyramid_valid = false;
+    c->frames[idx].border_valid = true;
     c->slot[0] = idx;
     return VP8HIP_OK;
 }
@@ -639,13 +641,16 @@ static void search_refs(vp8hip_ctx *c, const RefSet &which) {
 // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
 static void pyramids(vp8hip_ctx *c) {
     FrameSurf &last = c->frames[c->slot[0]];
+    // LAST fresh out of the loop filter: its replicated edges ride in the pyramid launch (they are invalid only together)
     if (!last.pyramid_valid && !c->cur_pyramid_valid) {
-        build_pyramid(c, &c->cur, &last.f);
+        build_pyramid(c, &c->cur, &last.f, last.border_valid ? 0u : 2u);
     } else {
         if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
-        if (!last.pyramid_valid) build_pyramid(c, &last.f, nullptr);
+        if (!last.pyramid_valid) build_pyramid(c, &last.f, nullptr, last.border_valid ? 0u : 1u);
+        else if (!last.border_valid) launch_border(c->stream, last.f);
     }
     last.pyramid_valid = true;
+    last.border_valid = true;
     c->cur_pyramid_valid = true;
 }
 
@@ -866,6 +871,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     const MBOut *outs[MAX_BATCH];
     const SegData *sds[MAX_BATCH];
     int n = 0, npyr = 0;
+    uint32_t pyr_border = 0;
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
@@ -873,8 +879,14 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         if (rc) return rc;
         FrameSurf &last = c->frames[c->slot[0]];
         if (!c->cur_pyramid_valid) pyr[npyr++] = &c->cur;
-        if (!last.pyramid_valid) pyr[npyr++] = &last.f;
+        if (!last.pyramid_valid) {
+            if (!last.border_valid) pyr_border |= 1u << npyr;
+            pyr[npyr++] = &last.f;
+        } else if (!last.border_valid) {
+            launch_border(b->stream, last.f);
+        }
         last.pyramid_valid = true;
+        last.border_valid = true;
         c->cur_pyramid_valid = true;
         refs[n] = ref_set(c, 1, use_golden[i], use_altref[i]);
         cur[n] = &c->cur;
@@ -888,7 +900,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     hipStream_t s = b->stream;
     {
         Timed t(c0, VP8HIP_K_DOWNSAMPLE);
-        launch_pyramid_batch(s, pyr, npyr);
+        launch_pyramid_batch(s, pyr, npyr, pyr_border);
     }
     const int net_width = c0->mbw * 2;
     int src = 0;
@@ -937,13 +949,10 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
         Timed t(c0, VP8HIP_K_LOOP_FILTER);
         launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n);
     }
-    {
-        Timed t(c0, VP8HIP_K_BORDER);
-        launch_border_batch(b->stream, recon, n);
-    }
     for (int i = 0; i < n; ++i) {   // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
         vp8hip_ctx *c = m[i];
         c->frames[c->recon].pyramid_valid = false;
+        c->frames[c->recon].border_valid = false;   // its replicated edges are made with its pyramid, in one launch
         c->slot[0] = c->recon;
         c->recon = -1;
         c->recon_ready = false;
@@ -1092,24 +1101,19 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         hipStream_t chain = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, chain));
         launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
-        launch_border(chain, f);
         HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
         c->stream = c->lf_stream;
         c->lf_stream = chain;
         c->lf_pending = true;
         c->lf_sd = c->d_sd;
     } else {
-        {
-            Timed t(c, VP8HIP_K_LOOP_FILTER);
-            launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
-        }
-        {
-            Timed t(c, VP8HIP_K_BORDER);
-            launch_border(c->stream, f);
-        }
+        Timed t(c, VP8HIP_K_LOOP_FILTER);
+        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
     }
-    // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
+    // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401); its replicated edges are made
+    // with its pyramid, in one launch, when that frame begins (pyramids())
     c->frames[c->recon].pyramid_valid = false;
+    c->frames[c->recon].border_valid = false;
     c->slot[0] = c->recon;
     c->recon = -1;
     c->recon_ready = false;

@@ -78,11 +78,11 @@ int persistent_workgroups();
 
 // ---- launchers (kernels_*.hip) ---------------------------------------------------------------
 void launch_border(hipStream_t s, const Frame &f);
-void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b);   // all four levels of one or two frames
+// all four levels of one or two frames; bit z of border_mask: also the replicated edges of surface z (launch_border's work, same launch)
+void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t border_mask = 0);
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v);
 // batched forms: n <= MAX_BATCH contexts (pyramid: nframes <= 2 * MAX_BATCH surfaces)
-void launch_border_batch(hipStream_t s, const Frame *const *f, int n);
-void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes);
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask = 0);
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n);
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
                           int net_width, int n);
