@@ -245,7 +245,7 @@ int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
  * so a member's own calls (vp8hip_intra_transform for a chunk's key frame, vp8hip_encode_frame, downloads) stay ordered
  * with the batched stages.  Arrays are indexed by member; `active` (may be NULL = all) leaves members out of a stage.
  * No reference counterpart: the reference codes one video on one in-order queue set. */
-#define VP8HIP_MAX_BATCH 4
+#define VP8HIP_MAX_BATCH 8
 typedef struct vp8hip_batch vp8hip_batch;
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n);
 void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream */

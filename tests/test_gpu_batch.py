@@ -11,7 +11,8 @@ from vp8oclenc_amd.synth import SynthSequence
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("W,H,n,frames,gop", [(320, 192, 4, 14, 6), (640, 352, 3, 8, 150), (1920, 1080, 2, 5, 150)])
+@pytest.mark.parametrize("W,H,n,frames,gop", [(320, 192, 4, 14, 6), (640, 352, 3, 8, 150), (1920, 1080, 2, 5, 150), (176, 144, 4, 9, 4), (320, 192, 8, 8, 5),
+                                               (1280, 720, 4, 6, 150)])
 def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop):
     import torch
     seqs = [SynthSequence(W, H, seed=40 + i) for i in range(n)]

@@ -491,6 +491,7 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
 }
 
 __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3(Args a) { loop_filter3_body(a); }
+static_assert(sizeof(BatchOf<Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3_b(BatchOf<Args> b) { loop_filter3_body(b.item[blockIdx.z]); }
 
 }  // namespace lf3

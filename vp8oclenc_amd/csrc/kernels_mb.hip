@@ -220,15 +220,21 @@ __device__ __forceinline__ void store_zigzag(int16_t *dst, const int L[16]) {
     d4[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Pointers only where a Frame would do: every surface of a context has the same layout (carve_frame), so one stride / size
+// pair per plane kind serves the five frames, and eight contexts' blocks fit the 4 KiB of a batched launch's arguments
+// (five Frames with their pyramids were 840 B of a 1 KB block).
+struct MBPlanes { uint8_t *y, *u, *v; };
 struct MBArgs {
-    Frame cur;
-    Frame ref[3];
-    Frame recon;
-    MBOut o;
+    MBPlanes cur, ref[3], recon;
+    int ystride, cstride, yw, yh, cw, ch;
+    int32_t *o_parts, *o_ref, *o_seg, *o_nz, *o_mask;
+    int16_t *o_vec, *o_coeffs;
+    float *o_ssim;
     const SegData *sd;
+    const int32_t *bdiff[3];
+    const int16_t *vnet[3];
     float ssim_target;
     int mbw, mbs;
-    NetSet nets;
     int use_golden, use_altref;
 };
 
@@ -294,30 +300,31 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const int b8w = a.mbw * 2;
     const int cell0 = (mby * 2) * b8w + mbx * 2;
     const int cidx[4] = {cell0, cell0 + 1, cell0 + b8w, cell0 + b8w + 1};
-    int diff1 = a.nets.bdiff[0][cidx[0]] + a.nets.bdiff[0][cidx[1]] + a.nets.bdiff[0][cidx[2]] + a.nets.bdiff[0][cidx[3]];
+    int diff1 = a.bdiff[0][cidx[0]] + a.bdiff[0][cidx[1]] + a.bdiff[0][cidx[2]] + a.bdiff[0][cidx[3]];
     int diff2 = 0x7fffffff;
     if (a.use_altref == 1)
-        diff2 = a.nets.bdiff[2][cidx[0]] + a.nets.bdiff[2][cidx[1]] + a.nets.bdiff[2][cidx[2]] + a.nets.bdiff[2][cidx[3]];
+        diff2 = a.bdiff[2][cidx[0]] + a.bdiff[2][cidx[1]] + a.bdiff[2][cidx[2]] + a.bdiff[2][cidx[3]];
     int ref = diff1 <= diff2 ? 0 : 2;
     diff1 = diff1 <= diff2 ? diff1 : diff2;
     diff2 = 0x7fffffff;
     if (a.use_golden == 1)
-        diff2 = a.nets.bdiff[1][cidx[0]] + a.nets.bdiff[1][cidx[1]] + a.nets.bdiff[1][cidx[2]] + a.nets.bdiff[1][cidx[3]];
+        diff2 = a.bdiff[1][cidx[0]] + a.bdiff[1][cidx[1]] + a.bdiff[1][cidx[2]] + a.bdiff[1][cidx[3]];
     ref = diff1 <= diff2 ? ref : 1;
-    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.nets.net[0][0] : (ref == 1 ? a.nets.net[1][0] : a.nets.net[2][0]));
+    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.vnet[0] : (ref == 1 ? a.vnet[1] : a.vnet[2]));
     uint32_t mbv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) mbv[k] = vnet[cidx[k]];
     const int parts = (mbv[1] == mbv[0] && mbv[2] == mbv[0] && mbv[3] == mbv[0]) ? 0 : 1;
     if (lane == 0 && live) {
-        a.o.ref[mb] = ref;
-        a.o.parts[mb] = parts;
-        *reinterpret_cast<uint4 *>(a.o.vec + 8 * mb) = make_uint4(mbv[0], mbv[1], mbv[2], mbv[3]);
+        a.o_ref[mb] = ref;
+        a.o_parts[mb] = parts;
+        *reinterpret_cast<uint4 *>(a.o_vec + 8 * mb) = make_uint4(mbv[0], mbv[1], mbv[2], mbv[3]);
     }
-    const Plane &cp = plane == 0 ? a.cur.Y[0] : (plane == 1 ? a.cur.U : a.cur.V);
-    const Plane &rc = plane == 0 ? a.recon.Y[0] : (plane == 1 ? a.recon.U : a.recon.V);
-    const Frame &rfm = ref == 0 ? a.ref[0] : (ref == 1 ? a.ref[1] : a.ref[2]);
-    const Plane &rp = plane == 0 ? rfm.Y[0] : (plane == 1 ? rfm.U : rfm.V);
+    const MBPlanes &rfm = ref == 0 ? a.ref[0] : (ref == 1 ? a.ref[1] : a.ref[2]);
+    const int pstride = plane == 0 ? a.ystride : a.cstride, pw = plane == 0 ? a.yw : a.cw, ph = plane == 0 ? a.yh : a.ch;
+    const Plane cp{plane == 0 ? a.cur.y : (plane == 1 ? a.cur.u : a.cur.v), pstride, pw, ph};
+    const Plane rc{plane == 0 ? a.recon.y : (plane == 1 ? a.recon.u : a.recon.v), pstride, pw, ph};
+    const Plane rp{plane == 0 ? rfm.y : (plane == 1 ? rfm.u : rfm.v), pstride, pw, ph};
     const int tile_off = plane == 0 ? 0 : (plane == 1 ? 256 : 320);
 
     // The predictor stays packed (four dwords of bytes) and the current block lives in the LDS tile: a pass re-forms the
@@ -376,7 +383,7 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     }
 
     float ssim = -2.0f;  // pack_8x8_into_16x16, :1352
-    int seg_final = a.o.seg[mb];
+    int seg_final = a.o_seg[mb];
     int nz_blk = 0;            // this lane's share of prepare_filter_mask's count, from the last pass that ran
     bool any_pass = false;
 
@@ -428,13 +435,13 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
                 coef[0] = (int16_t)nd;           // stored as short, :1537
             }
             if (lane == 24) {                    // block 24 and its share of the non-zero count (CPU_kernels.cl:800-819)
-                if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + 24) * 16, q24);
+                if (live) store_zigzag(a.o_coeffs + ((size_t)mb * 25 + 24) * 16, q24);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) nz_blk += iabs((int16_t)q24[k]);
             }
         }
         if (blk) {                               // idct4x4, :1545-1608
-            if (live) store_zigzag(a.o.coeffs + ((size_t)mb * 25 + lane) * 16, coef);
+            if (live) store_zigzag(a.o_coeffs + ((size_t)mb * 25 + lane) * 16, coef);
             // prepare_filter_mask, CPU_kernels.cl:800-819
 #pragma unroll
             for (int k = 1; k < 16; ++k) nz_blk += iabs((int16_t)coef[k]);
@@ -499,11 +506,11 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     for (int m = 16; m >= 1; m >>= 1) nz += __shfl_xor(nz, m, 32);
     if (lane == 0 && live) {
         if (any_pass) {
-            a.o.seg[mb] = seg_final;
-            a.o.nz[mb] = nz;
-            a.o.mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
+            a.o_seg[mb] = seg_final;
+            a.o_nz[mb] = nz;
+            a.o_mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
         }
-        a.o.ssim[mb] = ssim;
+        a.o_ssim[mb] = ssim;
     }
 }
 
@@ -527,15 +534,19 @@ __global__ __launch_bounds__(256, 2) void k_mb_b(BatchOf<MBArgs> b) {
 static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon, const MBOut &o, const SegData *d_sd,
                       float ssim_target, int mbw, int mbh) {
     MBArgs a;
-    a.cur = cur;
-    for (int r = 0; r < 3; ++r) a.ref[r] = refs.ref[r];
-    a.recon = recon;
-    a.o = o;
+    auto planes = [](const Frame &f) { return MBPlanes{f.Y[0].p, f.U.p, f.V.p}; };
+    a.cur = planes(cur);
+    for (int r = 0; r < 3; ++r) a.ref[r] = planes(refs.ref[r]);
+    a.recon = planes(recon);
+    a.ystride = cur.Y[0].stride; a.yw = cur.Y[0].w; a.yh = cur.Y[0].h;
+    a.cstride = cur.U.stride; a.cw = cur.U.w; a.ch = cur.U.h;
+    a.o_parts = o.parts; a.o_ref = o.ref; a.o_seg = o.seg; a.o_nz = o.nz; a.o_mask = o.mask;
+    a.o_vec = o.vec; a.o_coeffs = o.coeffs; a.o_ssim = o.ssim;
     a.sd = d_sd;
+    for (int r = 0; r < 3; ++r) { a.bdiff[r] = nets.bdiff[r]; a.vnet[r] = nets.net[r][0]; }
     a.ssim_target = ssim_target;
     a.mbw = mbw;
     a.mbs = mbw * mbh;
-    a.nets = nets;
     a.use_golden = refs.use[1];
     a.use_altref = refs.use[2];
     return a;

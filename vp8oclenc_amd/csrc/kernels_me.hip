@@ -323,6 +323,7 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
 
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_search1(Search1Args a) { search1_body<SPLIT>(a); }
+static_assert(sizeof(BatchOf<Search1Args>) <= 4096 && sizeof(PyrArgs) <= 4096 && sizeof(BatchOf<PackItem>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z]); }
 

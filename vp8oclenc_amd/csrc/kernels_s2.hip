@@ -277,6 +277,7 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
 }
 
 __global__ __launch_bounds__(256) void k_search2(S2Args a) { search2_body(a, blockIdx.x, blockIdx.y); }
+static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 __global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) { search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y); }
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
 // block group) space with a stride.  A command-processor pipe stays busy with a launch until its last workgroup is

@@ -281,7 +281,7 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
 // ---- several GOP chunks one frame at a time, every stage one launch for all of them (vp8hip_batch_*) -----------------------
 struct vp8drv_batch {
     int n = 0;
-    vp8drv *d[VP8HIP_MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
+    vp8drv *d[VP8HIP_MAX_BATCH] = {};
     vp8hip_batch *hb = nullptr;
 };
 
@@ -316,7 +316,7 @@ void vp8drv_batch_destroy(vp8drv_batch *b) {
 int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
                                      const int *force_key, int *was_key) {
     if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
-    int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {0, 0, 0, 0};
+    int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {};
     int pg[VP8HIP_MAX_BATCH], pa[VP8HIP_MAX_BATCH], ug[VP8HIP_MAX_BATCH], ua[VP8HIP_MAX_BATCH];
     int32_t refqi[VP8HIP_MAX_BATCH][4];
     for (int i = 0; i < b->n; ++i) {

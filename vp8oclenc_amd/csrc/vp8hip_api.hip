@@ -752,7 +752,7 @@ int vp8hip_export_last(vp8hip_ctx *c, void *d_y, void *d_u, void *d_v) {
 // the entropy stage, downloads) stay ordered with the batched stages.
 struct vp8hip_batch {
     int n = 0;
-    vp8hip_ctx *c[MAX_BATCH] = {nullptr, nullptr, nullptr, nullptr};
+    vp8hip_ctx *c[MAX_BATCH] = {};
     hipStream_t stream = nullptr;
 };
 

@@ -71,7 +71,7 @@ struct SegData { int32_t v[4 * SD_INTS]; };
 // one wide kernel at a time (loop filters of 9 workgroups hold two of the slots on average).  So the same kernels also
 // exist in a batched form: ONE launch does a stage for up to MAX_BATCH contexts of equal geometry (blockIdx.z = context),
 // the argument blocks of the single form travel as an array in the kernel arguments, and a few streams carry what sixteen did.
-constexpr int MAX_BATCH = 4;
+constexpr int MAX_BATCH = 8;
 template <typename A> struct BatchOf { int n; A item[MAX_BATCH]; };
 // workgroups of a persistent launch (0 = launch the full grid); VP8HIP_PERSIST overrides (same-box A/B runs)
 int persistent_workgroups();
