@@ -1,0 +1,41 @@
+"""Register / scratch budget of the hot kernels, read from the gfx950 code hipcc emits (no GPU needed).
+
+A kernel argument block that is indexed by a per-lane value gets copied to scratch memory without a word from the compiler
+(k_mb did, once: 21 -> 38 us per 1080p frame), and a register count past 128 halves k_mb's waves per SIMD; both are
+invisible to the parity tests."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vp8oclenc_amd", "csrc")
+HOT = {   # file -> {kernel name fragment: max VGPRs}
+    "kernels_mb.hip": {"k_mb_b": 128},
+    "kernels_s2.hip": {"k_search2E": 96, "k_search2_b": 96},
+    "kernels_me.hip": {"k_search1": 128, "k_pyramid": 128, "k_pack_b": 64},
+    "kernels_lf3.hip": {"k_loop_filter3": 128},
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+@pytest.mark.parametrize("src", sorted(HOT))
+def test_hot_kernels_use_no_scratch_and_stay_inside_their_register_budget(src, tmp_path):
+    out = tmp_path / "k.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-x", "hip",
+                    "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out), "-w"], check=True, timeout=600)
+    text = out.read_text()
+    seen = set()
+    for m in re.finditer(r"\.name:\s+(\S+)\n((?:.*\n)*?)\s+\.wavefront_size", text):
+        name, body = m.group(1), m.group(2)
+        for frag, max_vgprs in HOT[src].items():
+            if frag in name:
+                seen.add(frag)
+                scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+                vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+                spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
+                assert scratch == 0 and spills == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs"
+                assert vgprs <= max_vgprs, f"{name}: {vgprs} VGPRs (budget {max_vgprs})"
+    assert seen == set(HOT[src]), f"kernels not found in {src}: {set(HOT[src]) - seen}"

@@ -225,14 +225,15 @@ __device__ __forceinline__ void store_zigzag(int16_t *dst, const int L[16]) {
 // (five Frames with their pyramids were 840 B of a 1 KB block).
 struct MBPlanes { uint8_t *y, *u, *v; };
 struct MBArgs {
-    MBPlanes cur, ref[3], recon;
+    MBPlanes cur, ref0, ref1, ref2, recon;   // (single members, not arrays: a three-way select over an array member becomes a
+                                             // dynamic index, and a dynamically indexed argument block is copied to scratch memory)
     int ystride, cstride, yw, yh, cw, ch;
     int32_t *o_parts, *o_ref, *o_seg, *o_nz, *o_mask;
     int16_t *o_vec, *o_coeffs;
     float *o_ssim;
     const SegData *sd;
-    const int32_t *bdiff[3];
-    const int16_t *vnet[3];
+    const int32_t *bdiff0, *bdiff1, *bdiff2;
+    const int16_t *vnet0, *vnet1, *vnet2;
     float ssim_target;
     int mbw, mbs;
     int use_golden, use_altref;
@@ -300,17 +301,17 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const int b8w = a.mbw * 2;
     const int cell0 = (mby * 2) * b8w + mbx * 2;
     const int cidx[4] = {cell0, cell0 + 1, cell0 + b8w, cell0 + b8w + 1};
-    int diff1 = a.bdiff[0][cidx[0]] + a.bdiff[0][cidx[1]] + a.bdiff[0][cidx[2]] + a.bdiff[0][cidx[3]];
+    int diff1 = a.bdiff0[cidx[0]] + a.bdiff0[cidx[1]] + a.bdiff0[cidx[2]] + a.bdiff0[cidx[3]];
     int diff2 = 0x7fffffff;
     if (a.use_altref == 1)
-        diff2 = a.bdiff[2][cidx[0]] + a.bdiff[2][cidx[1]] + a.bdiff[2][cidx[2]] + a.bdiff[2][cidx[3]];
+        diff2 = a.bdiff2[cidx[0]] + a.bdiff2[cidx[1]] + a.bdiff2[cidx[2]] + a.bdiff2[cidx[3]];
     int ref = diff1 <= diff2 ? 0 : 2;
     diff1 = diff1 <= diff2 ? diff1 : diff2;
     diff2 = 0x7fffffff;
     if (a.use_golden == 1)
-        diff2 = a.bdiff[1][cidx[0]] + a.bdiff[1][cidx[1]] + a.bdiff[1][cidx[2]] + a.bdiff[1][cidx[3]];
+        diff2 = a.bdiff1[cidx[0]] + a.bdiff1[cidx[1]] + a.bdiff1[cidx[2]] + a.bdiff1[cidx[3]];
     ref = diff1 <= diff2 ? ref : 1;
-    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.vnet[0] : (ref == 1 ? a.vnet[1] : a.vnet[2]));
+    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.vnet0 : (ref == 1 ? a.vnet1 : a.vnet2));
     uint32_t mbv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) mbv[k] = vnet[cidx[k]];
@@ -320,11 +321,14 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
         a.o_parts[mb] = parts;
         *reinterpret_cast<uint4 *>(a.o_vec + 8 * mb) = make_uint4(mbv[0], mbv[1], mbv[2], mbv[3]);
     }
-    const MBPlanes &rfm = ref == 0 ? a.ref[0] : (ref == 1 ? a.ref[1] : a.ref[2]);
+    // (pointer by pointer: selecting one of three argument STRUCTS by a per-lane index sends the argument block to scratch memory)
+    uint8_t *const rpy = ref == 0 ? a.ref0.y : (ref == 1 ? a.ref1.y : a.ref2.y);
+    uint8_t *const rpu = ref == 0 ? a.ref0.u : (ref == 1 ? a.ref1.u : a.ref2.u);
+    uint8_t *const rpv = ref == 0 ? a.ref0.v : (ref == 1 ? a.ref1.v : a.ref2.v);
     const int pstride = plane == 0 ? a.ystride : a.cstride, pw = plane == 0 ? a.yw : a.cw, ph = plane == 0 ? a.yh : a.ch;
     const Plane cp{plane == 0 ? a.cur.y : (plane == 1 ? a.cur.u : a.cur.v), pstride, pw, ph};
     const Plane rc{plane == 0 ? a.recon.y : (plane == 1 ? a.recon.u : a.recon.v), pstride, pw, ph};
-    const Plane rp{plane == 0 ? rfm.y : (plane == 1 ? rfm.u : rfm.v), pstride, pw, ph};
+    const Plane rp{plane == 0 ? rpy : (plane == 1 ? rpu : rpv), pstride, pw, ph};
     const int tile_off = plane == 0 ? 0 : (plane == 1 ? 256 : 320);
 
     // The predictor stays packed (four dwords of bytes) and the current block lives in the LDS tile: a pass re-forms the
@@ -514,18 +518,11 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     }
 }
 
-// The body holds a macroblock's predictor, residual, coefficients and reconstruction in registers: 193 VGPRs, two waves per
-// SIMD -- and with the frame loads, the LDS tile and the float SSIM chains it is latency-bound at that occupancy (0.5 of its
-// issue cycles when alone; its waves also take the register file away from the search waves of other GOP chunks).  MINW is
-// the waves per SIMD the register allocator must make room for; what does not fit spills to scratch (L1/L2-resident).
-// Same-box A/B with 16 chunks (VP8HIP_MB_WAVES=2/3/4, scripts/ab.sh): 2 waves 48.7-49.6, 3 waves (168 VGPRs, 52 B of
-// scratch) 45.1-49.5, 4 waves (128 VGPRs, 204 B) 42.8-43.8 M MB/s -- spilling costs more than the occupancy returns.
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void k_mb(MBArgs a) {
-    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
-    mb_body(a, s_t);
-}
-
+// One kernel for one context and for a batch (blockIdx.z = member; a single context is a batch of one).  The argument block
+// is read through the kernel-argument pointer: a by-value MBArgs whose members are picked by a per-lane index (the reference
+// of the macroblock) is copied to scratch memory by hipcc (296 B per lane, 21 -> 38 us per 1080p frame when it happened).
+// Register budget: 127 VGPRs = four waves per SIMD, nothing spilled (history: 193 VGPRs and two waves; forcing three or
+// four waves on that body by spilling was slower, 42.8-49.5 against 48.7-49.6 M MB/s).
 __global__ __launch_bounds__(256, 2) void k_mb_b(BatchOf<MBArgs> b) {
     __shared__ __attribute__((aligned(16))) MBTile s_t[8];
     mb_body(b.item[blockIdx.z], s_t);
@@ -536,14 +533,15 @@ static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, 
     MBArgs a;
     auto planes = [](const Frame &f) { return MBPlanes{f.Y[0].p, f.U.p, f.V.p}; };
     a.cur = planes(cur);
-    for (int r = 0; r < 3; ++r) a.ref[r] = planes(refs.ref[r]);
+    a.ref0 = planes(refs.ref[0]); a.ref1 = planes(refs.ref[1]); a.ref2 = planes(refs.ref[2]);
     a.recon = planes(recon);
     a.ystride = cur.Y[0].stride; a.yw = cur.Y[0].w; a.yh = cur.Y[0].h;
     a.cstride = cur.U.stride; a.cw = cur.U.w; a.ch = cur.U.h;
     a.o_parts = o.parts; a.o_ref = o.ref; a.o_seg = o.seg; a.o_nz = o.nz; a.o_mask = o.mask;
     a.o_vec = o.vec; a.o_coeffs = o.coeffs; a.o_ssim = o.ssim;
     a.sd = d_sd;
-    for (int r = 0; r < 3; ++r) { a.bdiff[r] = nets.bdiff[r]; a.vnet[r] = nets.net[r][0]; }
+    a.bdiff0 = nets.bdiff[0]; a.bdiff1 = nets.bdiff[1]; a.bdiff2 = nets.bdiff[2];
+    a.vnet0 = nets.net[0][0]; a.vnet1 = nets.net[1][0]; a.vnet2 = nets.net[2][0];
     a.ssim_target = ssim_target;
     a.mbw = mbw;
     a.mbs = mbw * mbh;
@@ -560,10 +558,10 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
     const MBArgs a = mb_args(cur, refs, nets, recon, o, d_sd, ssim_target, mbw, mbh);
     if (mb_skip()) return;
-    static const int minw = [] { const char *v = getenv("VP8HIP_MB_WAVES"); return v && v[0] >= '2' && v[0] <= '4' ? v[0] - '0' : 2; }();
-    if (minw == 4) VP8_LAUNCH(k_mb<4>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
-    else if (minw == 3) VP8_LAUNCH(k_mb<3>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
-    else VP8_LAUNCH(k_mb<2>, dim3((a.mbs + 7) / 8), dim3(256), 0, s, a);
+    BatchOf<MBArgs> b;
+    b.n = 1;
+    b.item[0] = a;
+    VP8_LAUNCH(k_mb_b, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
 }
 
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,

@@ -159,13 +159,16 @@ __device__ __forceinline__ void pack_body(const PackItem &a) {
     *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
 }
 
-__global__ __launch_bounds__(256) void k_pack(PackItem a) { pack_body(a); }
 __global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b) { pack_body(b.item[blockIdx.z]); }
 
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
-    VP8_LAUNCH(k_pack, dim3((n + 255) / 256), dim3(256), 0, s,
-               PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v});
+    // (a batch of one: the by-value form of the kernel picks the plane through a pointer into its argument block, which hipcc
+    // answers by copying the block to scratch memory)
+    BatchOf<PackItem> b;
+    b.n = 1;
+    b.item[0] = PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v};
+    VP8_LAUNCH(k_pack_b, dim3((n + 255) / 256, 1, 1), dim3(256), 0, s, b);
 }
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n) {
     BatchOf<PackItem> b;
