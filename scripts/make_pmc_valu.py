@@ -47,6 +47,8 @@ def main():
     table = {}
 
     def put(key, per_ref, instr, kernel):
+        if kernel not in cpi:          # single launches of k_mb / k_pack go through the batched kernels (a batch of one)
+            kernel += "_b"
         n, cyc = cpi[kernel]
         e = {"per_ref" if per_ref else "fixed": round(instr, 1), "cycles_per_ref" if per_ref else "cycles_fixed": round(instr * cyc / n, 1),
              "static_stream": {"kernel": kernel, "valu": n, "cycles": round(cyc, 1)}}
