@@ -294,6 +294,11 @@ int vp8hip_profile_read_clock(vp8hip_ctx *ctx, double *loop_filter_ms, int64_t *
  * another hardware slot than it started on -- it was context-switched, which happens when the process holds more queues than
  * the part's scheduler keeps resident (24 on MI355X: GPU_MAX_HW_QUEUES plus what torch / RCCL create).  0 when healthy. */
 int64_t vp8hip_profile_context_switches(const vp8hip_ctx *ctx);
+/* k_search2's launches by the kernel's own clock (earliest workgroup start to latest workgroup end, sampled every 64th
+ * workgroup) since the last call; a batched launch counts once, on the batch's first member. */
+int vp8hip_profile_read_search2_clock(vp8hip_ctx *ctx, double *ms, int64_t *launches);
+/* the stamping costs about 1 % of throughput: off until asked for (on = 1), per context (a batch follows its first member) */
+int vp8hip_profile_search2_clock(vp8hip_ctx *ctx, int on);
 
 /* stage outputs of the last vp8hip_inter_transform, for parity tests */
 typedef enum {

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "vp8hip_hw_queues", "vp8hip_profile_read_clock", "vp8hip_inter_search", "vp8hip_inter_finish", "vp8hip_export_search",
     "vp8hip_import_search", "vp8hip_export_last", "vp8hip_batch_create", "vp8hip_batch_destroy", "vp8hip_batch_set_current_device",
     "vp8hip_batch_auto_segments", "vp8hip_batch_inter_transform", "vp8hip_batch_loop_filter", "vp8drv_batch_create", "vp8drv_batch_destroy",
-    "vp8drv_batch_encode_frame_device", "vp8hip_batch_encode_frame_begin", "vp8drv_batch_get_frame_begin", "vp8hip_profile_context_switches",
+    "vp8drv_batch_encode_frame_device", "vp8hip_batch_encode_frame_begin", "vp8drv_batch_get_frame_begin", "vp8hip_profile_context_switches", "vp8hip_profile_read_search2_clock", "vp8hip_profile_search2_clock",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
@@ -586,6 +586,17 @@ class Vp8Hip:
         self.lib.vp8hip_profile_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         self._chk(self.lib.vp8hip_profile_read_clock(self.h, C.byref(ms), C.byref(n), C.byref(ghz)), "profile_read_clock")
         return ms.value, n.value, ghz.value
+
+    def profile_read_search2_clock(self):
+        """(ms, launches) of k_search2 by the kernel's own clock since the last call (vp8hip_profile_read_search2_clock)"""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self.lib.vp8hip_profile_read_search2_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        self._chk(self.lib.vp8hip_profile_read_search2_clock(self.h, C.byref(ms), C.byref(n)), "profile_read_search2_clock")
+        return ms.value, n.value
+
+    def profile_search2_clock(self, on: bool) -> None:
+        self.lib.vp8hip_profile_search2_clock.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.lib.vp8hip_profile_search2_clock(self.h, int(on)), "profile_search2_clock")
 
     def profile_context_switches(self) -> int:
         """among the launches of the last profile_read_clock(): how many had the loop filter's last wave change its hardware slot

@@ -65,6 +65,7 @@ struct S2Args {
     uint32_t bw_inv;   // ceil(2^32 / bw)
     uint32_t *dbg;   // test tap: per-candidate prediction (column-major) and cost of block dbg_block, or nullptr
     int dbg_block;
+    unsigned long long *clk;   // launch clock (launch_clock_end, vp8hip_dev.h) or nullptr; a batched launch uses its first member's
 };
 
 __device__ __forceinline__ uint32_t halfwave_min(uint32_t key) {
@@ -276,9 +277,17 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
 }
 
-__global__ __launch_bounds__(256) void k_search2(S2Args a) { search2_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_search2(S2Args a) {
+    launch_clock_begin(a.clk);
+    search2_body(a, blockIdx.x, blockIdx.y);
+    launch_clock_end(a.clk);
+}
 static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
-__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) { search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) {
+    launch_clock_begin(b.item[0].clk);
+    search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y);
+    launch_clock_end(b.item[0].clk);
+}
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
 // block group) space with a stride.  A command-processor pipe stays busy with a launch until its last workgroup is
 // placed -- for a grid of tens of thousands of workgroups on a full chip that is the kernel's whole duration, and the
@@ -295,8 +304,9 @@ __global__ __launch_bounds__(256) void k_search2_p(BatchOf<S2Args> b, int nbx, i
 
 }  // namespace
 
-static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
+static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block, unsigned long long *clk) {
     S2Args a;
+    a.clk = clk;
     a.cur = cur.Y[0];
     int n = 0;
     for (int r = 0; r < 3; ++r) {
@@ -322,18 +332,18 @@ static bool search2_skip() {
     return skip;   // timing experiment only
 }
 
-void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block) {
-    const S2Args a = search2_args(cur, refs, nets, dbg, dbg_block);
+void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block, unsigned long long *clk) {
+    const S2Args a = search2_args(cur, refs, nets, dbg, dbg_block, clk);
     if (a.nrefs == 0 || search2_skip()) return;
     VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
 }
 
-void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n) {
+void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n, unsigned long long *clk) {
     BatchOf<S2Args> b;
     b.n = n;
     int maxrefs = 0;
     for (int i = 0; i < n; ++i) {
-        b.item[i] = search2_args(*cur[i], refs[i], *nets[i], nullptr, -1);
+        b.item[i] = search2_args(*cur[i], refs[i], *nets[i], nullptr, -1, clk);
         maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
     }
     if (maxrefs == 0 || search2_skip()) return;

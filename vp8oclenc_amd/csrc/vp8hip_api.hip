@@ -76,6 +76,7 @@ struct vp8hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     bool lf_overlap = false, lf_pending = false;
     int64_t lf_context_switches = 0;   // see vp8hip_profile_context_switches
+    bool s2_clock_on = false;          // k_search2 stamps its launches (vp8hip_profile_search2_clock)
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
     bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
@@ -371,6 +372,7 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
     CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
     CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
+    CR(hipMemsetAsync(c->d_progress + S2_CLOCK_WORD, 0xff, 8, c->stream));   // k_search2's launch clock: "earliest start" is ~0 at rest
     CR(hipMalloc(&c->scratch, (size_t)width * height));
     CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
     CR(hipMalloc(&c->ent_third, (size_t)c->mbs * 25));
@@ -622,6 +624,11 @@ static RefSet ref_set(const vp8hip_ctx *c, int use_last, int use_golden, int use
     return refs;
 }
 
+static unsigned long long *s2_clock_words(const vp8hip_ctx *c) { return reinterpret_cast<unsigned long long *>(c->d_progress + S2_CLOCK_WORD); }
+// what the launches get: the stamping costs 1.1 % of the headline (same-box A/B, 57.1 against 57.8 M MB/s), so it is on only
+// while a host asks for it (vp8hip_profile_search2_clock; bench.py: during its warm-up steps)
+static unsigned long long *s2_clock(const vp8hip_ctx *c) { return c->s2_clock_on ? s2_clock_words(c) : nullptr; }
+
 // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
 // references in `which` (the reference runs the three references on three queues, inter_part.h:122-135)
 static void search_refs(vp8hip_ctx *c, const RefSet &which) {
@@ -635,7 +642,8 @@ static void search_refs(vp8hip_ctx *c, const RefSet &which) {
         src ^= 1;
     }
     Timed t(c, VP8HIP_K_SEARCH2);
-    launch_search2(s, c->cur, which, c->nets);
+    // (the launch clock only where launches of this context cannot overlap: the one that searches LAST)
+    launch_search2(s, c->cur, which, c->nets, nullptr, -1, which.use[0] ? s2_clock(c) : nullptr);
 }
 
 // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
@@ -911,7 +919,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     }
     {
         Timed t(c0, VP8HIP_K_SEARCH2);
-        launch_search2_batch(s, cur, refs, nets, n);
+        launch_search2_batch(s, cur, refs, nets, n, s2_clock(c0));
     }
     {
         Timed t(c0, VP8HIP_K_MB);
@@ -1578,6 +1586,27 @@ int vp8hip_profile_read_clock(vp8hip_ctx *c, double *loop_filter_ms, int64_t *lo
     *loop_filter_ms = (double)clk[1] * 1e-5;   // 100 MHz ticks
     *loop_filter_launches = (int64_t)clk[2];
     if (shader_clock_ghz) *shader_clock_ghz = clk[2] > clk[4] ? (double)clk[3] / (double)(clk[2] - clk[4]) * 1e-4 : 0.0;   // (cycles per tick x 1000) x 100 MHz
+    return VP8HIP_OK;
+}
+
+int vp8hip_profile_search2_clock(vp8hip_ctx *c, int on) {
+    if (!c) return VP8HIP_ERR_ARG;
+    c->s2_clock_on = on != 0;
+    return VP8HIP_OK;
+}
+
+// k_search2's launches by the kernel's own clock since the last call: total ms and launches (a batched launch counts once, on
+// the batch's first member).  See launch_clock_end (vp8hip_dev.h).
+int vp8hip_profile_read_search2_clock(vp8hip_ctx *c, double *ms, int64_t *launches) {
+    USE_DEVICE(c);
+    if (!c || !ms || !launches) return VP8HIP_ERR_ARG;
+    JOIN_LF(c);
+    unsigned long long w[5] = {0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, s2_clock_words(c), sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(s2_clock_words(c) + 3, 0, 16, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *ms = (double)w[3] * 1e-5;   // 100 MHz ticks
+    *launches = (int64_t)w[4];
     return VP8HIP_OK;
 }
 

@@ -28,6 +28,8 @@ extern thread_local LaunchTiming tl_timing;
 constexpr int PAD = 32;        // allocated margin (pixels) around every plane
 constexpr int EXT = 8;         // replicated-edge width actually filled (max reach of any filter: 3)
 constexpr int LF_ERR_WORD = 1536;   // int index inside the loop filter's progress buffer of its time-out flag
+constexpr int S2_CLOCK_WORD = LF_ERR_WORD + 32;   // ... and of k_search2's launch clock (five 64-bit words, see launch_clock_end)
+constexpr int CLOCK_SAMPLE = 64;    // every 64th workgroup of a launch stamps the clock
 constexpr int SD_INTS = 11;    // ints per segment_data, src/vp8enc.h:80-92
 enum { SD_Y_AC_I = 0, SD_Y_DC_IDELTA, SD_Y2_DC_IDELTA, SD_Y2_AC_IDELTA, SD_UV_DC_IDELTA, SD_UV_AC_IDELTA,
        SD_LOOP_FILTER_LEVEL, SD_MBEDGE_LIMIT, SD_SUB_BEDGE_LIMIT, SD_INTERIOR_LIMIT, SD_HEV_THRESHOLD };
@@ -73,6 +75,36 @@ struct SegData { int32_t v[4 * SD_INTS]; };
 // the argument blocks of the single form travel as an array in the kernel arguments, and a few streams carry what sixteen did.
 constexpr int MAX_BATCH = 8;
 template <typename A> struct BatchOf { int n; A item[MAX_BATCH]; };
+
+// A launch's duration by the kernel's own clock (s_memrealtime, 100 MHz), for kernels of many workgroups: every CLOCK_SAMPLE-th
+// workgroup (in dispatch order, the first one included) stamps w = {earliest start, latest end, sampled workgroups done,
+// sum over launches of (end - start), launches}; the last sampled workgroup to finish closes the launch.  HIP events around a
+// launch also count the time its packet waits for its hardware queue; this does not, and it is what a rocprofv3 kernel trace
+// shows.  w[0] is ~0 at rest.  (Stamping every workgroup would put 150 000 atomics per launch on one cache line.)
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool launch_clock_sampled() {
+    const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    return wg % CLOCK_SAMPLE == 0;
+}
+__device__ __forceinline__ void launch_clock_begin(unsigned long long *w) {
+    if (w && threadIdx.x == 0 && launch_clock_sampled()) atomicMin(&w[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void launch_clock_end(unsigned long long *w) {   // every thread of the workgroup gets here
+    if (!w || !launch_clock_sampled()) return;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    atomicMax(&w[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    __threadfence();
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z, sampled = (total + CLOCK_SAMPLE - 1) / CLOCK_SAMPLE;
+    if (atomicAdd(&w[2], 1ull) + 1 == sampled) {
+        __threadfence();
+        const unsigned long long t1 = atomicExch(&w[1], 0ull), t0 = atomicExch(&w[0], ~0ull);
+        atomicExch(&w[2], 0ull);
+        atomicAdd(&w[3], t1 - t0);
+        atomicAdd(&w[4], 1ull);
+    }
+}
+#endif
 // workgroups of a persistent launch (0 = launch the full grid); VP8HIP_PERSIST overrides (same-box A/B runs)
 int persistent_workgroups();
 
@@ -86,7 +118,8 @@ void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uin
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n);
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
                           int net_width, int n);
-void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n);
+void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n,
+                          unsigned long long *clk = nullptr);   // clk: launch clock words (launch_clock_end) or nullptr
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
                      const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n);
 void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
@@ -96,7 +129,7 @@ void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
                     int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
-                    int dbg_block = -1);
+                    int dbg_block = -1, unsigned long long *clk = nullptr);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh);
