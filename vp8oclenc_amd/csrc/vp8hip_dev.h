@@ -347,7 +347,11 @@ __device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t
         const s16x2 o3 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3h, (uint32_t)t3l, 0x07060302u));
         // |o1 + (d1 != 0)| per half: the +1 rides in the subtrahend of the absolute difference.  Plain 32-bit logic on
         // the packed pair (as a 16-bit vector compare hipcc scalarises it into two v_cmp and two v_cndmask per pair)
-        const uint32_t nz = ((as_u32(d1) | as_u32(s16x2{0, 0} - d1)) >> 15) & 0x00010001u;   // d1 != 0, per half
+        // d1 != 0, per half: min(d1 as unsigned, 1), one v_pk_min_u16 (was sub / or / shift / and on the pair).  The 1s pass
+        // through an empty asm: min(x, 1) with a constant hipcc can see becomes x != 0 and is scalarised as described above.
+        uint32_t ones = 0x00010001u;
+        asm("" : "+s"(ones));
+        const uint32_t nz = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, ones)));
         acc = abs_acc(o0, acc);
         acc = __builtin_amdgcn_sad_u16(as_u32(o1) ^ 0x80008000u, 0x80008000u - nz, acc);
         acc = abs_acc(o2, acc);
