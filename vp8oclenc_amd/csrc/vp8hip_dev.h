@@ -329,34 +329,38 @@ __device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t
         A[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1, (uint32_t)R0, 0x07060100u));   // (low half of R0, high half of t1)
         B[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3, (uint32_t)R2, 0x07060100u));
     }
+    // Row pass.  |a| + |b| of a packed pair is one v_sad_u16 against a constant once the pair carries a bias that makes it
+    // unsigned; the biases ride on work that is done anyway: +0x8000 joins the rounding 7 of a1 (then ">> 4" is a LOGICAL
+    // shift and the pair comes out with +2048: floor((x + 32768) / 16) = floor(x / 16) + 2048), and +2^28 joins the rounding
+    // constants of the rotations (the high half comes out with +4096; |sums| < 2^28, so nothing saturates).
     uint32_t acc = 0;
     int o00 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const s16x2 *X = h == 0 ? A : B;
         const s16x2 a1 = X[0] + X[3], d1 = X[0] - X[3], b1 = X[1] + X[2], c1 = X[1] - X[2];
-        const s16x2 a7 = a1 + s16x2{7, 7};
-        const s16x2 o0 = (a7 + b1) >> s16x2{4, 4};
-        const s16x2 o2 = (a7 - b1) >> s16x2{4, 4};
+        const u16x2 a7 = __builtin_bit_cast(u16x2, a1) + u16x2{0x8007, 0x8007};
+        const u16x2 o0 = (a7 + __builtin_bit_cast(u16x2, b1)) >> u16x2{4, 4};
+        const u16x2 o2 = (a7 - __builtin_bit_cast(u16x2, b1)) >> u16x2{4, 4};
         const uint32_t xy_lo = __builtin_amdgcn_perm(as_u32(d1), as_u32(c1), 0x05040100u);   // (c1, d1) of the first row
         const uint32_t xy_hi = __builtin_amdgcn_perm(as_u32(d1), as_u32(c1), 0x07060302u);   // ... of the second row
-        const int t1l = dot2(xy_lo, K_ROT_A, 12000), t1h = dot2(xy_hi, K_ROT_A, 12000);
-        const int t3l = dot2(xy_lo, K_ROT_B, 51000), t3h = dot2(xy_hi, K_ROT_B, 51000);
-        // (x >> 16) of both rows = the high halves, packed
-        const s16x2 o1 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1h, (uint32_t)t1l, 0x07060302u));
-        const s16x2 o3 = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3h, (uint32_t)t3l, 0x07060302u));
-        // |o1 + (d1 != 0)| per half: the +1 rides in the subtrahend of the absolute difference.  Plain 32-bit logic on
-        // the packed pair (as a 16-bit vector compare hipcc scalarises it into two v_cmp and two v_cndmask per pair)
+        const int t1l = dot2(xy_lo, K_ROT_A, 12000 + (1 << 28)), t1h = dot2(xy_hi, K_ROT_A, 12000 + (1 << 28));
+        const int t3l = dot2(xy_lo, K_ROT_B, 51000 + (1 << 28)), t3h = dot2(xy_hi, K_ROT_B, 51000 + (1 << 28));
+        // (x >> 16) of both rows = the high halves, packed (+4096 each)
+        const uint32_t o1 = __builtin_amdgcn_perm((uint32_t)t1h, (uint32_t)t1l, 0x07060302u);
+        const uint32_t o3 = __builtin_amdgcn_perm((uint32_t)t3h, (uint32_t)t3l, 0x07060302u);
+        // |o1 + (d1 != 0)| per half: the +1 rides in the subtrahend of the absolute difference.
         // d1 != 0, per half: min(d1 as unsigned, 1), one v_pk_min_u16 (was sub / or / shift / and on the pair).  The 1s pass
-        // through an empty asm: min(x, 1) with a constant hipcc can see becomes x != 0 and is scalarised as described above.
+        // through an empty asm: min(x, 1) with a constant hipcc can see becomes x != 0, which it scalarises into two v_cmp and
+        // two v_cndmask per pair.
         uint32_t ones = 0x00010001u;
         asm("" : "+s"(ones));
         const uint32_t nz = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, d1), __builtin_bit_cast(u16x2, ones)));
-        acc = abs_acc(o0, acc);
-        acc = __builtin_amdgcn_sad_u16(as_u32(o1) ^ 0x80008000u, 0x80008000u - nz, acc);
-        acc = abs_acc(o2, acc);
-        acc = abs_acc(o3, acc);
-        if (h == 0) o00 = o0.x;
+        acc = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, o0), 0x08000800u, acc);
+        acc = __builtin_amdgcn_sad_u16(o1, 0x10001000u - nz, acc);
+        acc = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, o2), 0x08000800u, acc);
+        acc = __builtin_amdgcn_sad_u16(o3, 0x10001000u, acc);
+        if (h == 0) o00 = (int)o0.x - 2048;
     }
     const int a00 = iabs(o00);
     return (int)acc - (a00 - (a00 >> 2));   // DC counts a quarter (DC_UNSIGNIFICANCE, :83,:183)
