@@ -20,16 +20,23 @@ namespace vp8 {
 // C division x / q (truncating toward zero, GPU_kernels.cl:1478-1481) by a quantiser that is the same for a
 // whole pass: floor(n/q) = (n*M) >> 24 with M = floor(2^24/q) + 1 is exact for n < 2^15 and 2 <= q < 512
 // (error term n*(M*q - 2^24)/(q*2^24) < 2^-9 < 1/q).  Every |coefficient| here is below 2^15 (fdct <= 2040,
-// WHT <= 16320) and every quantiser below 512 (y2ac <= 440).  n*M needs 39 bits: the two full-rate 24-bit
-// multiplies give its low 32 and high 16 bits.  q == 1 (the DC of a 16x16 macroblock) is passed through.
-struct TDiv { uint32_t M; bool one; };
-__device__ __forceinline__ TDiv tdiv_make(int q) { return TDiv{(1u << 24) / (uint32_t)q + 1u, q == 1}; }
+// WHT <= 16320) and every quantiser below 512 (y2ac <= 440).  (n*M) >> 24 = the HIGH half of n * (M << 8): one
+// v_mul_hi_u32 (M < 2^23 for q >= 2, so M << 8 fits; the 64-bit product by two 24-bit multiplies and a funnel shift was
+// seven instructions per coefficient).  q == 1 (the DC of a 16x16 macroblock) is passed through.  M << 8 comes from a
+// table: the quantisers are table entries and small functions of them, all below 512.
+struct TDiv { uint32_t M8; bool one; };
+struct Recip24 { uint32_t m8[512]; };
+static constexpr Recip24 make_recip24() {
+    Recip24 t{};
+    for (uint32_t q = 0; q < 512; ++q) t.m8[q] = q < 2 ? 0u : (((1u << 24) / q + 1u) << 8);
+    return t;
+}
+static __device__ __constant__ const Recip24 k_recip24 = make_recip24();
+__device__ __forceinline__ TDiv tdiv_make(int q) { return TDiv{k_recip24.m8[q & 511], q == 1}; }
 __device__ __forceinline__ int tdiv(int x, const TDiv &d) {
     const int s = x >> 31;
     const uint32_t n = (uint32_t)((x ^ s) - s);
-    // both factors provably below 2^24: hipcc selects v_mul_u32_u24 + v_mul_hi_u32_u24 + v_alignbit
-    const uint64_t p = (uint64_t)(n & 0xffffffu) * (uint64_t)(d.M & 0xffffffu);
-    const uint32_t r = d.one ? n : (uint32_t)(p >> 24);
+    const uint32_t r = d.one ? n : __umulhi(n, d.M8);
     return ((int)r ^ s) - s;
 }
 
@@ -158,49 +165,29 @@ __device__ __forceinline__ void idct4x4(int L[16]) {
     }
 }
 
-// WHT_and_quant + dequant_and_iWHT, GPU_kernels.cl:257-401.  X: the 16 luma DCs (raster) in, the
-// reconstructed DCs out; Q: the quantised second-order block (raster).
-__device__ __forceinline__ void wht_roundtrip(int X[16], int Q[16], int dc_q, int ac_q, const TDiv &ddc, const TDiv &dac) {
-    int T[16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int a = X[c] + X[12 + c], b = X[4 + c] + X[8 + c], cc = X[4 + c] - X[8 + c], d = X[c] - X[12 + c];
-        T[c] = a + b;
-        T[4 + c] = cc + d;
-        T[8 + c] = a - b;
-        T[12 + c] = d - cc;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int x = T[4 * r], y = T[4 * r + 1], z = T[4 * r + 2], w = T[4 * r + 3];
-        const int a1 = x + w, b1 = y + z, c1 = y - z, d1 = x - w;
-        int o[4] = {a1 + b1, c1 + d1, a1 - b1, d1 - c1};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o[k] += (o[k] > 0);
-            o[k] >>= 1;
-            Q[4 * r + k] = tdiv(o[k], (r == 0 && k == 0) ? ddc : dac);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) X[k] = __mul24(Q[k], k == 0 ? dc_q : ac_q);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int x = X[4 * r], y = X[4 * r + 1], z = X[4 * r + 2], w = X[4 * r + 3];
-        const int a1 = x + w, b1 = y + z, c1 = y - z, d1 = x - w;
-        T[4 * r] = a1 + b1;
-        T[4 * r + 1] = c1 + d1;
-        T[4 * r + 2] = a1 - b1;
-        T[4 * r + 3] = d1 - c1;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int a = T[c] + T[12 + c], b = T[4 + c] + T[8 + c], cc = T[4 + c] - T[8 + c], d = T[c] - T[12 + c];
-        X[c] = (a + b + 3) >> 3;
-        X[4 + c] = (cc + d + 3) >> 3;
-        X[8 + c] = (a - b + 3) >> 3;
-        X[12 + c] = (d - cc + 3) >> 3;
-    }
+// WHT_and_quant + dequant_and_iWHT, GPU_kernels.cl:257-401, spread over the sixteen luma lanes of the macroblock: lane
+// L = 4r + c holds element (r, c) of the 4x4 block of luma DCs.  Both transforms are two passes of the same four-point
+// pattern -- out[i] = v0 + s1(i) v1 + s2(i) v2 + s3(i) v3 with the signs of row i of {++++, ++--, +--+, +-+-} -- first down
+// the column, then along the row (forward), first along the row, then down the column (inverse): four gathers of four
+// lanes, three multiply-adds each, ONE division per lane.  (Every lane used to gather all sixteen values and run the whole
+// round trip with its sixteen divisions: 300 instructions per lane, a seventh of the kernel.)
+// x: this lane's DC in; returns this lane's reconstructed DC, q = this lane's element of the quantised second-order block.
+__device__ __forceinline__ int had4(int v0, int v1, int v2, int v3, int i) {
+    const int s1 = i >= 2 ? -1 : 1, s2 = (i == 1 || i == 2) ? -1 : 1, s3 = (i & 1) ? -1 : 1;
+    return v0 + __mul24(s1, v1) + __mul24(s2, v2) + __mul24(s3, v3);
+}
+__device__ __forceinline__ int wht_roundtrip_lane(int x, int lane, int dc_q, int ac_q, const TDiv &ddc, const TDiv &dac, int &q) {
+    const int L = lane & 15, r = L >> 2, c = L & 3, row0 = L & 12;
+    // forward: columns (T[4r + c] from X[c], X[4 + c], X[8 + c], X[12 + c]), then rows
+    const int t = had4(__shfl(x, c, 32), __shfl(x, 4 + c, 32), __shfl(x, 8 + c, 32), __shfl(x, 12 + c, 32), r);
+    int o = had4(__shfl(t, row0, 32), __shfl(t, row0 + 1, 32), __shfl(t, row0 + 2, 32), __shfl(t, row0 + 3, 32), c);
+    o += (o > 0);
+    o >>= 1;
+    q = tdiv(o, L == 0 ? ddc : dac);
+    const int xq = __mul24(q, L == 0 ? dc_q : ac_q);
+    // inverse: rows, then columns with (. + 3) >> 3
+    const int u = had4(__shfl(xq, row0, 32), __shfl(xq, row0 + 1, 32), __shfl(xq, row0 + 2, 32), __shfl(xq, row0 + 3, 32), c);
+    return (had4(__shfl(u, c, 32), __shfl(u, 4 + c, 32), __shfl(u, 8 + c, 32), __shfl(u, 12 + c, 32), r) + 3) >> 3;
 }
 
 // zig-zag position of raster coefficient k: coeff[inv_zigzag[k]] = L[k], GPU_kernels.cl:1489
@@ -208,6 +195,8 @@ __device__ __forceinline__ constexpr int inv_zigzag(int k) {
     constexpr int t[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
     return t[k];
 }
+// the same for an index known only at run time: sixteen nibbles
+__device__ __forceinline__ int inv_zigzag_rt(int k) { return (int)((0xfea9db83c7426510ull >> (4 * k)) & 15); }
 __device__ __forceinline__ void store_zigzag(int16_t *dst, const int L[16]) {
     int z[16];
 #pragma unroll
@@ -425,23 +414,16 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
             for (int k = 1; k < 16; ++k) coef[k] = tdiv(coef[k], dac);
         }
         nz_blk = 0;
-        if (parts == 0) {                        // wht4x4_iwht4x4, :1498-1543 (all lanes: shuffles)
-            int X[16], q24[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) X[k] = (int16_t)__shfl(coef[0], k, 32);
+        if (parts == 0) {                        // wht4x4_iwht4x4, :1498-1543 (every lane takes part in the gathers)
             const int y2dc = k_dc_q[qi(SD[SD_Y2_DC_IDELTA] + i)] * 2;
             const int y2ac = imax(31 * k_ac_q[qi(SD[SD_Y2_AC_IDELTA] + i)] / 20, 8);
-            wht_roundtrip(X, q24, y2dc, y2ac, tdiv_make(y2dc), tdiv_make(y2ac));
+            int q24 = 0;
+            const int nd = wht_roundtrip_lane((int16_t)coef[0], lane, y2dc, y2ac, tdiv_make(y2dc), tdiv_make(y2ac), q24);
             if (lane < 16) {
-                int nd = X[0];
-#pragma unroll
-                for (int k = 1; k < 16; ++k) nd = (lane == k) ? X[k] : nd;
                 coef[0] = (int16_t)nd;           // stored as short, :1537
-            }
-            if (lane == 24) {                    // block 24 and its share of the non-zero count (CPU_kernels.cl:800-819)
-                if (live) store_zigzag(a.o_coeffs + ((size_t)mb * 25 + 24) * 16, q24);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) nz_blk += iabs((int16_t)q24[k]);
+                // block 24, element by element, and its share of the non-zero count (CPU_kernels.cl:800-819)
+                if (live) a.o_coeffs[((size_t)mb * 25 + 24) * 16 + inv_zigzag_rt(lane)] = (int16_t)q24;
+                nz_blk += iabs((int16_t)q24);
             }
         }
         if (blk) {                               // idct4x4, :1545-1608
