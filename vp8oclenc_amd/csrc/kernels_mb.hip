@@ -176,18 +176,24 @@ __device__ __forceinline__ int had4(int v0, int v1, int v2, int v3, int i) {
     const int s1 = i >= 2 ? -1 : 1, s2 = (i == 1 || i == 2) ? -1 : 1, s3 = (i & 1) ? -1 : 1;
     return v0 + __mul24(s1, v1) + __mul24(s2, v2) + __mul24(s3, v3);
 }
+// (gathers by ds_bpermute with the eight byte addresses made once: __shfl recomputes its lane arithmetic, four instructions,
+// at each of the sixteen calls)
 __device__ __forceinline__ int wht_roundtrip_lane(int x, int lane, int dc_q, int ac_q, const TDiv &ddc, const TDiv &dac, int &q) {
-    const int L = lane & 15, r = L >> 2, c = L & 3, row0 = L & 12;
+    const int L = lane & 15, r = L >> 2, c = L & 3;
+    const int base = (int)(threadIdx.x & 32u) * 4;             // byte address (in the wave) of the macroblock's lane 0
+    const int col = base + 4 * c, row = base + 4 * (L & 12);   // ... of lane c (top of this lane's column), of lane 4r (head of its row)
+    auto gather_col = [&](int v, int i) { return had4(__builtin_amdgcn_ds_bpermute(col, v), __builtin_amdgcn_ds_bpermute(col + 16, v),
+                                                      __builtin_amdgcn_ds_bpermute(col + 32, v), __builtin_amdgcn_ds_bpermute(col + 48, v), i); };
+    auto gather_row = [&](int v, int i) { return had4(__builtin_amdgcn_ds_bpermute(row, v), __builtin_amdgcn_ds_bpermute(row + 4, v),
+                                                      __builtin_amdgcn_ds_bpermute(row + 8, v), __builtin_amdgcn_ds_bpermute(row + 12, v), i); };
     // forward: columns (T[4r + c] from X[c], X[4 + c], X[8 + c], X[12 + c]), then rows
-    const int t = had4(__shfl(x, c, 32), __shfl(x, 4 + c, 32), __shfl(x, 8 + c, 32), __shfl(x, 12 + c, 32), r);
-    int o = had4(__shfl(t, row0, 32), __shfl(t, row0 + 1, 32), __shfl(t, row0 + 2, 32), __shfl(t, row0 + 3, 32), c);
+    int o = gather_row(gather_col(x, r), c);
     o += (o > 0);
     o >>= 1;
     q = tdiv(o, L == 0 ? ddc : dac);
     const int xq = __mul24(q, L == 0 ? dc_q : ac_q);
     // inverse: rows, then columns with (. + 3) >> 3
-    const int u = had4(__shfl(xq, row0, 32), __shfl(xq, row0 + 1, 32), __shfl(xq, row0 + 2, 32), __shfl(xq, row0 + 3, 32), c);
-    return (had4(__shfl(u, c, 32), __shfl(u, 4 + c, 32), __shfl(u, 8 + c, 32), __shfl(u, 12 + c, 32), r) + 3) >> 3;
+    return (gather_col(gather_row(xq, c), r) + 3) >> 3;
 }
 
 // zig-zag position of raster coefficient k: coeff[inv_zigzag[k]] = L[k], GPU_kernels.cl:1489

@@ -396,7 +396,7 @@ __device__ __forceinline__ void load_taps(int phase, int f[6]) {
 // (0xffff after a negative sum), which corrupted two neighbouring pixels.  Found by the parity tests.
 __device__ __forceinline__ int sat8_shr7(int s) { return iclamp(s, 0, 32767) >> 7; }
 // (sum + 64)/128 with C truncation toward zero
-__device__ __forceinline__ int div128(int s) { return s >= 0 ? (s >> 7) : -((-s) >> 7); }
+__device__ __forceinline__ int div128(int s) { return (s + ((s >> 31) & 127)) >> 7; }   // s / 128 toward zero
 #endif
 
 }  // namespace vp8
