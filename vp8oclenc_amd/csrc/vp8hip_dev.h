@@ -360,9 +360,9 @@ __device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t
         acc = __builtin_amdgcn_sad_u16(o1, 0x10001000u - nz, acc);
         acc = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, o2), 0x08000800u, acc);
         acc = __builtin_amdgcn_sad_u16(o3, 0x10001000u, acc);
-        if (h == 0) o00 = (int)o0.x - 2048;
+        if (h == 0) o00 = (int)(__builtin_bit_cast(uint32_t, o0) & 0xffffu);   // the DC, still carrying its +2048
     }
-    const int a00 = iabs(o00);
+    const int a00 = (int)__builtin_amdgcn_sad_u16((uint32_t)o00, 2048u, 0u);   // |DC| (the high halves are both zero)
     return (int)acc - (a00 - (a00 >> 2));   // DC counts a quarter (DC_UNSIGNIFICANCE, :83,:183)
 }
 
