@@ -128,7 +128,7 @@ def spawn_ranks(args) -> int:
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
-    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1):
+    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None):
         from vp8oclenc_amd.synth import SynthSequence
         self.torch, self.api = torch, api
         seq = SynthSequence(W0, H0, seed=seed)
@@ -140,7 +140,7 @@ class Leg:
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
         self.drv, self.t, self.batches = [], [], []
         for k in range(G):
-            d = api.NativeDriver(self.W, self.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
+            d = api.NativeDriver(self.W, self.H, device=device, gop_size=gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
                                  ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
                                  overlap_filter=overlap_filter)
             t = (k * 3) % nd                                   # chunks start at different frames of the sequence
@@ -154,36 +154,44 @@ class Leg:
             if batch > 1 and (len(self.drv) % batch == 0 or k == G - 1):
                 k0 = len(self.drv) - 1 - (len(self.drv) - 1) % batch
                 self.batches.append((list(range(k0, len(self.drv))), api.NativeBatch(self.drv[k0:])))
-        self.frames = self.refsum = 0
+        self.frames = self.refsum = self.keys = 0
         # GOP steady state, untimed and independent of --warmup: every chunk past two altref periods, phases staggered so
-        # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames
+        # that every step sees the long-run mix of LAST / LAST+GOLDEN / LAST+GOLDEN+ALTREF frames (and, with a finite GOP, the
+        # chunks spread evenly over the positions of the GOP: key frames come one chunk at a time, not all at once)
+        pre = [PREROLL + k % ALTREF_RANGE + ((k * gop) // G if gop else 0) for k in range(G)]
         if self.batches:
             for members, nb in self.batches:
-                for r in range(PREROLL + ALTREF_RANGE - 1):
-                    self.step_group(members, nb, [r < PREROLL + k % ALTREF_RANGE for k in members])
+                for r in range(max(pre[k] for k in members)):
+                    self.step_group(members, nb, [r < pre[k] for k in members])
         else:
             for k in range(G):
-                for _ in range(PREROLL + k % ALTREF_RANGE):
+                for _ in range(pre[k]):
                     self.step_one(k)
         torch.cuda.synchronize()
-        self.frames = self.refsum = 0
+        self.frames = self.refsum = self.keys = 0
 
     def step_group(self, members, nb, on=None):
-        nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members], on)
+        keys = nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members], on)
         for i, k in enumerate(members):
             if on is not None and not on[i]:
                 continue
             self.t[k] += 1
-            st = self.drv[k].stats()
             self.frames += 1
+            if keys[i]:
+                self.keys += 1
+                continue
+            st = self.drv[k].stats()
             self.refsum += 1 + st.last_use_golden + st.last_use_altref
 
     def step_one(self, k):
         d = self.drv[k]
-        d.encode_frame_device(*self.ptrs[self.t[k] % self.nd])
+        key = d.encode_frame_device(*self.ptrs[self.t[k] % self.nd])
         self.t[k] += 1
-        st = d.stats()
         self.frames += 1
+        if key:
+            self.keys += 1
+            return
+        st = d.stats()
         self.refsum += 1 + st.last_use_golden + st.last_use_altref
 
     def step(self):
@@ -223,7 +231,7 @@ class Leg:
     def run(self, steps, barrier=None):
         """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
         sync = barrier or self.torch.cuda.synchronize
-        self.frames = self.refsum = 0
+        self.frames = self.refsum = self.keys = 0
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -233,7 +241,7 @@ class Leg:
         el = time.perf_counter() - t0
         for d in self.drv:
             d.hip.synchronize()   # raises if a bounded device-side wait (loop filter / intra wavefronts) expired: no number then
-        return el, enq, self.refsum / max(self.frames, 1)
+        return el, enq, self.refsum / max(self.frames - self.keys, 1)
 
     def close(self):
         for _, nb in self.batches:
@@ -245,9 +253,9 @@ class Leg:
         self.dev_frames = []
 
 
-def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1):
+def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1, gop=None):
     # one chunk = one video coded frame after frame: the loop filter on its own stream, GOLDEN/ALTREF searched beside it
-    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1)
+    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1, gop=gop)
     for _ in range(warm):
         leg.step()
     leg.clock_read()
@@ -260,6 +268,8 @@ def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4
            "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs,
            "loop_filter_ms_by_its_own_clock": round(lf_ms / max(lf_n, 1), 4), "shader_clock_ghz": round(ghz, 3),
            "waves_context_switched": leg.context_switches}
+    if gop:
+        out["gop_size"], out["key_frames"] = gop, leg.keys
     leg.close()
     return out
 
@@ -425,6 +435,9 @@ def main():
             "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local, batch=min(B, 4)),
             "4k_3refs": side_leg(torch, api, 3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3, local, batch=min(B, 2)),
             "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local, batch=B),
+            # the reference's default GOP of 150: key frames (a raster-order wavefront each, 1.5 ms alone) among the inter frames;
+            # value counts every frame
+            "1080p_gop150": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, gop=150),
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
