@@ -175,6 +175,8 @@ void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *
     b.n = n;
     for (int i = 0; i < n; ++i) b.item[i] = PackItem{f[i]->Y[0], f[i]->U, f[i]->V, (const uint8_t *)y[i], (const uint8_t *)u[i], (const uint8_t *)v[i]};
     const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
+    static const bool skip = [] { const char *e = getenv("VP8HIP_EXPERIMENT_SKIP"); return e && strstr(e, "pack") != nullptr; }();
+    if (skip) return;   // timing experiment only
     VP8_LAUNCH(k_pack_b, dim3((units + 255) / 256, 1, n), dim3(256), 0, s, b);
 }
 
