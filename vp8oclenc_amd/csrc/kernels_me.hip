@@ -137,29 +137,38 @@ void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch (8 bytes per thread).
+// Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch.  A thread copies `per` units of 8 bytes,
+// 256 units apart (a workgroup = per x 2 KB): with one unit per thread a 1080p frame is 1530 workgroups of next to no work,
+// and under load it is the dispatch of workgroups, not the copying, that such a launch waits for (same box, headline with 1 / 8 /
+// 16 / 32 units per thread: 62.0 / 62.4 / 62.5 / 62.5 M MB/s).
 // ------------------------------------------------------------------------------------------------
 struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; };
-__device__ __forceinline__ void pack_body(const PackItem &a) {
+__device__ __forceinline__ void pack_body(const PackItem &a, int per) {
     const Plane &py = a.py, &pu = a.pu, &pv = a.pv;
     const uint8_t *sy = a.sy, *su = a.su, *sv = a.sv;
-    int i = blockIdx.x * 256 + threadIdx.x;
     const int ny = (py.w >> 3) * py.h, nc = (pu.w >> 3) * pu.h;
-    const Plane *pl = &py;
-    const uint8_t *src = sy;
-    if (i >= ny) {
-        i -= ny;
-        pl = &pu;
-        src = su;
-        if (i >= nc) { i -= nc; pl = &pv; src = sv; }
-        if (i >= nc) return;
+    for (int k = 0; k < per; ++k) {
+        int i = ((int)blockIdx.x * per + k) * 256 + (int)threadIdx.x;
+        const Plane *pl = &py;
+        const uint8_t *src = sy;
+        if (i >= ny) {
+            i -= ny;
+            pl = &pu;
+            src = su;
+            if (i >= nc) { i -= nc; pl = &pv; src = sv; }
+            if (i >= nc) return;
+        }
+        const int upr = pl->w >> 3;     // 8-byte units per row
+        const int y = i / upr, x = (i % upr) * 8;
+        *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
     }
-    const int upr = pl->w >> 3;     // 8-byte units per row
-    const int y = i / upr, x = (i % upr) * 8;
-    *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
 }
 
-__global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b) { pack_body(b.item[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b, int per) { pack_body(b.item[blockIdx.z], per); }
+static int pack_units_per_thread() {
+    static const int per = [] { const char *e = getenv("VP8HIP_PACK_UNITS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    return per;
+}
 
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
@@ -168,7 +177,8 @@ void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, co
     BatchOf<PackItem> b;
     b.n = 1;
     b.item[0] = PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v};
-    VP8_LAUNCH(k_pack_b, dim3((n + 255) / 256, 1, 1), dim3(256), 0, s, b);
+    const int per = pack_units_per_thread();
+    VP8_LAUNCH(k_pack_b, dim3((n + 256 * per - 1) / (256 * per), 1, 1), dim3(256), 0, s, b, per);
 }
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n) {
     BatchOf<PackItem> b;
@@ -177,7 +187,8 @@ void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *
     const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
     static const bool skip = [] { const char *e = getenv("VP8HIP_EXPERIMENT_SKIP"); return e && strstr(e, "pack") != nullptr; }();
     if (skip) return;   // timing experiment only
-    VP8_LAUNCH(k_pack_b, dim3((units + 255) / 256, 1, n), dim3(256), 0, s, b);
+    const int per = pack_units_per_thread();
+    VP8_LAUNCH(k_pack_b, dim3((units + 256 * per - 1) / (256 * per), 1, n), dim3(256), 0, s, b, per);
 }
 
 // ------------------------------------------------------------------------------------------------
