@@ -7,8 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 from vp8oclenc_amd import api
-G = int(os.environ.get("VP8_CHUNKS", "16"))
-leg = bench.Leg(torch, api, 1920, 1080, G, "all", -1.0, 8, 0, 1)
+G = int(os.environ.get("VP8_CHUNKS", "48"))
+leg = bench.Leg(torch, api, 1920, 1080, G, "all", -1.0, 8, 0, 1, batch=int(os.environ.get("VP8_BATCH", "6")))
 r = bench.bitstream_leg(torch, leg, int(os.environ.get("VP8_FRAMES", "40")))
 print(r["value"] / 1e6, "M MB/s", r["fps"], "frames/s", r["avg_frame_bytes"], "B/frame")
 leg.close()
