@@ -125,9 +125,23 @@ int vp8hip_intra_transform(vp8hip_ctx *ctx);
  * the filter parameters when it exceeds 0.95, :260).  Blocks until the three values are back. */
 int vp8hip_check_ssim(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim);
 /* e_data[].mode[16] of the last vp8hip_intra_transform / vp8hip_check_ssim (the sub-block modes the header coder
- * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference, 0 where none was made) and
+ * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference -- see
+ * vp8hip_conformant_stream -- and 0 where none was made) and
  * e_data[].is_inter_mb (check_ssim only).  Either pointer may be NULL. */
 int vp8hip_download_intra(vp8hip_ctx *ctx, int32_t *modes, int32_t *is_inter_mb);
+/* NOT the reference's behaviour, off by default: with on = 1 the emitted stream decodes, in any VP8 decoder, to exactly the
+ * reconstruction the encoder keeps as its references.  The reference's does not, in two places (found by decoding the frames
+ * with a decoder written from RFC 6386, tests/vp8_decode.py, tests/test_decode_roundtrip.py):
+ *  1. `construct` (GPU_kernels.cl:702-758) wraps the last three of the nine first-pass lines of a 4x4 predictor to 8 bits
+ *     where the format saturates them (RFC 6386 section 18.3): wherever the six-tap filter overshoots on one of those lines --
+ *     hard edges, text, graphics -- the encoder predicts from other samples than every decoder will;
+ *  2. check_SSIM writes e_data.mode on every attempt (intra_part.h:964) but coefficients and reconstruction only when the
+ *     attempt is kept (:1058-1086): a macroblock whose AQ attempt was kept and whose HQ / UQ attempts then failed goes out with
+ *     sub-block modes that do not belong to its coefficients.
+ * Either error lives on through inter prediction until the next key frame.  on = 1 saturates all nine lines and keeps the
+ * modes of the attempt that was KEPT; the output is then no longer the reference's byte for byte wherever one of the two
+ * cases occurs (and identical where none does).  All members of a batch must agree. */
+int vp8hip_conformant_stream(vp8hip_ctx *ctx, int on);
 
 /* prepare_filter_mask_and_non_zero_coeffs(), loop_filter.h:25-55.  nz_out: [MBs] or NULL.
  * (vp8hip_inter_transform already produced mask and counts for its own coefficients; this call

@@ -44,9 +44,12 @@ typedef struct {
     int32_t ref_mask;        /* which of the two optional references inter frames may search besides LAST: bit 0 GOLDEN,
                                 bit 1 ALTREF, ANDed onto the reference's own rule (inter_part.h:103-104).  Default 3 (= the
                                 reference); 0 = LAST only (BASELINE configs[1]) */
+    int32_t conformant_stream;   /* 1 = vp8hip_conformant_stream: the stream decodes to the encoder's own reconstruction (the
+                                format's predictor, the kept attempt's modes); 0 = the reference's stream, byte for byte.
+                                Default 0 */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);

@@ -321,6 +321,13 @@ void vp8o_intra_transform(int width, int height, const uint8_t *cy, const uint8_
         }
 }
 
+/* vp8o_conformant (vp8_oracle.c; NOT the reference's behaviour, off by default), first half: keep the sub-block modes of
+ * the attempt that was KEPT instead of those of the last attempt MADE.  The reference writes e_data.mode on every attempt
+ * (src/intra_part.h:964) but coefficients and reconstruction only when the attempt is kept (:1058-1086), so a macroblock
+ * whose AQ attempt was kept and whose HQ / UQ attempts then failed goes into the stream with modes that do not belong to its
+ * coefficients: a decoder reconstructs something else than the encoder did (tests/test_decode_roundtrip.py shows it). */
+#define g_modes_of_kept vp8o_conformant
+
 /* check_SSIM, src/vp8enc.cpp:231-263: every macroblock below the target is tried as intra in segments AQ (2),
  * HQ (1), UQ (0), each only while it is still below; an attempt is kept when its SSIM beats the current one. */
 void vp8o_check_ssim(int width, int height, float ssim_target, const uint8_t *cy, const uint8_t *cu, const uint8_t *cv,
@@ -339,7 +346,7 @@ void vp8o_check_ssim(int width, int height, float ssim_target, const uint8_t *cy
             for (int k = 0; k < 3; ++k) {
                 if (!(ssim[mb] < ssim_target)) continue;
                 intra_mb(r, c, width, mbw, cy, cu, cv, ry, ru, rv, steps_of(sd, order[k]), &m);
-                memcpy(modes + 16 * mb, m.mode, sizeof m.mode);
+                if (!g_modes_of_kept) memcpy(modes + 16 * mb, m.mode, sizeof m.mode);
                 const float s = vp8o_count_ssim_16x16(m.y, m.u, m.v, 16, cy + (r * width + c) * 16, cu + r * 8 * cw + c * 8,
                                                       cv + r * 8 * cw + c * 8, width);
                 if (s > ssim[mb]) {
@@ -348,6 +355,7 @@ void vp8o_check_ssim(int width, int height, float ssim_target, const uint8_t *cy
                     seg[mb] = order[k];
                     commit_mb(&m, mb, r, c, width, ry, ru, rv, coeffs);
                     is_inter[mb] = 0;
+                    if (g_modes_of_kept) memcpy(modes + 16 * mb, m.mode, sizeof m.mode);
                 }
             }
             repl += !is_inter[mb];

@@ -179,9 +179,18 @@ static void interp4x4_sat(const uint8_t *ref, int w, int h, int ix, int iy, int 
         }
 }
 
+int vp8o_conformant = 0;   /* see vp8_oracle.h: NOT the reference, off by default */
+void vp8o_set_conformant_stream(int on) { vp8o_conformant = on; }
+
 /* construct (:574-774): lines 0..5 saturated (:600,616,632,648,664,680), lines 6..8 narrowed
- * with a plain (uchar) cast, i.e. wrapped mod 256 (:702-708, :727-733, :752-758). */
+ * with a plain (uchar) cast, i.e. wrapped mod 256 (:702-708, :727-733, :752-758).  A decoder saturates all nine (RFC 6386
+ * section 18.3), so where one of the three lines below a 4x4 block overshoots, the encoder predicts from other samples than the
+ * decoder will: with vp8o_conformant the format's rule is used. */
 static void interp4x4_construct(const uint8_t *ref, int w, int h, int ix, int iy, int fx, int fy, int out[16]) {
+    if (vp8o_conformant) {
+        interp4x4_sat(ref, w, h, ix, iy, fx, fy, out);
+        return;
+    }
     int H[9][4];
     for (int L = 0; L < 9; ++L)
         for (int c = 0; c < 4; ++c) {

@@ -155,6 +155,13 @@ const int32_t *vp8o_debug_bdiff(const vp8o_ctx *c, int ref);
 const uint8_t *vp8o_debug_pyramid(const vp8o_ctx *c, int ref /*0..2, 3 = current*/, int level /*0..4 = 1x..1/16*/);
 int vp8o_num_threads(void);
 void vp8o_set_num_threads(int n);
+/* NOT the reference, default 0.  1 = the two places where the reference's encoder and a decoder of its stream part ways
+ * are closed: check_SSIM keeps the sub-block modes of the attempt it kept (vp8_intra_oracle.c), and the predictor saturates
+ * all nine first-pass lines as the format says instead of wrapping the last three (vp8_oracle.c, interp4x4_construct).
+ * Exists to prove that these two are the whole difference (tests/test_decode_roundtrip.py) and to check the product's
+ * opt-in of the same meaning, vp8hip_conformant_stream. */
+extern int vp8o_conformant;
+void vp8o_set_conformant_stream(int on);
 
 #ifdef __cplusplus
 }

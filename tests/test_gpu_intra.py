@@ -38,11 +38,13 @@ def hip_key_frame(cur, sd):
             "MB_parts": r["MB_parts"], "MB_segment_id": r["MB_segment_id"], "modes": modes}
 
 
-def hip_check_ssim(cur, sd, target, inter):
+def hip_check_ssim(cur, sd, target, inter, modes_of_kept=False):
     """Put the inter results on the device exactly as vp8hip_inter_transform would have left them, then check_ssim."""
     H, W = cur[0].shape
     enc = api.Vp8Hip(W, H, target)
     try:
+        if modes_of_kept:
+            enc.conformant_stream(True)
         enc.upload_current(*cur)
         enc.set_segments(sd)
         enc.upload_recon(inter["recon_Y"], inter["recon_U"], inter["recon_V"])
@@ -98,6 +100,39 @@ def test_check_ssim_matches_oracle(W, H, seed, target, cut, qi):
     b = oracle_intra().check_ssim(cur, sd, target, inter)
     compare_check(a, b, f"{W}x{H} t{target}")
     assert np.float32(a["min_SSIM"]) == np.float32(b["min_SSIM"])
+
+
+@pytest.mark.parametrize("legacy", [0, 1])
+def test_check_ssim_modes_of_kept_attempt(legacy, monkeypatch):
+    """vp8hip_conformant_stream (NOT the reference: the decodable variant, include/vp8hip.h), its check_SSIM half, against the oracle's
+    switch of the same meaning; nothing but the modes of macroblocks with a kept attempt followed by a failed one may change"""
+    from oracle_lib import Oracle
+    import subprocess, sys, textwrap
+    if legacy:     # the one-wavefront kernel behind VP8HIP_INTRA_CHECK_1WAVE (read once per process): its own interpreter
+        code = textwrap.dedent("""
+            import sys; sys.path[:0] = [%r, %r]
+            import pytest; sys.exit(pytest.main(["-q", "-x", "-m", "gpu", %r + "::test_check_ssim_modes_of_kept_attempt[0]"]))
+        """) % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__), __file__)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP8HIP_INTRA_CHECK_1WAVE="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    changed = 0
+    for (W, H, seed, target, qi) in ((96, 64, 12, 0.93, (70, 127)), (352, 288, 17, 0.97, (40, 100)), (176, 144, 8, 0.93, (40, 100))):
+        cur, sd, inter = fallback_case(W, H, seed, target, scene_cut=True, qi=qi)
+        ref = oracle_intra().check_ssim(cur, sd, target, inter)
+        Oracle.lib().vp8o_set_conformant_stream(1)
+        try:
+            b = oracle_intra().check_ssim(cur, sd, target, inter)
+        finally:
+            Oracle.lib().vp8o_set_conformant_stream(0)
+        a = hip_check_ssim(cur, sd, target, inter, modes_of_kept=True)
+        compare_check(a, b, f"{W}x{H} kept")
+        for k in CHECK_KEYS:
+            if k != "modes":
+                assert np.array_equal(np.asarray(a[k]), np.asarray(ref[k])), k      # everything but the modes is the reference's
+        kept = np.asarray(a["is_inter"]) == 0
+        changed += int((np.asarray(a["modes"]).reshape(-1, 16)[kept] != np.asarray(ref["modes"]).reshape(-1, 16)[kept]).any(axis=1).sum())
+    assert changed > 0      # the cases do contain macroblocks where the reference's modes are not those of its coefficients
 
 
 @pytest.mark.parametrize("device_params", [0, 1])

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
@@ -209,7 +209,8 @@ class DrvConfig(C.Structure):
     _fields_ = [("gop_size", C.c_int32), ("altref_range", C.c_int32), ("qi_min", C.c_int32), ("qi_max", C.c_int32),
                 ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32),
                 ("num_partitions", C.c_int32), ("display_width", C.c_int32), ("display_height", C.c_int32),
-                ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32), ("ref_mask", C.c_int32)]
+                ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32), ("ref_mask", C.c_int32),
+                ("conformant_stream", C.c_int32)]
 
 
 class DrvStats(C.Structure):
@@ -472,6 +473,11 @@ class Vp8Hip:
     def intra_transform(self):
         """intra_transform (intra_part.h:1089-1109): the current frame as a key frame, on the device."""
         self._chk(self.lib.vp8hip_intra_transform(self.h), "intra_transform")
+
+    def conformant_stream(self, on: bool = True):
+        """NOT the reference: the stream decodes to the encoder's own reconstruction (include/vp8hip.h)"""
+        self.lib.vp8hip_conformant_stream.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.lib.vp8hip_conformant_stream(self.h, int(on)), "conformant_stream")
 
     def check_ssim(self):
         """check_SSIM (vp8enc.cpp:231-263) on the device: (replaced, new_SSIM, min SSIM)."""

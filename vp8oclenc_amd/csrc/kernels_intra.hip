@@ -327,6 +327,7 @@ struct IntraArgs {
     int key;                // 1: key frame (every macroblock, segment 0); 0: fallback of an inter frame
     int mbw, mbh;
     int stall_test;         // test hook: row 0 never publishes, so every other row must run into its bounded wait
+    int modes_of_kept;      // 0: modes of the last attempt MADE (the reference); 1: of the attempt KEPT (decodable)
 };
 
 __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
             LUMA(3, 0) LUMA(3, 1) LUMA(3, 2) LUMA(3, 3)
 #undef LUMA
             chroma_blocks(sh, lane, k, st.uv_dc, st.uv_ac);
-            if (lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode is overwritten by every attempt (:970)
+            if (lane < 16 && !a.modes_of_kept) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode is overwritten by every attempt (:970)
             bool commit = true;
             float s = 0.0f;
             if (!a.key) {
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
                 commit = s > cur_ssim;
             }
             if (commit) {
+                if (lane < 16 && a.modes_of_kept) a.modes[(size_t)mb * 16 + lane] = mymode;
                 cur_ssim = s;
                 st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
                          *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
             last_run = t;
             if (s_ssim[t] > cur) { kept = t; cur = s_ssim[t]; }
         }
-        if (wave == last_run && lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode: of the last attempt made (:970)
+        if (wave == (a.modes_of_kept ? kept : last_run) && lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode: of the last attempt made (:970)
         if (wave == kept) {
             st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
                      *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int
 }  // namespace
 
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test) {
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test,
+                  int modes_of_kept) {
     IntraArgs a;
     a.cy = cur.Y[0]; a.cu = cur.U; a.cv = cur.V;
     a.ry = recon.Y[0]; a.ru = recon.U; a.rv = recon.V;
@@ -891,6 +894,7 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.mbw = mbw;
     a.mbh = mbh;
     a.stall_test = stall_test;
+    a.modes_of_kept = modes_of_kept;
     (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
     static const bool legacy_key = getenv("VP8HIP_INTRA_KEY_MB") != nullptr;   // A/B switch: key frames on the per-macroblock wavefront
     static const bool legacy_check = getenv("VP8HIP_INTRA_CHECK_1WAVE") != nullptr;   // A/B switch: the three attempts one after the other

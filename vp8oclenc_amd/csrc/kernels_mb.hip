@@ -74,7 +74,9 @@ __device__ __forceinline__ uint32_t pack_sat4(const int s[4]) {   // sat8(s >> 7
     const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(s[0], s[1], 7), hi = __builtin_amdgcn_ashr_pk_u8_i32(s[2], s[3], 7);
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
-// rows out[r] (byte c = column c) of the 4x4 predictor
+// rows out[r] (byte c = column c) of the 4x4 predictor.  CONFORMANT (vp8hip_conformant_stream, NOT the reference): all nine
+// lines saturated, as RFC 6386 section 18.3 has it and as every decoder will predict.
+template <bool CONFORMANT>
 __device__ __forceinline__ void predict4x4(const Plane &rf, int ix, int iy, int fx, int fy, uint32_t out[4]) {
     uint32_t tx[9], ty[9];
 #pragma unroll
@@ -87,7 +89,7 @@ __device__ __forceinline__ void predict4x4(const Plane &rf, int ix, int iy, int 
         int sm[4];
         six_tap4(w0, w1, w2, tx, sm);
         uint32_t h;
-        if (L < 6) {
+        if (L < 6 || CONFORMANT) {
             h = pack_sat4(sm);                    // saturated lines, :600-680
         } else {                                  // the last three: C division toward zero, then a plain (uchar) cast, :702-758
             h = 0;
@@ -274,6 +276,7 @@ __device__ __forceinline__ float sum4(float acc, int lane) {   // (((c0 + c1) + 
 // be contracted (the reference's mad is a*b+c, unfused).
 // All LDS traffic of a macroblock stays inside its own 32 lanes = half of one wave, so program order is the
 // only synchronisation needed: there is no workgroup barrier in this kernel.
+template <bool CONFORMANT>
 __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int mb_raw = blockIdx.x * 8 + g;
@@ -340,7 +343,7 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
         const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;  // >= 0 for every in-frame vector
         const int dx = (fxp & gm) * (plane == 0 ? 2 : 1), dy = (fyp & gm) * (plane == 0 ? 2 : 1);
         const int ix = iclamp(fxp >> gsh, 2 - EXT, rp.w + EXT - 7), iy = iclamp(fyp >> gsh, 2 - EXT, rp.h + EXT - 7);
-        predict4x4(rp, ix, iy, dx, dy, predw);
+        predict4x4<CONFORMANT>(rp, ix, iy, dx, dy, predw);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t cw = *reinterpret_cast<const uint32_t *>(cp.p + (ptrdiff_t)(posy + r) * cp.stride + posx);
@@ -513,7 +516,13 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
 // four waves on that body by spilling was slower, 42.8-49.5 against 48.7-49.6 M MB/s).
 __global__ __launch_bounds__(256, 2) void k_mb_b(BatchOf<MBArgs> b) {
     __shared__ __attribute__((aligned(16))) MBTile s_t[8];
-    mb_body(b.item[blockIdx.z], s_t);
+    mb_body<false>(b.item[blockIdx.z], s_t);
+}
+// the same with the format's predictor instead of the reference's (vp8hip_conformant_stream): its own kernel, so that the
+// reference path stays the code that was measured
+__global__ __launch_bounds__(256, 2) void k_mb_b_conformant(BatchOf<MBArgs> b) {
+    __shared__ __attribute__((aligned(16))) MBTile s_t[8];
+    mb_body<true>(b.item[blockIdx.z], s_t);
 }
 
 static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon, const MBOut &o, const SegData *d_sd,
@@ -543,23 +552,25 @@ static bool mb_skip() {
 }
 
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
-               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh) {
+               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh, bool conformant) {
     const MBArgs a = mb_args(cur, refs, nets, recon, o, d_sd, ssim_target, mbw, mbh);
     if (mb_skip()) return;
     BatchOf<MBArgs> b;
     b.n = 1;
     b.item[0] = a;
-    VP8_LAUNCH(k_mb_b, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
+    if (conformant) VP8_LAUNCH(k_mb_b_conformant, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
+    else VP8_LAUNCH(k_mb_b, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
 }
 
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
-                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n) {
+                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n, bool conformant) {
     static_assert(sizeof(BatchOf<MBArgs>) <= 4096, "the batch travels in the kernel arguments");
     BatchOf<MBArgs> b;
     b.n = n;
     for (int i = 0; i < n; ++i) b.item[i] = mb_args(*cur[i], refs[i], *nets[i], *recon[i], *o[i], d_sd[i], ssim_target, mbw, mbh);
     if (mb_skip()) return;
-    VP8_LAUNCH(k_mb_b, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
+    if (conformant) VP8_LAUNCH(k_mb_b_conformant, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
+    else VP8_LAUNCH(k_mb_b, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->host_bitstream = 0;
     c->overlap_filter = 0;
     c->ref_mask = 3;
+    c->conformant_stream = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -57,6 +58,7 @@ int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const
         return rc;
     }
     if (cfg->overlap_filter) vp8hip_filter_overlap(d->hip, 1);
+    if (cfg->conformant_stream) vp8hip_conformant_stream(d->hip, 1);
     d->W = width;
     d->H = height;
     d->mbs = (width / 16) * (height / 16);

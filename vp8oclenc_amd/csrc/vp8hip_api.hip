@@ -59,6 +59,7 @@ struct vp8hip_ctx {
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
+    int conformant = 0;             // vp8hip_conformant_stream (NOT the reference; off by default)
     int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters / intra wavefronts time out
     void *scratch = nullptr;        // device staging for debug pyramid downloads
     // coefficient entropy stage: per-block flags and third contexts, token counts per partition, probabilities
@@ -686,7 +687,7 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
     search_refs(c, split ? ref_set(c, 1, 0, 0) : refs);
     {
         Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
-        launch_mb(c->stream, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh);
+        launch_mb(c->stream, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh, c->conformant != 0);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
@@ -718,7 +719,7 @@ int vp8hip_inter_finish(vp8hip_ctx *c, int use_golden, int use_altref) {
     {
         Timed t(c, VP8HIP_K_MB);
         launch_mb(c->stream, c->cur, ref_set(c, 1, use_golden, use_altref), c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target,
-                  c->mbw, c->mbh);
+                  c->mbw, c->mbh, c->conformant != 0);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
@@ -769,7 +770,7 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     *out = nullptr;
     for (int i = 0; i < n; ++i)
         if (!ctxs[i] || ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->device != ctxs[0]->device ||
-            ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap)
+            ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap || ctxs[i]->conformant != ctxs[0]->conformant)
             return VP8HIP_ERR_ARG;
     vp8hip_batch *b = new (std::nothrow) vp8hip_batch();
     if (!b) return VP8HIP_ERR_ARG;
@@ -883,6 +884,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
+        if (c->conformant != c0->conformant) return VP8HIP_ERR_ARG;   // one launch, one predictor
         const int rc = inter_begin(c, prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
         if (rc) return rc;
         FrameSurf &last = c->frames[c->slot[0]];
@@ -923,7 +925,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     }
     {
         Timed t(c0, VP8HIP_K_MB);
-        launch_mb_batch(s, cur, refs, nets, recon, outs, sds, c0->ssim_target, c0->mbw, c0->mbh, n);
+        launch_mb_batch(s, cur, refs, nets, recon, outs, sds, c0->ssim_target, c0->mbw, c0->mbh, n, c0->conformant != 0);
     }
     for (int i = 0; i < n; ++i) m[i]->recon_ready = true;
     HIPCHK(c0, hipGetLastError());
@@ -1056,7 +1058,7 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
-                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh, c->lf_stall_test);
+                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh, c->lf_stall_test, c->conformant);
     }
     launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->d_progress + LF_ERR_WORD, c->intra_stats);
     HIPCHK(c, hipGetLastError());
@@ -1677,6 +1679,12 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(dd);
     hipFree(dout);
+    return VP8HIP_OK;
+}
+
+int vp8hip_conformant_stream(vp8hip_ctx *c, int on) {
+    if (!c) return VP8HIP_ERR_ARG;
+    c->conformant = on ? 1 : 0;
     return VP8HIP_OK;
 }
 

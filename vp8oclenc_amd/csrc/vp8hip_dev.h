@@ -121,7 +121,8 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
 void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n,
                           unsigned long long *clk = nullptr);   // clk: launch clock words (launch_clock_end) or nullptr
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
-                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n);
+                     const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n,
+                     bool conformant = false);
 void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
                                int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n);
 void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
@@ -132,7 +133,7 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
                     int dbg_block = -1, unsigned long long *clk = nullptr);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
-               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh);
+               const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh, bool conformant = false);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
                          int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
@@ -213,7 +214,8 @@ void launch_frame_code_batch(hipStream_t s, const FrameEntropy *e, const FrameOu
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0);
+                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0,
+                  int modes_of_kept = 0);   // modes_of_kept: vp8hip_conformant_stream
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out);   // out[3] = *err
 
 // ---- device helpers ---------------------------------------------------------------------------
