@@ -189,6 +189,37 @@ def test_reference_predictor_wraps_where_a_decoder_saturates(qi):
     assert seen["fractional"] > 0
 
 
+class _PannedNoise:
+    """white noise panned by whole pixels plus fresh noise on top: costs wrap, every coefficient is alive"""
+
+    def __init__(self, W, H, seed, amp=8):
+        self.W, self.H, self.amp = W, H, amp
+        self.rng = np.random.default_rng(seed)
+        self.base = self.rng.integers(0, 256, (H + 64, W + 64)).astype(np.int32)
+
+    def frame(self, t):
+        y = self.base[t:t + self.H, 2 * t:2 * t + self.W] + self.rng.integers(-self.amp, self.amp + 1, (self.H, self.W))
+        y = np.clip(y, 0, 255).astype(np.uint8)
+        return y, np.ascontiguousarray(y[::2, ::2]), np.ascontiguousarray(255 - y[1::2, 1::2])
+
+
+@pytest.mark.parametrize("qi", [(0, 48), (60, 127), (120, 127)])
+@pytest.mark.parametrize("content", ["noise", "hard", "synth+fallback"])
+def test_conformant_streams_decode_exactly_whatever_the_content(content, qi):
+    """with the two repairs there is nothing left between the encoder and a decoder: noise, hard edges panned by 1.25 / 0.25
+    pixels, and the SSIM fallback, each at fine, coarse and the coarsest quantisers (loop filter levels up to 63)"""
+    from hard_edges import HardEdgeSequence
+    from oracle_lib import Oracle
+    W, H = 176, 144
+    seq = {"noise": _PannedNoise(W, H, 1), "hard": HardEdgeSequence(W, H, seed=2, step=(1.25, 0.25)), "synth+fallback": SynthSequence(W, H, seed=3)}[content]
+    Oracle.lib().vp8o_set_conformant_stream(1)
+    try:
+        seen = _decode_sequence(_oracle_frames(W, H, 0, 5, 1, 0.9 if "fallback" in content else -1.0, seq=seq, qi=qi), f"{content} {qi}")
+    finally:
+        Oracle.lib().vp8o_set_conformant_stream(0)
+    assert seen["inter_frames"] >= 2      # the fallback may recode a frame as a key frame
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,frames,P,cfg", [
     (176, 144, 8, 1, dict(gop_size=150, altref_range=3, check_ssim=1)),
