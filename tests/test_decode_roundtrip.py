@@ -217,7 +217,7 @@ def test_conformant_streams_decode_exactly_whatever_the_content(content, qi):
         seen = _decode_sequence(_oracle_frames(W, H, 0, 5, 1, 0.9 if "fallback" in content else -1.0, seq=seq, qi=qi), f"{content} {qi}")
     finally:
         Oracle.lib().vp8o_set_conformant_stream(0)
-    assert seen["inter_frames"] >= 2      # the fallback may recode a frame as a key frame
+    assert seen["inter_frames"] == 4 or "fallback" in content      # check_SSIM may recode frames as key frames (all of them at the coarsest)
 
 
 @pytest.mark.gpu
