@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--frames", type=int, default=60); ap.add_argument("--gop", type=int, default=30)
     ap.add_argument("--partitions", type=int, default=1); ap.add_argument("--qmin", type=int, default=0); ap.add_argument("--qmax", type=int, default=48)
     ap.add_argument("--ssim-target", type=float, default=-1.0); ap.add_argument("--framerate", type=int, default=30)
+    ap.add_argument("--conformant", action="store_true", help="vp8hip_conformant_stream: NOT the reference byte for byte, but a stream that decodes to the encoder's own reconstruction")
     a = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     dist = None
@@ -48,7 +49,7 @@ def main():
     t0 = time.perf_counter()
     mine = gop_shard.encode_chunks_frames(
         lambda: gop_shard.NativeEncoder(seq.W, seq.H, device=local, num_partitions=a.partitions, qi_min=a.qmin, qi_max=a.qmax,
-                                        ssim_target=a.ssim_target, check_ssim=1),
+                                        ssim_target=a.ssim_target, check_ssim=1, conformant_stream=int(a.conformant)),
         seq, gop_shard.chunks_of_rank(frames, a.gop, rank, world))
     allf = gop_shard.gather_frames(mine, frames, dist)
     if rank == 0:

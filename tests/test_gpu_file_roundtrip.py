@@ -1,0 +1,55 @@
+"""File in, file out, and back: scripts/encode_ivf.py (raw I420 or the synthetic sequence -> GOP chunks through the native
+frame loop -> .ivf) and scripts/decode_ivf.py (the tests' RFC 6386 decoder).  What comes back must LOOK like what went in
+(luma PSNR per frame), which none of the byte-level pins says, and with --conformant must be the encoder's reconstruction."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("W,H,frames,gop,extra,floor", [
+    (320, 192, 12, 5, [], 31.0),
+    (640, 352, 8, 4, ["--partitions", "4", "--qmin", "40", "--qmax", "100"], 29.0),
+    (320, 192, 10, 5, ["--conformant", "--ssim-target", "0.92", "--qmin", "40", "--qmax", "110", "--partitions", "2"], 29.0),
+])
+def test_encode_ivf_then_decode_gives_the_pictures_back(tmp_path, W, H, frames, gop, extra, floor):
+    import decode_ivf
+    import vp8_decode
+    from vp8oclenc_amd.synth import SynthSequence
+    seq = SynthSequence(W, H, seed=1)
+    yuv = tmp_path / "in.yuv"
+    with open(yuv, "wb") as f:                       # the raw I420 file the reference reads (encIO.h:141-196)
+        for t in range(frames):
+            for p in seq.frame(t):
+                f.write(np.ascontiguousarray(p).tobytes())
+    ivf = tmp_path / "out.ivf"
+    out = _run(os.path.join(ROOT, "scripts", "encode_ivf.py"), str(ivf), "--yuv", str(yuv), "--width", str(seq.W), "--height", str(seq.H),
+               "--frames", str(frames), "--gop", str(gop), *extra)
+    assert f"{frames} frames" in out
+    Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(ivf))
+    assert (Wf, Hf, len(packets)) == (seq.W, seq.H, frames) and rate == 30
+    dec = vp8_decode.Decoder()
+    keys = 0
+    for t, fr in enumerate(packets):
+        f, (Y, U, V) = dec.decode(fr)
+        keys += int(f.key)
+        assert f.key == (t % gop == 0) or "--ssim-target" in extra, t          # GOP chunks start with their key frame
+        y, u, v = seq.frame(t)
+        p = decode_ivf.psnr(Y, y)
+        assert p > floor and decode_ivf.psnr(U, u) > floor and decode_ivf.psnr(V, v) > floor, (t, p)
+    assert keys >= (frames + gop - 1) // gop
+    # the same file through the command-line decoder (its PSNR report against the synthetic source)
+    rep = _run(os.path.join(ROOT, "scripts", "decode_ivf.py"), str(ivf), "--synth-seed", "1", "--out", str(tmp_path / "dec.yuv"))
+    assert "lowest luma PSNR" in rep and os.path.getsize(tmp_path / "dec.yuv") == frames * seq.W * seq.H * 3 // 2
