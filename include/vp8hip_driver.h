@@ -5,8 +5,8 @@
  * The reference host is C++ and this is its C++ counterpart (vp8oclenc_amd/csrc/vp8_driver.cpp): frame-type
  * state machine, per-frame loop-filter strength and segment data, key frames (intra_transform), inter_transform,
  * check_SSIM with its intra fallback, its filter-parameter update and its "redo as key frame" decision, filter
- * mask, loop filter -- in the reference's order, every stage on the device.  Not here: scene_change()'s decision
- * (the caller passes force_key; vp8hip_chroma_change + vp8host_scene_change produce it), the header/MV entropy
+ * mask, loop filter -- in the reference's order, every stage on the device.  scene_change()'s decision is the caller's
+ * (force_key; vp8hip_chroma_change + vp8host_scene_change produce it) or, with cfg.scene_detect, made here the same way.  Not here: the header/MV entropy
  * coder and the container.
  * vp8oclenc_amd/driver.py is the same loop in Python for the parity tests (it also runs the CPU oracle).
  */
@@ -47,9 +47,13 @@ typedef struct {
     int32_t conformant_stream;   /* 1 = vp8hip_conformant_stream: the stream decodes to the encoder's own reconstruction (the
                                 format's predictor, the kept attempt's modes); 0 = the reference's stream, byte for byte.
                                 Default 0 */
+    int32_t scene_detect;        /* 1: scene_change() (vp8enc.cpp:265-311, 408-416) inside the loop: the chroma differences to the
+                                previous input frame on the device (vp8hip_chroma_change; blocks for two words per frame),
+                                the decision with its hold-over on the host (vp8host_scene_change); a detected cut is coded
+                                as a key frame.  0 (default): the caller's force_key alone decides */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);
@@ -98,6 +102,7 @@ typedef struct {
     int32_t redone_as_key;            /* inter frames recoded as key frames by check_SSIM's verdict (vp8enc.cpp:443-453) */
     int32_t last_replaced;            /* frames.replaced, frames.new_SSIM and min1 of the last check_SSIM */
     float last_new_ssim, last_min_ssim;
+    int32_t scene_changes;            /* encStat.scene_changes_by_color: key frames forced by scene_detect (vp8enc.cpp:411) */
 } vp8drv_stats;
 void vp8drv_get_stats(const vp8drv *d, vp8drv_stats *s);
 

@@ -253,3 +253,49 @@ def test_intra_wavefront_waits_are_bounded():
     exp = oracle_intra().intra_transform(cur, sd)
     assert np.array_equal(r["prefilter_Y"], exp["recon_Y"]) and np.array_equal(r["MB_coeffs"][:, :24], exp["MB_coeffs"][:, :24])
     enc.close()
+
+
+def test_native_frame_loop_detects_scene_cuts_itself():
+    """vp8drv_config.scene_detect: scene_change() (vp8enc.cpp:265-311, 408-416) inside the native loop -- chroma differences on
+    the device, decision with its hold-over on the host.  Against the same decision made outside (numpy on the source planes +
+    vp8host_scene_change) and handed to a second driver as force_key: the same key frames, the same bytes.  The sequence has
+    two cuts three frames apart (the second one falls into the "no two forced key frames within 4 frames" rule and comes out of
+    the hold-over later) and a GOP boundary."""
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H = 320, 192
+    a, b, c = (SynthSequence(W, H, seed=s) for s in (3, 50, 77))
+    def tint(planes, du, dv):
+        y, u, v = planes
+        return y, np.clip(u.astype(int) + du, 0, 255).astype(np.uint8), np.clip(v.astype(int) + dv, 0, 255).astype(np.uint8)
+    frames = [a.frame(t) for t in range(5)] + [tint(b.frame(t), 40, -30) for t in range(3)] + [tint(c.frame(t), -35, 25) for t in range(9)]
+    cfg = dict(gop_size=12, altref_range=3, num_partitions=2)
+    auto = api.NativeDriver(W, H, scene_detect=1, **cfg)
+    manual = api.NativeDriver(W, H, **cfg)
+    st = api.SceneState(0, 0)
+    gop = api.Gop(12, 3)
+    prev = None
+    forced, keys = [], []
+    for t, (y, u, v) in enumerate(frames):
+        g = gop.next()
+        force = False
+        if not g.current_is_key:
+            ud = int(np.abs(prev[1].astype(np.int64) - u).sum() // u.size)
+            vd = int(np.abs(prev[2].astype(np.int64) - v).sum() // v.size)
+            force = api.scene_change(st, ud, vd, t)
+        if g.current_is_key or force:
+            st.last_key_detect = t                      # intra_transform, intra_part.h:1093
+            gop.key_coded()
+        gop.frame_done()
+        prev = (y, u, v)
+        k1 = auto.encode_frame_host(y, u, v)
+        k2 = manual.encode_frame_host(y, u, v, force_key=force)
+        assert k1 == k2 == bool(g.current_is_key or force), t
+        assert auto.get_frame() == manual.get_frame(), t
+        forced.append(force)
+        keys.append(k1)
+    assert forced[5] and sum(forced) == 2 and forced.index(True, 6) >= 9, forced       # the second cut waits for the hold-over
+    assert auto.stats().scene_changes == 2 and manual.stats().scene_changes == 0
+    assert keys[0] and sum(keys) >= 3
+    with pytest.raises(api.Vp8HipError):               # the batched loop never blocks: it takes force_key only
+        api.NativeBatch([auto, api.NativeDriver(W, H, scene_detect=1, **cfg)])
+    auto.close(); manual.close()

@@ -210,14 +210,14 @@ class DrvConfig(C.Structure):
                 ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32),
                 ("num_partitions", C.c_int32), ("display_width", C.c_int32), ("display_height", C.c_int32),
                 ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32), ("ref_mask", C.c_int32),
-                ("conformant_stream", C.c_int32)]
+                ("conformant_stream", C.c_int32), ("scene_detect", C.c_int32)]
 
 
 class DrvStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame_number", "inter_frames", "key_frames", "last_use_golden",
                                           "last_use_altref", "last_prev_is_golden", "last_prev_is_altref",
                                           "last_was_altref", "redone_as_key", "last_replaced")] + \
-               [("last_new_ssim", C.c_float), ("last_min_ssim", C.c_float)]
+               [("last_new_ssim", C.c_float), ("last_min_ssim", C.c_float), ("scene_changes", C.c_int32)]
 
 
 class NativeDriver:

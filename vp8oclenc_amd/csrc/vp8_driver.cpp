@@ -13,6 +13,7 @@ struct vp8drv {
     vp8drv_config cfg{};
     int W = 0, H = 0, mbs = 0;
     vp8host_gop gop{};
+    vp8host_scene_state scene{};     // scene_change()'s hold-over and frames.last_key_detect
     int32_t lastqi[4]{}, altrefqi[4]{};
     int qi_min = 0;
     vp8drv_stats st{};
@@ -44,6 +45,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->overlap_filter = 0;
     c->ref_mask = 3;
     c->conformant_stream = 0;
+    c->scene_detect = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -107,6 +109,7 @@ int segments(vp8drv *d, const uint8_t *host_y, bool key, const int32_t *refqi) {
 int key_frame(vp8drv *d, const uint8_t *host_y) {
     DRV_CHK(segments(d, host_y, true, d->altrefqi));
     DRV_CHK(vp8hip_intra_transform(d->hip));
+    d->scene.last_key_detect = d->gop.frame_number;       // intra_part.h:1093, for every key frame whoever asked for it
     vp8host_gop_key_coded(&d->gop);
     DRV_CHK(vp8hip_prepare_filter_mask(d->hip, nullptr));
     DRV_CHK(vp8hip_loop_filter(d->hip));
@@ -122,6 +125,14 @@ int key_frame(vp8drv *d, const uint8_t *host_y) {
 
 // the loop body once the current frame is on the device; host_y: the caller's luma plane or nullptr
 int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
+    if (!key && d->cfg.scene_detect) {     // vp8enc.cpp:408-416: only frames that would be inter frames are looked at
+        int32_t Udiff = 0, Vdiff = 0;
+        DRV_CHK(vp8hip_chroma_change(d->hip, &Udiff, &Vdiff));
+        if (vp8host_scene_change(&d->scene, Udiff, Vdiff, d->gop.frame_number)) {
+            d->st.scene_changes++;
+            key = true;
+        }
+    }
     if (key) return key_frame(d, host_y);
     // vp8enc.cpp:390, 419: loop-filter strength of the current frame -> segment data
     const int32_t *refqi = d->gop.current_is_altref ? d->altrefqi : d->lastqi;   // vp8enc.cpp:149-151
@@ -293,7 +304,8 @@ int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n) {
     vp8hip_ctx *ctx[VP8HIP_MAX_BATCH];
     for (int i = 0; i < n; ++i) {
         // the batched loop is the device-parameter loop without check_SSIM (what bench.py and a file-to-file transcode run)
-        if (!drv[i] || !drv[i]->cfg.device_params || drv[i]->cfg.check_ssim || drv[i]->cfg.overlap_filter) return VP8HIP_ERR_ARG;
+        if (!drv[i] || !drv[i]->cfg.device_params || drv[i]->cfg.check_ssim || drv[i]->cfg.overlap_filter || drv[i]->cfg.scene_detect)
+            return VP8HIP_ERR_ARG;
         ctx[i] = drv[i]->hip;
     }
     vp8drv_batch *b = new (std::nothrow) vp8drv_batch();
