@@ -142,6 +142,14 @@ int vp8hip_download_intra(vp8hip_ctx *ctx, int32_t *modes, int32_t *is_inter_mb)
  * modes of the attempt that was KEPT; the output is then no longer the reference's byte for byte wherever one of the two
  * cases occurs (and identical where none does).  All members of a batch must agree. */
 int vp8hip_conformant_stream(vp8hip_ctx *ctx, int on);
+/* copy_with_padding(), encIO.h:141-196, on the device: after this call the planes handed to vp8hip_upload_current /
+ * vp8hip_set_current_device / vp8hip_batch_set_current_device are tight planes of src_width x src_height (both even, less than
+ * 16 below the coded size the context was created with -- 1920x1080 for a 1920x1088 context), and the step that brings them
+ * into the context's surfaces repeats the last row downwards and every row's last sample to the right.  0, 0 = back to planes
+ * of the coded size.  (Reconstruction planes -- vp8hip_upload_last, vp8hip_set_last_device, downloads -- always have the coded
+ * size.)  Identical to the reference whenever the width needs no padding, which covers every BASELINE config; for other
+ * widths the reference never writes V's right padding (:180-183 read and write U instead) and this is what it means. */
+int vp8hip_set_source_size(vp8hip_ctx *ctx, int src_width, int src_height);
 
 /* prepare_filter_mask_and_non_zero_coeffs(), loop_filter.h:25-55.  nz_out: [MBs] or NULL.
  * (vp8hip_inter_transform already produced mask and counts for its own coefficients; this call
@@ -324,7 +332,8 @@ typedef enum {
     VP8HIP_DBG_PYRAMID,    /* ref(3=cur), level 0..4 : tight (W>>l)x(H>>l) plane                   */
     VP8HIP_DBG_MB_MASK,    /* -           : int[MBs]                                              */
     VP8HIP_DBG_MB_NZ,      /* -           : int[MBs]                                              */
-    VP8HIP_DBG_THIRD_CONTEXT /* -         : uchar[MBs][25] (entries of coded macroblocks, after vp8hip_count_probs) */
+    VP8HIP_DBG_THIRD_CONTEXT, /* -        : uchar[MBs][25] (entries of coded macroblocks, after vp8hip_count_probs) */
+    VP8HIP_DBG_CURRENT_CHROMA /* ref 0 = U, 1 = V : tight (W/2)x(H/2) plane of the current frame (after copy_with_padding) */
 } vp8hip_debug_id;
 int vp8hip_debug_download(vp8hip_ctx *ctx, int what, int ref, int level, void *dst, size_t bytes);
 

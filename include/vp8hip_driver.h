@@ -51,9 +51,14 @@ typedef struct {
                                 previous input frame on the device (vp8hip_chroma_change; blocks for two words per frame),
                                 the decision with its hold-over on the host (vp8host_scene_change); a detected cut is coded
                                 as a key frame.  0 (default): the caller's force_key alone decides */
+    int32_t src_width, src_height;   /* size of the frames handed to vp8drv_encode_frame_* when it is below the coded size
+                                (video.src_* against video.wrk_*, init.h:375-392): copy_with_padding (encIO.h:141-196) then
+                                runs on the device (vp8hip_set_source_size) and key frames carry this size as the display
+                                size unless display_width/height say otherwise.  0 = frames of the coded size.  Needs
+                                device_params = 1 */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0, 0, 0, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);

@@ -111,6 +111,23 @@ int ref_pick_luma_predictor(const uint8_t *orig, uint8_t *pred, int16_t *resid, 
 }
 }
 
+/* copy_with_padding, src/encIO.h:141-196: the reference's own function on the caller's planes (source planes tight at
+ * src_w x src_h, destination planes tight at w x h, pre-filled by the caller so that what the function never writes shows) */
+extern "C" void ref_copy_with_padding(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int src_w, int src_h, uint8_t *dy,
+                                      uint8_t *du, uint8_t *dv, int w, int h) {
+    video.src_width = src_w;
+    video.src_height = src_h;
+    video.wrk_width = w;
+    video.wrk_height = h;
+    frames.tmp_Y = const_cast<uint8_t *>(sy);
+    frames.tmp_U = const_cast<uint8_t *>(su);
+    frames.tmp_V = const_cast<uint8_t *>(sv);
+    frames.current_Y = dy;
+    frames.current_U = du;
+    frames.current_V = dv;
+    copy_with_padding();
+}
+
 /* ---- frame header / first partition (src/entropy_host.cpp), container (src/encIO.h) ------------------------------- */
 extern "C" {
 

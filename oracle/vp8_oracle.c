@@ -179,6 +179,21 @@ static void interp4x4_sat(const uint8_t *ref, int w, int h, int ix, int iy, int 
         }
 }
 
+/* copy_with_padding, src/encIO.h:141-196 (see vp8_oracle.h for the chroma lines) */
+static void pad_plane(const uint8_t *s, int sw, int sh, uint8_t *d, int w, int h) {
+    for (int y = 0; y < sh; ++y) {                       /* :152-185: copy a line, extend it to the right with its last sample */
+        memcpy(d + (size_t)y * w, s + (size_t)y * sw, (size_t)sw);
+        for (int x = sw; x < w; ++x) d[(size_t)y * w + x] = s[(size_t)y * sw + sw - 1];
+    }
+    for (int y = sh; y < h; ++y) memcpy(d + (size_t)y * w, d + (size_t)(sh - 1) * w, (size_t)w);   /* :186-200: last line downwards */
+}
+void vp8o_copy_with_padding(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int src_w, int src_h, uint8_t *dy, uint8_t *du,
+                            uint8_t *dv, int w, int h) {
+    pad_plane(sy, src_w, src_h, dy, w, h);
+    pad_plane(su, src_w / 2, src_h / 2, du, w / 2, h / 2);
+    pad_plane(sv, src_w / 2, src_h / 2, dv, w / 2, h / 2);
+}
+
 int vp8o_conformant = 0;   /* see vp8_oracle.h: NOT the reference, off by default */
 void vp8o_set_conformant_stream(int on) { vp8o_conformant = on; }
 

@@ -153,6 +153,12 @@ void vp8o_upload_recon(vp8o_ctx *c, const uint8_t *y, const uint8_t *u, const ui
 const int16_t *vp8o_debug_net(const vp8o_ctx *c, int ref, int which /*1 or 2*/);
 const int32_t *vp8o_debug_bdiff(const vp8o_ctx *c, int ref);
 const uint8_t *vp8o_debug_pyramid(const vp8o_ctx *c, int ref /*0..2, 3 = current*/, int level /*0..4 = 1x..1/16*/);
+/* copy_with_padding, src/encIO.h:141-196: tight src_w x src_h planes -> tight w x h planes (w, h = the padded "wrk" size).
+ * Y, U and the bottom rows as the reference has them; the right padding of V as the reference MEANS it (its V lines,
+ * :180-183, read from U and write into U's next row, so with a width that needs padding V's is never written -- undefined,
+ * and none of BASELINE's configs has such a width; pinned and shown in tests/test_padding.py). */
+void vp8o_copy_with_padding(const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int src_w, int src_h, uint8_t *dy, uint8_t *du,
+                            uint8_t *dv, int w, int h);
 int vp8o_num_threads(void);
 void vp8o_set_num_threads(int n);
 /* NOT the reference, default 0.  1 = the two places where the reference's encoder and a decoder of its stream part ways

@@ -4,8 +4,9 @@
     python scripts/encode_ivf.py out.ivf [--yuv in.yuv] [--width 1920 --height 1080 --frames 120 --gop 30 --partitions 4]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/encode_ivf.py out.ivf ...
 
-Without --yuv the synthetic sequence of the tests is used.  A raw I420 file must have the given width/height (multiples
-of 16: padding is the caller's job, as it is copy_with_padding's in the reference, encIO.h:141-196)."""
+Without --yuv the synthetic sequence of the tests is used.  A raw I420 file has the given width/height (even numbers); when
+they are not multiples of 16 the frames are padded on the device (vp8hip_set_source_size = copy_with_padding, encIO.h:141-196)
+and the key frames carry the source size as display size."""
 import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,9 +47,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     seq = YuvFile(a.yuv, a.width, a.height) if a.yuv else SynthSequence(a.width, a.height, seed=1)
     frames = min(a.frames, seq.n) if a.yuv else a.frames
+    Wc, Hc = (seq.W + 15) // 16 * 16, (seq.H + 15) // 16 * 16            # the coded ("wrk") size, init.h:375-392
+    src = dict(src_width=seq.W, src_height=seq.H) if (Wc, Hc) != (seq.W, seq.H) else {}
     t0 = time.perf_counter()
     mine = gop_shard.encode_chunks_frames(
-        lambda: gop_shard.NativeEncoder(seq.W, seq.H, device=local, num_partitions=a.partitions, qi_min=a.qmin, qi_max=a.qmax,
+        lambda: gop_shard.NativeEncoder(Wc, Hc, device=local, **src, num_partitions=a.partitions, qi_min=a.qmin, qi_max=a.qmax,
                                         ssim_target=a.ssim_target, check_ssim=1, conformant_stream=int(a.conformant)),
         seq, gop_shard.chunks_of_rank(frames, a.gop, rank, world))
     allf = gop_shard.gather_frames(mine, frames, dist)

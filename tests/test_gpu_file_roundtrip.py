@@ -23,12 +23,22 @@ def _run(*args):
     (320, 192, 12, 5, [], 31.0),
     (640, 352, 8, 4, ["--partitions", "4", "--qmin", "40", "--qmax", "100"], 29.0),
     (320, 192, 10, 5, ["--conformant", "--ssim-target", "0.92", "--qmin", "40", "--qmax", "110", "--partitions", "2"], 29.0),
+    (500, 300, 7, 4, ["--partitions", "2"], 31.0),          # not multiples of 16: padded on the device, display size in the key frames
 ])
 def test_encode_ivf_then_decode_gives_the_pictures_back(tmp_path, W, H, frames, gop, extra, floor):
     import decode_ivf
     import vp8_decode
     from vp8oclenc_amd.synth import SynthSequence
     seq = SynthSequence(W, H, seed=1)
+    if W % 16 or H % 16:      # the synthetic source is made at multiples of 16: cut the picture out of a larger one
+        big = SynthSequence(W + 16, H + 16, seed=1)
+
+        class Crop:
+            def frame(self, t):
+                y, u, v = big.frame(t)
+                return (np.ascontiguousarray(y[:H, :W]), np.ascontiguousarray(u[:H // 2, :W // 2]), np.ascontiguousarray(v[:H // 2, :W // 2]))
+        seq = Crop()
+        seq.W, seq.H = W, H
     yuv = tmp_path / "in.yuv"
     with open(yuv, "wb") as f:                       # the raw I420 file the reference reads (encIO.h:141-196)
         for t in range(frames):
@@ -47,9 +57,11 @@ def test_encode_ivf_then_decode_gives_the_pictures_back(tmp_path, W, H, frames, 
         keys += int(f.key)
         assert f.key == (t % gop == 0) or "--ssim-target" in extra, t          # GOP chunks start with their key frame
         y, u, v = seq.frame(t)
+        Y, U, V = Y[:seq.H, :seq.W], U[:seq.H // 2, :seq.W // 2], V[:seq.H // 2, :seq.W // 2]      # the display size
+        assert (f.width, f.height) == (seq.W, seq.H) or not f.key
         p = decode_ivf.psnr(Y, y)
         assert p > floor and decode_ivf.psnr(U, u) > floor and decode_ivf.psnr(V, v) > floor, (t, p)
     assert keys >= (frames + gop - 1) // gop
     # the same file through the command-line decoder (its PSNR report against the synthetic source)
-    rep = _run(os.path.join(ROOT, "scripts", "decode_ivf.py"), str(ivf), "--synth-seed", "1", "--out", str(tmp_path / "dec.yuv"))
+    rep = _run(os.path.join(ROOT, "scripts", "decode_ivf.py"), str(ivf), "--yuv", str(yuv), "--out", str(tmp_path / "dec.yuv"))
     assert "lowest luma PSNR" in rep and os.path.getsize(tmp_path / "dec.yuv") == frames * seq.W * seq.H * 3 // 2

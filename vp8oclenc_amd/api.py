@@ -17,7 +17,7 @@ K_NAMES = ["pack", "downsample", "search1_l4", "search1_l3", "search1_l2", "sear
            "select", "mb", "filter_mask", "loop_filter", "border", "ent_count", "ent_encode", "intra", "hdr_encode"]
 K_COUNT = len(K_NAMES)
 
-DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT = range(7)
+DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CONTEXT, DBG_CURRENT_CHROMA = range(8)
 
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
@@ -210,7 +210,8 @@ class DrvConfig(C.Structure):
                 ("ssim_target", C.c_float), ("device_params", C.c_int32), ("check_ssim", C.c_int32),
                 ("num_partitions", C.c_int32), ("display_width", C.c_int32), ("display_height", C.c_int32),
                 ("host_bitstream", C.c_int32), ("overlap_filter", C.c_int32), ("ref_mask", C.c_int32),
-                ("conformant_stream", C.c_int32), ("scene_detect", C.c_int32)]
+                ("conformant_stream", C.c_int32), ("scene_detect", C.c_int32),
+                ("src_width", C.c_int32), ("src_height", C.c_int32)]
 
 
 class DrvStats(C.Structure):
@@ -474,6 +475,12 @@ class Vp8Hip:
         """intra_transform (intra_part.h:1089-1109): the current frame as a key frame, on the device."""
         self._chk(self.lib.vp8hip_intra_transform(self.h), "intra_transform")
 
+    def set_source_size(self, src_width: int, src_height: int):
+        """copy_with_padding on the device: current frames come as tight planes of this size (include/vp8hip.h)"""
+        self.lib.vp8hip_set_source_size.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._chk(self.lib.vp8hip_set_source_size(self.h, int(src_width), int(src_height)), "set_source_size")
+        self.src = (int(src_width), int(src_height))
+
     def conformant_stream(self, on: bool = True):
         """NOT the reference: the stream decodes to the encoder's own reconstruction (include/vp8hip.h)"""
         self.lib.vp8hip_conformant_stream.argtypes = [C.c_void_p, C.c_int]
@@ -620,6 +627,8 @@ class Vp8Hip:
             a = np.zeros((self.H >> level, self.W >> level), np.uint8)
         elif what == DBG_THIRD_CONTEXT:
             a = np.zeros((self.mbs, 25), np.uint8)
+        elif what == DBG_CURRENT_CHROMA:
+            a = np.zeros((self.H // 2, self.W // 2), np.uint8)
         else:
             a = np.zeros(self.mbs, np.int32)
         self._chk(self.lib.vp8hip_debug_download(self.h, what, ref, level, a.ctypes.data, a.nbytes), "debug_download")

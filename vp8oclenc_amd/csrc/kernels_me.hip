@@ -142,7 +142,12 @@ void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uin
 // and under load it is the dispatch of workgroups, not the copying, that such a launch waits for (same box, headline with 1 / 8 /
 // 16 / 32 units per thread: 62.0 / 62.4 / 62.5 / 62.5 M MB/s).
 // ------------------------------------------------------------------------------------------------
-struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; };
+// The source may be smaller than the coded ("wrk") size -- 1920x1080 in, 1920x1088 coded: copy_with_padding, encIO.h:141-196,
+// happens here.  Rows below the source repeat its last row, samples to its right repeat the row's last sample (what the
+// reference does for Y and U and means for V: its V lines read and write U, :180-183, so V's right padding is never
+// written -- which bites only when the width is not a multiple of 16, none of BASELINE's configs; there this is the
+// intended result, not the reference's undefined one; tests/test_padding.py shows both).  sw, sh: luma size of the source; ssy, ssc: its row strides.
+struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; int sw, sh, ssy, ssc; };
 __device__ __forceinline__ void pack_body(const PackItem &a, int per) {
     const Plane &py = a.py, &pu = a.pu, &pv = a.pv;
     const uint8_t *sy = a.sy, *su = a.su, *sv = a.sv;
@@ -151,16 +156,28 @@ __device__ __forceinline__ void pack_body(const PackItem &a, int per) {
         int i = ((int)blockIdx.x * per + k) * 256 + (int)threadIdx.x;
         const Plane *pl = &py;
         const uint8_t *src = sy;
+        int sw = a.sw, sh = a.sh, ss = a.ssy;
         if (i >= ny) {
             i -= ny;
             pl = &pu;
             src = su;
+            sw >>= 1; sh >>= 1; ss = a.ssc;
             if (i >= nc) { i -= nc; pl = &pv; src = sv; }
             if (i >= nc) return;
         }
         const int upr = pl->w >> 3;     // 8-byte units per row
         const int y = i / upr, x = (i % upr) * 8;
-        *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = *reinterpret_cast<const uint2 *>(src + (size_t)y * pl->w + x);
+        const uint8_t *row = src + (size_t)(y < sh ? y : sh - 1) * ss;
+        uint2 v;
+        if (x + 8 <= sw && ((ss | (int)(reinterpret_cast<uintptr_t>(src) & 7)) & 7) == 0) {
+            v = *reinterpret_cast<const uint2 *>(row + x);
+        } else {          // the unit hangs over the source's right edge, or the source rows are not 8-byte aligned
+            uint32_t w[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j >> 2] |= (uint32_t)row[x + j < sw ? x + j : sw - 1] << (8 * (j & 3));
+            v = make_uint2(w[0], w[1]);
+        }
+        *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = v;
     }
 }
 
@@ -170,20 +187,26 @@ static int pack_units_per_thread() {
     return per;
 }
 
-void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v) {
+static PackItem pack_item(const Frame &f, const void *y, const void *u, const void *v, int sw, int sh, int ssy, int ssc) {
+    if (sw <= 0) { sw = f.Y[0].w; sh = f.Y[0].h; }
+    if (ssy <= 0) { ssy = sw; ssc = sw >> 1; }
+    return PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v, sw, sh, ssy, ssc};
+}
+void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v, int sw, int sh, int ssy, int ssc) {
     const int n = (f.Y[0].w >> 3) * f.Y[0].h + 2 * ((f.U.w >> 3) * f.U.h);
     // (a batch of one: the by-value form of the kernel picks the plane through a pointer into its argument block, which hipcc
     // answers by copying the block to scratch memory)
     BatchOf<PackItem> b;
     b.n = 1;
-    b.item[0] = PackItem{f.Y[0], f.U, f.V, (const uint8_t *)y, (const uint8_t *)u, (const uint8_t *)v};
+    b.item[0] = pack_item(f, y, u, v, sw, sh, ssy, ssc);
     const int per = pack_units_per_thread();
     VP8_LAUNCH(k_pack_b, dim3((n + 256 * per - 1) / (256 * per), 1, 1), dim3(256), 0, s, b, per);
 }
-void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n) {
+void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n,
+                       int sw, int sh) {
     BatchOf<PackItem> b;
     b.n = n;
-    for (int i = 0; i < n; ++i) b.item[i] = PackItem{f[i]->Y[0], f[i]->U, f[i]->V, (const uint8_t *)y[i], (const uint8_t *)u[i], (const uint8_t *)v[i]};
+    for (int i = 0; i < n; ++i) b.item[i] = pack_item(*f[i], y[i], u[i], v[i], sw, sh, 0, 0);
     const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
     static const bool skip = [] { const char *e = getenv("VP8HIP_EXPERIMENT_SKIP"); return e && strstr(e, "pack") != nullptr; }();
     if (skip) return;   // timing experiment only

@@ -46,6 +46,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->ref_mask = 3;
     c->conformant_stream = 0;
     c->scene_detect = 0;
+    c->src_width = c->src_height = 0;
 }
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg) {
@@ -61,6 +62,16 @@ int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const
     }
     if (cfg->overlap_filter) vp8hip_filter_overlap(d->hip, 1);
     if (cfg->conformant_stream) vp8hip_conformant_stream(d->hip, 1);
+    if (cfg->src_width || cfg->src_height) {
+        const int rc = cfg->device_params ? vp8hip_set_source_size(d->hip, cfg->src_width, cfg->src_height) : VP8HIP_ERR_ARG;
+        if (rc != VP8HIP_OK) {
+            vp8hip_destroy(d->hip);
+            delete d;
+            return rc;
+        }
+        if (!d->cfg.display_width) d->cfg.display_width = cfg->src_width;       // video.dst_width/height = the source's
+        if (!d->cfg.display_height) d->cfg.display_height = cfg->src_height;
+    }
     d->W = width;
     d->H = height;
     d->mbs = (width / 16) * (height / 16);

@@ -59,6 +59,7 @@ struct vp8hip_ctx {
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
+    int src_w = 0, src_h = 0;       // vp8hip_set_source_size: size of the planes handed over as current frames (0 = coded size)
     int conformant = 0;             // vp8hip_conformant_stream (NOT the reference; off by default)
     int lf_stall_test = 0;          // test hook (vp8hip_debug_lf_stall): make the next loop filters / intra wavefronts time out
     void *scratch = nullptr;        // device staging for debug pyramid downloads
@@ -214,10 +215,20 @@ int copy_out(vp8hip_ctx *c, void *dst, const Plane &src) {
     return VP8HIP_OK;
 }
 
-int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, const void *v, hipMemcpyKind kind) {
+// sw, sh: size of the planes that come in (0 = the coded size): the current frames of a context with a source size
+int set_frame_planes(vp8hip_ctx *c, Frame &f, const void *y, const void *u, const void *v, hipMemcpyKind kind, int sw = 0, int sh = 0) {
     Timed t(c, VP8HIP_K_PACK);
     if (kind == hipMemcpyDeviceToDevice) {
-        launch_pack(c->stream, f, y, u, v);
+        launch_pack(c->stream, f, y, u, v, sw, sh);
+        return VP8HIP_OK;
+    }
+    if (sw > 0) {
+        // the source rectangle into the surface, then copy_with_padding in place: the pack kernel with the surface as its own
+        // source (samples inside the rectangle are rewritten with themselves, the rest repeats the rectangle's edge)
+        HIPCHK(c, hipMemcpy2DAsync(f.Y[0].p, f.Y[0].stride, y, sw, sw, sh, kind, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(f.U.p, f.U.stride, u, sw / 2, sw / 2, sh / 2, kind, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(f.V.p, f.V.stride, v, sw / 2, sw / 2, sh / 2, kind, c->stream));
+        launch_pack(c->stream, f, f.Y[0].p, f.U.p, f.V.p, sw, sh, f.Y[0].stride, f.U.stride);
         return VP8HIP_OK;
     }
     int rc;
@@ -496,7 +507,7 @@ int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, con
     USE_DEVICE(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
-    int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice);
+    int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice, c->src_w, c->src_h);
     if (rc) return rc;
     // pageable host memory: the call must not return while the copy still reads the host buffer
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -507,7 +518,19 @@ int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const
     USE_DEVICE(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
     next_current(c);
-    return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice);
+    return set_frame_planes(c, c->cur, y, u, v, hipMemcpyDeviceToDevice, c->src_w, c->src_h);
+}
+
+int vp8hip_set_source_size(vp8hip_ctx *c, int src_width, int src_height) {
+    if (!c) return VP8HIP_ERR_ARG;
+    if (src_width == 0 && src_height == 0) { c->src_w = c->src_h = 0; return VP8HIP_OK; }
+    if (src_width <= 0 || src_height <= 0 || (src_width & 1) || (src_height & 1) || src_width > c->W || src_height > c->H ||
+        c->W - src_width >= 16 || c->H - src_height >= 16)
+        return VP8HIP_ERR_ARG;
+    const bool same = src_width == c->W && src_height == c->H;
+    c->src_w = same ? 0 : src_width;
+    c->src_h = same ? 0 : src_height;
+    return VP8HIP_OK;
 }
 
 int vp8hip_loopfilter_strength(vp8hip_ctx *c, int32_t *reductor, int32_t *sharpness) {
@@ -770,7 +793,8 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     *out = nullptr;
     for (int i = 0; i < n; ++i)
         if (!ctxs[i] || ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->device != ctxs[0]->device ||
-            ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap || ctxs[i]->conformant != ctxs[0]->conformant)
+            ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap || ctxs[i]->conformant != ctxs[0]->conformant ||
+            ctxs[i]->src_w != ctxs[0]->src_w || ctxs[i]->src_h != ctxs[0]->src_h)
             return VP8HIP_ERR_ARG;
     vp8hip_batch *b = new (std::nothrow) vp8hip_batch();
     if (!b) return VP8HIP_ERR_ARG;
@@ -825,6 +849,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
         if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
+        if (b->c[i]->src_w != c0->src_w || b->c[i]->src_h != c0->src_h) return VP8HIP_ERR_ARG;   // one launch, one source size
         next_current(b->c[i]);
         f[n] = &b->c[i]->cur;
         py[n] = y[i]; pu[n] = u[i]; pv[n] = v[i];
@@ -832,7 +857,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
     }
     if (!n) return VP8HIP_OK;
     Timed t(c0, VP8HIP_K_PACK);
-    launch_pack_batch(b->stream, f, py, pu, pv, n);
+    launch_pack_batch(b->stream, f, py, pu, pv, n, c0->src_w, c0->src_h);
     HIPCHK(c0, hipGetLastError());
     return VP8HIP_OK;
 }
@@ -1652,6 +1677,14 @@ int vp8hip_debug_download(vp8hip_ctx *c, int what, int ref, int level, void *dst
             if (bytes != (size_t)c->mbs * 25) return VP8HIP_ERR_ARG;
             HIPCHK(c, hipMemcpyAsync(dst, c->ent_third, bytes, hipMemcpyDeviceToHost, s));
             break;
+        case VP8HIP_DBG_CURRENT_CHROMA: {
+            if (ref < 0 || ref > 1 || c->cur_count == 0) return VP8HIP_ERR_ARG;
+            const Plane &p = ref ? c->cur.V : c->cur.U;
+            if (bytes != (size_t)p.w * p.h) return VP8HIP_ERR_ARG;
+            int rc = copy_out(c, dst, p);
+            if (rc) return rc;
+            break;
+        }
         case 100:  // diagnostic build only (-DLF2_STAMPS): cycle sums written by the loop filter
             if (bytes != 512) return VP8HIP_ERR_ARG;
             HIPCHK(c, hipMemcpyAsync(dst, (const char *)c->d_progress + 4096, 512, hipMemcpyDeviceToHost, s));

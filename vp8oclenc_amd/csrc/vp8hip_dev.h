@@ -112,10 +112,12 @@ int persistent_workgroups();
 void launch_border(hipStream_t s, const Frame &f);
 // all four levels of one or two frames; bit z of border_mask: also the replicated edges of surface z (launch_border's work, same launch)
 void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t border_mask = 0);
-void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v);
+// sw, sh: luma size of the source planes (0 = the coded size); ssy, ssc: their row strides (0 = tight)
+void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v, int sw = 0, int sh = 0, int ssy = 0, int ssc = 0);
 // batched forms: n <= MAX_BATCH contexts (pyramid: nframes <= 2 * MAX_BATCH surfaces)
 void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask = 0);
-void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n);
+void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n,
+                       int sw = 0, int sh = 0);
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
                           int net_width, int n);
 void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n,
