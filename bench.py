@@ -136,13 +136,26 @@ class Leg:
         self.mbs = (self.W // 16) * (self.H // 16)
         self.G, self.nd, self.refs = G, nd, refs
         self.host_frames = [seq.frame(t) for t in range(nd)]
-        self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in self.host_frames]
+        # a source below the coded size (1920x1080 in a 1920x1088 context) is handed over as it is: copy_with_padding
+        # (encIO.h:141-196) runs inside the launch that takes a frame in, i.e. inside every timed step (vp8hip_set_source_size)
+        src = {}
+        if (W0, H0) != (self.W, self.H) and W0 % 2 == 0 and H0 % 2 == 0 and self.W - W0 < 16 and self.H - H0 < 16:
+            import numpy as np
+            source = [(np.ascontiguousarray(y[:H0, :W0]), np.ascontiguousarray(u[:H0 // 2, :W0 // 2]), np.ascontiguousarray(v[:H0 // 2, :W0 // 2]))
+                      for y, u, v in self.host_frames]
+            pad = lambda p, h, w: np.pad(p, ((0, h - p.shape[0]), (0, w - p.shape[1])), mode="edge")
+            self.host_frames = [(pad(y, self.H, self.W), pad(u, self.H // 2, self.W // 2), pad(v, self.H // 2, self.W // 2)) for y, u, v in source]   # what the CPU baseline codes
+            src = dict(src_width=W0, src_height=H0)
+        else:
+            source = self.host_frames
+        self.source_size = (W0, H0) if src else (self.W, self.H)
+        self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in source]
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
         self.drv, self.t, self.batches = [], [], []
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
                                  ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
-                                 overlap_filter=overlap_filter)
+                                 overlap_filter=overlap_filter, **src)
             t = (k * 3) % nd                                   # chunks start at different frames of the sequence
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
             self.drv.append(d)
@@ -404,7 +417,8 @@ def main():
                                    f"(avg {nrefs_avg:.2f} refs/frame, GOP steady state), loop filter on GPU, {G} GOP chunk(s) in flight per GPU"
                                    + (f", {B} chunks per batched launch ({(G + B - 1) // B} streams)" if B > 1 else ""),
                        "step": f"one inter frame on each of the {G} GOP chunks = {G} frames per GPU",
-                       "wrk_size": [W, H], "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": list(api.quantizer_ladders(0, 48)[0]),
+                       "wrk_size": [W, H], "source_size": list(leg.source_size), "padding": "on the device, inside the step (copy_with_padding)" if tuple(leg.source_size) != (W, H) else "none needed",
+                       "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": list(api.quantizer_ladders(0, 48)[0]),
                        "altref_range": ALTREF_RANGE, "preroll_frames_per_chunk": f"{PREROLL}..{PREROLL + ALTREF_RANGE - 1}", "frames_per_gpu": frames_per_gpu,
                        "gops_per_gpu": G, "chunks_per_batched_launch": B, "refs_per_frame": round(nrefs_avg, 3),
                        "ms_per_frame": round(ms_frame, 5),
