@@ -33,7 +33,11 @@ typedef enum {
     VP8HIP_ERR_ARCH = -5,      /* device is not gfx950: the kernels are built for MI355X only */
     VP8HIP_ERR_TIMEOUT = -6,   /* a bounded device-side wait of the loop filter expired: the frame is invalid
                                   (reported by vp8hip_synchronize / vp8hip_download_*; the context stays usable) */
-    VP8HIP_ERR_OVERFLOW = -7   /* vp8hip_encode_coefficients: output or scratch too small for this frame */
+    VP8HIP_ERR_OVERFLOW = -7,  /* vp8hip_encode_coefficients: output or scratch too small for this frame */
+    VP8HIP_ERR_FORMAT = -8     /* the frame cannot be written as VP8: its first partition has 512 KB or more and the frame tag
+                                  has 19 bits for that size (RFC 6386 section 9.1) -- key frames of about 7000x4000 and up.  The
+                                  reference writes the low 19 bits (entropy_host.cpp:1245-1250) and emits a frame no decoder
+                                  can read; here the call fails */
 } vp8hip_status;
 
 /* segment_data[4], vp8enc.h:80-92: 11 ints per segment */

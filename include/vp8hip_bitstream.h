@@ -51,7 +51,8 @@ typedef struct {
 void vp8bs_default_probs(uint32_t *new_probs, const uint32_t *new_probs_denom);
 
 /* First partition with its uncompressed chunk (3 bytes, 10 for a key frame).  Returns its size
- * (= frames.encoded_frame_size after encode_header), or 0 if `capacity` is too small.  out_mv_probs (may be NULL)
+ * (= frames.encoded_frame_size after encode_header), 0 if `capacity` is too small, or (size_t)-1 if the partition has 512 KB
+ * or more, which the frame tag's 19-bit size field cannot say (VP8HIP_ERR_FORMAT in vp8hip.h).  out_mv_probs (may be NULL)
  * receives the frame's 2 x 19 motion-vector probabilities (new_mv_context). */
 size_t vp8bs_encode_header(const vp8bs_frame *f, uint8_t *out, size_t capacity, uint8_t *out_mv_probs);
 

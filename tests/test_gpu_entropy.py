@@ -54,6 +54,8 @@ CASES = [  # mbw, mbh, seed, partitions, kwargs
     (5, 4, 6, 2, dict(p16=0.0)),
     (5, 4, 7, 2, dict(p16=1.0, density=0.9, big=0.3)),
     (120, 68, 8, 8, {}),                          # 1080p geometry
+    (480, 270, 9, 8, dict(skip=0.5)),             # 7680x4320: 3.2 million block slots (the scan of their bool counts in two levels)
+    (480, 270, 10, 1, dict(skip=0.8, density=0.2)),
 ]
 
 

@@ -77,6 +77,40 @@ def test_4k_three_references_frame_pair():
     assert len(np.unique(h["MB_reference_frame"])) >= 2
 
 
+@pytest.mark.parametrize("W,H", [(7680, 4320), (8192, 16), (16, 4096), (16, 16)])
+def test_beyond_the_baseline_sizes(W, H):
+    """four times BASELINE's largest frame, one macroblock row / column of the largest extent, and a single macroblock: every
+    stage tap of a three-reference frame against the oracle"""
+    from test_gpu_parity import _compare, _frames, _one_frame
+    f = _frames(W, H, 23)
+    h, o = _one_frame(W, H, [f[2], f[0], f[1], f[3]], default_segments(), (1, 1), -1.0)
+    _compare(h, o, [k for k in o if k in h], f"{W}x{H}")
+
+
+@pytest.mark.parametrize("host_bitstream", [0, 1])
+def test_8k_frames_do_not_fit_the_format_and_say_so(host_bitstream):
+    """7680x4320: the first partition of a key frame (sixteen sub-block modes for each of 129 600 macroblocks) and, with this
+    content, of the inter frames too (nearly every macroblock split, four vectors each) passes the 512 KB the frame tag's 19-bit
+    size field can say (RFC 6386 section 9.1).  The reference writes the low 19 bits and emits a frame no decoder can read;
+    here the call fails with VP8HIP_ERR_FORMAT, from the device coder and from the host one, and the encoder itself goes on:
+    the reconstructions stay the oracle's."""
+    s = SynthSequence(7680, 4320, seed=13)
+    drv = api.NativeDriver(s.W, s.H, gop_size=150, num_partitions=8, check_ssim=1, host_bitstream=host_bitstream)
+    ora = Oracle(s.W, s.H, -1.0)
+    do = InterPathDriver(ora, s.W, s.H, gop_size=150)
+    for t in range(2):
+        y, u, v = s.frame(t)
+        was_key = drv.encode_frame_host(y, u, v)
+        out = do.encode_frame(y, u, v)
+        assert was_key == (out is None)
+        with pytest.raises(api.Vp8HipError, match="19 bits"):
+            drv.get_frame()
+        for p_, q_ in zip(drv.hip.download_last(), ora.download_last()):
+            assert np.array_equal(p_, q_), f"frame {t}: filtered reconstruction differs"
+    drv.close()
+    ora.close()
+
+
 def test_fuzz_one_seed():
     """scripts/fuzz_parity.py, 12 cases of one seed: random geometry / quantizers / SSIM target / GOP / partitions / content."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "--cases", "12", "--seed", "7"],

@@ -46,6 +46,7 @@ class Vp8HipError(RuntimeError):
 
 
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
+ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
 
 class _Results(C.Structure):

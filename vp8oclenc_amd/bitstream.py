@@ -66,6 +66,8 @@ def encode_header(width, height, flags, segments, seg, nz, probs, denom, skip_pr
     out = np.zeros(cap, np.uint8)
     mvp = np.zeros((2, 19), np.uint8)
     n = _lib().vp8bs_encode_header(C.byref(f), out.ctypes.data, cap, mvp.ctypes.data)
+    if n == C.c_size_t(-1).value:
+        raise api.Vp8HipError("vp8bs_encode_header: first partition of 512 KB or more: the VP8 frame tag has 19 bits for its size")
     if n == 0:
         raise api.Vp8HipError("vp8bs_encode_header failed (bad arguments or the partition does not fit)")
     return out[:n].copy(), mvp

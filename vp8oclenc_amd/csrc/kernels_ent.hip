@@ -320,10 +320,11 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *v, uint32_t 
     }
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = s[0];
 }
-__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *tile_sum, int ntiles) {   // ntiles <= 1024; exclusive, total at [ntiles]
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t *tile_sum, int ntiles) {   // exclusive, total at [ntiles]; any ntiles
     __shared__ uint32_t s[1024];
-    const int t = threadIdx.x;
-    const uint32_t own = t < ntiles ? tile_sum[t] : 0u;
+    const int t = threadIdx.x, per = (ntiles + 1023) / 1024, i0 = t * per;   // a thread owns `per` consecutive tile sums
+    uint32_t own = 0;
+    for (int j = 0; j < per; ++j) own += i0 + j < ntiles ? tile_sum[i0 + j] : 0u;
     s[t] = own;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -332,8 +333,13 @@ __global__ __launch_bounds__(1024) void k_scan_top(uint32_t *tile_sum, int ntile
         s[t] += add;
         __syncthreads();
     }
-    if (t < ntiles) tile_sum[t] = s[t] - own;
-    if (t == ntiles - 1) tile_sum[ntiles] = s[t];
+    uint32_t run = s[t] - own;
+    for (int j = 0; j < per && i0 + j < ntiles; ++j) {
+        const uint32_t x = tile_sum[i0 + j];
+        tile_sum[i0 + j] = run;
+        run += x;
+    }
+    if (t == 1023) tile_sum[ntiles] = s[t];
 }
 __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *v, const uint32_t *tile_sum, int n, int ntiles) {
     __shared__ uint32_t s[256];
@@ -442,7 +448,7 @@ __device__ __forceinline__ void boolcount_slots_body(int vb, const int16_t *coef
     wg_scan256(sink.n, s_w, total);
     if (threadIdx.x == 0) tile_sum[vb] = total;
 }
-// one workgroup: exclusive scan of the ntiles (<= 4096) workgroup sums in place, then the plan
+// one workgroup: exclusive scan of the ntiles workgroup sums in place, then the plan
 __device__ __forceinline__ void scan_plan_body(const uint32_t *cnt, uint32_t *tile_sum, int ntiles, const Geom &g, Plan *plan) {
     __shared__ uint32_t s_w[4], s_off[ENT_MAX_PARTITIONS + 1];
     const int t = threadIdx.x, per = (ntiles + 255) / 256, i0 = t * per;
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(uint32_t *v, int n) {
 
 }  // namespace ent
 
-// exclusive prefix sum of v[0..n) in place, total in v[n]; n <= 1024 * 1024
+// exclusive prefix sum of v[0..n) in place, total in v[n]
 void launch_scan_exclusive(hipStream_t s, uint32_t *v, uint32_t *tile_sum, int n) {
     if (n <= 65536) {
         hipLaunchKernelGGL(ent::k_scan_small, dim3(1), dim3(1024), 0, s, v, n);

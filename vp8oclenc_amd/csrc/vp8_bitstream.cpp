@@ -263,7 +263,7 @@ size_t vp8bs_encode_header(const vp8bs_frame *f, uint8_t *out, size_t capacity, 
     w.finish();
     if (w.overflow()) return 0;
     const size_t first_part = w.count();
-    if (first_part >= ((size_t)1 << 19)) return 0;   // does not fit the frame tag's 19-bit size field: not a decodable frame
+    if (first_part >= ((size_t)1 << 19)) return (size_t)-1;   // does not fit the frame tag's 19-bit size field: not a decodable frame
 
     // frame tag: key/inter bit, version 0, show_frame, 19 bits of first-partition size (section 9.1)
     const uint32_t tag = (key ? 0u : 1u) | 0x10u | ((uint32_t)first_part << 5);

@@ -277,6 +277,7 @@ int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     f.new_probs = probs;
     f.new_probs_denom = denom;
     const size_t head = vp8bs_encode_header(&f, out, capacity, nullptr);          // :84
+    if (head == (size_t)-1) return VP8HIP_ERR_FORMAT;   // 19-bit size field of the frame tag
     if (!head) return VP8HIP_ERR_OVERFLOW;
     const size_t total = vp8bs_gather_frame(out, head, capacity, P, d->partitions.data(), step, sizes);
     if (!total) return VP8HIP_ERR_OVERFLOW;

@@ -1224,7 +1224,6 @@ int vp8hip_encode_coefficients(vp8hip_ctx *c, const uint32_t *coeff_probs, int n
     if (!c || !coeff_probs || !partitions || !partition_sizes || partition_step < 4) return VP8HIP_ERR_ARG;
     if (num_partitions != 1 && num_partitions != 2 && num_partitions != 4 && num_partitions != 8) return VP8HIP_ERR_ARG;
     if (c->ent_counted_partitions != num_partitions) return VP8HIP_ERR_STATE;   // needs vp8hip_count_probs first
-    if (c->mbs * 25 > 1024 * 1024) return VP8HIP_ERR_ARG;                       // single-level scan of the tile sums
     int rc = ent_alloc(c);
     if (rc) return rc;
     hipStream_t s = c->stream;
@@ -1303,7 +1302,7 @@ int vp8hip_encode_header(vp8hip_ctx *c, const vp8hip_header_params *p, uint8_t *
     HIPCHK(c, hipMemcpyAsync(&plan, c->hdr.plan, sizeof(plan), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (plan.overflow || head + plan.nbytes[0] > capacity) return VP8HIP_ERR_OVERFLOW;
-    if (plan.nbytes[0] >= (1u << 19)) return VP8HIP_ERR_OVERFLOW;   // the frame tag has 19 bits for the first partition's size
+    if (plan.nbytes[0] >= (1u << 19)) return VP8HIP_ERR_FORMAT;   // the frame tag has 19 bits for the first partition's size
     HIPCHK(c, hipMemcpyAsync(out + head, c->hdr.bytes, plan.nbytes[0], hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     // frame tag (entropy_host.cpp:1214-1247): key/inter bit, version 0, show_frame, size of the first partition
@@ -1498,7 +1497,7 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
         c->frame_pending = true;   // the coded frame stays in h_frame: the caller may come back with a larger buffer
         return VP8HIP_ERR_OVERFLOW;
     }
-    if (reinterpret_cast<const uint32_t *>(c->h_frame)[1] >= (1u << 19)) return VP8HIP_ERR_OVERFLOW;   // 19-bit size field of the frame tag
+    if (reinterpret_cast<const uint32_t *>(c->h_frame)[1] >= (1u << 19)) return VP8HIP_ERR_FORMAT;   // 19-bit size field of the frame tag
     const size_t head = p->is_key ? 10 : 3;
     const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     if (16 + n > first && !frame_zero_copy()) {
@@ -1572,6 +1571,7 @@ const char *vp8hip_status_string(int status) {
         case VP8HIP_ERR_ARCH: return "device is not gfx950";
         case VP8HIP_ERR_TIMEOUT: return "a bounded device-side wait expired; the frame is invalid";
         case VP8HIP_ERR_OVERFLOW: return "coefficient partitions do not fit the output or the device scratch";
+        case VP8HIP_ERR_FORMAT: return "first partition of 512 KB or more: the VP8 frame tag has 19 bits for its size";
         default: return "unknown";
     }
 }
