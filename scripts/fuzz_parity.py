@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised end-to-end parity on the GPU box: random geometry, quantizer range, SSIM target, GOP/altref periods,
-partitions, content (synthetic motion, noise, scene cuts); the native frame loop's frames and filtered
-reconstructions against the oracle loop + reference encode_header.
+partitions, content (synthetic motion, noise, scene cuts), source sizes below the coded size (padded on the device) and the
+conformant switch; the native frame loop's frames and filtered reconstructions against the oracle loop + reference
+encode_header.
     python scripts/fuzz_parity.py [--cases 40 --seed 1]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +13,14 @@ from oracle_lib import Oracle
 from vp8oclenc_amd import api
 from vp8oclenc_amd.driver import InterPathDriver
 from vp8oclenc_amd.synth import SynthSequence
+import vp8_decode
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--decode", type=int, default=1, help="decode the frames of the conformant cases with the tests' RFC 6386 decoder: exactly the device's reconstruction")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-t0 = time.time(); nframes = 0; nbytes = 0; nkey = 0; nrepl = 0; nredo = 0
+t0 = time.time(); nframes = 0; nbytes = 0; nkey = 0; nrepl = 0; nredo = 0; ndecoded = 0
 for case in range(a.cases):
     W, H = 16 * int(rng.integers(1, 41)), 16 * int(rng.integers(1, 31))
     if W < 32 and H < 32:
@@ -34,25 +37,45 @@ for case in range(a.cases):
     nz = [(nrng.integers(0, 256, (H, W)).astype(np.uint8), nrng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8),
            nrng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)) for _ in range(nfr)] if kind == "noise" else None
     host_bs = int(rng.random() < 0.25); dev_params = int(rng.random() < 0.5)
+    conformant = int(rng.random() < 0.3)          # vp8hip_conformant_stream against the oracle's switch of the same meaning
+    sw, sh = W, H
+    if dev_params and rng.random() < 0.4:         # a source below the coded size: copy_with_padding on the device
+        sw, sh = W - 2 * int(rng.integers(0, 8)), H - 2 * int(rng.integers(0, 8))
+    src = dict(src_width=sw, src_height=sh) if (sw, sh) != (W, H) else {}
     drv = api.NativeDriver(W, H, gop_size=gop, altref_range=alt, qi_min=qmin, qi_max=qmax, ssim_target=target, num_partitions=P,
-                           check_ssim=1, host_bitstream=host_bs, device_params=dev_params)
+                           check_ssim=1, host_bitstream=host_bs, device_params=dev_params, conformant_stream=conformant, **src)
+    Oracle.lib().vp8o_set_conformant_stream(conformant)
     ora = Oracle(W, H, target)
     do = InterPathDriver(ora, W, H, gop_size=gop, altref_range=alt, qi_min=qmin, qi_max=qmax, ssim_target=target)
-    tag = f"case {case}: {W}x{H} q{qmin}-{qmax} t{target} gop{gop}/{alt} P{P} {kind} seed{seed} hostbs{host_bs} devp{dev_params}"
+    dec = vp8_decode.Decoder() if (conformant and a.decode) else None
+    tag = f"case {case}: {W}x{H} (source {sw}x{sh}) q{qmin}-{qmax} t{target} gop{gop}/{alt} P{P} {kind} seed{seed} hostbs{host_bs} devp{dev_params} conformant{conformant}"
     for t in range(nfr):
         y, u, v = nz[t] if kind == "noise" else (s2.frame(t) if (kind == "cut" and t >= nfr // 2) else s.frame(t))
-        was_key = drv.encode_frame_host(y, u, v)
+        if src:      # the driver gets the source rectangle, the oracle loop the same rectangle padded by edge replication
+            crop = [np.ascontiguousarray(p[:sh // k, :sw // k]) for p, k in ((y, 1), (u, 2), (v, 2))]
+            y, u, v = (np.pad(c, ((0, p.shape[0] - c.shape[0]), (0, p.shape[1] - c.shape[1])), mode="edge") for c, p in zip(crop, (y, u, v)))
+            was_key = drv.encode_frame_host(*crop)
+        else:
+            was_key = drv.encode_frame_host(y, u, v)
         got = drv.get_frame()
         out = do.encode_frame(y, u, v)
         assert was_key == (out is None), f"{tag} frame {t}: key decision"
-        exp = expected_frame(W, H, do.last_key if out is None else out, out is None, P)
+        exp = expected_frame(W, H, do.last_key if out is None else out, out is None, P, dst=(sw, sh) if src else None)
         assert got == exp, f"{tag} frame {t}: bitstream differs ({len(got)} vs {len(exp)} bytes)"
-        for p_, q_ in zip(drv.hip.download_last(), ora.download_last()):
+        last = drv.hip.download_last()
+        for p_, q_ in zip(last, ora.download_last()):
             assert np.array_equal(p_, q_), f"{tag} frame {t}: filtered reconstruction"
+        if dec is not None:
+            f, planes = dec.decode(got)
+            assert (f.width, f.height) == (sw, sh) or not f.key, f"{tag} frame {t}: display size"
+            for p_, q_ in zip(planes, last):
+                assert np.array_equal(p_, q_), f"{tag} frame {t}: a decoder does not arrive at the encoder's reconstruction"
+            ndecoded += 1
         nframes += 1; nbytes += len(got); nkey += was_key
         if out is not None:
             nrepl += int(out["replaced"])
     nredo += drv.stats().redone_as_key
     drv.close(); ora.close()
+    Oracle.lib().vp8o_set_conformant_stream(0)
 print(f"fuzz seed {a.seed}: {a.cases} cases, {nframes} frames ({nkey} key, {nredo} recoded as key, {nrepl} macroblocks replaced by intra), "
-      f"{nbytes} bytes: all identical; {time.time() - t0:.0f} s")
+      f"{nbytes} bytes: all identical; {ndecoded} frames of conformant cases decoded to the device's reconstruction; {time.time() - t0:.0f} s")
