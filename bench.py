@@ -128,7 +128,7 @@ def spawn_ranks(args) -> int:
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
-    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None):
+    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None, conformant=0):
         from vp8oclenc_amd.synth import SynthSequence
         self.torch, self.api = torch, api
         seq = SynthSequence(W0, H0, seed=seed)
@@ -155,7 +155,7 @@ class Leg:
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
                                  ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
-                                 overlap_filter=overlap_filter, **src)
+                                 overlap_filter=overlap_filter, conformant_stream=conformant, **src)
             t = (k * 3) % nd                                   # chunks start at different frames of the sequence
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
             self.drv.append(d)
@@ -266,9 +266,10 @@ class Leg:
         self.dev_frames = []
 
 
-def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1, gop=None):
+def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1, gop=None, conformant=0):
     # one chunk = one video coded frame after frame: the loop filter on its own stream, GOLDEN/ALTREF searched beside it
-    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1, gop=gop)
+    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1, gop=gop,
+              conformant=conformant)
     for _ in range(warm):
         leg.step()
     leg.clock_read()
@@ -452,6 +453,9 @@ def main():
             # the reference's default GOP of 150: key frames (a raster-order wavefront each, 1.5 ms alone) among the inter frames;
             # value counts every frame
             "1080p_gop150": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, gop=150),
+            # vp8hip_conformant_stream (NOT the reference's bytes: the format's predictor, so that the stream decodes to the
+            # encoder's own reconstruction): what the opt-in costs
+            "1080p_conformant_stream": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, conformant=1),
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
