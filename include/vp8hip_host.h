@@ -32,6 +32,16 @@ int vp8host_scene_change(vp8host_scene_state *st, int Udiff, int Vdiff, int fram
 void vp8host_prepare_segments_data(int is_key_frame, const int32_t refqi[4], int qi_min, int reductor,
                                    int sharpness, int update_filter, int shrpnss, int32_t sd[44]);
 
+/* The input format: YUV4MPEG2.  OpenYUV420FileAndParseHeader(), init.h:1610-1737, on the first `size` bytes of the stream
+ * (128 are plenty: the reference keeps the header in a 128-byte array): the magic word, then the FIRST THREE tags that start
+ * with W, H or F -- width, height, frame rate num:denom rounded to (num + denom / 2) / denom -- each ended by a space, then
+ * everything up to and including the first "FRAME\n" (a FRAME line with parameters is refused, :1724-1726).  Returns 0 and
+ * the offset of the first frame's samples, or -1 as the reference does (not YUV4MPEG2, no size, no plain FRAME line, or the
+ * buffer ends first).  Frames follow as tight I420 of width x height, each followed by the next one's 6-byte "FRAME\n"
+ * (get_yuv420_frame checks bytes 0 and 4 of it, encIO.h:243-248: vp8host_y4m_frame_marker_ok). */
+int vp8host_y4m_parse_header(const uint8_t *data, size_t size, int32_t *width, int32_t *height, int32_t *framerate, size_t *first_frame_offset);
+int vp8host_y4m_frame_marker_ok(const uint8_t marker[6]);
+
 /* frames.skip_prob, loop_filter.h:37-44 */
 int vp8host_skip_prob(const int32_t *MB_non_zero_coeffs, int mb_count);
 

@@ -128,6 +128,24 @@ extern "C" void ref_copy_with_padding(const uint8_t *sy, const uint8_t *su, cons
     copy_with_padding();
 }
 
+/* OpenYUV420FileAndParseHeader, src/init.h:1610-1737, on a file of the caller (it also opens the output file: `scratch` is
+ * a path it may create).  Returns the function's result; on success the sizes, the frame rate and where the file position
+ * stands (= the first frame's samples). */
+extern "C" int ref_parse_y4m_header(const char *path, const char *scratch, int32_t *w, int32_t *h, int32_t *fps, int64_t *offset) {
+    input_file.path = const_cast<char *>(path);
+    output_file.path = const_cast<char *>(scratch);
+    video.framerate = 0;
+    const int rc = OpenYUV420FileAndParseHeader();
+    *w = video.src_width;
+    *h = video.src_height;
+    *fps = video.framerate;
+    *offset = input_file.handle ? (int64_t)ftell(input_file.handle) : -1;
+    if (input_file.handle) fclose(input_file.handle);
+    if (output_file.handle) fclose(output_file.handle);
+    input_file.handle = output_file.handle = nullptr;
+    return rc;
+}
+
 /* ---- frame header / first partition (src/entropy_host.cpp), container (src/encIO.h) ------------------------------- */
 extern "C" {
 

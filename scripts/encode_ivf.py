@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Encode a sequence to .ivf with the native frame loop, GOP chunks sharded over the visible GPUs.
 
-    python scripts/encode_ivf.py out.ivf [--yuv in.yuv] [--width 1920 --height 1080 --frames 120 --gop 30 --partitions 4]
+    python scripts/encode_ivf.py out.ivf [--y4m in.y4m | --yuv in.yuv --width 1920 --height 1080] [--frames 120 --gop 30 --partitions 4]
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/encode_ivf.py out.ivf ...
 
-Without --yuv the synthetic sequence of the tests is used.  A raw I420 file has the given width/height (even numbers); when
+--y4m: YUV4MPEG2, the reference's own input format (size and frame rate from its header, vp8oclenc_amd/y4m.py); --yuv: raw
+I420 of the given size; without either the synthetic sequence of the tests is used.  A raw I420 file has the given width/height (even numbers); when
 they are not multiples of 16 the frames are padded on the device (vp8hip_set_source_size = copy_with_padding, encIO.h:141-196)
 and the key frames carry the source size as display size."""
 import argparse, os, sys, time
@@ -32,7 +33,7 @@ class YuvFile:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("out"); ap.add_argument("--yuv")
+    ap.add_argument("out"); ap.add_argument("--yuv"); ap.add_argument("--y4m")
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=60); ap.add_argument("--gop", type=int, default=30)
     ap.add_argument("--partitions", type=int, default=1); ap.add_argument("--qmin", type=int, default=0); ap.add_argument("--qmax", type=int, default=48)
@@ -45,8 +46,13 @@ def main():
         import torch, torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    seq = YuvFile(a.yuv, a.width, a.height) if a.yuv else SynthSequence(a.width, a.height, seed=1)
-    frames = min(a.frames, seq.n) if a.yuv else a.frames
+    if a.y4m:
+        from vp8oclenc_amd.y4m import Y4mFile
+        seq = Y4mFile(a.y4m)
+        a.framerate = seq.framerate or a.framerate
+    else:
+        seq = YuvFile(a.yuv, a.width, a.height) if a.yuv else SynthSequence(a.width, a.height, seed=1)
+    frames = min(a.frames, seq.n) if (a.yuv or a.y4m) else a.frames
     Wc, Hc = (seq.W + 15) // 16 * 16, (seq.H + 15) // 16 * 16            # the coded ("wrk") size, init.h:375-392
     src = dict(src_width=seq.W, src_height=seq.H) if (Wc, Hc) != (seq.W, seq.H) else {}
     t0 = time.perf_counter()

@@ -65,3 +65,25 @@ def test_encode_ivf_then_decode_gives_the_pictures_back(tmp_path, W, H, frames, 
     # the same file through the command-line decoder (its PSNR report against the synthetic source)
     rep = _run(os.path.join(ROOT, "scripts", "decode_ivf.py"), str(ivf), "--yuv", str(yuv), "--out", str(tmp_path / "dec.yuv"))
     assert "lowest luma PSNR" in rep and os.path.getsize(tmp_path / "dec.yuv") == frames * seq.W * seq.H * 3 // 2
+
+
+def test_y4m_in_ivf_out(tmp_path):
+    """the reference's own input format: size and frame rate from the YUV4MPEG2 header (vp8oclenc_amd/y4m.py), 354x290 frames
+    (padded to 368x304 on the device), frame rate 25 into the IVF header"""
+    import decode_ivf
+    import vp8_decode
+    from vp8oclenc_amd import y4m
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H, frames = 354, 290, 6
+    big = SynthSequence(W + 16, H + 16, seed=2)
+    src = [tuple(np.ascontiguousarray(p[:h, :w]) for p, (h, w) in zip(big.frame(t), ((H, W), (H // 2, W // 2), (H // 2, W // 2)))) for t in range(frames)]
+    y4m.write_y4m(str(tmp_path / "in.y4m"), src, framerate=25)
+    ivf = tmp_path / "out.ivf"
+    _run(os.path.join(ROOT, "scripts", "encode_ivf.py"), str(ivf), "--y4m", str(tmp_path / "in.y4m"), "--gop", "4", "--partitions", "2")
+    Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(ivf))
+    assert (Wf, Hf, rate, len(packets)) == (W, H, 25, frames)
+    dec = vp8_decode.Decoder()
+    for t, fr in enumerate(packets):
+        f, (Y, U, V) = dec.decode(fr)
+        assert (f.mbw, f.mbh) == (23, 19) and ((f.width, f.height) == (W, H) or not f.key)
+        assert decode_ivf.psnr(Y[:H, :W], src[t][0]) > 31.0, t

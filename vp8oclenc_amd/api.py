@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
-    "vp8host_gop_frame_done", "vp8host_scene_change",
+    "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
     "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",

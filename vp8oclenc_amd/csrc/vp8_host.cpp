@@ -63,6 +63,77 @@ void vp8host_loopfilter_strength(const uint8_t *y, int width, int height, int32_
     *sharpness = sh > 7 ? 7 : sh;
 }
 
+// OpenYUV420FileAndParseHeader, init.h:1610-1737, as a walk over a buffer: `next` stands for its fread of one char
+int vp8host_y4m_parse_header(const uint8_t *data, size_t size, int32_t *width, int32_t *height, int32_t *framerate, size_t *first_frame_offset) {
+    if (!data || !width || !height || !framerate || !first_frame_offset) return -1;
+    static const char magic[] = "YUV4MPEG2 ";
+    size_t j = 0;
+    int ch = 0;
+    auto next = [&]() -> bool {
+        if (j >= size) return false;
+        ch = data[j++];
+        return true;
+    };
+    int w = 0, h = 0, fps = 0;
+    for (int i = 0; i < 10; ++i) {
+        if (!next() || ch != magic[i]) return -1;
+    }
+    for (int i = 0; i < 3; ++i) {                    // three tags, whichever of W / H / F come first (:1634-1690)
+        while (ch != 'W' && ch != 'H' && ch != 'F')
+            if (!next()) return -1;
+        if (ch == 'W') {
+            for (;;) {
+                if (!next()) return -1;
+                if (ch == 0x20) break;
+                w = w * 10 + (ch - 0x30);
+            }
+        } else if (ch == 'H') {
+            for (;;) {
+                if (!next()) return -1;
+                if (ch == 0x20) break;
+                h = h * 10 + (ch - 0x30);
+            }
+        } else {
+            int num = 0, denom = 0;
+            for (;;) {
+                if (!next()) return -1;
+                if (ch == ':') break;
+                num = num * 10 + (ch - 0x30);
+            }
+            for (;;) {
+                if (!next()) return -1;
+                if (ch == 0x20) break;
+                denom = denom * 10 + (ch - 0x30);
+            }
+            if (denom == 0) return -1;               // the reference divides by it (:1688)
+            fps = (num + denom / 2) / denom;
+        }
+    }
+    if (w + h == 0) return -1;
+    for (;;) {                                       // the first "FRAME" followed by a line feed (:1696-1728)
+        while (ch != 'F')
+            if (!next()) return -1;
+        if (!next()) return -1;
+        if (ch != 'R') continue;
+        if (!next()) return -1;
+        if (ch != 'A') continue;
+        if (!next()) return -1;
+        if (ch != 'M') continue;
+        if (!next()) return -1;
+        if (ch != 'E') continue;
+        if (!next()) return -1;
+        if (ch != 0x0A) return -1;
+        break;
+    }
+    *width = w;
+    *height = h;
+    *framerate = fps;
+    *first_frame_offset = j;
+    return 0;
+}
+
+int vp8host_y4m_frame_marker_ok(const uint8_t m[6]) { return m && m[0] == 'F' && m[4] == 'E'; }   // encIO.h:245
+
 int vp8host_scene_change(vp8host_scene_state *st, int Udiff, int Vdiff, int frame_number) {
     // vp8enc.cpp:285-310
     const int detect = (Udiff > 7) || (Vdiff > 7) || (Udiff + Vdiff > 10);
