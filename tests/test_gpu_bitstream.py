@@ -262,7 +262,7 @@ def test_overlap_three_references_device_frames(frames_out):
 
 def test_frames_beyond_a_million_blocks():
     """4096x2736 = 1.09 million 4x4 block slots: the frame path's prefix sums have no size limit (the step-by-step
-    vp8hip_encode_coefficients keeps its 1 Mi one); key frame + inter frame, 8 partitions, byte-exact.  (The format
+    vp8hip_encode_coefficients had a 1 Mi one until its top-level scan learnt to walk: tests/test_gpu_entropy.py at 480x270 macroblocks); key frame + inter frame, 8 partitions, byte-exact.  (The format
     itself stops a little further on: the frame tag holds the first partition's size in 19 bits, see the next test.)"""
     W, H = 4096, 2736
     s = SynthSequence(W, H, seed=5)
@@ -273,7 +273,8 @@ def test_frames_beyond_a_million_blocks():
 def test_first_partition_beyond_the_frame_tag_is_an_error():
     """A 7680x4320 key frame codes 129 600 x 16 sub-block modes: its first partition passes 512 KiB, which the frame tag's
     19-bit size field cannot say (RFC 6386 9.1).  The reference writes the truncated size and the frame cannot be decoded;
-    here the call fails with VP8HIP_ERR_OVERFLOW instead of returning such a frame."""
+    here the call fails with VP8HIP_ERR_FORMAT instead of returning such a frame (both coders and the inter frames
+    of that size: tests/test_gpu_soak.py::test_8k_frames_do_not_fit_the_format_and_say_so)."""
     W, H = 7680, 4320
     s = SynthSequence(W, H, seed=5)
     d = api.NativeDriver(W, H, num_partitions=8)
@@ -281,7 +282,7 @@ def test_first_partition_beyond_the_frame_tag_is_an_error():
     try:
         frame = d.get_frame()
     except api.Vp8HipError as e:
-        assert "(-7)" in str(e)
+        assert "(-8)" in str(e) and "19 bits" in str(e)
     else:   # content whose key frame happens to fit: then the tag must tell the truth
         first = (frame[0] | frame[1] << 8 | frame[2] << 16) >> 5
         assert first < (1 << 19) and len(frame) > first
