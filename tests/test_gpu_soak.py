@@ -239,3 +239,51 @@ def test_reference_split_exchanges_over_rccl(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ref shard over rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_contexts_driven_from_worker_threads_at_once():
+    """one GPU, six host threads, each with a driver of its own (different sizes, one with the intra fallback, one with frames
+    through the host coder), all coding at the same time: every thread's frames are those of the same driver run alone.  The
+    library keeps no state outside a context; this is what bench.py --bitstream and a transcoder with a thread per stream do."""
+    import threading
+    cfgs = [(320, 192, dict(num_partitions=2)), (176, 144, dict(num_partitions=1, gop_size=4)), (640, 352, dict(num_partitions=8)),
+            (320, 192, dict(num_partitions=4, check_ssim=1, ssim_target=0.92, qi_min=40, qi_max=110)),
+            (352, 288, dict(num_partitions=2, host_bitstream=1)), (336, 256, dict(num_partitions=1, src_width=330, src_height=250, conformant_stream=1))]
+    seqs = [SynthSequence(c[2].get("src_width", c[0]) + (16 if "src_width" in c[2] else 0), c[2].get("src_height", c[1]) + (16 if "src_height" in c[2] else 0), seed=60 + i)
+            for i, c in enumerate(cfgs)]
+    FR = 10
+
+    def frames_of(i):
+        W, H, cfg = cfgs[i]
+        sw, sh = cfg.get("src_width", W), cfg.get("src_height", H)
+        return [tuple(np.ascontiguousarray(p[:sh // k, :sw // k]) for p, k in zip(seqs[i].frame(t), (1, 2, 2))) for t in range(FR)]
+
+    inputs = [frames_of(i) for i in range(len(cfgs))]
+
+    def run(i, out):
+        W, H, cfg = cfgs[i]
+        d = api.NativeDriver(W, H, **cfg)
+        for f in inputs[i]:
+            d.encode_frame_host(*f)
+            out.append(d.get_frame())
+        d.close()
+
+    alone = [[] for _ in cfgs]
+    for i in range(len(cfgs)):
+        run(i, alone[i])
+    for rep in range(3):
+        together = [[] for _ in cfgs]
+        errors = []
+
+        def guarded(i):
+            try:
+                run(i, together[i])
+            except Exception as e:      # noqa: BLE001 -- reported below, with the thread's number
+                errors.append((i, repr(e)))
+
+        th = [threading.Thread(target=guarded, args=(i,)) for i in range(len(cfgs))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errors, errors
+        for i in range(len(cfgs)):
+            assert together[i] == alone[i], (rep, i)
