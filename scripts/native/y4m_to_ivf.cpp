@@ -1,0 +1,81 @@
+// y4m_to_ivf.cpp -- the reference's program with the path swapped in, as a complete C++ user of the C ABI: YUV4MPEG2 in,
+// IVF out (main() of src/vp8enc.cpp reduced to: parse the header, per frame read / code / write, patch the frame count).
+//   y4m_to_ivf <in.y4m> <out.ivf> [-g gop] [-partitions P] [-qmin q] [-qmax q] [-SSIM-target t] [-scene-detect] [-conformant]
+// Everything between the two files runs behind include/vp8hip_driver.h; the frames are handed over at their source size
+// and padded on the device (cfg.src_width / src_height), key frames carry that size as the display size.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "vp8hip_bitstream.h"
+#include "vp8hip_driver.h"
+#include "vp8hip_host.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #x, rc_, vp8hip_status_string(rc_)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: see the head of y4m_to_ivf.cpp\n"); return 2; }
+    vp8drv_config cfg;
+    vp8drv_default_config(&cfg);
+    for (int i = 3; i < argc; ++i) {
+        auto val = [&]() { return i + 1 < argc ? argv[++i] : "0"; };
+        if (!strcmp(argv[i], "-g")) cfg.gop_size = atoi(val());
+        else if (!strcmp(argv[i], "-partitions")) cfg.num_partitions = atoi(val());
+        else if (!strcmp(argv[i], "-qmin")) cfg.qi_min = atoi(val());
+        else if (!strcmp(argv[i], "-qmax")) cfg.qi_max = atoi(val());
+        else if (!strcmp(argv[i], "-SSIM-target")) { cfg.ssim_target = (float)atof(val()); cfg.check_ssim = 1; }
+        else if (!strcmp(argv[i], "-scene-detect")) cfg.scene_detect = 1;
+        else if (!strcmp(argv[i], "-conformant")) cfg.conformant_stream = 1;
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) { perror(argv[1]); return 1; }
+    uint8_t head[256];
+    const size_t got = fread(head, 1, sizeof head, in);
+    int32_t W = 0, H = 0, fps = 0;
+    size_t first = 0;
+    if (vp8host_y4m_parse_header(head, got, &W, &H, &fps, &first) != 0 || (W & 1) || (H & 1)) {
+        fprintf(stderr, "%s: not a YUV4MPEG2 stream the reference accepts\n", argv[1]);
+        return 1;
+    }
+    fseek(in, (long)first, SEEK_SET);
+    const int Wc = (W + 15) / 16 * 16, Hc = (H + 15) / 16 * 16;      // video.wrk_*, init.h:375-392
+    if (Wc != W || Hc != H) { cfg.src_width = W; cfg.src_height = H; }
+    vp8drv *drv = nullptr;
+    CK(vp8drv_create(&drv, Wc, Hc, 0, &cfg));
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) { perror(argv[2]); return 1; }
+    uint8_t fh[32];
+    fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, 0), out);     // frame count patched at the end (encIO.h:100-139)
+    const size_t ysz = (size_t)W * H, csz = ysz / 4;
+    std::vector<uint8_t> frame(ysz + 2 * csz), bytes((size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20));
+    uint32_t n = 0, keys = 0;
+    size_t total = 32;
+    for (;;) {
+        if (fread(frame.data(), 1, frame.size(), in) != frame.size()) break;                // get_yuv420_frame, encIO.h:203-254
+        uint8_t marker[6];
+        const size_t m = fread(marker, 1, 6, in);
+        if (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) { fprintf(stderr, "broken stream!\n"); return 1; }
+        const int key = vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0);
+        CK(key);
+        keys += key;
+        size_t size = 0;
+        CK(vp8drv_get_frame(drv, bytes.data(), bytes.size(), &size));
+        uint8_t ph[12];
+        fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)size, n), out);
+        fwrite(bytes.data(), 1, size, out);
+        total += 12 + size;
+        ++n;
+    }
+    fseek(out, 0, SEEK_SET);
+    fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, n), out);
+    fclose(out);
+    fclose(in);
+    vp8drv_stats st;
+    vp8drv_get_stats(drv, &st);
+    vp8drv_destroy(drv);
+    printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes\n", argv[2], n, W, H, Wc, Hc, keys,
+           st.scene_changes, st.redone_as_key, total);
+    return 0;
+}

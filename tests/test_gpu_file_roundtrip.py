@@ -87,3 +87,39 @@ def test_y4m_in_ivf_out(tmp_path):
         f, (Y, U, V) = dec.decode(fr)
         assert (f.mbw, f.mbh) == (23, 19) and ((f.width, f.height) == (W, H) or not f.key)
         assert decode_ivf.psnr(Y[:H, :W], src[t][0]) > 31.0, t
+
+
+def test_native_y4m_to_ivf_program(tmp_path):
+    """scripts/native/y4m_to_ivf.cpp: the reference's program with the path swapped in, as plain C++ over the C ABI (built
+    here with g++: the headers are C).  Its .ivf == the frames of the same loop driven through ctypes, byte for byte, with a
+    scene cut found by -scene-detect and the source padded on the device."""
+    import shutil
+    import decode_ivf
+    from vp8oclenc_amd import api, y4m
+    from vp8oclenc_amd.synth import SynthSequence
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "y4m_to_ivf")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
+                    "-L", os.path.join(ROOT, "vp8oclenc_amd"), "-lvp8hip", "-Wl,-rpath," + os.path.join(ROOT, "vp8oclenc_amd")], check=True, timeout=300)
+    W, H = 360, 200
+    a, b = SynthSequence(W + 16, H + 16, seed=3), SynthSequence(W + 16, H + 16, seed=90)
+
+    def crop(planes, du=0):
+        y, u, v = planes
+        return (np.ascontiguousarray(y[:H, :W]), np.ascontiguousarray(np.clip(u[:H // 2, :W // 2].astype(int) + du, 0, 255).astype(np.uint8)),
+                np.ascontiguousarray(v[:H // 2, :W // 2]))
+    src = [crop(a.frame(t)) for t in range(6)] + [crop(b.frame(t), 45) for t in range(6)]      # a cut at frame 6
+    y4m.write_y4m(str(tmp_path / "in.y4m"), src, framerate=24)
+    r = subprocess.run([exe, str(tmp_path / "in.y4m"), str(tmp_path / "out.ivf"), "-g", "9", "-partitions", "2", "-scene-detect"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "12 frames 360x200 (coded 368x208)" in r.stdout and "(1 by scene change" in r.stdout, r.stdout
+    Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(tmp_path / "out.ivf"))
+    assert (Wf, Hf, rate, len(packets)) == (W, H, 24, 12)
+    assert int.from_bytes(open(tmp_path / "out.ivf", "rb").read(32)[24:28], "little") == 12          # the frame count, patched at the end
+    drv = api.NativeDriver(368, 208, gop_size=9, num_partitions=2, scene_detect=1, src_width=W, src_height=H)
+    for t, f in enumerate(src):
+        drv.encode_frame_host(*f)
+        assert drv.get_frame() == packets[t], t
+    assert drv.stats().scene_changes == 1
+    drv.close()
