@@ -152,7 +152,8 @@ int vp8hip_conformant_stream(vp8hip_ctx *ctx, int on);
  * into the context's surfaces repeats the last row downwards and every row's last sample to the right.  0, 0 = back to planes
  * of the coded size.  (Reconstruction planes -- vp8hip_upload_last, vp8hip_set_last_device, downloads -- always have the coded
  * size.)  Identical to the reference whenever the width needs no padding, which covers every BASELINE config; for other
- * widths the reference never writes V's right padding (:180-183 read and write U instead) and this is what it means. */
+ * widths the reference never writes V's right padding (:180-183 read and write U instead) and this is what it means.
+ * All members of a batch must have the same source size (vp8hip_batch_create and the batched launch check it). */
 int vp8hip_set_source_size(vp8hip_ctx *ctx, int src_width, int src_height);
 
 /* prepare_filter_mask_and_non_zero_coeffs(), loop_filter.h:25-55.  nz_out: [MBs] or NULL.
