@@ -14,13 +14,15 @@ from vp8oclenc_amd import api
 from vp8oclenc_amd.driver import InterPathDriver
 from vp8oclenc_amd.synth import SynthSequence
 import vp8_decode
+import vp8_parse
+from test_parse_roundtrip import check_frame
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--decode", type=int, default=1, help="decode the frames of the conformant cases with the tests' RFC 6386 decoder: exactly the device's reconstruction")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-t0 = time.time(); nframes = 0; nbytes = 0; nkey = 0; nrepl = 0; nredo = 0; ndecoded = 0
+t0 = time.time(); nframes = 0; nbytes = 0; nkey = 0; nrepl = 0; nredo = 0; ndecoded = 0; nparsed = 0
 for case in range(a.cases):
     W, H = 16 * int(rng.integers(1, 41)), 16 * int(rng.integers(1, 31))
     if W < 32 and H < 32:
@@ -48,6 +50,7 @@ for case in range(a.cases):
     ora = Oracle(W, H, target)
     do = InterPathDriver(ora, W, H, gop_size=gop, altref_range=alt, qi_min=qmin, qi_max=qmax, ssim_target=target)
     dec = vp8_decode.Decoder() if (conformant and a.decode) else None
+    pst = vp8_parse.StreamState()
     tag = f"case {case}: {W}x{H} (source {sw}x{sh}) q{qmin}-{qmax} t{target} gop{gop}/{alt} P{P} {kind} seed{seed} hostbs{host_bs} devp{dev_params} conformant{conformant}"
     for t in range(nfr):
         y, u, v = nz[t] if kind == "noise" else (s2.frame(t) if (kind == "cut" and t >= nfr // 2) else s.frame(t))
@@ -65,6 +68,9 @@ for case in range(a.cases):
         last = drv.hip.download_last()
         for p_, q_ in zip(last, ora.download_last()):
             assert np.array_equal(p_, q_), f"{tag} frame {t}: filtered reconstruction"
+        if dec is None and a.decode:      # every other frame is at least read back: header, modes, vectors, every token
+            check_frame(vp8_parse.parse_frame(got, pst), do.last_key if out is None else out, out is None, P, f"{tag} frame {t}")
+            nparsed += 1
         if dec is not None:
             f, planes = dec.decode(got)
             assert (f.width, f.height) == (sw, sh) or not f.key, f"{tag} frame {t}: display size"
@@ -78,4 +84,4 @@ for case in range(a.cases):
     drv.close(); ora.close()
     Oracle.lib().vp8o_set_conformant_stream(0)
 print(f"fuzz seed {a.seed}: {a.cases} cases, {nframes} frames ({nkey} key, {nredo} recoded as key, {nrepl} macroblocks replaced by intra), "
-      f"{nbytes} bytes: all identical; {ndecoded} frames of conformant cases decoded to the device's reconstruction; {time.time() - t0:.0f} s")
+      f"{nbytes} bytes: all identical; {nparsed} frames read back by the RFC 6386 parser, {ndecoded} frames of conformant cases decoded to the device's reconstruction; {time.time() - t0:.0f} s")
