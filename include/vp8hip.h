@@ -287,6 +287,11 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
  * every member is then between _begin and _end: take each frame with vp8hip_encode_frame_end) */
 int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_partitions, const vp8hip_header_params *params);
 const char *vp8hip_status_string(int status);
+/* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
+ * layout (vp8drv_config grew in round 2: 2), MINOR when entry points are added.  A host built against an older header checks
+ * it once after loading the library. */
+#define VP8HIP_ABI_VERSION 2004
+int vp8hip_abi_version(void);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */
 typedef enum {

@@ -28,6 +28,38 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in decl if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(api.ABI_SYMBOLS) == decl, "api.ABI_SYMBOLS out of sync with include/*.h"
+    # the version the header states, the library reports and the binding expects
+    header = open(os.path.join(ROOT, "include", "vp8hip.h")).read()
+    stated = int(re.search(r"#define VP8HIP_ABI_VERSION (\d+)", header).group(1))
+    assert lib.vp8hip_abi_version() == stated == api.ABI_VERSION
+
+
+def test_binding_structs_have_the_c_layout(tmp_path):
+    """DrvConfig / DrvStats / the header and bitstream structs mirrored in Python against sizeof and offsetof from a C compiler"""
+    import shutil
+    import subprocess
+    from vp8oclenc_amd import bitstream
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "s.c"
+    src.write_text("""
+        #include <stdio.h>
+        #include <stddef.h>
+        #include "vp8hip_driver.h"
+        #include "vp8hip_bitstream.h"
+        #include "vp8hip_host.h"
+        int main(void) {
+            printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vp8drv_config), offsetof(vp8drv_config, src_height), sizeof(vp8drv_stats),
+                   offsetof(vp8drv_stats, scene_changes), sizeof(vp8hip_header_params), sizeof(vp8bs_frame), sizeof(vp8host_scene_state));
+            return 0;
+        }""")
+    exe = tmp_path / "s"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    c = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert c[0] == C.sizeof(api.DrvConfig) and c[1] == api.DrvConfig.src_height.offset
+    assert c[2] == C.sizeof(api.DrvStats) and c[3] == api.DrvStats.scene_changes.offset
+    assert c[5] == C.sizeof(bitstream.Frame)
+    assert c[6] == C.sizeof(api.SceneState)
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
@@ -45,6 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2004  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
@@ -79,6 +80,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise Vp8HipError(f"{p} not found: build it with `python -m vp8oclenc_amd.build`")
     lib = C.CDLL(p)
+    # the struct layouts below (DrvConfig, DrvStats, ...) belong to one ABI: a library built from other sources is refused
+    if not hasattr(lib, "vp8hip_abi_version") or lib.vp8hip_abi_version() != ABI_VERSION:
+        raise Vp8HipError(f"{p} is not ABI {ABI_VERSION} (include/vp8hip.h): rebuild it with `python -m vp8oclenc_amd.build`")
     u8 = C.c_void_p
     vp = C.c_void_p
     lib.vp8hip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_int]

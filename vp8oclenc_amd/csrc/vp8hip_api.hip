@@ -1715,6 +1715,8 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
     return VP8HIP_OK;
 }
 
+int vp8hip_abi_version(void) { return VP8HIP_ABI_VERSION; }
+
 int vp8hip_conformant_stream(vp8hip_ctx *c, int on) {
     if (!c) return VP8HIP_ERR_ARG;
     c->conformant = on ? 1 : 0;
