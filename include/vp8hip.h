@@ -36,7 +36,7 @@ typedef enum {
     VP8HIP_ERR_OVERFLOW = -7,  /* vp8hip_encode_coefficients: output or scratch too small for this frame */
     VP8HIP_ERR_FORMAT = -8     /* the frame cannot be written as VP8: its first partition has 512 KB or more and the frame tag
                                   has 19 bits for that size (RFC 6386 section 9.1) -- key frames of about 7000x4000 and up.  The
-                                  reference writes the low 19 bits (entropy_host.cpp:1245-1250) and emits a frame no decoder
+                                  reference writes the low 19 bits (entropy_host.cpp:1237-1241) and emits a frame no decoder
                                   can read; here the call fails */
 } vp8hip_status;
 
