@@ -325,3 +325,61 @@ def test_gpu_sequences_decode_to_the_device_reconstruction(W, H, seed, frames, P
     if "ssim_target" in cfg:
         assert seen["intra_in_inter"] > 0, seen
     drv.close()
+
+
+# ---- the decoder on streams it has never seen the encoder of ---------------------------------------------------------------------
+
+def _foreign_key_frame(rgb, quality, method):
+    """a VP8 key frame made by libwebp's ENCODER (through Pillow): the 'VP8 ' chunk of a lossy .webp"""
+    import io
+    import struct
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(buf, format="WEBP", quality=quality, method=method)
+    webp = buf.getvalue()
+    assert webp[:4] == b"RIFF" and webp[8:12] == b"WEBP"
+    off = 12
+    while off < len(webp):
+        tag, size = webp[off:off + 4], struct.unpack("<I", webp[off + 4:off + 8])[0]
+        if tag == b"VP8 ":
+            return webp[off + 8:off + 8 + size]
+        off += 8 + size + (size & 1)
+    raise ValueError("no VP8 chunk")
+
+
+def _pillow_writes_webp():
+    try:
+        from PIL import features
+        return bool(features.check("webp"))
+    except Exception:
+        return False
+
+
+@needs_libwebp
+@pytest.mark.skipif(not _pillow_writes_webp(), reason="no Pillow with WebP in this image")
+def test_the_rfc_decoder_decodes_foreign_streams_as_libwebp_does():
+    """tests/vp8_decode.py is a VP8 decoder, not an echo of this encoder: key frames made by libwebp's encoder -- segments with
+    their own quantisers and filter levels, all four 16x16 luma modes beside B_PRED, every chroma mode, sizes that are not
+    multiples of 16, qualities 5 to 99 -- decode to exactly what libwebp's decoder makes of them"""
+    import vp8_decode
+    import vp8_parse as vp
+    rng = np.random.default_rng(1)
+    ymodes, uvmodes, segs, levels = np.zeros(5, np.int64), np.zeros(4, np.int64), 0, set()
+    for case in range(24):
+        W, H = int(rng.integers(2, 30)) * 8 + int(rng.integers(0, 8)), int(rng.integers(2, 24)) * 8 + int(rng.integers(0, 8))
+        y = SynthSequence(320, 256, seed=case).frame(case)[0]
+        rgb = np.stack([y[:H, :W], np.roll(y, 3, 1)[:H, :W], 255 - y[:H, :W]], axis=2)
+        if case % 3 == 0:
+            rgb = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        elif case % 3 == 1:
+            rgb = (rgb // 64 * 64).astype(np.uint8)            # flat areas: the 16x16 modes
+        frame = _foreign_key_frame(np.ascontiguousarray(rgb), int(rng.integers(5, 100)), int(rng.integers(0, 7)))
+        f, planes = vp8_decode.Decoder().decode(frame)
+        ref = webp_decode.decode_key_frame(frame)
+        for name, a, b in zip("YUV", planes, ref):
+            assert np.array_equal(a[:b.shape[0], :b.shape[1]], b), (case, W, H, name)
+        ymodes += np.bincount(f.ymode, minlength=5)
+        uvmodes += np.bincount(f.uvmode, minlength=4)
+        segs += int(f.segmentation_enabled)
+        levels.add(int(f.loop_filter_level))
+    assert (ymodes > 0).all() and (uvmodes > 0).all() and segs > 0 and len(levels) > 5, (ymodes, uvmodes, segs, levels)
