@@ -75,3 +75,40 @@ def test_frames_come_back(tmp_path):
     g.frame(0)
     with pytest.raises(ValueError, match="broken stream"):
         g.frame(1)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HOST_SO), reason="oracle/_ref/libvp8refhost.so not built (no /root/reference here)")
+def test_random_headers_against_the_reference_function(tmp_path):
+    """400 random headers -- tags in any order, repeated, with letters inside numbers, FRAME look-alikes, truncations -- through the
+    reference's own parser and the restatement: the same verdict and the same numbers (kept below the reference's 128-byte header
+    array and away from a zero denominator, which it divides by)"""
+    ref = C.CDLL(REF_HOST_SO)
+    ref.ref_parse_y4m_header.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(11)
+    tags = [lambda: b"W%d" % rng.integers(0, 5000), lambda: b"H%d" % rng.integers(0, 5000), lambda: b"F%d:%d" % (rng.integers(0, 99999), rng.integers(1, 2000)),
+            lambda: b"Ip", lambda: b"A%d:%d" % (rng.integers(1, 200), rng.integers(1, 200)), lambda: b"C420jpeg", lambda: b"XYSCSS=420", lambda: b"W1x7",
+            lambda: b"H", lambda: b"It", lambda: b"C444"]
+    p, scratch = str(tmp_path / "h.y4m"), str(tmp_path / "o.ivf")
+    agree_ok = agree_bad = 0
+    for _ in range(400):
+        head = b"YUV4MPEG2 " if rng.random() < 0.95 else b"YUV4MPEG1 "
+        picks = [int(i) for i in rng.integers(0, len(tags), int(rng.integers(1, 7)))]
+        if rng.random() < 0.6:       # the three tags the reference needs, in a random order, before whatever else
+            picks = [int(i) for i in rng.permutation(3)] + [i for i in picks if i > 2]
+        body = b" ".join(tags[i]() for i in picks)
+        tail = [b" \nFRAME\n", b"\nFRAME\n", b" \nFRAMX\nFRAME\n", b" \nFRAME Ip\n", b" \nFRA", b" \nFFRAME\n"][int(rng.integers(0, 6))]
+        data = (head + body + tail)[:110] + bytes(range(32))
+        open(p, "wb").write(data)
+        w, h, f, off = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        rc = ref.ref_parse_y4m_header(p.encode(), scratch.encode(), C.byref(w), C.byref(h), C.byref(f), C.byref(off))
+        try:
+            got = y4m.parse_header(data)
+        except ValueError:
+            got = None
+        if rc != 0:
+            assert got is None, (data, got)
+            agree_bad += 1
+        else:
+            assert got == (w.value, h.value, f.value, off.value), (data, got, (w.value, h.value, f.value, off.value))
+            agree_ok += 1
+    assert agree_ok > 100 and agree_bad > 50, (agree_ok, agree_bad)
