@@ -128,6 +128,67 @@ extern "C" void ref_copy_with_padding(const uint8_t *sy, const uint8_t *su, cons
     copy_with_padding();
 }
 
+/* ---- the host producers of the path's parameters, the reference's own functions (src/vp8enc.cpp, src/init.h) -------------------- */
+extern "C" {
+
+/* get_loopfilter_strength, src/vp8enc.cpp:96-127 */
+void ref_loopfilter_strength(const uint8_t *y, int w, int h, int32_t *reductor, int32_t *sharpness) {
+    video.wrk_width = w;
+    video.wrk_height = h;
+    video.wrk_frame_size_luma = w * h;
+    frames.current_Y = const_cast<uint8_t *>(y);
+    int red = 0;
+    cl_int sh = 0;
+    get_loopfilter_strength(&red, &sh);
+    *reductor = red;
+    *sharpness = sh;
+}
+
+/* prepare_segments_data, src/vp8enc.cpp:129-229 (GOP_size 1: it returns before its uploads, :221).  sd_out: 4 x 11 ints */
+void ref_prepare_segments_data(const uint8_t *y, int w, int h, int is_key, int is_altref, const int32_t *lastqi, const int32_t *altrefqi,
+                               int qi_min, int update_filter, int shrpnss, int32_t *sd_out, int32_t *sharpness_out) {
+    video.wrk_width = w;
+    video.wrk_height = h;
+    video.wrk_frame_size_luma = w * h;
+    video.GOP_size = 1;
+    video.qi_min = qi_min;
+    frames.current_Y = const_cast<uint8_t *>(y);
+    frames.current_is_key_frame = is_key;
+    frames.current_is_altref_frame = is_altref;
+    for (int i = 0; i < 4; ++i) { video.lastqi[i] = lastqi[i]; video.altrefqi[i] = altrefqi[i]; }
+    memset(frames.segments_data, 0, sizeof(frames.segments_data));
+    prepare_segments_data(update_filter, shrpnss);
+    memcpy(sd_out, frames.segments_data, 4 * sizeof(segment_data));
+    *sharpness_out = video.loop_filter_sharpness;
+}
+
+/* scene_change, src/vp8enc.cpp:265-311 (its hold-over is a function-static: one sequence per process).  Returns its verdict;
+ * last_key_detect goes in and comes out (intra_transform sets it when the key frame is coded: the caller's job here) */
+int ref_scene_change(const uint8_t *cur_u, const uint8_t *cur_v, const uint8_t *last_u, const uint8_t *last_v, int n_chroma, int frame_number,
+                     int32_t *last_key_detect) {
+    video.wrk_frame_size_chroma = n_chroma;
+    frames.current_U = const_cast<uint8_t *>(cur_u);
+    frames.current_V = const_cast<uint8_t *>(cur_v);
+    frames.last_U = const_cast<uint8_t *>(last_u);
+    frames.last_V = const_cast<uint8_t *>(last_v);
+    frames.frame_number = frame_number;
+    frames.last_key_detect = *last_key_detect;
+    const int r = scene_change();
+    *last_key_detect = frames.last_key_detect;
+    return r;
+}
+
+/* ParseArgs, src/init.h:1295-1608, on an argument vector of the caller ("-i" and "-o" must be in it): the defaults and the two
+ * quantizer ladders it derives.  out = {qi_min, qi_max, GOP_size, altref_range, number_of_partitions, lastqi[4], altrefqi[4]} */
+int ref_parse_args(int argc, char **argv, int32_t *out, float *ssim_target) {
+    const int rc = ParseArgs(argc, argv);
+    out[0] = video.qi_min; out[1] = video.qi_max; out[2] = video.GOP_size; out[3] = video.altref_range; out[4] = (int32_t)video.number_of_partitions;
+    for (int i = 0; i < 4; ++i) { out[5 + i] = video.lastqi[i]; out[9 + i] = video.altrefqi[i]; }
+    *ssim_target = video.SSIM_target;
+    return rc;
+}
+}
+
 /* OpenYUV420FileAndParseHeader, src/init.h:1610-1737, on a file of the caller (it also opens the output file: `scratch` is
  * a path it may create).  Returns the function's result; on success the sizes, the frame rate and where the file position
  * stands (= the first frame's samples). */
