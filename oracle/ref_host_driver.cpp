@@ -189,6 +189,32 @@ int ref_parse_args(int argc, char **argv, int32_t *out, float *ssim_target) {
 }
 }
 
+/* write_output_header / write_output_file, src/encIO.h:32-139: an .ivf of the caller's frames written by the reference's own
+ * functions the way main() uses them (header first, every frame, the header again with the final count; init.h:104-105 for the
+ * time base) */
+extern "C" int ref_write_ivf(const char *path, int w, int h, int framerate, int nframes, const uint8_t *const *frame, const int32_t *size) {
+    output_file.handle = fopen(path, "wb");
+    if (!output_file.handle) return -1;
+    video.dst_width = w;
+    video.dst_height = h;
+    video.framerate = framerate;
+    video.timestep = 1;
+    video.timescale = 1;
+    frames.frame_number = -1;
+    write_output_header();
+    for (int t = 0; t < nframes; ++t) {
+        frames.frame_number = t;
+        frames.encoded_frame = const_cast<uint8_t *>(frame[t]);
+        frames.encoded_frame_size = size[t];
+        write_output_file();
+    }
+    frames.frame_number = nframes - 1;
+    write_output_header();
+    fclose(output_file.handle);
+    output_file.handle = nullptr;
+    return 0;
+}
+
 /* OpenYUV420FileAndParseHeader, src/init.h:1610-1737, on a file of the caller (it also opens the output file: `scratch` is
  * a path it may create).  Returns the function's result; on success the sizes, the frame rate and where the file position
  * stands (= the first frame's samples). */

@@ -117,3 +117,22 @@ def test_header_matches_reference_golden_vectors(path):
                                       is_inter=opt("is_inter"), modes=opt("modes"), replaced=int(z["replaced"]), sharpness=int(z["sharpness"]),
                                       partitions_log2=int(z["partitions_log2"]))
     assert np.array_equal(mine, z["header"]), np.nonzero(mine[:min(len(mine), len(z["header"]))] != z["header"][:min(len(mine), len(z["header"]))])[0][:8]
+
+
+@needs_ref
+def test_ivf_file_against_the_reference_writers(tmp_path):
+    """write_output_header / write_output_file (encIO.h:32-139), the reference's own functions, against gop_shard.write_ivf
+    (vp8bs_ivf_file_header / vp8bs_ivf_frame_header): the same file, byte for byte"""
+    import ctypes as C
+    from oracle_lib import REF_HOST_SO
+    from vp8oclenc_amd import gop_shard
+    rng = np.random.default_rng(8)
+    frames = [rng.integers(0, 256, int(n)).astype(np.uint8).tobytes() for n in (10, 70000, 3, 513, 1 << 17)]
+    ref = C.CDLL(REF_HOST_SO)
+    ref.ref_write_ivf.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
+    arr = (C.c_char_p * len(frames))(*frames)
+    sizes = (C.c_int32 * len(frames))(*[len(f) for f in frames])
+    a, b = str(tmp_path / "ref.ivf"), str(tmp_path / "own.ivf")
+    assert ref.ref_write_ivf(a.encode(), 1918, 1078, 25, len(frames), arr, sizes) == 0
+    gop_shard.write_ivf(b, frames, 1918, 1078, framerate=25)
+    assert open(a, "rb").read() == open(b, "rb").read()
