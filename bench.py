@@ -323,10 +323,13 @@ def main():
     G = max(1, args.gops_per_gpu)
     B = max(1, min(8, args.batch))   # VP8HIP_MAX_BATCH
     nd = max(2, args.distinct_frames)
+    free_before = torch.cuda.mem_get_info(local)[0]
     leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
               overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")),   # experiment switch: every chunk's filter on a second stream
               batch=B)
     W, H, mbs = leg.W, leg.H, leg.mbs
+    torch.cuda.synchronize()
+    hbm_used = free_before - torch.cuda.mem_get_info(local)[0]      # contexts (surfaces, nets, coefficient buffers) + the synthetic frames
 
     # ---- warmup; every kernel of chunk 0 timed to find the dominant one --------------------------------------
     leg.drv[0].hip.profile_enable(api.K_NAMES)
@@ -421,7 +424,7 @@ def main():
                        "wrk_size": [W, H], "source_size": list(leg.source_size), "padding": "on the device, inside the step (copy_with_padding)" if tuple(leg.source_size) != (W, H) else "none needed",
                        "macroblocks_per_frame": mbs, "ssim_target": args.ssim_target, "qi_ladder": list(api.quantizer_ladders(0, 48)[0]),
                        "altref_range": ALTREF_RANGE, "preroll_frames_per_chunk": f"{PREROLL}..{PREROLL + ALTREF_RANGE - 1}", "frames_per_gpu": frames_per_gpu,
-                       "gops_per_gpu": G, "chunks_per_batched_launch": B, "refs_per_frame": round(nrefs_avg, 3),
+                       "gops_per_gpu": G, "chunks_per_batched_launch": B, "hbm_bytes_in_use": int(hbm_used), "hbm_bytes_per_chunk": int(hbm_used // G), "refs_per_frame": round(nrefs_avg, 3),
                        "ms_per_frame": round(ms_frame, 5),
                        "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
