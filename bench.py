@@ -581,9 +581,27 @@ def cpu_baseline(args, api, host_frames, W, H, mbs):
         if el >= args.cpu_seconds or n >= 64:   # a bounded sample: ~12 s of host time
             break
     ora.close()
-    return {"value": round(mbs * n / el, 1), "unit": "macroblocks/s", "cores": threads, "kind": "port",
-            "sample": f"{n} inter frames {W}x{H}, 3 references, oracle/vp8_oracle.c with OpenMP on {threads} threads, "
-                      f"{el:.1f} s"}
+    out = {"value": round(mbs * n / el, 1), "unit": "macroblocks/s", "cores": threads, "kind": "port",
+           "sample": f"{n} inter frames {W}x{H}, 3 references, oracle/vp8_oracle.c with OpenMP on {threads} threads, "
+                     f"{el:.1f} s"}
+    # beside it, where oracle/_ref travelled: the REFERENCE'S OWN kernels (GPU_kernels.cl + CPU_kernels.cl compiled for x86,
+    # oracle/build_ref.sh) through the same frame -- work-item loops on one core, the way oracle/ref_driver.c drives them
+    try:
+        import numpy as np
+        from oracle_lib import ref_stages
+        from pipeline import run_inter_frame
+        st = ref_stages()
+        if st is not None and args.cpu_seconds >= 5:
+            t0 = time.perf_counter()
+            run_inter_frame(st, host_frames[3 % len(host_frames)], [host_frames[2 % len(host_frames)], host_frames[0], host_frames[1]],
+                            np.asarray(segs[3 % len(segs)]).reshape(4, 11), 1, 1, args.ssim_target)
+            el1 = time.perf_counter() - t0
+            out["reference_kernels_on_one_core"] = {"value": round(mbs / el1, 1), "unit": "macroblocks/s", "cores": 1, "kind": "reference",
+                                                    "sample": f"1 inter frame {W}x{H}, 3 references + loop filter, the reference's kernels compiled for x86 "
+                                                              f"(oracle/_ref/libvp8ref.so), {el1:.1f} s"}
+    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
+        out["reference_kernels_on_one_core"] = {"error": repr(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":
