@@ -74,6 +74,13 @@ int vp8host_y4m_parse_header(const uint8_t *data, size_t size, int32_t *width, i
         ch = data[j++];
         return true;
     };
+    // The reference accumulates whatever bytes follow a tag (ch - 0x30, no digit check) in an int; here the same arithmetic
+    // modulo 2^32 (what its overflow does, without the undefined behaviour), and a size outside the format's 14 bits is
+    // refused at the end -- the one deviation: the reference would go on with it.
+    auto digit = [&](int &acc) -> bool {
+        acc = (int)((uint32_t)acc * 10u + (uint32_t)(ch - 0x30));
+        return true;
+    };
     int w = 0, h = 0, fps = 0;
     for (int i = 0; i < 10; ++i) {
         if (!next() || ch != magic[i]) return -1;
@@ -85,31 +92,32 @@ int vp8host_y4m_parse_header(const uint8_t *data, size_t size, int32_t *width, i
             for (;;) {
                 if (!next()) return -1;
                 if (ch == 0x20) break;
-                w = w * 10 + (ch - 0x30);
+                if (!digit(w)) return -1;
             }
         } else if (ch == 'H') {
             for (;;) {
                 if (!next()) return -1;
                 if (ch == 0x20) break;
-                h = h * 10 + (ch - 0x30);
+                if (!digit(h)) return -1;
             }
         } else {
             int num = 0, denom = 0;
             for (;;) {
                 if (!next()) return -1;
                 if (ch == ':') break;
-                num = num * 10 + (ch - 0x30);
+                if (!digit(num)) return -1;
             }
             for (;;) {
                 if (!next()) return -1;
                 if (ch == 0x20) break;
-                denom = denom * 10 + (ch - 0x30);
+                if (!digit(denom)) return -1;
             }
             if (denom == 0) return -1;               // the reference divides by it (:1688)
             fps = (num + denom / 2) / denom;
         }
     }
     if (w + h == 0) return -1;
+    if (w < 1 || h < 1 || w > 16383 || h > 16383) return -1;   // RFC 6386 section 9.1: 14 bits each
     for (;;) {                                       // the first "FRAME" followed by a line feed (:1696-1728)
         while (ch != 'F')
             if (!next()) return -1;

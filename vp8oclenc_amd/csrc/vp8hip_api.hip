@@ -80,6 +80,7 @@ struct vp8hip_ctx {
     int64_t lf_context_switches = 0;   // see vp8hip_profile_context_switches
     bool s2_clock_on = false;          // k_search2 stamps its launches (vp8hip_profile_search2_clock)
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
+    bool frame_overflowed = false;  // ... and _end found the caller's buffer too small: the coded frame waits in h_frame for a retry
     bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
     int frame_partitions = 0;
@@ -291,12 +292,13 @@ static SegData *sd_for_writing(vp8hip_ctx *c) {
 static int join_lf(vp8hip_ctx *c) {
     if (!c->lf_pending) return VP8HIP_OK;
     c->lf_pending = false;
-    // back to the stream the filter is on, behind it and behind everything that ran beside it
-    HIPCHK(c, hipEventRecord(c->ev_lf, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_lf, 0));
+    // back to the stream the filter is on, behind it and behind everything that ran beside it.  The streams trade places
+    // first: whatever the two calls below return, `stream` is the one vp8hip_create made again (vp8hip_destroy relies on it)
     hipStream_t side = c->stream;
     c->stream = c->lf_stream;
     c->lf_stream = side;
+    HIPCHK(c, hipEventRecord(c->ev_lf, side));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
     return VP8HIP_OK;
 }
 // HIP's current device is per host thread: a context may be driven from a thread other than its creator's, or two contexts
@@ -623,10 +625,25 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
     return VP8HIP_OK;
 }
 
+// A frame that did not fit its caller's buffer (VP8HIP_ERR_OVERFLOW from vp8hip_encode_frame_end) stays pending for a retry
+// with a larger one; a caller that goes on to the next frame instead has given it up.
+static void drop_overflowed_frame(vp8hip_ctx *c) {
+    if (c->frame_overflowed) c->frame_pending = c->frame_overflowed = false;
+}
+
+// what inter_begin would refuse, without touching the context (a batch validates every member before it changes any)
+static int inter_check(const vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
+    if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
+    const int golden = prev_is_golden ? c->slot[0] : c->slot[1], altref = prev_is_altref ? c->slot[0] : c->slot[2];
+    if ((use_golden && golden < 0) || (use_altref && altref < 0)) return VP8HIP_ERR_STATE;
+    return VP8HIP_OK;   // (a surface for the reconstruction always exists: five surfaces, at most three references)
+}
+
 // reference rotation + the reconstruction surface of the new frame: the head of every inter frame
 static int inter_begin(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, int use_golden, int use_altref) {
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
+    drop_overflowed_frame(c);
     // reference rotation, inter_part.h:35-50,72-83: golden/altref := the frame that is LAST now
     if (prev_is_golden) c->slot[1] = c->slot[0];
     if (prev_is_altref) c->slot[2] = c->slot[0];
@@ -791,11 +808,15 @@ struct vp8hip_batch {
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     if (!out || !ctxs || n < 1 || n > MAX_BATCH) return VP8HIP_ERR_ARG;
     *out = nullptr;
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (!ctxs[i] || ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H || ctxs[i]->device != ctxs[0]->device ||
             ctxs[i]->ssim_target != ctxs[0]->ssim_target || ctxs[i]->lf_overlap || ctxs[i]->conformant != ctxs[0]->conformant ||
             ctxs[i]->src_w != ctxs[0]->src_w || ctxs[i]->src_h != ctxs[0]->src_h)
             return VP8HIP_ERR_ARG;
+        if (!ctxs[i]->own_stream) return VP8HIP_ERR_STATE;            // already a member of a batch
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return VP8HIP_ERR_ARG;            // the same context twice
+    }
     vp8hip_batch *b = new (std::nothrow) vp8hip_batch();
     if (!b) return VP8HIP_ERR_ARG;
     USE_DEVICE(ctxs[0]);
@@ -820,22 +841,26 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         ctxs[i]->stream = b->stream;
         b->c[i] = ctxs[i];
+        if (ctxs[i]->counted) --g_live_contexts;   // the batch's one stream is counted in their place
+        ctxs[i]->counted = false;
     }
-    g_live_contexts -= n - 1;   // one stream for all of them now
+    ++g_live_contexts;
     *out = b;
     return VP8HIP_OK;
 }
 
-void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay, each back on its own stream
+void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the batch before its members), each back on its own stream
     if (!b) return;
     hipSetDevice(b->c[0]->device);
     hipStreamSynchronize(b->stream);
     hipStreamDestroy(b->stream);
+    --g_live_contexts;
     for (int i = 0; i < b->n; ++i) {
         if (!b->c[i]->own_stream) hipStreamCreateWithFlags(&b->c[i]->own_stream, hipStreamNonBlocking);
         b->c[i]->stream = b->c[i]->own_stream;
+        if (!b->c[i]->counted) ++g_live_contexts;
+        b->c[i]->counted = true;
     }
-    g_live_contexts += b->n - 1;
     delete b;
 }
 
@@ -906,10 +931,15 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     const SegData *sds[MAX_BATCH];
     int n = 0, npyr = 0;
     uint32_t pyr_border = 0;
+    for (int i = 0; i < b->n; ++i) {   // every member is checked before any member's state changes
+        if (active && !active[i]) continue;
+        if (b->c[i]->conformant != c0->conformant) return VP8HIP_ERR_ARG;   // one launch, one predictor
+        const int rc = inter_check(b->c[i], prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
+        if (rc) return rc;
+    }
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
-        if (c->conformant != c0->conformant) return VP8HIP_ERR_ARG;   // one launch, one predictor
         const int rc = inter_begin(c, prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
         if (rc) return rc;
         FrameSurf &last = c->frames[c->slot[0]];
@@ -1064,6 +1094,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
     int rc = claim_recon(c);
     if (rc) return rc;
     c->ent_counted_partitions = 0;
+    drop_overflowed_frame(c);
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
@@ -1412,6 +1443,7 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
     if (!c || !p) return VP8HIP_ERR_ARG;
     const int P = num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    drop_overflowed_frame(c);                        // a frame given up after VP8HIP_ERR_OVERFLOW is coded again
     if (c->frame_pending) return VP8HIP_ERR_STATE;   // (no size limit here: the frame path's prefix sums take any number of blocks)
     const int rc = frame_enqueue(c, P, p);
     if (rc) return rc;
@@ -1479,7 +1511,7 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
     USE_DEVICE(c);
     if (!c || !out || !size) return VP8HIP_ERR_ARG;
     if (!c->frame_pending) return VP8HIP_ERR_STATE;
-    c->frame_pending = false;
+    c->frame_pending = c->frame_overflowed = false;
     const vp8hip_header_params *p = &c->frame_params;
     hipStream_t s = c->stream;
     size_t n;
@@ -1494,8 +1526,8 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
         if (rc) return rc;
     }
     if (n > capacity) {
-        c->frame_pending = true;   // the coded frame stays in h_frame: the caller may come back with a larger buffer
-        return VP8HIP_ERR_OVERFLOW;
+        c->frame_pending = c->frame_overflowed = true;   // the coded frame stays in h_frame: the caller may come back with a larger
+        return VP8HIP_ERR_OVERFLOW;                      // buffer (_end again, or the one-shot vp8hip_encode_frame / vp8drv_get_frame)
     }
     if (reinterpret_cast<const uint32_t *>(c->h_frame)[1] >= (1u << 19)) return VP8HIP_ERR_FORMAT;   // 19-bit size field of the frame tag
     const size_t head = p->is_key ? 10 : 3;
@@ -1523,7 +1555,8 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
 int vp8hip_encode_frame(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p, uint8_t *out, size_t capacity, size_t *size) {
     USE_DEVICE(c);
     if (!c || !p || !out || !size) return VP8HIP_ERR_ARG;
-    const int rc = vp8hip_encode_frame_begin(c, num_partitions, p);
+    // the retry after VP8HIP_ERR_OVERFLOW: the frame is coded and waiting, only the delivery is repeated
+    const int rc = (c->frame_pending && c->frame_overflowed) ? VP8HIP_OK : vp8hip_encode_frame_begin(c, num_partitions, p);
     return rc ? rc : vp8hip_encode_frame_end(c, out, capacity, size);
 }
 

@@ -37,6 +37,8 @@ class Y4mFile:
         self._ok = lib.vp8host_y4m_frame_marker_ok
 
     def frame(self, t: int):
+        if not 0 <= t < self.n:
+            raise IndexError(f"frame {t} of {self.n}")
         a = self.first + t * (self.fsz + 6)
         if t > 0 and not self._ok(bytes(self.m[a - 6:a])):
             raise ValueError(f"broken stream before frame {t}")          # encIO.h:245-248
