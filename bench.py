@@ -45,6 +45,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+# check_SSIM after every inter frame, as the reference's loop has it (vp8enc.cpp:442): the intra fallback of macroblocks below the
+# SSIM target, the loop-filter update when even the worst macroblock is above 0.95, "redo as key frame".  On the device, nobody
+# waiting (vp8drv_config.check_ssim with device parameters).  VP8_BENCH_CHECK=0 leaves it out (A/B runs only).
+CHECK_SSIM = int(os.environ.get("VP8_BENCH_CHECK", "1"))
 ALTREF_RANGE = 5
 PREROLL = 2 * ALTREF_RANGE + 2
 
@@ -154,7 +158,7 @@ class Leg:
         self.drv, self.t, self.batches = [], [], []
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
-                                 ssim_target=ssim_target, device_params=1, check_ssim=0, ref_mask=3 if refs == "all" else 0,
+                                 ssim_target=ssim_target, device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0,
                                  overlap_filter=overlap_filter, conformant_stream=conformant, **src)
             t = (k * 3) % nd                                   # chunks start at different frames of the sequence
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
@@ -361,6 +365,9 @@ def main():
         elapsed = float(tt.item())
     prof = leg.profile_read()
     clk_ms, clk_n, clk_ghz = leg.clock_read()
+    for d in leg.drv:
+        d.resolve()
+    redone = sum(d.stats().redone_as_key for d in leg.drv)
     frames_per_gpu = args.steps * G
     if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:
         raise SystemExit(f"bench.py: the timed frames averaged {nrefs_avg:.2f} references per frame; LAST+GOLDEN+ALTREF in GOP "
@@ -427,6 +434,10 @@ def main():
                        "gops_per_gpu": G, "chunks_per_batched_launch": B, "hbm_bytes_in_use": int(hbm_used), "hbm_bytes_per_chunk": int(hbm_used // G), "refs_per_frame": round(nrefs_avg, 3),
                        "ms_per_frame": round(ms_frame, 5),
                        "segment_params": "device, inside the step", "frame_loop": "native (vp8_driver.cpp), one call per frame",
+                       "check_ssim": ("on the device inside the step: intra fallback, filter update at min SSIM > 0.95, verdict read one call later"
+                                      if CHECK_SSIM else "OFF (A/B run: not the reference's loop)"),
+                       "frames_redone_as_key": redone, "frames_with_filter_update": None,
+                       "batch_prep_stream": os.environ.get("VP8HIP_BATCH_PREP", "1"),
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
             "loop_filter_by_its_own_clock": lf_clock,

@@ -128,6 +128,17 @@ int vp8hip_intra_transform(vp8hip_ctx *ctx);
  * scores higher.  Returns frames.replaced, frames.new_SSIM and the minimum SSIM (`min1`; the reference updates
  * the filter parameters when it exceeds 0.95, :260).  Blocks until the three values are back. */
 int vp8hip_check_ssim(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim);
+/* The same without the host in the middle -- what a frame loop at thousands of frames per second needs: check_SSIM's
+ * fallback, its statistics AND its filter update (`if (min1 > 0.95) prepare_segments_data(1, 7)`, :260-261, rewriting the
+ * segment data in force on the device from the strength pair vp8hip_auto_segments left there, so it needs segment data
+ * made by vp8hip_auto_segments; refqi / qi_min as for that call) are enqueued and the call returns; the loop filter and the
+ * entropy stage can follow at once.  It also renews the filter mask and non-zero count of every macroblock it replaces
+ * (no vp8hip_prepare_filter_mask needed).  vp8hip_check_ssim_result waits for the verdict -- three words the device writes
+ * to host memory -- when the host next needs it: the reference's "redo as key frame" decision (:443-453), which the native
+ * frame loop takes at the start of the NEXT call (include/vp8hip_driver.h).  filter_updated: 1 when the segment data were
+ * rewritten (video.loop_filter_sharpness is then 7).  VP8HIP_ERR_STATE without a pending verdict. */
+int vp8hip_check_ssim_async(vp8hip_ctx *ctx, const int32_t refqi[4], int qi_min);
+int vp8hip_check_ssim_result(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim, int32_t *filter_updated);
 /* e_data[].mode[16] of the last vp8hip_intra_transform / vp8hip_check_ssim (the sub-block modes the header coder
  * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference -- see
  * vp8hip_conformant_stream -- and 0 where none was made) and
@@ -273,16 +284,22 @@ int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
  * in ONE kernel launch per stage (same kernels, blockIdx.z = member), on one stream that the members share from then on --
  * so a member's own calls (vp8hip_intra_transform for a chunk's key frame, vp8hip_encode_frame, downloads) stay ordered
  * with the batched stages.  Arrays are indexed by member; `active` (may be NULL = all) leaves members out of a stage.
+ * A batch has a second, low-priority stream for the head of a frame -- vp8hip_batch_set_current_device,
+ * vp8hip_batch_auto_segments and the new frame's pyramid run there, beside the PREVIOUS frame's chain, because none of them
+ * depends on the previous frame's reconstruction; the chain that does (LAST's pyramid, the searches, the transform, the
+ * loop filter) waits for them where it starts (VP8HIP_BATCH_PREP=0 in the environment keeps everything on one stream).
  * No reference counterpart: the reference codes one video on one in-order queue set. */
 #define VP8HIP_MAX_BATCH 8
 typedef struct vp8hip_batch vp8hip_batch;
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n);
-void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream */
+void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream; destroy a batch before its members */
 int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v);
 int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min);
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);
 int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
+/* vp8hip_check_ssim_async for the active members in the same two launches; vp8hip_check_ssim_result per member afterwards */
+int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int32_t (*refqi)[4], int qi_min);
 /* vp8hip_encode_frame_begin for the active members in the same nine launches (params[i] = member i's header parameters;
  * every member is then between _begin and _end: take each frame with vp8hip_encode_frame_end) */
 int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_partitions, const vp8hip_header_params *params);
@@ -290,7 +307,7 @@ const char *vp8hip_status_string(int status);
 /* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
  * layout (vp8drv_config grew in round 2: 2), MINOR when entry points are added.  A host built against an older header checks
  * it once after loading the library. */
-#define VP8HIP_ABI_VERSION 2004
+#define VP8HIP_ABI_VERSION 2005
 int vp8hip_abi_version(void);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

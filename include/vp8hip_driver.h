@@ -31,9 +31,15 @@ typedef struct {
     float ssim_target;       /* -SSIM-target (init.h:1512,1576) */
     int32_t device_params;   /* 1: loop-filter strength + segment data on the device, no host round trip
                                 (vp8hip_auto_segments); 0: host mirror on the caller's luma plane */
-    int32_t check_ssim;      /* 1: check_SSIM after every inter_transform (vp8enc.cpp:231-263, 442-453): intra fallback,
-                                filter update, redo as key frame; blocks for three words per frame.
-                                0: skip it (what the reference's defaults amount to except for the filter update) */
+    int32_t check_ssim;      /* 1: check_SSIM after every inter_transform (vp8enc.cpp:231-263, 442-453) -- what the reference does:
+                                intra fallback, filter update when even the worst macroblock is above 0.95, redo as key frame.
+                                With device_params the call does not wait for it (vp8hip_check_ssim_async): fallback, statistics
+                                and filter update run on the device in front of the loop filter, and the one decision that is the
+                                host's -- redo as key frame -- is taken when the verdict is next needed: at the start of the next
+                                vp8drv_encode_frame_* / vp8drv_batch_encode_frame_device, in vp8drv_get_frame[_begin], or in
+                                vp8drv_resolve.  Until then the return value "inter frame" and the counters of vp8drv_get_stats
+                                are provisional.  With device_params == 0 the host sits in the middle, as in the reference.
+                                0: skip it (the reference's loop minus the filter update; kept for A/B runs) */
     int32_t num_partitions;  /* -partitions: 1, 2, 4 or 8 coefficient partitions (init.h:1451-1469, default 1) */
     int32_t display_width, display_height;   /* video.dst_width/height written into key frames; 0 = the coded size */
     int32_t host_bitstream;  /* vp8drv_get_frame: 0 = the whole entropy stage on the device (vp8hip_encode_frame);
@@ -71,6 +77,11 @@ int vp8drv_encode_frame_device(vp8drv *d, const void *d_y, const void *d_u, cons
 /* same for host planes (blocks for the upload).  With device_params == 0 the host mirror scans y. */
 int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v, int force_key);
 
+/* With check_ssim: waits for the verdict on the frame just coded and, if it sends the frame back (vp8enc.cpp:443-453), codes it
+ * again as a key frame.  Returns 1 if the last frame ended as a key frame, 0 if as an inter frame, < 0 = vp8hip_status.  Implied by
+ * the next vp8drv_encode_frame_* and by vp8drv_get_frame[_begin]; a no-op when nothing is open. */
+int vp8drv_resolve(vp8drv *d);
+
 /* The frame just coded, as bytes: entropy_encode() + gather_frame() of the reference (vp8enc.cpp:48-94, 476-481;
  * encIO.h:1-30) -- coefficient statistics, coefficient partitions and the first partition (frame header, macroblock
  * modes, motion vectors) coded on the device and assembled into `out` (vp8hip_encode_frame; with host_bitstream the
@@ -88,7 +99,7 @@ int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size)
 /* Several GOP chunks advanced one frame at a time, every stage ONE launch for all of them (vp8hip_batch_* in vp8hip.h): what a
  * host with many chunks in flight uses instead of one stream per chunk -- the part runs four to five kernels at once, so
  * sixteen narrow launches queue where four wide ones fill it.  Members: up to VP8HIP_MAX_BATCH drivers of one geometry
- * with device_params = 1, check_ssim = 0, overlap_filter = 0.  One call = vp8drv_encode_frame_device on every member
+ * with device_params = 1, overlap_filter = 0, scene_detect = 0 and the same qi_min / qi_max / num_partitions / check_ssim.  One call = vp8drv_encode_frame_device on every member
  * (force_key / was_key indexed by member, either may be NULL); a member whose frame is a key frame takes its ordinary key-frame
  * path on the shared stream.  vp8drv_get_frame[_begin/_end] per member afterwards, as usual. */
 typedef struct vp8drv_batch vp8drv_batch;

@@ -11,13 +11,20 @@ from vp8oclenc_amd.synth import SynthSequence
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("W,H,n,frames,gop", [(320, 192, 4, 14, 6), (640, 352, 3, 8, 150), (1920, 1080, 2, 5, 150), (176, 144, 4, 9, 4), (320, 192, 8, 8, 5),
-                                               (1280, 720, 4, 6, 150)])
-def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop):
+# extra: check_SSIM inside the batch (the reference's loop): low quantizers put the worst macroblock above 0.95 (the filter update
+# on the device), an SSIM target gives replaced macroblocks and frames sent back to be key frames one call later
+@pytest.mark.parametrize("W,H,n,frames,gop,extra", [(320, 192, 4, 14, 6, {}), (640, 352, 3, 8, 150, {}), (1920, 1080, 2, 5, 150, {}), (176, 144, 4, 9, 4, {}),
+                                                     (320, 192, 8, 8, 5, {}), (1280, 720, 4, 6, 150, {}),
+                                                     (320, 192, 4, 12, 6, dict(check_ssim=1, qi_min=0, qi_max=6)),
+                                                     (320, 192, 5, 12, 150, dict(check_ssim=1, qi_min=40, qi_max=110, ssim_target=0.92)),
+                                                     (640, 352, 3, 8, 5, dict(check_ssim=1, qi_min=50, qi_max=110, ssim_target=0.9)),
+                                                     (1920, 1080, 3, 4, 150, dict(check_ssim=1, ssim_target=0.93))])
+def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop, extra):
     import torch
     seqs = [SynthSequence(W, H, seed=40 + i) for i in range(n)]
     Wp, Hp = seqs[0].W, seqs[0].H
     cfg = dict(gop_size=gop, altref_range=3, num_partitions=2, device_params=1, check_ssim=0)
+    cfg.update(extra)
     # chunks start at different points of their GOPs (different frame types inside one batched launch): member i has
     # already coded i frames on its own when the batch takes over
     single = [api.NativeDriver(Wp, Hp, **cfg) for _ in range(n)]
@@ -53,9 +60,12 @@ def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop):
             for p_, q_ in zip(single[i].hip.download_last(), batched[i].hip.download_last()):
                 assert np.array_equal(p_, q_), (t, i)
             sa, sb = single[i].stats(), batched[i].stats()
-            assert (sa.last_use_golden, sa.last_use_altref, sa.inter_frames, sa.key_frames) == (sb.last_use_golden, sb.last_use_altref, sb.inter_frames, sb.key_frames)
+            assert (sa.last_use_golden, sa.last_use_altref, sa.inter_frames, sa.key_frames, sa.redone_as_key, sa.last_replaced) == \
+                   (sb.last_use_golden, sb.last_use_altref, sb.inter_frames, sb.key_frames, sb.redone_as_key, sb.last_replaced)
             pos[i] += 1
     assert keys_seen >= (1 if gop < frames else 0)
+    if extra.get("ssim_target", -1) > 0.9 and W < 1000:
+        assert sum(d.stats().redone_as_key for d in batched) + sum(d.stats().last_replaced for d in batched) > 0
     nb.close()
     for d in single + batched:
         d.close()

@@ -22,8 +22,9 @@ def run_sequence(W, H, frames, P=1, **cfg):
                          qi_min=cfg.get("qi_min", 0), qi_max=cfg.get("qi_max", 48), ssim_target=cfg.get("ssim_target", -1.0))
     stream = []
     for t, (y, u, v) in enumerate(frames):
-        was_key = drv.encode_frame_host(y, u, v)
+        drv.encode_frame_host(y, u, v)     # "inter frame" is provisional until check_SSIM's verdict is in (get_frame waits for it)
         got = drv.get_frame()
+        was_key = drv.resolve()
         out = do.encode_frame(y, u, v)
         assert was_key == (out is None), t
         exp = expected_frame(W, H, do.last_key if out is None else out, out is None, P)

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_resolve", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2004  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 2005  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
@@ -267,6 +267,11 @@ class NativeDriver:
     def encode_frame_host(self, y, u, v, force_key: bool = False) -> bool:
         y, u, v = (np.ascontiguousarray(p, np.uint8) for p in (y, u, v))
         return self._ret(self.lib.vp8drv_encode_frame_host(self.h, y.ctypes.data, u.ctypes.data, v.ctypes.data, int(force_key)))
+
+    def resolve(self) -> bool:
+        """check_SSIM's verdict on the frame just coded (vp8drv_resolve): True if the frame ended as a key frame"""
+        self.lib.vp8drv_resolve.argtypes = [C.c_void_p]
+        return self._ret(self.lib.vp8drv_resolve(self.h))
 
     def get_frame(self) -> bytes:
         """The frame just coded as the reference's entropy_encode() + gather_frame() emit it (vp8drv_get_frame)."""
@@ -496,6 +501,19 @@ class Vp8Hip:
         repl, new, mn = C.c_int32(), C.c_float(), C.c_float()
         self._chk(self.lib.vp8hip_check_ssim(self.h, C.byref(repl), C.byref(new), C.byref(mn)), "check_ssim")
         return repl.value, np.float32(new.value), np.float32(mn.value)
+
+    def check_ssim_async(self, refqi, qi_min: int):
+        """check_SSIM enqueued, nobody waiting (vp8hip_check_ssim_async); check_ssim_result() collects the verdict"""
+        q = (C.c_int32 * 4)(*[int(x) for x in refqi])
+        self.lib.vp8hip_check_ssim_async.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+        self._chk(self.lib.vp8hip_check_ssim_async(self.h, q, int(qi_min)), "check_ssim_async")
+
+    def check_ssim_result(self):
+        """(replaced, new_SSIM, min SSIM, filter updated) of the last check_ssim_async"""
+        repl, new, mn, upd = C.c_int32(), C.c_float(), C.c_float(), C.c_int32()
+        self.lib.vp8hip_check_ssim_result.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        self._chk(self.lib.vp8hip_check_ssim_result(self.h, C.byref(repl), C.byref(new), C.byref(mn), C.byref(upd)), "check_ssim_result")
+        return repl.value, np.float32(new.value), np.float32(mn.value), bool(upd.value)
 
     def download_intra(self):
         """(modes[MBs][16], is_inter[MBs]) of the last intra_transform / check_ssim."""

@@ -68,7 +68,7 @@ struct Params {
     int mbs, key;
     int is_golden, is_altref, loop_filter_type, sharpness, partitions_log2;   // sharpness < 0: take it from `strength`
     const SegData *sd;
-    const int32_t *strength;      // {reductor, sharpness} of vp8hip_auto_segments
+    const int32_t *strength;      // {reductor, sharpness, sharpness in force} of vp8hip_auto_segments / the check_SSIM verdict
     const uint32_t *probs, *denom0;
     uint32_t cap_bools, cap_chunks, cap_words;
 };
@@ -161,7 +161,7 @@ __device__ __forceinline__ void hdr_frame_body(const Params &a, uint32_t *partia
     const int mbs = a.mbs;
     const bool key = a.key != 0;
     const int32_t *sd = s_sd;
-    const int sharpness = a.sharpness >= 0 ? a.sharpness : a.strength[1];
+    const int sharpness = a.sharpness >= 0 ? a.sharpness : a.strength[2];
     const int replaced = key ? 0 : (int)s_tot[ST_REPLACED];
     if (t == 0) {
         // ---- the probability table of this frame (what the macroblock headers refer to symbolically) ----

@@ -321,7 +321,8 @@ struct IntraArgs {
     const SegData *sd;
     int32_t *modes;         // [MBs][16] sub-block modes of the last attempt (e_data.mode)
     int32_t *is_inter;      // [MBs] 0 where check_SSIM replaced the macroblock
-    int32_t *prog;          // [mbh] macroblocks of the row that are final
+    int32_t *prog;          // [mbh] macroblocks of the row that are final, + gen_base
+    uint32_t gen_base;      // launch number * 1024: a counter left by an earlier launch reads as negative progress
     int32_t *err;           // set to 1 when a bounded wait expired (shared with the loop filter: VP8HIP_ERR_TIMEOUT)
     float target;
     int key;                // 1: key frame (every macroblock, segment 0); 0: fallback of an inter frame
@@ -329,6 +330,27 @@ struct IntraArgs {
     int stall_test;         // test hook: row 0 never publishes, so every other row must run into its bounded wait
     int modes_of_kept;      // 0: modes of the last attempt MADE (the reference); 1: of the attempt KEPT (decodable)
 };
+
+// Row progress carries the launch's generation, so the counters need no clearing between launches (the clearing was a
+// command of its own in every frame's chain): whatever an earlier launch left is below this launch's base.
+__device__ __forceinline__ int prog_load(const IntraArgs &a, int r) {
+    return (int)((uint32_t)__hip_atomic_load(&a.prog[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.gen_base);
+}
+__device__ __forceinline__ void prog_store(const IntraArgs &a, int r, int c) {
+    __hip_atomic_store(&a.prog[r], (int32_t)(a.gen_base + (uint32_t)c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// prepare_filter_mask (CPU_kernels.cl:782-827) of a macroblock the fallback has just replaced: its parts are 4x4, so the
+// mask is set and the count is the sum of |coefficient| over blocks 0..23 (sh.coef); all 64 lanes, result in every lane
+__device__ __forceinline__ int replaced_nz(const Sh &sh, int lane) {
+    const uint32_t *lc = reinterpret_cast<const uint32_t *>(sh.coef);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t w = lc[lane + 64 * i];
+        s += iabs((int)(int16_t)(w & 0xffffu)) + iabs((int)(int16_t)(w >> 16));
+    }
+    return wave_sum(s);
+}
 
 __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
     __shared__ __attribute__((aligned(16))) Sh sh;
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
             if (!m) { c += 64; continue; }
             c += __builtin_ctzll(m);
         }
-        if (lane == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everything before c is final
+        if (lane == 0) prog_store(a, r, c);   // everything before c is final
         const int mb = mb_row0 + c;
         // ---- source tiles --------------------------------------------------------------------------------------
         *reinterpret_cast<uint32_t *>(&sh.srcY[lane * 4]) =
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
         if (r > 0) {
             const int need = imin(c + 2, mbw);
             int spins = 0;
-            while (__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            while (prog_load(a, r - 1) < need) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > INTRA_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -426,6 +448,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
             if (commit) {
                 if (lane < 16 && a.modes_of_kept) a.modes[(size_t)mb * 16 + lane] = mymode;
                 cur_ssim = s;
+                const int nz = a.key ? 0 : replaced_nz(sh, lane);
                 st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
                          *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
                 if (lane < 32) {
@@ -444,15 +467,17 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
                     if (!a.key) {
                         a.o.ssim[mb] = s;
                         a.is_inter[mb] = 0;
+                        a.o.nz[mb] = nz;
+                        a.o.mask[mb] = -1;
                     }
                 }
             }
         }
         ++c;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) prog_store(a, r, c);
     }
-    if (lane == 0) __hip_atomic_store(&a.prog[r], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) prog_store(a, r, mbw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -464,7 +489,7 @@ __global__ __launch_bounds__(64) void k_intra(IntraArgs a) {
 // e_data.mode), which one is kept (the last that raised the SSIM).  A flagged macroblock costs one attempt's time
 // instead of up to three.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
+__device__ __forceinline__ void intra_check3_body(const IntraArgs &a) {
     __shared__ __attribute__((aligned(16))) Sh sh3[3];
     __shared__ float s_ssim[3];
     __shared__ int s_abort;
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
             if (!m) { c += 64; continue; }
             c += __builtin_ctzll(m);
         }
-        if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) prog_store(a, r, c);
         const int mb = mb_row0 + c;
         const float cur0 = a.o.ssim[mb];   // read before anybody may replace it
         *reinterpret_cast<uint32_t *>(&sh.srcY[lane * 4]) =
@@ -503,7 +528,7 @@ __global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
         if (r > 0 && wave == 0) {
             const int need = imin(c + 2, mbw);
             int spins = 0;
-            while (__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            while (prog_load(a, r - 1) < need) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > INTRA_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (lane == 0) {
@@ -564,6 +589,7 @@ __global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
         }
         if (wave == (a.modes_of_kept ? kept : last_run) && lane < 16) a.modes[(size_t)mb * 16 + lane] = mymode;   // e_data.mode: of the last attempt made (:970)
         if (wave == kept) {
+            const int nz = replaced_nz(sh, lane);
             st_agent(a.ry.p + (ptrdiff_t)(16 * r + (lane >> 2)) * a.ry.stride + 16 * c + 4 * (lane & 3),
                      *reinterpret_cast<const uint32_t *>(&sh.img[((lane >> 2) + 1) * IMG_S + 4 + 4 * (lane & 3)]));
             if (lane < 32) {
@@ -581,15 +607,20 @@ __global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) {
                 a.o.seg[mb] = seg;
                 a.o.ssim[mb] = cur;
                 a.is_inter[mb] = 0;
+                a.o.nz[mb] = nz;        // prepare_filter_mask of the replaced macroblock: no launch of its own afterwards
+                a.o.mask[mb] = -1;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         ++c;
         __syncthreads();   // the kept attempt's stores are complete: the row may advance
-        if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) prog_store(a, r, c);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&a.prog[r], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) prog_store(a, r, mbw);
 }
+__global__ __launch_bounds__(192) void k_intra_check3(IntraArgs a) { intra_check3_body(a); }
+// the same for the members of a batch: blockIdx.z = member
+__global__ __launch_bounds__(192) void k_intra_check3_b(BatchOf<IntraArgs> b) { intra_check3_body(b.item[blockIdx.z]); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Key frames, pipelined at 4x4-block granularity.  In k_intra one wavefront walks the 16 luma blocks of a macroblock
@@ -674,7 +705,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
             if (wave == 0 && r > 0) {
                 // the pixel row above this macroblock row, x = 16c - 4 .. 16c + 19, once the row above has finished c + 1
                 const int need = imin(c + 2, mbw);
-                K4_WAIT(__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need, 2)
+                K4_WAIT(prog_load(a, r - 1) < need, 2)
                 if (lane < 6) {
                     const bool ar_last = lane == 5 && c == mbw - 1;   // no macroblock above-right: repeat top[15] (:596-601)
                     uint32_t v = ld_agent(a.ry.p + (ptrdiff_t)(16 * r - 1) * a.ry.stride + 16 * c - 4 + 4 * (ar_last ? 4 : lane));
@@ -761,7 +792,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
             *reinterpret_cast<uint32_t *>(csrc + 64 * (lane >> 4) + 4 * l) =
                 *reinterpret_cast<const uint32_t *>(P.p + (ptrdiff_t)(8 * r + (l >> 1)) * P.stride + 8 * c + 4 * (l & 1));
         }
-        if (r > 0) K4_WAIT(__hip_atomic_load(&a.prog[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c + 1, 2)
+        if (r > 0) K4_WAIT(prog_load(a, r - 1) < c + 1, 2)
         if (lane < 22) {
             // lanes 0..2 / 3..5: the chroma row above (x = -4 .. 7); lanes 6..13 / 14..21: the column left (first macroblock: 129)
             const bool top = lane < 6;
@@ -816,7 +847,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
         if (lane < 4)
             st_agent(a.ry.p + (ptrdiff_t)(16 * r + 15) * a.ry.stride + 16 * c + 4 * lane, *reinterpret_cast<const uint32_t *>(bot + 4 * BW + 16 * c + 4 + 4 * lane));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&a.prog[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) prog_store(a, r, c + 1);
     }
 }
 #undef K4_WAIT
@@ -826,7 +857,9 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
 // in LDS by all threads, 8192 at a time, so that the one summing thread reads four per ds_read_b128 instead of
 // waiting for HBM once per element.
 constexpr int STATS_CHUNK = 8192;
-__global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
+struct SsimStats { int replaced; float mean, mn; };
+// all 256 threads; the result is valid in thread 0
+__device__ __forceinline__ SsimStats ssim_stats_body(const float *ssim, const int32_t *is_inter, int mbs) {
     __shared__ int s_repl;
     __shared__ float s_min[256];
     __shared__ __attribute__((aligned(16))) float s_val[STATS_CHUNK];
@@ -866,20 +899,57 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int
     atomicAdd(&s_repl, repl);
     s_min[threadIdx.x] = mn;
     __syncthreads();
+    SsimStats r{0, 0.0f, 2.0f};
     if (threadIdx.x == 0) {
         for (int i = 0; i < 256; ++i) mn = s_min[i] < mn ? s_min[i] : mn;
-        out[0] = s_repl;
-        out[1] = __float_as_int(__fdiv_rn(sum, (float)mbs));
-        out[2] = __float_as_int(mn);
+        r.replaced = s_repl;
+        r.mean = __fdiv_rn(sum, (float)mbs);
+        r.mn = mn;
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
+    const SsimStats r = ssim_stats_body(ssim, is_inter, mbs);
+    if (threadIdx.x == 0) {
+        out[0] = r.replaced;
+        out[1] = __float_as_int(r.mean);
+        out[2] = __float_as_int(r.mn);
         out[3] = *err;   // the time-out flag of the wavefront kernels travels with the statistics: one read-back
     }
 }
 
+// check_SSIM's tail (src/vp8enc.cpp:237-261) for the members of a batch, one workgroup each: the statistics, and what the
+// host does with the minimum -- above 0.95 prepare_segments_data(1, 7) rewrites the segment data in force (reductor doubled,
+// sharpness 7) before the loop filter and the frame header read them.  The five words also go to host memory the device
+// can write (`verdict`): the host reads them when it next needs to know (redo as a key frame, statistics), not now.
+struct VerdictItem {
+    const float *ssim;
+    const int32_t *is_inter, *err;
+    SegData *sd;
+    int32_t *strength, *stats, *verdict;
+    int32_t refqi[4];
+};
+__global__ __launch_bounds__(256) void k_ssim_verdict_b(BatchOf<VerdictItem> b, int mbs, int qi_min) {
+    const VerdictItem &a = b.item[blockIdx.x];
+    const SsimStats r = ssim_stats_body(a.ssim, a.is_inter, mbs);
+    if (threadIdx.x != 0) return;
+    const int updated = r.mn > 0.95f ? 1 : 0;   // the reference compares the float with the double 0.95: the same verdict (no float lies between 0.95f and 0.95)
+    if (updated) {
+        const int refqi[4] = {a.refqi[0], a.refqi[1], a.refqi[2], a.refqi[3]};
+        a.strength[2] = fill_segment_data(a.sd, 0, refqi, qi_min, a.strength[0], a.strength[1], true);
+    }
+    const int32_t w[5] = {r.replaced, __float_as_int(r.mean), __float_as_int(r.mn), *a.err, updated};
+    for (int i = 0; i < 5; ++i) {
+        a.stats[i] = w[i];
+        a.verdict[i] = w[i];
+    }
+    __threadfence_system();
+}
+
 }  // namespace
 
-void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test,
-                  int modes_of_kept) {
+static IntraArgs intra_args(const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes, int32_t *is_inter,
+                            int32_t *prog, unsigned gen, int32_t *err, float target, int key, int mbw, int mbh, int stall_test, int modes_of_kept) {
     IntraArgs a;
     a.cy = cur.Y[0]; a.cu = cur.U; a.cv = cur.V;
     a.ry = recon.Y[0]; a.ru = recon.U; a.rv = recon.V;
@@ -888,6 +958,7 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.modes = modes;
     a.is_inter = is_inter;
     a.prog = prog;
+    a.gen_base = gen * 1024u;   // progress within a launch stays below 1024 (512 macroblocks per row at most)
     a.err = err;
     a.target = target;
     a.key = key;
@@ -895,7 +966,13 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     a.mbh = mbh;
     a.stall_test = stall_test;
     a.modes_of_kept = modes_of_kept;
-    (void)hipMemsetAsync(prog, 0, sizeof(int32_t) * mbh, s);
+    return a;
+}
+
+void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
+                  int32_t *is_inter, int32_t *prog, unsigned gen, int32_t *err, float target, int key, int mbw, int mbh, int stall_test,
+                  int modes_of_kept) {
+    const IntraArgs a = intra_args(cur, recon, o, d_sd, modes, is_inter, prog, gen, err, target, key, mbw, mbh, stall_test, modes_of_kept);
     static const bool legacy_key = getenv("VP8HIP_INTRA_KEY_MB") != nullptr;   // A/B switch: key frames on the per-macroblock wavefront
     static const bool legacy_check = getenv("VP8HIP_INTRA_CHECK_1WAVE") != nullptr;   // A/B switch: the three attempts one after the other
     if (key && !legacy_key) {
@@ -910,6 +987,28 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
 
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
     hipLaunchKernelGGL(k_ssim_stats, dim3(1), dim3(256), 0, s, o.ssim, is_inter, mbs, err, out);
+}
+
+void launch_check_async(hipStream_t s, const CheckItem *items, int n, float target, int qi_min, int mbw, int mbh, int modes_of_kept) {
+    static_assert(sizeof(BatchOf<IntraArgs>) <= 4096 && sizeof(BatchOf<VerdictItem>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
+    BatchOf<IntraArgs> b;
+    BatchOf<VerdictItem> v;
+    b.n = v.n = n;
+    for (int i = 0; i < n; ++i) {
+        const CheckItem &c = items[i];
+        b.item[i] = intra_args(*c.cur, *c.recon, *c.o, c.sd, c.modes, c.is_inter, c.prog, c.gen, c.err, target, 0, mbw, mbh, 0, modes_of_kept);
+        VerdictItem &w = v.item[i];
+        w.ssim = c.o->ssim;
+        w.is_inter = c.is_inter;
+        w.err = c.err;
+        w.sd = c.sd;
+        w.strength = c.strength;
+        w.stats = c.stats;
+        w.verdict = c.verdict;
+        for (int k = 0; k < 4; ++k) w.refqi[k] = c.refqi[k];
+    }
+    hipLaunchKernelGGL(k_intra_check3_b, dim3(mbh, 1, n), dim3(192), 0, s, b);
+    hipLaunchKernelGGL(k_ssim_verdict_b, dim3(n), dim3(256), 0, s, v, mbw * mbh, qi_min);
 }
 
 }  // namespace vp8

@@ -120,33 +120,9 @@ __device__ __forceinline__ void auto_segments_body(const uint32_t *partial, int 
     sharpness = sharpness > 7 ? 7 : sharpness;
     strength_out[0] = reductor;
     strength_out[1] = sharpness;
-    int32_t *v = sd->v;
-    for (int i = 0; i < 4 * SD_INTS; ++i) v[i] = 0;
-    v[SD_Y_DC_IDELTA] = 15;                         // segment 0 carries the deltas, :133-148
-    v[SD_UV_DC_IDELTA] = is_key ? 0 : -15;
-    v[SD_UV_AC_IDELTA] = is_key ? 0 : -15;
+    strength_out[2] = sharpness;                    // video.loop_filter_sharpness in force (check_SSIM may raise it to 7)
     const int refqi[4] = {q0, q1, q2, q3};
-    for (int i = 0; i < 4; ++i) {
-        int32_t *s = v + SD_INTS * i;
-        s[SD_Y_AC_I] = is_key ? qi_min : refqi[i];  // :164
-        const int y_dc_q = k_dc_q[qi(s[SD_Y_AC_I] + v[SD_Y_DC_IDELTA])];
-        int lvl = y_dc_q / reductor;                // :187-189
-        lvl = lvl > 63 ? 63 : (lvl < 0 ? 0 : lvl);
-        s[SD_LOOP_FILTER_LEVEL] = lvl;
-        int il = lvl;                               // :192-199
-        if (sharpness) {
-            il >>= sharpness > 4 ? 2 : 1;
-            if (il > 9 - sharpness) il = 9 - sharpness;
-        }
-        if (!il) il = 1;
-        s[SD_INTERIOR_LIMIT] = il;
-        s[SD_MBEDGE_LIMIT] = ((lvl + 2) * 2) + il;
-        s[SD_SUB_BEDGE_LIMIT] = (lvl * 2) + il;
-        int hev = 0;                                // :204-220
-        if (is_key) hev = lvl >= 40 ? 2 : (lvl >= 15 ? 1 : 0);
-        else hev = lvl >= 40 ? 3 : (lvl >= 20 ? 2 : (lvl >= 15 ? 1 : 0));
-        s[SD_HEV_THRESHOLD] = hev;
-    }
+    fill_segment_data(sd, is_key, refqi, qi_min, reductor, sharpness, false);
 }
 __global__ __launch_bounds__(256) void k_auto_segments(const uint32_t *partial, int nblocks, uint32_t *stats, SegData *sd,
                                                        int32_t *strength_out, SegArgs g) {

@@ -21,6 +21,7 @@ struct vp8drv {
     bool have_frame = false, last_key = false, last_altref = false, checked = false;
     int sharpness = -1;              // video.loop_filter_sharpness in force; -1 = still on the device (vp8hip_get_segments)
     int replaced = 0;
+    bool verdict_pending = false;    // check_SSIM's verdict on the frame just coded is still on its way (resolve())
     // read-back buffers of vp8drv_get_frame
     std::vector<int32_t> seg, nz, ref, parts, is_inter, modes;
     std::vector<int16_t> vectors;
@@ -134,6 +135,37 @@ int key_frame(vp8drv *d, const uint8_t *host_y) {
     return 1;
 }
 
+// the inter frame just coded is final: the counters of main()'s loop tail
+void inter_frame_done(vp8drv *d) {
+    vp8host_gop_frame_done(&d->gop);
+    d->st.inter_frames++;
+    d->st.frame_number = d->gop.frame_number;
+}
+
+// The verdict of the asynchronous check_SSIM on the frame just coded (vp8enc.cpp:442-453): statistics, and -- when more than a
+// sixth of the macroblocks were replaced or the frame's SSIM is below the target -- the frame again as a key frame, on the
+// current frame the context still holds.  (The inter version's loop filter has run by then: its output is simply never used.)
+// Returns 1 if the frame ended as a key frame, 0 if not, < 0 = vp8hip_status.
+int resolve(vp8drv *d) {
+    if (!d->verdict_pending) return 0;
+    d->verdict_pending = false;
+    int32_t replaced = 0, updated = 0;
+    float new_ssim = 0.0f, min1 = 2.0f;
+    DRV_CHK(vp8hip_check_ssim_result(d->hip, &replaced, &new_ssim, &min1, &updated));
+    d->st.last_replaced = replaced;
+    d->st.last_new_ssim = new_ssim;
+    d->st.last_min_ssim = min1;
+    d->checked = true;
+    d->replaced = replaced;
+    if (updated) d->sharpness = 7;      // prepare_segments_data(1, 7), :260-261, happened on the device
+    if (replaced > d->mbs / 6 || new_ssim < d->cfg.ssim_target) {
+        d->st.redone_as_key++;
+        return key_frame(d, nullptr);
+    }
+    inter_frame_done(d);
+    return 0;
+}
+
 // the loop body once the current frame is on the device; host_y: the caller's luma plane or nullptr
 int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     if (!key && d->cfg.scene_detect) {     // vp8enc.cpp:408-416: only frames that would be inter frames are looked at
@@ -160,8 +192,20 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     d->st.last_was_altref = d->gop.current_is_altref;
     d->checked = false;
     d->replaced = 0;
+    if (d->cfg.check_ssim && (d->cfg.device_params || !host_y)) {
+        // check_SSIM (vp8enc.cpp:231-263) with nobody waiting for it: fallback, statistics and the filter update on the device,
+        // the loop filter right behind them.  What the host has to decide -- "redo as key frame", :443-453 -- it decides when it
+        // next needs to know: at the start of the next call or in vp8drv_get_frame (resolve()).
+        DRV_CHK(vp8hip_check_ssim_async(d->hip, refqi, d->qi_min));
+        DRV_CHK(vp8hip_loop_filter(d->hip));
+        d->verdict_pending = true;
+        d->have_frame = true;
+        d->last_key = false;
+        d->last_altref = d->st.last_was_altref != 0;
+        return 0;
+    }
     if (d->cfg.check_ssim) {
-        // check_SSIM, vp8enc.cpp:231-263, on the device: intra fallback of the macroblocks below the target
+        // the same with the host in the middle (host parameter mirror: the reference's own sequence of calls)
         int32_t replaced = 0;
         float new_ssim = 0.0f, min1 = 2.0f;
         DRV_CHK(vp8hip_check_ssim(d->hip, &replaced, &new_ssim, &min1));
@@ -189,9 +233,7 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     // otherwise prepare_filter_mask was produced by vp8hip_inter_transform for its own coefficients;
     // do_loop_filter (loop_filter.h:185-190) follows directly
     DRV_CHK(vp8hip_loop_filter(d->hip));
-    vp8host_gop_frame_done(&d->gop);
-    d->st.inter_frames++;
-    d->st.frame_number = d->gop.frame_number;
+    inter_frame_done(d);
     d->have_frame = true;
     d->last_key = false;
     d->last_altref = d->st.last_was_altref != 0;
@@ -291,6 +333,7 @@ extern "C" {
 
 int vp8drv_encode_frame_device(vp8drv *d, const void *y, const void *u, const void *v, int force_key) {
     if (!d || !y || !u || !v) return VP8HIP_ERR_ARG;
+    { const int rc = resolve(d); if (rc < 0) return rc; }                        // the previous frame's check_SSIM verdict, if still open
     vp8host_gop_next(&d->gop);
     DRV_CHK(vp8hip_set_current_device(d->hip, y, u, v));                          // vp8enc.cpp:386-388
     return frame_body(d, nullptr, d->gop.current_is_key || force_key);
@@ -298,6 +341,7 @@ int vp8drv_encode_frame_device(vp8drv *d, const void *y, const void *u, const vo
 
 int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v, int force_key) {
     if (!d || !y || !u || !v) return VP8HIP_ERR_ARG;
+    { const int rc = resolve(d); if (rc < 0) return rc; }
     vp8host_gop_next(&d->gop);
     DRV_CHK(vp8hip_upload_current(d->hip, y, u, v));
     return frame_body(d, y, d->gop.current_is_key || force_key);
@@ -315,8 +359,11 @@ int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n) {
     *out = nullptr;
     vp8hip_ctx *ctx[VP8HIP_MAX_BATCH];
     for (int i = 0; i < n; ++i) {
-        // the batched loop is the device-parameter loop without check_SSIM (what bench.py and a file-to-file transcode run)
-        if (!drv[i] || !drv[i]->cfg.device_params || drv[i]->cfg.check_ssim || drv[i]->cfg.overlap_filter || drv[i]->cfg.scene_detect)
+        // the batched loop is the device-parameter loop (what bench.py and a file-to-file transcode run); one launch serves all
+        // members, so what travels as ONE kernel argument must agree: quantizer range, check_SSIM on or off, partitions
+        if (!drv[i] || !drv[i]->cfg.device_params || drv[i]->cfg.overlap_filter || drv[i]->cfg.scene_detect) return VP8HIP_ERR_ARG;
+        const vp8drv_config &a = drv[i]->cfg, &z = drv[0]->cfg;
+        if (a.qi_min != z.qi_min || a.qi_max != z.qi_max || a.num_partitions != z.num_partitions || (a.check_ssim != 0) != (z.check_ssim != 0))
             return VP8HIP_ERR_ARG;
         ctx[i] = drv[i]->hip;
     }
@@ -345,6 +392,10 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
     int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {};
     int pg[VP8HIP_MAX_BATCH], pa[VP8HIP_MAX_BATCH], ug[VP8HIP_MAX_BATCH], ua[VP8HIP_MAX_BATCH];
     int32_t refqi[VP8HIP_MAX_BATCH][4];
+    for (int i = 0; i < b->n; ++i) {   // the members' open check_SSIM verdicts: a frame sent back is recoded as a key frame now
+        const int rc = resolve(b->d[i]);
+        if (rc < 0) return rc;
+    }
     for (int i = 0; i < b->n; ++i) {
         vp8drv *d = b->d[i];
         key[i] = active[i] = 0;
@@ -379,6 +430,8 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
     if (!n_inter) return VP8HIP_OK;
     DRV_CHK(vp8hip_batch_auto_segments(b->hb, active, zero, refqi, b->d[0]->qi_min));   // vp8enc.cpp:390, 419
     DRV_CHK(vp8hip_batch_inter_transform(b->hb, active, pg, pa, ug, ua));
+    const bool check = b->d[0]->cfg.check_ssim != 0;
+    if (check) DRV_CHK(vp8hip_batch_check_ssim_async(b->hb, active, refqi, b->d[0]->qi_min));   // vp8enc.cpp:442, nobody waiting
     DRV_CHK(vp8hip_batch_loop_filter(b->hb, active));
     for (int i = 0; i < b->n; ++i) {
         if (!active[i]) continue;
@@ -390,9 +443,8 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
         d->st.last_was_altref = d->gop.current_is_altref;
         d->checked = false;
         d->replaced = 0;
-        vp8host_gop_frame_done(&d->gop);
-        d->st.inter_frames++;
-        d->st.frame_number = d->gop.frame_number;
+        if (check) d->verdict_pending = true;   // counted when the verdict is in (resolve())
+        else inter_frame_done(d);
         d->have_frame = true;
         d->last_key = false;
         d->last_altref = d->st.last_was_altref != 0;
@@ -400,11 +452,18 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
     return VP8HIP_OK;
 }
 
+int vp8drv_resolve(vp8drv *d) {
+    if (!d) return VP8HIP_ERR_ARG;
+    const int rc = resolve(d);
+    return rc < 0 ? rc : (d->have_frame && d->last_key ? 1 : 0);
+}
+
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     if (!d || !out || !size) return VP8HIP_ERR_ARG;
     if (!d->have_frame) return VP8HIP_ERR_STATE;
     const int P = d->cfg.num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    { const int rc = resolve(d); if (rc < 0) return rc; }    // the frame's type and intra information must be final
     return get_frame(d, out, capacity, size);
 }
 
@@ -413,6 +472,7 @@ int vp8drv_get_frame_begin(vp8drv *d) {
     if (!d->have_frame || d->cfg.host_bitstream) return VP8HIP_ERR_STATE;
     const int P = d->cfg.num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
+    { const int rc = resolve(d); if (rc < 0) return rc; }
     const vp8hip_header_params hp = header_params(d);
     return vp8hip_encode_frame_begin(d->hip, P, &hp);
 }
@@ -429,6 +489,8 @@ int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members) {
         vp8drv *d = b->d[i];
         if (d->cfg.num_partitions != P) return VP8HIP_ERR_ARG;
         if (!d->have_frame || d->cfg.host_bitstream) return VP8HIP_ERR_STATE;
+        const int rc = resolve(d);
+        if (rc < 0) return rc;
         hp[i] = header_params(d);
     }
     return vp8hip_batch_encode_frame_begin(b->hb, members, P, hp);

@@ -31,6 +31,7 @@ struct FrameSurf {
 
 }  // namespace
 
+struct vp8hip_batch;
 struct vp8hip_ctx {
     int W = 0, H = 0, mbw = 0, mbh = 0, mbs = 0, b8 = 0;
     float ssim_target = -1.0f;
@@ -48,7 +49,14 @@ struct vp8hip_ctx {
     bool cur_pyramid_valid = false;
     Frame cur_prev;                 // the previous current frame (the two surfaces swap on every upload)
     int cur_count = 0;              // current frames received so far
-    uint32_t *d_stats = nullptr;    // reductions of kernels_rc.hip
+    uint32_t *d_stats = nullptr;    // reductions of kernels_rc.hip: the block in force (one of d_stats2), travels with d_sd
+    uint32_t *d_stats2[2] = {nullptr, nullptr};
+    vp8hip_batch *batch = nullptr;  // the batch this context is a member of
+    // check_SSIM without the host round trip (vp8hip_check_ssim_async): the verdict lands in host memory the device writes
+    int32_t *h_verdict = nullptr;   // {replaced, new_SSIM, min SSIM, time-out flag, filter updated}
+    hipEvent_t ev_verdict = nullptr, verdict_wait = nullptr;   // recorded behind the verdict kernel (a batch records its own for all members)
+    bool verdict_pending = false;
+    unsigned intra_gen = 0;         // launches on intra_prog (its counters carry the launch number: nothing to clear)
 
     NetSet nets{};
     MBOut out{};
@@ -261,6 +269,24 @@ int make_last(vp8hip_ctx *c, const void *y, const void *u, const void *v, hipMem
 
 }  // namespace
 
+// Up to MAX_BATCH contexts of one geometry on one device advance one frame together (see "batched contexts" below).
+// `prep` is the batch's second stream: what a frame needs done before its searches but what does not depend on the previous
+// frame's reconstruction -- taking the new frame in (pack / copy_with_padding), the parameter scan with the segment data, the
+// new frame's pyramid -- runs there, beside the previous frame's chain on `stream`, instead of at the head of the chain behind the
+// loop filter.  In the kernel trace of 48 chunks in 8 batches those three launches, a few microseconds of work each, lasted
+// 0.2-0.45 ms per frame waiting for their turn: a fifth of the summed kernel time.
+struct vp8hip_batch {
+    int n = 0;
+    vp8hip_ctx *c[MAX_BATCH] = {};
+    hipStream_t stream = nullptr;
+    hipStream_t prep = nullptr;          // nullptr: everything on `stream` (VP8HIP_BATCH_PREP=0)
+    bool prep_shared = false;            // prep is the process-wide one (VP8HIP_BATCH_PREP=2), not this batch's to destroy
+    hipEvent_t ev_gate = nullptr;        // on `stream`, at the start of a frame call: everything of the earlier frames
+    hipEvent_t ev_prep = nullptr;        // on `prep`: the head-of-frame work enqueued so far
+    hipEvent_t ev_verdict = nullptr;     // behind the batched check_SSIM verdict
+    bool prep_pending = false;           // `stream` has not yet been told to wait for ev_prep
+};
+
 static std::atomic<int> g_live_contexts{0};   // contexts that launch on a stream of their own (members of a batch share one)
 
 // Contexts overlap only if their streams sit on different hardware queues, and the HIP runtime multiplexes all streams
@@ -287,6 +313,14 @@ static SegData *sd_for_writing(vp8hip_ctx *c) {
     if (c->lf_pending && c->lf_sd == c->d_sd) c->d_sd = c->d_sd == c->d_sd2[0] ? c->d_sd2[1] : c->d_sd2[0];
     return c->d_sd;
 }
+// The parameter scan of a new frame (vp8hip_auto_segments) always takes the OTHER pair of blocks -- segment data and the
+// strength words beside them -- and makes it the one in force: every consumer gets its pointers when it is enqueued, so the
+// previous frame's loop filter and entropy stage keep reading theirs while this frame's scan already runs (on the second
+// stream of vp8hip_filter_overlap, or on a batch's head-of-frame stream).
+static void next_params(vp8hip_ctx *c) {
+    c->d_sd = c->d_sd == c->d_sd2[0] ? c->d_sd2[1] : c->d_sd2[0];
+    c->d_stats = c->d_stats == c->d_stats2[0] ? c->d_stats2[1] : c->d_stats2[0];
+}
 
 // work enqueued on the context's stream from here on sees the filtered reconstruction
 static int join_lf(vp8hip_ctx *c) {
@@ -301,9 +335,18 @@ static int join_lf(vp8hip_ctx *c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
     return VP8HIP_OK;
 }
+// work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
+static void batch_join_prep(vp8hip_batch *b) {
+    if (!b || !b->prep || !b->prep_pending) return;
+    b->prep_pending = false;
+    (void)hipEventRecord(b->ev_prep, b->prep);
+    (void)hipStreamWaitEvent(b->stream, b->ev_prep, 0);
+}
 // HIP's current device is per host thread: a context may be driven from a thread other than its creator's, or two contexts
 // on two GPUs from one thread -- every entry point that may allocate or use the null stream selects the context's device.
-#define USE_DEVICE(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
+// A member of a batch launches on the batch's stream: whatever it does there comes after the batch's head-of-frame work.
+#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); } } while (0)
+#define USE_DEVICE_ONLY(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
 #define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
 
 int vp8hip_filter_overlap(vp8hip_ctx *c, int on) {
@@ -364,8 +407,16 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     for (int i = 0; i < NFRAMES; ++i) cur = carve_frame(cur, width, height, &c->frames[i].f);
     cur = carve_frame(cur, width, height, &c->cur);
     carve_frame(cur, width, height, &c->cur_prev);
-    CR(hipMalloc(&c->d_stats, (8 + rc_partial_words()) * sizeof(uint32_t)));   // [0..3] sums, [4] reductor, [5] sharpness, [8..] partials
-    CR(hipMemsetAsync(c->d_stats, 0, (8 + rc_partial_words()) * sizeof(uint32_t), c->stream));   // (holds a completion counter that is zero at rest)
+    // [0..3] sums, [4] reductor, [5] sharpness, [6] sharpness in force, [8..] partials; two blocks, like the segment data they
+    // belong to: a frame's parameters are produced while the previous frame's are still being read
+    const size_t stats_words = 8 + rc_partial_words();
+    CR(hipMalloc(&c->d_stats2[0], 2 * stats_words * sizeof(uint32_t)));
+    CR(hipMemsetAsync(c->d_stats2[0], 0, 2 * stats_words * sizeof(uint32_t), c->stream));   // (holds a completion counter that is zero at rest)
+    c->d_stats2[1] = c->d_stats2[0] + stats_words;
+    c->d_stats = c->d_stats2[0];
+    CR(hipHostMalloc(&c->h_verdict, 8 * sizeof(int32_t)));
+    memset(c->h_verdict, 0, 8 * sizeof(int32_t));
+    CR(hipEventCreateWithFlags(&c->ev_verdict, hipEventDisableTiming));
     for (int r = 0; r < 3; ++r) {
         CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
         CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
@@ -397,7 +448,8 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->intra_modes, (size_t)c->mbs * 64));
     CR(hipMalloc(&c->intra_is_inter, (size_t)c->mbs * 4));
     CR(hipMalloc(&c->intra_prog, (size_t)c->mbh * 4));
-    CR(hipMalloc(&c->intra_stats, 16));
+    CR(hipMalloc(&c->intra_stats, 32));
+    CR(hipMemsetAsync(c->intra_prog, 0, (size_t)c->mbh * 4, c->stream));
     CR(hipMemsetAsync(c->intra_modes, 0, (size_t)c->mbs * 64, c->stream));
     CR(hipMemsetAsync(c->intra_is_inter, 0, (size_t)c->mbs * 4, c->stream));
     CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
@@ -459,7 +511,9 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     if (c->h_frame) hipHostFree(c->h_frame);
     hipFree(c->d_frame);
     hipFree(c->d_progress);
-    hipFree(c->d_stats);
+    hipFree(c->d_stats2[0]);
+    if (c->h_verdict) hipHostFree(c->h_verdict);
+    if (c->ev_verdict) hipEventDestroy(c->ev_verdict);
     hipFree(c->scratch);
     hipFree(c->ent_flags);
     hipFree(c->ent_third);
@@ -607,7 +661,8 @@ int vp8hip_auto_segments(vp8hip_ctx *c, int is_key_frame, const int32_t refqi[4]
     USE_DEVICE(c);
     if (!c || !refqi) return VP8HIP_ERR_ARG;
     if (c->cur_count == 0) return VP8HIP_ERR_STATE;
-    launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, sd_for_writing(c), reinterpret_cast<int32_t *>(c->d_stats + 4),
+    next_params(c);
+    launch_auto_segments(c->stream, c->cur, c->d_stats + 8, c->d_stats, c->d_sd, reinterpret_cast<int32_t *>(c->d_stats + 4),
                          is_key_frame ? 1 : 0, refqi, qi_min);
     HIPCHK(c, hipGetLastError());
     return VP8HIP_OK;
@@ -799,11 +854,6 @@ int vp8hip_export_last(vp8hip_ctx *c, void *d_y, void *d_u, void *d_v) {
 // Up to MAX_BATCH contexts of one geometry on one device advance one frame together: every stage is ONE launch for all of
 // them (vp8hip_dev.h, "batched launches").  The members share the batch's stream, so their own entry points (key frames,
 // the entropy stage, downloads) stay ordered with the batched stages.
-struct vp8hip_batch {
-    int n = 0;
-    vp8hip_ctx *c[MAX_BATCH] = {};
-    hipStream_t stream = nullptr;
-};
 
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     if (!out || !ctxs || n < 1 || n > MAX_BATCH) return VP8HIP_ERR_ARG;
@@ -840,11 +890,36 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     }
     for (int i = 0; i < n; ++i) {
         ctxs[i]->stream = b->stream;
+        ctxs[i]->batch = b;
         b->c[i] = ctxs[i];
         if (ctxs[i]->counted) --g_live_contexts;   // the batch's one stream is counted in their place
         ctxs[i]->counted = false;
     }
     ++g_live_contexts;
+    // the head-of-frame stream: 1 (default) = one per batch, in the lowest priority class (queues are per priority, so it
+    // never shares a hardware queue with a chain, and its work -- which has a frame time of slack -- is the one that yields);
+    // 2 = one for all batches of the process; 0 = none, the head of the frame stays at the head of the chain
+    static const int prep_mode = [] { const char *v = getenv("VP8HIP_BATCH_PREP"); return v && v[0] ? atoi(v) : 1; }();
+    bool ok = hipEventCreateWithFlags(&b->ev_verdict, hipEventDisableTiming) == hipSuccess;
+    if (ok && prep_mode) {
+        ok = hipEventCreateWithFlags(&b->ev_gate, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b->ev_prep, hipEventDisableTiming) == hipSuccess;
+        int least = 0, greatest = 0;
+        ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        if (ok && prep_mode == 2) {
+            static hipStream_t shared[64] = {};
+            hipStream_t &sh = shared[ctxs[0]->device & 63];
+            if (!sh) ok = hipStreamCreateWithPriority(&sh, hipStreamNonBlocking, least) == hipSuccess;
+            b->prep = sh;
+            b->prep_shared = true;
+        } else if (ok) {
+            ok = hipStreamCreateWithPriority(&b->prep, hipStreamNonBlocking, least) == hipSuccess;
+        }
+    }
+    if (!ok) {
+        vp8hip_batch_destroy(b);
+        return VP8HIP_ERR_HIP;
+    }
     *out = b;
     return VP8HIP_OK;
 }
@@ -852,10 +927,17 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
 void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the batch before its members), each back on its own stream
     if (!b) return;
     hipSetDevice(b->c[0]->device);
+    if (b->prep) hipStreamSynchronize(b->prep);
     hipStreamSynchronize(b->stream);
     hipStreamDestroy(b->stream);
+    if (b->prep && !b->prep_shared) hipStreamDestroy(b->prep);
+    if (b->ev_gate) hipEventDestroy(b->ev_gate);
+    if (b->ev_prep) hipEventDestroy(b->ev_prep);
+    if (b->ev_verdict) hipEventDestroy(b->ev_verdict);
     --g_live_contexts;
     for (int i = 0; i < b->n; ++i) {
+        b->c[i]->batch = nullptr;
+        if (b->c[i]->verdict_wait == b->ev_verdict) b->c[i]->verdict_pending = false;   // (the streams are idle: nothing to wait for)
         if (!b->c[i]->own_stream) hipStreamCreateWithFlags(&b->c[i]->own_stream, hipStreamNonBlocking);
         b->c[i]->stream = b->c[i]->own_stream;
         if (!b->c[i]->counted) ++g_live_contexts;
@@ -867,7 +949,7 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the
 int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v) {
     if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
-    USE_DEVICE(c0);
+    USE_DEVICE_ONLY(c0);
     const Frame *f[MAX_BATCH];
     const void *py[MAX_BATCH], *pu[MAX_BATCH], *pv[MAX_BATCH];
     int n = 0;
@@ -881,8 +963,18 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
         ++n;
     }
     if (!n) return VP8HIP_OK;
+    hipStream_t ps = b->stream;
+    if (b->prep) {
+        // A new frame goes into the surface (and its parameters into the blocks) of the frame before the previous one: all
+        // of that frame's work -- enqueued on `stream` before the PREVIOUS frame call began, which is where ev_gate was last
+        // recorded -- must be over; the previous frame's chain may still be running, and that is the point.
+        HIPCHK(c0, hipStreamWaitEvent(b->prep, b->ev_gate, 0));
+        HIPCHK(c0, hipEventRecord(b->ev_gate, b->stream));
+        b->prep_pending = true;
+        ps = b->prep;
+    }
     Timed t(c0, VP8HIP_K_PACK);
-    launch_pack_batch(b->stream, f, py, pu, pv, n, c0->src_w, c0->src_h);
+    launch_pack_batch(ps, f, py, pu, pv, n, c0->src_w, c0->src_h);
     HIPCHK(c0, hipGetLastError());
     return VP8HIP_OK;
 }
@@ -892,7 +984,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
 int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min) {
     if (!b || !is_key_frame || !refqi) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
-    USE_DEVICE(c0);
+    USE_DEVICE_ONLY(c0);
     const Frame *cur[MAX_BATCH];
     uint32_t *partial[MAX_BATCH], *stats[MAX_BATCH];
     SegData *sd[MAX_BATCH];
@@ -904,16 +996,18 @@ int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is
         if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
         if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+        next_params(c);
         cur[n] = &c->cur;
         partial[n] = c->d_stats + 8;
         stats[n] = c->d_stats;
-        sd[n] = sd_for_writing(c);
+        sd[n] = c->d_sd;
         strength[n] = reinterpret_cast<int32_t *>(c->d_stats + 4);
         key[n] = is_key_frame[i] ? 1 : 0;
         for (int k = 0; k < 4; ++k) qi[n][k] = refqi[i][k];
         ++n;
     }
-    if (n) launch_auto_segments_batch(b->stream, cur, partial, stats, sd, strength, key, qi, qi_min, n);
+    if (n && b->prep) b->prep_pending = true;
+    if (n) launch_auto_segments_batch(b->prep ? b->prep : b->stream, cur, partial, stats, sd, strength, key, qi, qi_min, n);
     HIPCHK(c0, hipGetLastError());
     return VP8HIP_OK;
 }
@@ -922,10 +1016,11 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
                                  const int *use_golden, const int *use_altref) {
     if (!b || !prev_is_golden || !prev_is_altref || !use_golden || !use_altref) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
-    USE_DEVICE(c0);
+    USE_DEVICE_ONLY(c0);
     vp8hip_ctx *m[MAX_BATCH];
     RefSet refs[MAX_BATCH];
-    const Frame *cur[MAX_BATCH], *recon[MAX_BATCH], *pyr[2 * MAX_BATCH];
+    const Frame *cur[MAX_BATCH], *recon[MAX_BATCH], *pyr[2 * MAX_BATCH], *pyr_cur[MAX_BATCH];
+    int npyr_cur = 0;
     const NetSet *nets[MAX_BATCH];
     const MBOut *outs[MAX_BATCH];
     const SegData *sds[MAX_BATCH];
@@ -943,11 +1038,19 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         const int rc = inter_begin(c, prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
         if (rc) return rc;
         FrameSurf &last = c->frames[c->slot[0]];
-        if (!c->cur_pyramid_valid) pyr[npyr++] = &c->cur;
+        if (!c->cur_pyramid_valid) {
+            if (b->prep) pyr_cur[npyr_cur++] = &c->cur;   // the new frame's pyramid: head-of-frame work
+            else pyr[npyr++] = &c->cur;
+        }
+        bool border_alone = false;
         if (!last.pyramid_valid) {
             if (!last.border_valid) pyr_border |= 1u << npyr;
             pyr[npyr++] = &last.f;
         } else if (!last.border_valid) {
+            border_alone = true;
+        }
+        if (border_alone) {
+            batch_join_prep(b);
             launch_border(b->stream, last.f);
         }
         last.pyramid_valid = true;
@@ -963,7 +1066,12 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     }
     if (!n) return VP8HIP_OK;
     hipStream_t s = b->stream;
-    {
+    if (npyr_cur) {
+        b->prep_pending = true;
+        launch_pyramid_batch(b->prep, pyr_cur, npyr_cur, 0);
+    }
+    batch_join_prep(b);   // the chain starts here: LAST's pyramid and replicated edges, the searches, the transform
+    if (npyr) {
         Timed t(c0, VP8HIP_K_DOWNSAMPLE);
         launch_pyramid_batch(s, pyr, npyr, pyr_border);
     }
@@ -990,7 +1098,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
 int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
     if (!b) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
-    USE_DEVICE(c0);
+    USE_DEVICE(c0);   // (joins the head-of-frame stream)
     vp8hip_ctx *m[MAX_BATCH];
     const Frame *recon[MAX_BATCH];
     const MBOut *outs[MAX_BATCH];
@@ -1098,7 +1206,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
-                     c->d_progress + LF_ERR_WORD, 0.0f, 1, c->mbw, c->mbh, c->lf_stall_test);
+                     ++c->intra_gen, c->d_progress + LF_ERR_WORD, 0.0f, 1, c->mbw, c->mbh, c->lf_stall_test);
     }
     c->recon_ready = true;
     HIPCHK(c, hipGetLastError());
@@ -1114,7 +1222,7 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
-                     c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh, c->lf_stall_test, c->conformant);
+                     ++c->intra_gen, c->d_progress + LF_ERR_WORD, c->ssim_target, 0, c->mbw, c->mbh, c->lf_stall_test, c->conformant);
     }
     launch_ssim_stats(c->stream, c->out, c->intra_is_inter, c->mbs, c->d_progress + LF_ERR_WORD, c->intra_stats);
     HIPCHK(c, hipGetLastError());
@@ -1124,6 +1232,92 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
     if (replaced) *replaced = st[0];
     if (new_ssim) memcpy(new_ssim, &st[1], 4);
     if (min_ssim) memcpy(min_ssim, &st[2], 4);
+    if (st[3]) {   // a bounded device-side wait expired (this frame or an earlier, unchecked one)
+        HIPCHK(c, hipMemset(c->d_progress + LF_ERR_WORD, 0, 4));
+        return VP8HIP_ERR_TIMEOUT;
+    }
+    return VP8HIP_OK;
+}
+
+// ---- check_SSIM without the host round trip ---------------------------------------------------------------------------------
+static void check_item(vp8hip_ctx *c, CheckItem &it, const int32_t refqi[4]) {
+    it.cur = &c->cur;
+    it.recon = &c->frames[c->recon].f;
+    it.o = &c->out;
+    it.sd = c->d_sd;
+    it.strength = reinterpret_cast<int32_t *>(c->d_stats + 4);
+    it.modes = c->intra_modes;
+    it.is_inter = c->intra_is_inter;
+    it.prog = c->intra_prog;
+    it.err = c->d_progress + LF_ERR_WORD;
+    it.stats = c->intra_stats;
+    it.verdict = c->h_verdict;
+    it.gen = ++c->intra_gen;
+    for (int k = 0; k < 4; ++k) it.refqi[k] = refqi[k];
+    c->ent_counted_partitions = 0;
+}
+
+int vp8hip_check_ssim_async(vp8hip_ctx *c, const int32_t refqi[4], int qi_min) {
+    USE_DEVICE(c);
+    JOIN_LF(c);
+    if (!c || !refqi) return VP8HIP_ERR_ARG;
+    if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending) return VP8HIP_ERR_STATE;
+    CheckItem it;
+    check_item(c, it, refqi);
+    {
+        Timed t(c, VP8HIP_K_INTRA);
+        launch_check_async(c->stream, &it, 1, c->ssim_target, qi_min, c->mbw, c->mbh, c->conformant);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_verdict, c->stream));
+    c->verdict_wait = c->ev_verdict;
+    c->verdict_pending = true;
+    return VP8HIP_OK;
+}
+
+int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int32_t (*refqi)[4], int qi_min) {
+    if (!b || !refqi) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        const vp8hip_ctx *c = b->c[i];
+        if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending) return VP8HIP_ERR_STATE;
+    }
+    CheckItem it[MAX_BATCH];
+    vp8hip_ctx *m[MAX_BATCH];
+    int n = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        check_item(b->c[i], it[n], refqi[i]);
+        m[n++] = b->c[i];
+    }
+    if (!n) return VP8HIP_OK;
+    {
+        Timed t(c0, VP8HIP_K_INTRA);
+        launch_check_async(b->stream, it, n, c0->ssim_target, qi_min, c0->mbw, c0->mbh, c0->conformant);
+    }
+    HIPCHK(c0, hipGetLastError());
+    HIPCHK(c0, hipEventRecord(b->ev_verdict, b->stream));
+    for (int i = 0; i < n; ++i) {
+        m[i]->verdict_wait = b->ev_verdict;
+        m[i]->verdict_pending = true;
+    }
+    return VP8HIP_OK;
+}
+
+int vp8hip_check_ssim_result(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *min_ssim, int32_t *filter_updated) {
+    USE_DEVICE_ONLY(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    if (!c->verdict_pending) return VP8HIP_ERR_STATE;
+    HIPCHK(c, hipEventSynchronize(c->verdict_wait));
+    c->verdict_pending = false;
+    int32_t st[5];
+    for (int i = 0; i < 5; ++i) st[i] = reinterpret_cast<volatile int32_t *>(c->h_verdict)[i];
+    if (replaced) *replaced = st[0];
+    if (new_ssim) memcpy(new_ssim, &st[1], 4);
+    if (min_ssim) memcpy(min_ssim, &st[2], 4);
+    if (filter_updated) *filter_updated = st[4];
     if (st[3]) {   // a bounded device-side wait expired (this frame or an earlier, unchecked one)
         HIPCHK(c, hipMemset(c->d_progress + LF_ERR_WORD, 0, 4));
         return VP8HIP_ERR_TIMEOUT;

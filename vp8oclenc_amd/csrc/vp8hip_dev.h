@@ -215,10 +215,26 @@ void launch_frame_code_batch(hipStream_t s, const FrameEntropy *e, const FrameOu
 
 // host intra path on the device (kernels_intra.hip): key frames (key = 1) and check_SSIM's intra fallback (key = 0).
 // prog: mbh ints (row progress), zeroed by the launcher; err: time-out flag; stats out: {replaced, new_SSIM, min SSIM, time-out flag}
+// gen: the launch number on this progress buffer (the rows' counters carry it, so nothing has to be cleared between launches)
 void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes,
-                  int32_t *is_inter, int32_t *prog, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0,
+                  int32_t *is_inter, int32_t *prog, unsigned gen, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0,
                   int modes_of_kept = 0);   // modes_of_kept: vp8hip_conformant_stream
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out);   // out[3] = *err
+// check_SSIM() (src/vp8enc.cpp:231-263) for up to MAX_BATCH contexts without a host round trip, two launches: the intra fallback
+// (it also renews nz / mask of the macroblocks it replaces), then the statistics AND what the host does with them -- with
+// min SSIM > 0.95 the segment data in force are rewritten by prepare_segments_data(1, 7) and strength[2] (the sharpness the
+// frame header carries) becomes 7.  verdict (device-visible host memory): {replaced, new_SSIM, min SSIM, time-out flag, filter updated}
+struct CheckItem {
+    const Frame *cur, *recon;
+    const MBOut *o;
+    SegData *sd;             // the segment data in force
+    int32_t *strength;       // {reductor, sharpness, sharpness in force}
+    int32_t *modes, *is_inter, *prog, *err, *stats;
+    int32_t *verdict;
+    unsigned gen;
+    int32_t refqi[4];
+};
+void launch_check_async(hipStream_t s, const CheckItem *items, int n, float target, int qi_min, int mbw, int mbh, int modes_of_kept);
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
@@ -245,6 +261,41 @@ static __device__ __constant__ const int k_ac_q[128] = {
     131, 134, 137, 140, 143, 146, 149, 152, 155, 158, 161, 164, 167, 170, 173, 177, 181, 185, 189, 193, 197, 201,
     205, 209, 213, 217, 221, 225, 229, 234, 239, 245, 249, 254, 259, 264, 269, 274, 279, 284};
 __device__ __forceinline__ int qi(int v) { return iclamp(v, 0, 127); }
+
+// prepare_segments_data(), src/vp8enc.cpp:129-221, from the strength pair of get_loopfilter_strength (:96-127).
+// update_filter: check_SSIM's call prepare_segments_data(1, 7) (:155-159, :260-261): reductor doubled, sharpness 7.
+// Returns video.loop_filter_sharpness as it stands afterwards (what the frame header carries).  One thread.
+__device__ __forceinline__ int fill_segment_data(SegData *sd, int is_key, const int refqi[4], int qi_min, int reductor, int sharpness,
+                                                 bool update_filter) {
+    if (update_filter) { reductor *= 2; sharpness = 7; }
+    int32_t *v = sd->v;
+    for (int i = 0; i < 4 * SD_INTS; ++i) v[i] = 0;
+    v[SD_Y_DC_IDELTA] = 15;                         // segment 0 carries the deltas, :133-148
+    v[SD_UV_DC_IDELTA] = is_key ? 0 : -15;
+    v[SD_UV_AC_IDELTA] = is_key ? 0 : -15;
+    for (int i = 0; i < 4; ++i) {
+        int32_t *s = v + SD_INTS * i;
+        s[SD_Y_AC_I] = is_key ? qi_min : refqi[i];  // :164
+        const int y_dc_q = k_dc_q[qi(s[SD_Y_AC_I] + v[SD_Y_DC_IDELTA])];
+        int lvl = y_dc_q / reductor;                // :187-189
+        lvl = lvl > 63 ? 63 : (lvl < 0 ? 0 : lvl);
+        s[SD_LOOP_FILTER_LEVEL] = lvl;
+        int il = lvl;                               // :192-199
+        if (sharpness) {
+            il >>= sharpness > 4 ? 2 : 1;
+            if (il > 9 - sharpness) il = 9 - sharpness;
+        }
+        if (!il) il = 1;
+        s[SD_INTERIOR_LIMIT] = il;
+        s[SD_MBEDGE_LIMIT] = ((lvl + 2) * 2) + il;
+        s[SD_SUB_BEDGE_LIMIT] = (lvl * 2) + il;
+        int hev = 0;                                // :204-220
+        if (is_key) hev = lvl >= 40 ? 2 : (lvl >= 15 ? 1 : 0);
+        else hev = lvl >= 40 ? 3 : (lvl >= 20 ? 2 : (lvl >= 15 ? 1 : 0));
+        s[SD_HEV_THRESHOLD] = hev;
+    }
+    return sharpness;
+}
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {  // byte-aligned dword load
     uint32_t v;
