@@ -213,8 +213,15 @@ class Leg:
 
     def step(self):
         if self.batches:
-            for members, nb in self.batches:
-                self.step_group(members, nb)
+            # one frame on every group; with check_SSIM in the loop a group's next frame needs the verdict on its previous one
+            # (a few words the device writes to host memory): the groups are served as those come in, not in a fixed order
+            todo = list(self.batches)
+            while todo:
+                for i, (members, nb) in enumerate(todo):
+                    if nb.ready():
+                        self.step_group(members, nb)
+                        del todo[i]
+                        break
             return
         for k in range(self.G):
             self.step_one(k)

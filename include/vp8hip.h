@@ -128,17 +128,22 @@ int vp8hip_intra_transform(vp8hip_ctx *ctx);
  * scores higher.  Returns frames.replaced, frames.new_SSIM and the minimum SSIM (`min1`; the reference updates
  * the filter parameters when it exceeds 0.95, :260).  Blocks until the three values are back. */
 int vp8hip_check_ssim(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim);
-/* The same without the host in the middle -- what a frame loop at thousands of frames per second needs: check_SSIM's
- * fallback, its statistics AND its filter update (`if (min1 > 0.95) prepare_segments_data(1, 7)`, :260-261, rewriting the
- * segment data in force on the device from the strength pair vp8hip_auto_segments left there, so it needs segment data
- * made by vp8hip_auto_segments; refqi / qi_min as for that call) are enqueued and the call returns; the loop filter and the
- * entropy stage can follow at once.  It also renews the filter mask and non-zero count of every macroblock it replaces
- * (no vp8hip_prepare_filter_mask needed).  vp8hip_check_ssim_result waits for the verdict -- three words the device writes
- * to host memory -- when the host next needs it: the reference's "redo as key frame" decision (:443-453), which the native
- * frame loop takes at the start of the NEXT call (include/vp8hip_driver.h).  filter_updated: 1 when the segment data were
- * rewritten (video.loop_filter_sharpness is then 7).  VP8HIP_ERR_STATE without a pending verdict. */
+/* The same without the host in the middle -- what a frame loop at thousands of frames per second needs.  The call enqueues
+ * check_SSIM's fallback (a launch whose workgroups leave at once unless the transform has flagged a macroblock below the
+ * target; it also renews the filter mask and non-zero count of what it replaces: no vp8hip_prepare_filter_mask needed) and
+ * arms the NEXT vp8hip_loop_filter / vp8hip_batch_loop_filter call, whose launch then carries the rest: every band of the
+ * filter takes the frame's minimum SSIM and, above 0.95, filters with the segment data `prepare_segments_data(1, 7)` gives
+ * (:260-261; from the strength pair vp8hip_auto_segments left on the device, so the frame's segment data must come from that
+ * call; refqi / qi_min as for it), and one extra workgroup writes those segment data back for the entropy stage, sums the
+ * frame's SSIM in the reference's order and hands replaced / new_SSIM / min SSIM to the host through memory the host polls.
+ * vp8hip_check_ssim_result collects them when the host next needs them -- the reference's "redo as key frame" decision
+ * (:443-453), which the native frame loop takes at the start of the NEXT call (include/vp8hip_driver.h) -- and returns as soon
+ * as the verdict workgroup has run, a few microseconds into the filter's launch.  filter_updated: 1 when the segment data were
+ * rewritten (video.loop_filter_sharpness is then 7).  VP8HIP_ERR_STATE while no armed loop filter has been launched.
+ * vp8hip_check_ssim_ready: 1 if _result would not wait. */
 int vp8hip_check_ssim_async(vp8hip_ctx *ctx, const int32_t refqi[4], int qi_min);
 int vp8hip_check_ssim_result(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim, int32_t *filter_updated);
+int vp8hip_check_ssim_ready(const vp8hip_ctx *ctx);
 /* e_data[].mode[16] of the last vp8hip_intra_transform / vp8hip_check_ssim (the sub-block modes the header coder
  * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference -- see
  * vp8hip_conformant_stream -- and 0 where none was made) and
@@ -298,7 +303,8 @@ int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);
 int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
-/* vp8hip_check_ssim_async for the active members in the same two launches; vp8hip_check_ssim_result per member afterwards */
+/* vp8hip_check_ssim_async for the active members (one launch; the verdicts ride in the following vp8hip_batch_loop_filter);
+ * vp8hip_check_ssim_result per member afterwards */
 int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int32_t (*refqi)[4], int qi_min);
 /* vp8hip_encode_frame_begin for the active members in the same nine launches (params[i] = member i's header parameters;
  * every member is then between _begin and _end: take each frame with vp8hip_encode_frame_end) */

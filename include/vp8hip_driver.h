@@ -81,6 +81,9 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
  * again as a key frame.  Returns 1 if the last frame ended as a key frame, 0 if as an inter frame, < 0 = vp8hip_status.  Implied by
  * the next vp8drv_encode_frame_* and by vp8drv_get_frame[_begin]; a no-op when nothing is open. */
 int vp8drv_resolve(vp8drv *d);
+/* 1 if the next call on this driver (this batch) would not wait for a verdict: a host that advances several chunks from one
+ * thread takes the ones that are ready first instead of waiting for them in a fixed order */
+int vp8drv_ready(const vp8drv *d);
 
 /* The frame just coded, as bytes: entropy_encode() + gather_frame() of the reference (vp8enc.cpp:48-94, 476-481;
  * encIO.h:1-30) -- coefficient statistics, coefficient partitions and the first partition (frame header, macroblock
@@ -110,6 +113,7 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL
 /* vp8drv_get_frame_begin for the members' frames in one set of launches (src/vp8enc.cpp:48-94 for up to four chunks at
  * once); then vp8drv_get_frame_end on every member */
 int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members);
+int vp8drv_batch_ready(const vp8drv_batch *b);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_resolve", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -371,6 +371,11 @@ class NativeBatch:
         if rc < 0:
             raise Vp8HipError(f"vp8drv_batch_encode_frame_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return [bool(k) for k in self._key]
+
+    def ready(self) -> bool:
+        """no member's check_SSIM verdict is still on its way: the next encode_frame_device would not wait (vp8drv_batch_ready)"""
+        self.lib.vp8drv_batch_ready.argtypes = [C.c_void_p]
+        return bool(self.lib.vp8drv_batch_ready(self.h))
 
     def get_frames_begin(self, members=None) -> None:
         """The entropy stage of the members' frames in one set of launches (vp8drv_batch_get_frame_begin); every member's

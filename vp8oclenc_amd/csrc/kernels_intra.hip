@@ -323,6 +323,8 @@ struct IntraArgs {
     int32_t *is_inter;      // [MBs] 0 where check_SSIM replaced the macroblock
     int32_t *prog;          // [mbh] macroblocks of the row that are final, + gen_base
     uint32_t gen_base;      // launch number * 1024: a counter left by an earlier launch reads as negative progress
+    const int32_t *flagged; // fallback riding in the frame's chain (vp8hip_check_ssim_async): *flagged == 0 = k_mb left no macroblock
+                            // below the target, nothing to do and nothing to initialise; nullptr = always run
     int32_t *err;           // set to 1 when a bounded wait expired (shared with the loop filter: VP8HIP_ERR_TIMEOUT)
     float target;
     int key;                // 1: key frame (every macroblock, segment 0); 0: fallback of an inter frame
@@ -498,6 +500,7 @@ __device__ __forceinline__ void intra_check3_body(const IntraArgs &a) {
     const LaneK k = lane_consts(lane);
     const int mb_row0 = r * mbw;
     if (a.stall_test && r == 0) return;
+    if (a.flagged && __builtin_nontemporal_load(a.flagged) == 0) return;   // (is_inter / modes are then not read either: replaced == 0)
     for (int i = threadIdx.x; i < mbw; i += 192) a.is_inter[mb_row0 + i] = 1;
     for (int i = threadIdx.x; i < mbw * 16; i += 192) a.modes[(size_t)mb_row0 * 16 + i] = 0;
     if (threadIdx.x == 0) s_abort = 0;
@@ -918,34 +921,6 @@ __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int
     }
 }
 
-// check_SSIM's tail (src/vp8enc.cpp:237-261) for the members of a batch, one workgroup each: the statistics, and what the
-// host does with the minimum -- above 0.95 prepare_segments_data(1, 7) rewrites the segment data in force (reductor doubled,
-// sharpness 7) before the loop filter and the frame header read them.  The five words also go to host memory the device
-// can write (`verdict`): the host reads them when it next needs to know (redo as a key frame, statistics), not now.
-struct VerdictItem {
-    const float *ssim;
-    const int32_t *is_inter, *err;
-    SegData *sd;
-    int32_t *strength, *stats, *verdict;
-    int32_t refqi[4];
-};
-__global__ __launch_bounds__(256) void k_ssim_verdict_b(BatchOf<VerdictItem> b, int mbs, int qi_min) {
-    const VerdictItem &a = b.item[blockIdx.x];
-    const SsimStats r = ssim_stats_body(a.ssim, a.is_inter, mbs);
-    if (threadIdx.x != 0) return;
-    const int updated = r.mn > 0.95f ? 1 : 0;   // the reference compares the float with the double 0.95: the same verdict (no float lies between 0.95f and 0.95)
-    if (updated) {
-        const int refqi[4] = {a.refqi[0], a.refqi[1], a.refqi[2], a.refqi[3]};
-        a.strength[2] = fill_segment_data(a.sd, 0, refqi, qi_min, a.strength[0], a.strength[1], true);
-    }
-    const int32_t w[5] = {r.replaced, __float_as_int(r.mean), __float_as_int(r.mn), *a.err, updated};
-    for (int i = 0; i < 5; ++i) {
-        a.stats[i] = w[i];
-        a.verdict[i] = w[i];
-    }
-    __threadfence_system();
-}
-
 }  // namespace
 
 static IntraArgs intra_args(const Frame &cur, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *modes, int32_t *is_inter,
@@ -959,6 +934,7 @@ static IntraArgs intra_args(const Frame &cur, const Frame &recon, const MBOut &o
     a.is_inter = is_inter;
     a.prog = prog;
     a.gen_base = gen * 1024u;   // progress within a launch stays below 1024 (512 macroblocks per row at most)
+    a.flagged = nullptr;
     a.err = err;
     a.target = target;
     a.key = key;
@@ -989,26 +965,16 @@ void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, i
     hipLaunchKernelGGL(k_ssim_stats, dim3(1), dim3(256), 0, s, o.ssim, is_inter, mbs, err, out);
 }
 
-void launch_check_async(hipStream_t s, const CheckItem *items, int n, float target, int qi_min, int mbw, int mbh, int modes_of_kept) {
-    static_assert(sizeof(BatchOf<IntraArgs>) <= 4096 && sizeof(BatchOf<VerdictItem>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
+void launch_check_fallback(hipStream_t s, const CheckItem *items, int n, float target, int mbw, int mbh, int modes_of_kept) {
+    static_assert(sizeof(BatchOf<IntraArgs>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
     BatchOf<IntraArgs> b;
-    BatchOf<VerdictItem> v;
-    b.n = v.n = n;
+    b.n = n;
     for (int i = 0; i < n; ++i) {
         const CheckItem &c = items[i];
         b.item[i] = intra_args(*c.cur, *c.recon, *c.o, c.sd, c.modes, c.is_inter, c.prog, c.gen, c.err, target, 0, mbw, mbh, 0, modes_of_kept);
-        VerdictItem &w = v.item[i];
-        w.ssim = c.o->ssim;
-        w.is_inter = c.is_inter;
-        w.err = c.err;
-        w.sd = c.sd;
-        w.strength = c.strength;
-        w.stats = c.stats;
-        w.verdict = c.verdict;
-        for (int k = 0; k < 4; ++k) w.refqi[k] = c.refqi[k];
+        b.item[i].flagged = c.o->flags;
     }
     hipLaunchKernelGGL(k_intra_check3_b, dim3(mbh, 1, n), dim3(192), 0, s, b);
-    hipLaunchKernelGGL(k_ssim_verdict_b, dim3(n), dim3(256), 0, s, v, mbw * mbh, qi_min);
 }
 
 }  // namespace vp8

@@ -139,7 +139,8 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 struct Args {
     Plane Y, U, V;
     MBOut o;
-    const SegData *sd;
+    SegData *sd;      // read; written only by the verdict workgroup when check_SSIM's filter update applies (chk)
+    LfCheck chk;
     int32_t *gprog;   // [bands] gbase + macroblocks of the band's bottom strip published so far
     int gbase;        // counters only grow: launch n uses the range (n*(mbw+2), (n+1)*(mbw+2)], so no memset
     int mbw, mbh, nbands;
@@ -153,6 +154,9 @@ struct Shared {
     int flag[8];                                  // worker progress, F_TOP, F_PUB; [F_ABORT]: a bounded wait expired somewhere in
                                                   // this workgroup, everybody leaves.  Read and written through `flag` below.
     uint32_t dummy[WORKERS * 64];                 // sink for stores of lanes that have nothing to store
+    SegData sd;                                   // the segment data check_SSIM's filter update gives, when it applies (chk)
+    float red[8];
+    int repl;
     int first_lf0;                                // first macroblock whose segment has loop_filter_level 0 (:990)
     int4 lim[4];                                  // per segment: {interior limit, mb_delta, b_delta, hev threshold} (struct Limits)
 };
@@ -179,6 +183,72 @@ constexpr int SPIN_LIMIT = 1 << 22;
         if (flag[F_ABORT]) return;                                                  \
     }
 
+// The workgroup behind the last band, present when check_SSIM rides in the launch: what check_SSIM reports (vp8enc.cpp:237-258:
+// replaced count, the raster-order float sum / count, the minimum), the updated segment data back to where the entropy stage
+// reads them, and the verdict to the host.  The sum must be the reference's -- one float accumulator over the macroblocks in
+// raster order -- so the values are staged in LDS by all threads (the strips and tiles this workgroup has no other use for)
+// and one thread adds them, four per ds_read_b128.
+__device__ __noinline__ void verdict_workgroup(const Args &a, Shared &sh, bool updated) {
+    constexpr int NT = NWAVES * 64, CHUNK = 8192;
+    static_assert(sizeof(sh.strip) + sizeof(sh.tile) >= CHUNK * sizeof(float), "staging area");
+    float *s_val = reinterpret_cast<float *>(&sh.strip[0][0]);
+    const int mbs = a.mbw * a.mbh, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) sh.repl = 0;
+    int repl = 0;
+    float mn = 2.0f, sum = 0.0f;
+    for (int base = 0; base < mbs; base += CHUNK) {
+        const int n = imin(CHUNK, mbs - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < CHUNK; i += NT) {
+            float v = 0.0f;
+            if (i < n) {
+                v = a.o.ssim[base + i];
+                repl += a.chk.is_inter[base + i] == 0;
+                mn = v < mn ? v : mn;
+            }
+            s_val[i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float4 *q = reinterpret_cast<const float4 *>(s_val);
+            int i = 0;
+            for (; i + 32 <= n; i += 32) {   // eight reads in flight, then the 32 dependent additions
+                float4 v[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) v[k2] = q[(i >> 2) + k2];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) sum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum, v[k2].x), v[k2].y), v[k2].z), v[k2].w);
+            }
+            for (; i + 4 <= n; i += 4) {
+                const float4 v = q[i >> 2];
+                sum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum, v.x), v.y), v.z), v.w);
+            }
+            for (; i < n; ++i) sum = __fadd_rn(sum, s_val[i]);
+        }
+    }
+    // with no macroblock flagged the fallback left is_inter untouched (stale): nothing was replaced
+    const bool fallback_ran = __builtin_nontemporal_load(a.o.flags) != 0;
+    if (fallback_ran) atomicAdd(&sh.repl, repl);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(mn, m, 64); mn = o < mn ? o : mn; }
+    __syncthreads();            // (sh.red was last read before this function)
+    if (lane == 0) sh.red[wave] = mn;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 0; w < NWAVES; ++w) mn = sh.red[w] < mn ? sh.red[w] : mn;
+    if (updated) {
+        for (int i = 0; i < 4 * SD_INTS; ++i) a.sd->v[i] = sh.sd.v[i];
+        a.chk.strength[2] = 7;      // video.loop_filter_sharpness after prepare_segments_data(1, 7)
+    }
+    a.o.flags[0] = 0;               // the fallback has run (the launch before this one): zero at rest
+    const int32_t w[5] = {sh.repl, __float_as_int(__fdiv_rn(sum, (float)mbs)), __float_as_int(mn), *a.err, updated ? 1 : 0};
+    for (int i = 0; i < 5; ++i) {
+        a.chk.stats[i] = w[i];
+        __hip_atomic_store(&a.chk.verdict[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(&a.chk.verdict[5], (int32_t)a.chk.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // the host polls this word
+}
+
 __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
     const int band = blockIdx.x;
@@ -186,8 +256,38 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     lds_flag_t *const flag = (lds_flag_t *)sh.flag;
     if (threadIdx.x < 8) flag[threadIdx.x] = 0;
     if (threadIdx.x == 0) sh.first_lf0 = 0x7fffffff;
+    // check_SSIM's tail in this launch (vp8enc.cpp:252-261): `if (min1 > 0.95) prepare_segments_data(1, 7)`.  Every workgroup
+    // takes the frame's minimum SSIM itself (8 160 floats at 1080p: a few microseconds) and, above 0.95, filters with the
+    // segment data that call produces -- nobody waits for a kernel that would have done it.
+    const int32_t *sdv = a.sd->v;
+    if (a.chk.on) {
+        float mn = 2.0f;
+        const int mbs_all = a.mbw * a.mbh;
+        for (int i = threadIdx.x; i < mbs_all; i += NWAVES * 64) { const float v = a.o.ssim[i]; mn = v < mn ? v : mn; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(mn, m, 64); mn = o < mn ? o : mn; }
+        if (lane == 0) sh.red[wave] = mn;
+        __syncthreads();
+        mn = sh.red[0];
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) mn = sh.red[w] < mn ? sh.red[w] : mn;
+        if (mn > 0.95f) {   // (the reference compares with the double 0.95: no float lies between 0.95f and 0.95)
+            if (threadIdx.x == 0) {
+                const int refqi[4] = {a.chk.refqi[0], a.chk.refqi[1], a.chk.refqi[2], a.chk.refqi[3]};
+                fill_segment_data(&sh.sd, 0, refqi, a.chk.qi_min, a.chk.strength[0], a.chk.strength[1], true);
+            }
+            sdv = sh.sd.v;
+            __syncthreads();
+        }
+        if (band >= a.nbands) {
+            verdict_workgroup(a, sh, sdv != a.sd->v);
+            return;
+        }
+    } else if (band >= a.nbands) {
+        return;
+    }
     if (threadIdx.x < 4) {   // a table read per macroblock: selecting among four registers by a per-lane index compiles to branches
-        const int32_t *sd = a.sd->v + threadIdx.x * SD_INTS;
+        const int32_t *sd = sdv + threadIdx.x * SD_INTS;
         const int il = sd[SD_INTERIOR_LIMIT] & 0xff;
         sh.lim[threadIdx.x] = make_int4(il, il - (sd[SD_MBEDGE_LIMIT] & 0xff) * 2 - 1, il - (sd[SD_SUB_BEDGE_LIMIT] & 0xff) * 2 - 1,
                                         sd[SD_HEV_THRESHOLD] & 0xff);
@@ -205,7 +305,6 @@ __device__ __forceinline__ void loop_filter3_body(const Args &a) {
     {
         // CPU_kernels.cl:990: a macroblock whose segment has level 0 ends the plane.  Levels are >= 1 for
         // every quantizer the host produces, so the scan over segment ids runs only if one IS zero.
-        const int32_t *sdv = a.sd->v;
         const bool any0 = sdv[SD_LOOP_FILTER_LEVEL] == 0 || sdv[SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 ||
                           sdv[2 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0 || sdv[3 * SD_INTS + SD_LOOP_FILTER_LEVEL] == 0;
         if (any0) {
@@ -496,9 +595,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_loop_filter3_b(BatchOf<Args> b)
 
 }  // namespace lf3
 
-static lf3::Args loop_filter3_args(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress, int mbw, int mbh,
-                                   unsigned launch_no, int stall_test) {
+static lf3::Args loop_filter3_args(hipStream_t s, const Frame &recon, const MBOut &o, SegData *d_sd, int32_t *progress, int mbw, int mbh,
+                                   unsigned launch_no, int stall_test, const LfCheck *chk) {
     lf3::Args a;
+    if (chk) a.chk = *chk;
+    else a.chk.on = 0;
     a.Y = recon.Y[0];
     a.U = recon.U;
     a.V = recon.V;
@@ -523,20 +624,24 @@ static bool lf_skip() {
     return skip;   // timing experiment only
 }
 
-void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no, int stall_test) {
-    const lf3::Args a = loop_filter3_args(s, recon, o, d_sd, progress, mbw, mbh, launch_no, stall_test);
+void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh, unsigned launch_no, int stall_test, const LfCheck *chk) {
+    const lf3::Args a = loop_filter3_args(s, recon, o, d_sd, progress, mbw, mbh, launch_no, stall_test, chk);
     if (lf_skip()) return;
-    VP8_LAUNCH(lf3::k_loop_filter3, dim3(a.nbands), dim3(lf3::NWAVES * 64), 0, s, a);
+    VP8_LAUNCH(lf3::k_loop_filter3, dim3(a.nbands + (a.chk.on ? 1 : 0)), dim3(lf3::NWAVES * 64), 0, s, a);   // + the verdict workgroup
 }
 
-void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
-                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n) {
+void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, SegData *const *d_sd,
+                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n, const LfCheck *chk) {
     BatchOf<lf3::Args> b;
     b.n = n;
-    for (int i = 0; i < n; ++i) b.item[i] = loop_filter3_args(s, *recon[i], *o[i], d_sd[i], progress[i], mbw, mbh, launch_no[i], 0);
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        b.item[i] = loop_filter3_args(s, *recon[i], *o[i], d_sd[i], progress[i], mbw, mbh, launch_no[i], 0, chk ? &chk[i] : nullptr);
+        any = any || b.item[i].chk.on;
+    }
     if (lf_skip()) return;
-    VP8_LAUNCH(lf3::k_loop_filter3_b, dim3(b.item[0].nbands, 1, n), dim3(lf3::NWAVES * 64), 0, s, b);
+    VP8_LAUNCH(lf3::k_loop_filter3_b, dim3(b.item[0].nbands + (any ? 1 : 0), 1, n), dim3(lf3::NWAVES * 64), 0, s, b);
 }
 
 }  // namespace vp8

@@ -228,6 +228,7 @@ struct MBArgs {
     int32_t *o_parts, *o_ref, *o_seg, *o_nz, *o_mask;
     int16_t *o_vec, *o_coeffs;
     float *o_ssim;
+    int32_t *o_flag;      // set when a macroblock ends below the SSIM target: check_SSIM's fallback has work (zero at rest)
     const SegData *sd;
     const int32_t *bdiff0, *bdiff1, *bdiff2;
     const int16_t *vnet0, *vnet1, *vnet2;
@@ -506,6 +507,7 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
             a.o_mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
         }
         a.o_ssim[mb] = ssim;
+        if (ssim < a.ssim_target) *a.o_flag = 1;   // (vp8enc.cpp:244: what the fallback acts on; rare, so no store otherwise)
     }
 }
 
@@ -535,7 +537,7 @@ static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, 
     a.ystride = cur.Y[0].stride; a.yw = cur.Y[0].w; a.yh = cur.Y[0].h;
     a.cstride = cur.U.stride; a.cw = cur.U.w; a.ch = cur.U.h;
     a.o_parts = o.parts; a.o_ref = o.ref; a.o_seg = o.seg; a.o_nz = o.nz; a.o_mask = o.mask;
-    a.o_vec = o.vec; a.o_coeffs = o.coeffs; a.o_ssim = o.ssim;
+    a.o_vec = o.vec; a.o_coeffs = o.coeffs; a.o_ssim = o.ssim; a.o_flag = o.flags;
     a.sd = d_sd;
     a.bdiff0 = nets.bdiff[0]; a.bdiff1 = nets.bdiff[1]; a.bdiff2 = nets.bdiff[2];
     a.vnet0 = nets.net[0][0]; a.vnet1 = nets.net[1][0]; a.vnet2 = nets.net[2][0];

@@ -458,6 +458,14 @@ int vp8drv_resolve(vp8drv *d) {
     return rc < 0 ? rc : (d->have_frame && d->last_key ? 1 : 0);
 }
 
+int vp8drv_ready(const vp8drv *d) { return !d || !d->verdict_pending || vp8hip_check_ssim_ready(d->hip); }
+int vp8drv_batch_ready(const vp8drv_batch *b) {
+    if (!b) return 1;
+    for (int i = 0; i < b->n; ++i)
+        if (!vp8drv_ready(b->d[i])) return 0;
+    return 1;
+}
+
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     if (!d || !out || !size) return VP8HIP_ERR_ARG;
     if (!d->have_frame) return VP8HIP_ERR_STATE;

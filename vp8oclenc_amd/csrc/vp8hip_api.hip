@@ -53,9 +53,12 @@ struct vp8hip_ctx {
     uint32_t *d_stats2[2] = {nullptr, nullptr};
     vp8hip_batch *batch = nullptr;  // the batch this context is a member of
     // check_SSIM without the host round trip (vp8hip_check_ssim_async): the verdict lands in host memory the device writes
-    int32_t *h_verdict = nullptr;   // {replaced, new_SSIM, min SSIM, time-out flag, filter updated}
-    hipEvent_t ev_verdict = nullptr, verdict_wait = nullptr;   // recorded behind the verdict kernel (a batch records its own for all members)
-    bool verdict_pending = false;
+    int32_t *h_verdict = nullptr;   // {replaced, new_SSIM, min SSIM, time-out flag, filter updated, seq}: polled, no event
+    uint32_t verdict_seq = 0;       // the seq the loop filter launch that carries the verdict will write last
+    bool verdict_pending = false;   // that launch is enqueued
+    bool chk_armed = false;         // vp8hip_check_ssim_async ran: the next loop filter launch carries the verdict
+    int32_t chk_refqi[4] = {0, 0, 0, 0};
+    int chk_qi_min = 0;
     unsigned intra_gen = 0;         // launches on intra_prog (its counters carry the launch number: nothing to clear)
 
     NetSet nets{};
@@ -282,8 +285,8 @@ struct vp8hip_batch {
     hipStream_t prep = nullptr;          // nullptr: everything on `stream` (VP8HIP_BATCH_PREP=0)
     bool prep_shared = false;            // prep is the process-wide one (VP8HIP_BATCH_PREP=2), not this batch's to destroy
     hipEvent_t ev_gate = nullptr;        // on `stream`, at the start of a frame call: everything of the earlier frames
+    hipEvent_t ev_gate2 = nullptr;       // (the two alternate: a wait never names an event that is recorded again right behind it)
     hipEvent_t ev_prep = nullptr;        // on `prep`: the head-of-frame work enqueued so far
-    hipEvent_t ev_verdict = nullptr;     // behind the batched check_SSIM verdict
     bool prep_pending = false;           // `stream` has not yet been told to wait for ev_prep
 };
 
@@ -335,6 +338,8 @@ static int join_lf(vp8hip_ctx *c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
     return VP8HIP_OK;
 }
+static void lf_check(vp8hip_ctx *c, LfCheck &k);   // (below, with check_SSIM)
+
 // work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
 static void batch_join_prep(vp8hip_batch *b) {
     if (!b || !b->prep || !b->prep_pending) return;
@@ -414,9 +419,8 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMemsetAsync(c->d_stats2[0], 0, 2 * stats_words * sizeof(uint32_t), c->stream));   // (holds a completion counter that is zero at rest)
     c->d_stats2[1] = c->d_stats2[0] + stats_words;
     c->d_stats = c->d_stats2[0];
-    CR(hipHostMalloc(&c->h_verdict, 8 * sizeof(int32_t)));
-    memset(c->h_verdict, 0, 8 * sizeof(int32_t));
-    CR(hipEventCreateWithFlags(&c->ev_verdict, hipEventDisableTiming));
+    CR(hipHostMalloc(&c->h_verdict, 16 * sizeof(int32_t), hipHostMallocCoherent));   // fine-grained: the device's stores arrive while its kernel runs
+    memset(c->h_verdict, 0, 16 * sizeof(int32_t));
     for (int r = 0; r < 3; ++r) {
         CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
         CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
@@ -430,7 +434,8 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMalloc(&c->out.ssim, (size_t)c->mbs * 4));
     CR(hipMalloc(&c->out.vec, (size_t)c->mbs * 16));
     CR(hipMalloc(&c->out.coeffs, (size_t)c->mbs * 800));
-    CR(hipMalloc(&c->out.first_lf0, 64));
+    CR(hipMalloc(&c->out.flags, 64));
+    CR(hipMemsetAsync(c->out.flags, 0, 64, c->stream));
     CR(hipMalloc(&c->d_sd2[0], 2 * sizeof(SegData)));
     c->d_sd2[1] = c->d_sd2[0] + 1;
     c->d_sd = c->d_sd2[0];
@@ -505,7 +510,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->out.ssim);
     hipFree(c->out.vec);
     hipFree(c->out.coeffs);
-    hipFree(c->out.first_lf0);
+    hipFree(c->out.flags);
     hipFree(c->d_sd2[0]);
     if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
     if (c->h_frame) hipHostFree(c->h_frame);
@@ -513,7 +518,6 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->d_progress);
     hipFree(c->d_stats2[0]);
     if (c->h_verdict) hipHostFree(c->h_verdict);
-    if (c->ev_verdict) hipEventDestroy(c->ev_verdict);
     hipFree(c->scratch);
     hipFree(c->ent_flags);
     hipFree(c->ent_third);
@@ -684,6 +688,7 @@ int vp8hip_get_segments(vp8hip_ctx *c, int32_t sd[VP8HIP_SD_INTS], int32_t *redu
 // with a larger one; a caller that goes on to the next frame instead has given it up.
 static void drop_overflowed_frame(vp8hip_ctx *c) {
     if (c->frame_overflowed) c->frame_pending = c->frame_overflowed = false;
+    c->chk_armed = false;   // (a new frame begins: a check armed for the previous reconstruction does not ride with this one's filter)
 }
 
 // what inter_begin would refuse, without touching the context (a batch validates every member before it changes any)
@@ -896,16 +901,20 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
         ctxs[i]->counted = false;
     }
     ++g_live_contexts;
-    // the head-of-frame stream: 1 (default) = one per batch, in the lowest priority class (queues are per priority, so it
-    // never shares a hardware queue with a chain, and its work -- which has a frame time of slack -- is the one that yields);
-    // 2 = one for all batches of the process; 0 = none, the head of the frame stays at the head of the chain
-    static const int prep_mode = [] { const char *v = getenv("VP8HIP_BATCH_PREP"); return v && v[0] ? atoi(v) : 1; }();
-    bool ok = hipEventCreateWithFlags(&b->ev_verdict, hipEventDisableTiming) == hipSuccess;
-    if (ok && prep_mode) {
+    // the head-of-frame stream (VP8HIP_BATCH_PREP): 0 (default) = none, the head of the frame stays at the head of the chain;
+    // 1 = one per batch, in the lowest priority class; 2 = one for all batches of the process.  Measured on MI355X, 48 chunks
+    // in 8 batches, same box: 62.2 M MB/s without, 59.5 with one per batch (59.9 in the default priority class), 60.9 with one
+    // for all -- the second set of queues costs more than the shorter chains win, so it is off unless asked for.
+    static const int prep_mode = [] { const char *v = getenv("VP8HIP_BATCH_PREP"); return v && v[0] ? atoi(v) : 0; }();
+    bool ok = true;
+    if (prep_mode) {
         ok = hipEventCreateWithFlags(&b->ev_gate, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b->ev_gate2, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b->ev_prep, hipEventDisableTiming) == hipSuccess;
         int least = 0, greatest = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        static const bool normal_priority = getenv("VP8HIP_BATCH_PREP_PRIO") != nullptr;   // A/B: the head-of-frame stream in the default class
+        if (normal_priority) least = 0;
         if (ok && prep_mode == 2) {
             static hipStream_t shared[64] = {};
             hipStream_t &sh = shared[ctxs[0]->device & 63];
@@ -932,12 +941,11 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the
     hipStreamDestroy(b->stream);
     if (b->prep && !b->prep_shared) hipStreamDestroy(b->prep);
     if (b->ev_gate) hipEventDestroy(b->ev_gate);
+    if (b->ev_gate2) hipEventDestroy(b->ev_gate2);
     if (b->ev_prep) hipEventDestroy(b->ev_prep);
-    if (b->ev_verdict) hipEventDestroy(b->ev_verdict);
     --g_live_contexts;
     for (int i = 0; i < b->n; ++i) {
         b->c[i]->batch = nullptr;
-        if (b->c[i]->verdict_wait == b->ev_verdict) b->c[i]->verdict_pending = false;   // (the streams are idle: nothing to wait for)
         if (!b->c[i]->own_stream) hipStreamCreateWithFlags(&b->c[i]->own_stream, hipStreamNonBlocking);
         b->c[i]->stream = b->c[i]->own_stream;
         if (!b->c[i]->counted) ++g_live_contexts;
@@ -969,7 +977,10 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
         // of that frame's work -- enqueued on `stream` before the PREVIOUS frame call began, which is where ev_gate was last
         // recorded -- must be over; the previous frame's chain may still be running, and that is the point.
         HIPCHK(c0, hipStreamWaitEvent(b->prep, b->ev_gate, 0));
-        HIPCHK(c0, hipEventRecord(b->ev_gate, b->stream));
+        HIPCHK(c0, hipEventRecord(b->ev_gate2, b->stream));
+        hipEvent_t t_ = b->ev_gate;
+        b->ev_gate = b->ev_gate2;
+        b->ev_gate2 = t_;
         b->prep_pending = true;
         ps = b->prep;
     }
@@ -1102,25 +1113,30 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
     vp8hip_ctx *m[MAX_BATCH];
     const Frame *recon[MAX_BATCH];
     const MBOut *outs[MAX_BATCH];
-    const SegData *sds[MAX_BATCH];
+    SegData *sds[MAX_BATCH];
     int32_t *prog[MAX_BATCH];
     unsigned launch_no[MAX_BATCH];
+    LfCheck chk[MAX_BATCH];
     int n = 0;
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
+        if (!b->c[i]->recon_ready || b->c[i]->recon < 0) return VP8HIP_ERR_STATE;
+    }
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
-        if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
         recon[n] = &c->frames[c->recon].f;
         outs[n] = &c->out;
         sds[n] = c->d_sd;
         prog[n] = c->d_progress;
         launch_no[n] = c->lf_launches++;
+        lf_check(c, chk[n]);
         m[n++] = c;
     }
     if (!n) return VP8HIP_OK;
     {
         Timed t(c0, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n);
+        launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n, chk);
     }
     for (int i = 0; i < n; ++i) {   // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
         vp8hip_ctx *c = m[i];
@@ -1240,38 +1256,48 @@ int vp8hip_check_ssim(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *
 }
 
 // ---- check_SSIM without the host round trip ---------------------------------------------------------------------------------
-static void check_item(vp8hip_ctx *c, CheckItem &it, const int32_t refqi[4]) {
+static void check_item(vp8hip_ctx *c, CheckItem &it, const int32_t refqi[4], int qi_min) {
     it.cur = &c->cur;
     it.recon = &c->frames[c->recon].f;
     it.o = &c->out;
     it.sd = c->d_sd;
-    it.strength = reinterpret_cast<int32_t *>(c->d_stats + 4);
     it.modes = c->intra_modes;
     it.is_inter = c->intra_is_inter;
     it.prog = c->intra_prog;
     it.err = c->d_progress + LF_ERR_WORD;
-    it.stats = c->intra_stats;
-    it.verdict = c->h_verdict;
     it.gen = ++c->intra_gen;
-    for (int k = 0; k < 4; ++k) it.refqi[k] = refqi[k];
     c->ent_counted_partitions = 0;
+    c->chk_armed = true;
+    for (int k = 0; k < 4; ++k) c->chk_refqi[k] = refqi[k];
+    c->chk_qi_min = qi_min;
+}
+// what the loop filter launch needs to carry an armed check's verdict (on = 0 otherwise)
+static void lf_check(vp8hip_ctx *c, LfCheck &k) {
+    k.on = c->chk_armed ? 1 : 0;
+    if (!k.on) return;
+    c->chk_armed = false;
+    k.qi_min = c->chk_qi_min;
+    for (int i = 0; i < 4; ++i) k.refqi[i] = c->chk_refqi[i];
+    k.is_inter = c->intra_is_inter;
+    k.strength = reinterpret_cast<int32_t *>(c->d_stats + 4);
+    k.stats = c->intra_stats;
+    k.verdict = c->h_verdict;
+    k.seq = ++c->verdict_seq;
+    c->verdict_pending = true;
 }
 
 int vp8hip_check_ssim_async(vp8hip_ctx *c, const int32_t refqi[4], int qi_min) {
     USE_DEVICE(c);
     JOIN_LF(c);
     if (!c || !refqi) return VP8HIP_ERR_ARG;
-    if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending) return VP8HIP_ERR_STATE;
+    if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending || c->chk_armed) return VP8HIP_ERR_STATE;
     CheckItem it;
-    check_item(c, it, refqi);
+    check_item(c, it, refqi, qi_min);
     {
         Timed t(c, VP8HIP_K_INTRA);
-        launch_check_async(c->stream, &it, 1, c->ssim_target, qi_min, c->mbw, c->mbh, c->conformant);
+        launch_check_fallback(c->stream, &it, 1, c->ssim_target, c->mbw, c->mbh, c->conformant);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev_verdict, c->stream));
-    c->verdict_wait = c->ev_verdict;
-    c->verdict_pending = true;
     return VP8HIP_OK;
 }
 
@@ -1282,38 +1308,51 @@ int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int3
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
         const vp8hip_ctx *c = b->c[i];
-        if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending) return VP8HIP_ERR_STATE;
+        if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending || c->chk_armed) return VP8HIP_ERR_STATE;
     }
     CheckItem it[MAX_BATCH];
-    vp8hip_ctx *m[MAX_BATCH];
     int n = 0;
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
-        check_item(b->c[i], it[n], refqi[i]);
-        m[n++] = b->c[i];
+        check_item(b->c[i], it[n++], refqi[i], qi_min);
     }
     if (!n) return VP8HIP_OK;
     {
         Timed t(c0, VP8HIP_K_INTRA);
-        launch_check_async(b->stream, it, n, c0->ssim_target, qi_min, c0->mbw, c0->mbh, c0->conformant);
+        launch_check_fallback(b->stream, it, n, c0->ssim_target, c0->mbw, c0->mbh, c0->conformant);
     }
     HIPCHK(c0, hipGetLastError());
-    HIPCHK(c0, hipEventRecord(b->ev_verdict, b->stream));
-    for (int i = 0; i < n; ++i) {
-        m[i]->verdict_wait = b->ev_verdict;
-        m[i]->verdict_pending = true;
-    }
     return VP8HIP_OK;
+}
+
+int vp8hip_check_ssim_ready(const vp8hip_ctx *c) {   // 1: vp8hip_check_ssim_result would not wait (or there is nothing to wait for)
+    if (!c || !c->verdict_pending) return 1;
+    return (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) == c->verdict_seq ? 1 : 0;
 }
 
 int vp8hip_check_ssim_result(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, float *min_ssim, int32_t *filter_updated) {
     USE_DEVICE_ONLY(c);
     if (!c) return VP8HIP_ERR_ARG;
-    if (!c->verdict_pending) return VP8HIP_ERR_STATE;
-    HIPCHK(c, hipEventSynchronize(c->verdict_wait));
+    if (!c->verdict_pending) return VP8HIP_ERR_STATE;    // (also: armed, but the loop filter that carries the verdict not yet launched)
+    // The verdict workgroup of the loop filter launch writes five words and then the sequence number, at system scope, into
+    // host memory the device sees: it is there a few microseconds into that launch, long before the launch ends.
+    volatile int32_t *v = c->h_verdict;
+    const uint32_t want = c->verdict_seq;
+    for (unsigned spins = 0; (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
+        if ((spins & 0xfff) == 0xfff) {   // every few thousand polls: is the stream still alive?
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want) {
+                // the stream is idle (or failed) and the word never came: the launch did not run its verdict workgroup
+                c->verdict_pending = false;
+                if (q != hipSuccess) { c->last_hip_error = (int)q; return VP8HIP_ERR_HIP; }
+                return VP8HIP_ERR_TIMEOUT;
+            }
+        }
+        __builtin_ia32_pause();
+    }
     c->verdict_pending = false;
     int32_t st[5];
-    for (int i = 0; i < 5; ++i) st[i] = reinterpret_cast<volatile int32_t *>(c->h_verdict)[i];
+    for (int i = 0; i < 5; ++i) st[i] = v[i];
     if (replaced) *replaced = st[0];
     if (new_ssim) memcpy(new_ssim, &st[1], 4);
     if (min_ssim) memcpy(min_ssim, &st[2], 4);
@@ -1357,10 +1396,12 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     if (!c) return VP8HIP_ERR_ARG;
     if (!c->recon_ready || c->recon < 0) return VP8HIP_ERR_STATE;
     Frame &f = c->frames[c->recon].f;
+    LfCheck chk;
+    lf_check(c, chk);
     if (c->lf_overlap && !c->prof_mask) {   // (the per-kernel timers bracket launches on the context's stream only)
         hipStream_t chain = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, chain));
-        launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
+        launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
         HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
         c->stream = c->lf_stream;
         c->lf_stream = chain;
@@ -1368,7 +1409,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         c->lf_sd = c->d_sd;
     } else {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test);
+        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
     }
     // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401); its replicated edges are made
     // with its pyramid, in one launch, when that frame begins (pyramids())

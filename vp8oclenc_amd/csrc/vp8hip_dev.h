@@ -61,7 +61,8 @@ struct MBOut {
     int16_t *vec;      // [MBs][4][2]
     int16_t *coeffs;   // [MBs][25][16]
     float *ssim;
-    int32_t *first_lf0; // smallest MB index whose segment has loop_filter_level == 0 (INT_MAX if none)
+    int32_t *flags;    // [0]: set by k_mb when a macroblock's SSIM is below the target, i.e. check_SSIM's fallback has work to do;
+                       //      cleared by the loop filter launch that carries the verdict (zero at rest)
 };
 
 struct SegData { int32_t v[4 * SD_INTS]; };
@@ -125,8 +126,9 @@ void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
                      const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n,
                      bool conformant = false);
-void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, const SegData *const *d_sd,
-                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n);
+struct LfCheck;
+void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, SegData *const *d_sd,
+                               int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n, const LfCheck *chk = nullptr);
 void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
                                 int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
@@ -137,8 +139,8 @@ void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh, bool conformant = false);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
-void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, const SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no, int stall_test = 0);  // banded wavefront in LDS, one-step row lag
+void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, SegData *d_sd, int32_t *progress,
+                         int mbw, int mbh, unsigned launch_no, int stall_test = 0, const LfCheck *chk = nullptr);  // banded wavefront in LDS, one-step row lag
 
 // per-frame parameter scans on the device copy of the current frame (kernels_rc.hip); stats = 4 uint32
 size_t rc_partial_words();   // uint32 words of per-workgroup partial sums the three launchers below need
@@ -220,21 +222,31 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
                   int32_t *is_inter, int32_t *prog, unsigned gen, int32_t *err, float target, int key, int mbw, int mbh, int stall_test = 0,
                   int modes_of_kept = 0);   // modes_of_kept: vp8hip_conformant_stream
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out);   // out[3] = *err
-// check_SSIM() (src/vp8enc.cpp:231-263) for up to MAX_BATCH contexts without a host round trip, two launches: the intra fallback
-// (it also renews nz / mask of the macroblocks it replaces), then the statistics AND what the host does with them -- with
-// min SSIM > 0.95 the segment data in force are rewritten by prepare_segments_data(1, 7) and strength[2] (the sharpness the
-// frame header carries) becomes 7.  verdict (device-visible host memory): {replaced, new_SSIM, min SSIM, time-out flag, filter updated}
+// check_SSIM() (src/vp8enc.cpp:231-263) for up to MAX_BATCH contexts without a host round trip and without a launch that is
+// not there anyway.  The intra fallback is a launch of its own whose workgroups leave at once unless k_mb has flagged a
+// macroblock below the target (o.flags[0]); it also renews nz / mask of the macroblocks it replaces.  The statistics and what
+// the host does with them ride in the loop filter's launch (LfCheck): every band takes the minimum SSIM itself and, above
+// 0.95, filters with the segment data prepare_segments_data(1, 7) gives; one extra workgroup sums the frame's SSIM in the
+// reference's order, writes the updated segment data back for the entropy stage (strength[2], the sharpness the frame header
+// carries, becomes 7), clears the flag and hands {replaced, new_SSIM, min SSIM, time-out flag, filter updated, seq} to the
+// host through memory the host polls -- the verdict is there long before the filter has finished.
 struct CheckItem {
     const Frame *cur, *recon;
     const MBOut *o;
-    SegData *sd;             // the segment data in force
-    int32_t *strength;       // {reductor, sharpness, sharpness in force}
-    int32_t *modes, *is_inter, *prog, *err, *stats;
-    int32_t *verdict;
+    const SegData *sd;
+    int32_t *modes, *is_inter, *prog, *err;
     unsigned gen;
-    int32_t refqi[4];
 };
-void launch_check_async(hipStream_t s, const CheckItem *items, int n, float target, int qi_min, int mbw, int mbh, int modes_of_kept);
+struct LfCheck {
+    int on, qi_min;
+    int32_t refqi[4];
+    const int32_t *is_inter;
+    int32_t *strength;       // {reductor, sharpness, sharpness in force}
+    int32_t *stats;          // device copy of the verdict (vp8hip_check_ssim's read-back buffer)
+    int32_t *verdict;        // host memory the device writes: the five words, then seq
+    uint32_t seq;
+};
+void launch_check_fallback(hipStream_t s, const CheckItem *items, int n, float target, int mbw, int mbh, int modes_of_kept);
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
