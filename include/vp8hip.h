@@ -147,7 +147,9 @@ int vp8hip_check_ssim_ready(const vp8hip_ctx *ctx);
 /* e_data[].mode[16] of the last vp8hip_intra_transform / vp8hip_check_ssim (the sub-block modes the header coder
  * writes; after check_ssim: of the LAST attempt on a macroblock, as in the reference -- see
  * vp8hip_conformant_stream -- and 0 where none was made) and
- * e_data[].is_inter_mb (check_ssim only).  Either pointer may be NULL. */
+ * e_data[].is_inter_mb (check_ssim only).  Either pointer may be NULL.  After vp8hip_check_ssim_async both are defined only
+ * if the verdict says that macroblocks were replaced (with none below the target the fallback does not touch them, and the
+ * header coder is not to read them: use_intra_info = 0 gives the reference's bits). */
 int vp8hip_download_intra(vp8hip_ctx *ctx, int32_t *modes, int32_t *is_inter_mb);
 /* NOT the reference's behaviour, off by default: with on = 1 the emitted stream decodes, in any VP8 decoder, to exactly the
  * reconstruction the encoder keeps as its references.  The reference's does not, in two places (found by decoding the frames

@@ -28,8 +28,9 @@ do = InterPathDriver(ora, W, H, gop_size=a.gop, ssim_target=a.ssim_target, qi_mi
 h = hashlib.sha256(); total = 0; keys = 0; t0 = time.time()
 for t in range(a.frames):
     y, u, v = (s2.frame(t - a.cut) if (a.cut >= 0 and t >= a.cut) else s.frame(t))
-    was_key = drv.encode_frame_host(y, u, v)
+    drv.encode_frame_host(y, u, v)
     got = drv.get_frame()
+    was_key = drv.resolve()
     out = do.encode_frame(y, u, v)
     assert was_key == (out is None), f"frame {t}: key decision differs"
     exp = expected_frame(W, H, do.last_key if out is None else out, out is None, a.partitions)

@@ -55,8 +55,9 @@ def test_gpu_key_frames_decode_to_the_device_reconstruction(W, H, seed, P, qi):
     drv = api.NativeDriver(s.W, s.H, gop_size=3, num_partitions=P, qi_min=qi[0], qi_max=qi[1])
     keys = 0
     for t in range(7 if W <= 1280 else 4):
-        was_key = drv.encode_frame_host(*s.frame(t))
+        drv.encode_frame_host(*s.frame(t))
         frame = drv.get_frame()
+        was_key = drv.resolve()
         if was_key:
             keys += 1
             _same(webp_decode.decode_key_frame(frame), drv.hip.download_last(), f"{W}x{H} frame {t}")
@@ -249,8 +250,9 @@ def test_gpu_conformant_stream_on_hard_edges(W, H, frames, P, cfg):
     try:
         for t in range(frames):
             y, u, v = s.frame(t)
-            key = drv.encode_frame_host(y, u, v)
+            drv.encode_frame_host(y, u, v)
             frame = drv.get_frame()
+            key = drv.resolve()
             out = do.encode_frame(y, u, v)
             assert bool(key) == (out is None), t
             assert frame == expected_frame(s.W, s.H, do.last_key if out is None else out, out is None, P), f"frame {t}: not the oracle's bytes"
@@ -317,8 +319,9 @@ def test_gpu_sequences_decode_to_the_device_reconstruction(W, H, seed, frames, P
 
     def run():
         for t in range(frames):
-            key = drv.encode_frame_host(*s.frame(t))
-            yield drv.get_frame(), bool(key), drv.hip.download_last()
+            drv.encode_frame_host(*s.frame(t))
+            frame = drv.get_frame()
+            yield frame, bool(drv.resolve()), drv.hip.download_last()
 
     seen = _decode_sequence(run(), f"{W}x{H}")
     assert seen["inter_frames"] >= 2 and seen["fractional"] > 0 and {1, 3} <= seen["refs"], seen

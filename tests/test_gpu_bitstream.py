@@ -73,7 +73,7 @@ def test_bitstream_from_device_resident_frames_and_device_parameters():
         y, u, v = s.frame(t)
         d = [torch.from_numpy(p).cuda() for p in (y, u, v)]
         torch.cuda.synchronize()
-        was_key = drv.encode_frame_device(*(x.data_ptr() for x in d))
+        drv.encode_frame_device(*(x.data_ptr() for x in d))
         got = drv.get_frame()
         out = do.encode_frame(y, u, v)
         assert got == expected_frame(W, H, do.last_key if out is None else out, out is None, 1), t

@@ -69,7 +69,8 @@ def test_async_check_equals_the_host_driven_sequence(W, H, qi, target, want):
             if k == "MB_coeffs":
                 x, y = x[:, :24], y[:, :24]
             assert np.array_equal(x, y), (t, k)
-        assert np.array_equal(ia[0], ib[0]) and np.array_equal(ia[1], ib[1]), t
+        if repl:      # e_data.mode / is_inter_mb: written (and read by the header coder) only when the fallback had work
+            assert np.array_equal(ia[0], ib[0]) and np.array_equal(ia[1], ib[1]), t
         assert np.array_equal(nza, nzb) and np.array_equal(maska, maskb), t
         assert np.array_equal(a.get_segments()[0], b.get_segments()[0]), t
         for p_, q_ in zip(a.download_last(), b.download_last()):
@@ -82,7 +83,7 @@ def test_async_check_equals_the_host_driven_sequence(W, H, qi, target, want):
         for hip, sh in ((a, sharp_a), (b, -1)):
             hip.lib.vp8hip_encode_frame.argtypes = [api.C.c_void_p, api.C.c_int, api.C.c_void_p, api.C.c_void_p, api.C.c_size_t, api.C.POINTER(api.C.c_size_t)]
             buf, n = np.zeros(hip.mbs * 900 + 65536, np.uint8), api.C.c_size_t(0)
-            p = P(0, 0, 0, 0, sh, 0, 0, 0, 1)
+            p = P(0, 0, 0, 0, sh, 0, 0, 0, 1 if repl else 0)
             assert hip.lib.vp8hip_encode_frame(hip.h, 2, api.C.byref(p), buf.ctypes.data, len(buf), api.C.byref(n)) == 0
             outs.append(buf[:n.value].tobytes())
         assert outs[0] == outs[1], t
@@ -100,7 +101,7 @@ def test_native_loop_with_async_check_emits_the_oracle_loops_bytes(W, H, qi, tar
     frames sent back to be key frames -- the native loop's bytes against the reference's loop on the CPU oracle"""
     import torch
     a, b = SynthSequence(W, H, seed=41), SynthSequence(W, H, seed=97)
-    frames = [a.frame(t) for t in range(5)] + [b.frame(t) for t in range(3)]
+    frames = [a.frame(t) for t in range(4)] + [b.frame(t) for t in range(4)]      # the cut hits an ordinary P frame
     drv = api.NativeDriver(W, H, num_partitions=2, check_ssim=1, device_params=1, gop_size=gop, qi_min=qi[0], qi_max=qi[1], ssim_target=target)
     ora = Oracle(W, H, target)
     do = InterPathDriver(ora, W, H, gop_size=gop, qi_min=qi[0], qi_max=qi[1], ssim_target=target)

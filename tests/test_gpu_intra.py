@@ -152,7 +152,8 @@ def test_native_frame_loop_with_intra_fallback_and_scene_cut(device_params):
     do = InterPathDriver(ora, W, H, gop_size=150, altref_range=5, qi_min=qmin, qi_max=qmax, ssim_target=target)
     replaced_total = 0
     for t, (y, u, v) in enumerate(frames):
-        was_key = drv.encode_frame_host(y, u, v)
+        drv.encode_frame_host(y, u, v)
+        was_key = drv.resolve()     # check_SSIM's verdict: with device parameters it is not waited for inside the call
         b = do.encode_frame(y, u, v)
         assert was_key == (b is None), f"frame {t}: key decision"
         st = drv.stats()
@@ -170,7 +171,8 @@ def test_native_frame_loop_with_intra_fallback_and_scene_cut(device_params):
         assert st.last_replaced == b["replaced"] and np.float32(st.last_new_ssim) == np.float32(b["new_SSIM"]), t
         replaced_total += b["replaced"]
         repl = b["is_inter"] == 0
-        assert np.array_equal(is_inter, b["is_inter"]) and np.array_equal(modes, b["modes"]), t
+        if b["replaced"] or not device_params:    # (defined only when something was replaced: vp8hip_check_ssim_async)
+            assert np.array_equal(is_inter, b["is_inter"]) and np.array_equal(modes, b["modes"]), t
         assert np.array_equal(got["MB_coeffs"][:, :24], b["MB_coeffs"][:, :24]), t
         y2 = b["MB_parts"] == 0        # only 16x16 macroblocks have a Y2 block; elsewhere block 24 is stale in every implementation
         assert np.array_equal(got["MB_coeffs"][y2, 24], b["MB_coeffs"][y2, 24]), t

@@ -155,7 +155,9 @@ int resolve(vp8drv *d) {
     d->st.last_replaced = replaced;
     d->st.last_new_ssim = new_ssim;
     d->st.last_min_ssim = min1;
-    d->checked = true;
+    // e_data.is_inter_mb / mode travel to the header coder only when something was replaced: with nothing below the target the
+    // fallback's launch left at once and did not even initialise them (all macroblocks inter: the same bits without them)
+    d->checked = replaced > 0;
     d->replaced = replaced;
     if (updated) d->sharpness = 7;      // prepare_segments_data(1, 7), :260-261, happened on the device
     if (replaced > d->mbs / 6 || new_ssim < d->cfg.ssim_target) {

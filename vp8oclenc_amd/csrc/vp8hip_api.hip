@@ -1338,7 +1338,8 @@ int vp8hip_check_ssim_result(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, 
     // host memory the device sees: it is there a few microseconds into that launch, long before the launch ends.
     volatile int32_t *v = c->h_verdict;
     const uint32_t want = c->verdict_seq;
-    for (unsigned spins = 0; (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
+    static const bool nowait = getenv("VP8HIP_EXPERIMENT_NOWAIT") != nullptr;   // timing experiment only: what the waiting costs
+    for (unsigned spins = 0; !nowait && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
         if ((spins & 0xfff) == 0xfff) {   // every few thousand polls: is the stream still alive?
             const hipError_t q = hipStreamQuery(c->stream);
             if (q != hipErrorNotReady && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want) {
