@@ -64,7 +64,7 @@ typedef struct {
                                 device_params = 1 */
 } vp8drv_config;
 
-void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 0, 1, 0, 0, 0, 0, 3, 0, 0, 0, 0 */
+void vp8drv_default_config(vp8drv_config *cfg);   /* the reference's defaults: 150, 5, 0, 48, -1, 1, 1, 1, 0, 0, 0, 0, 3, 0, 0, 0, 0 */
 
 int vp8drv_create(vp8drv **out, int width, int height, int device_ordinal, const vp8drv_config *cfg);
 void vp8drv_destroy(vp8drv *d);

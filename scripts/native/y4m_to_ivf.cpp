@@ -1,6 +1,8 @@
 // y4m_to_ivf.cpp -- the reference's program with the path swapped in, as a complete C++ user of the C ABI: YUV4MPEG2 in,
 // IVF out (main() of src/vp8enc.cpp reduced to: parse the header, per frame read / code / write, patch the frame count).
-//   y4m_to_ivf <in.y4m> <out.ivf> [-g gop] [-partitions P] [-qmin q] [-qmax q] [-SSIM-target t] [-scene-detect] [-conformant]
+//   y4m_to_ivf <in.y4m> <out.ivf> [-g gop] [-partitions P] [-qmin q] [-qmax q] [-SSIM-target t] [-altref-range n] [-no-scene-detect]
+//              [-no-check-ssim] [-conformant]
+// As in the reference, check_SSIM runs after every inter frame and scene_change() looks at every frame that would be an inter frame.
 // Everything between the two files runs behind include/vp8hip_driver.h; the frames are handed over at their source size
 // and padded on the device (cfg.src_width / src_height), key frames carry that size as the display size.
 #include <cstdio>
@@ -18,14 +20,18 @@ int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: see the head of y4m_to_ivf.cpp\n"); return 2; }
     vp8drv_config cfg;
     vp8drv_default_config(&cfg);
+    cfg.scene_detect = 1;                       // main() calls scene_change() for every would-be inter frame (vp8enc.cpp:408)
     for (int i = 3; i < argc; ++i) {
         auto val = [&]() { return i + 1 < argc ? argv[++i] : "0"; };
         if (!strcmp(argv[i], "-g")) cfg.gop_size = atoi(val());
         else if (!strcmp(argv[i], "-partitions")) cfg.num_partitions = atoi(val());
         else if (!strcmp(argv[i], "-qmin")) cfg.qi_min = atoi(val());
         else if (!strcmp(argv[i], "-qmax")) cfg.qi_max = atoi(val());
-        else if (!strcmp(argv[i], "-SSIM-target")) { cfg.ssim_target = (float)atof(val()); cfg.check_ssim = 1; }
+        else if (!strcmp(argv[i], "-SSIM-target")) cfg.ssim_target = (float)atof(val());
+        else if (!strcmp(argv[i], "-altref-range")) cfg.altref_range = atoi(val());
         else if (!strcmp(argv[i], "-scene-detect")) cfg.scene_detect = 1;
+        else if (!strcmp(argv[i], "-no-scene-detect")) cfg.scene_detect = 0;
+        else if (!strcmp(argv[i], "-no-check-ssim")) cfg.check_ssim = 0;
         else if (!strcmp(argv[i], "-conformant")) cfg.conformant_stream = 1;
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
@@ -57,11 +63,12 @@ int main(int argc, char **argv) {
         uint8_t marker[6];
         const size_t m = fread(marker, 1, 6, in);
         if (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) { fprintf(stderr, "broken stream!\n"); return 1; }
-        const int key = vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0);
-        CK(key);
-        keys += key;
+        CK(vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0));
         size_t size = 0;
         CK(vp8drv_get_frame(drv, bytes.data(), bytes.size(), &size));
+        const int key = vp8drv_resolve(drv);       // the frame's final type: check_SSIM may have sent it back to be a key frame
+        CK(key);
+        keys += key;
         uint8_t ph[12];
         fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)size, n), out);
         fwrite(bytes.data(), 1, size, out);

@@ -58,6 +58,13 @@ def build_oracle(force: bool = False) -> str:
     drvs = [(REF_SO, os.path.join(ORACLE_DIR, "ref_driver.c")), (REF_HOST_SO, os.path.join(ORACLE_DIR, "ref_host_driver.cpp"))]
     if os.path.isdir("/root/reference/src") and (force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(d) for so, d in drvs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+    # the reference's own main() against libvp8hip.so (oracle/ref_main/build.sh; needs the library: skipped where it is not built yet)
+    main_sh = os.path.join(ORACLE_DIR, "ref_main", "build.sh")
+    main_bin = os.path.join(ORACLE_DIR, "_ref", "vp8oclenc_hip")
+    lib = os.path.join(os.path.dirname(ORACLE_DIR), "vp8oclenc_amd", "libvp8hip.so")
+    deps = [main_sh, os.path.join(ORACLE_DIR, "ref_main", "vp8hip_drop_in.h"), lib]
+    if os.path.isdir("/root/reference/src") and os.path.exists(lib) and (force or not os.path.exists(main_bin) or os.path.getmtime(main_bin) < max(os.path.getmtime(d) for d in deps)):
+        subprocess.check_call(["sh", main_sh], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
 

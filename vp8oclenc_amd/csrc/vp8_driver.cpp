@@ -38,7 +38,7 @@ void vp8drv_default_config(vp8drv_config *c) {
     c->qi_max = 48;
     c->ssim_target = -1.0f;
     c->device_params = 1;
-    c->check_ssim = 0;
+    c->check_ssim = 1;
     c->num_partitions = 1;
     c->display_width = 0;
     c->display_height = 0;
