@@ -208,7 +208,7 @@ extern "C" int ref_write_ivf(const char *path, int w, int h, int framerate, int 
         frames.encoded_frame_size = size[t];
         write_output_file();
     }
-    frames.frame_number = nframes - 1;
+    frames.frame_number = nframes;          // main() has counted the last frame too by the time it rewrites the header (vp8enc.cpp:487-489)
     write_output_header();
     fclose(output_file.handle);
     output_file.handle = nullptr;

@@ -108,7 +108,7 @@ def test_two_gloo_ranks_write_the_same_ivf_as_one_process(tmp_path):
     one = str(tmp_path / "one.ivf")
     n = gop_shard.write_ivf(one, gop_shard.gather_frames(serial, FRAMES), seq.W, seq.H)
     data = open(one, "rb").read()
-    assert len(data) == n and data[:4] == b"DKIF" and int.from_bytes(data[24:28], "little") == FRAMES
+    assert len(data) == n and data[:4] == b"DKIF" and int.from_bytes(data[24:28], "little") == FRAMES + 1   # (one too many, as the reference writes it: REFERENCE_DEFECTS.md #8)
     # frame 0 of every chunk is a key frame (start code after the 3-byte tag), the others are inter frames
     off = 32
     for t in range(FRAMES):

