@@ -28,7 +28,7 @@
 #                430-1276 init_all(): buffers, images, kernel arguments, queues
 #   inter_part.h 1-384    prepare_GPU_buffers() + inter_transform(): all of it
 #   loop_filter.h 1-190   all of it
-#   intra_part.h 1100-1126 intra_transform(): the host loop and the uploads (device build) / 1110-1125 the uploads (host build)
+#   intra_part.h 1100-1126 intra_transform(): the host loop and the uploads (device build) / 1112-1126 the uploads (host build)
 #   encIO.h      3-28     gather_frame()'s body (device build) / 4, 24-25 its read-backs -> memcpy (host build)
 #   debug.h      12-23    dump(): read-back of the filtered reconstruction
 set -e
@@ -72,7 +72,7 @@ SED
         printf '1100,1126c\\\n\thip_intra_transform();\n' > "$TMP/intra.sed"
         printf '3,28d\n' > "$TMP/encio.sed"
     else
-        printf '1110,1125c\\\n\thip_upload_intra_results();\n' > "$TMP/intra.sed"
+        printf '1112,1126c\\\n\thip_upload_intra_results();\n' > "$TMP/intra.sed"
         cat > "$TMP/encio.sed" <<'SED'
 4d
 24,25c\

@@ -114,7 +114,7 @@ static void hip_intra_transform()
     HIP_CK(vp8hip_intra_transform(hip_ctx));
 }
 #else
-// intra_transform()'s uploads, intra_part.h:1110-1125: the host-coded key frame goes to the device
+// intra_transform()'s uploads, intra_part.h:1112-1126: the host-coded key frame goes to the device
 static void hip_upload_intra_results()
 {
     HIP_CK(vp8hip_upload_mb_data(hip_ctx, (const int16_t *)frames.MB, frames.MB_parts, frames.MB_segment_id));
