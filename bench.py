@@ -156,6 +156,9 @@ class Leg:
         self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in source]
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
         self.drv, self.t, self.batches = [], [], []
+        self.frames = self.refsum = self.keys = 0
+        if G == 0:
+            return          # (the synthetic frames only: literal_gops brings its own drivers)
         for k in range(G):
             d = api.NativeDriver(self.W, self.H, device=device, gop_size=gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
                                  ssim_target=ssim_target, device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0,
@@ -299,6 +302,76 @@ def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4
     return out
 
 
+def pin_to_gpu_numa_node(torch, local: int):
+    """this rank's host threads onto the CPUs of its GPU's NUMA node (best effort; returns what was done, for the JSON line)"""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return f"{bdf}: no NUMA node reported"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"{bdf}: node {node} has none of this process's CPUs"
+        os.sched_setaffinity(0, cpus)
+        return f"{bdf}: NUMA node {node}, {len(cpus)} CPUs"
+    except Exception as e:      # a report, never a reason to lose the bench line
+        return f"not pinned ({type(e).__name__})"
+
+
+def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream=False, seed=1, frames_out=None, frame_base=0):
+    """`chunks` closed GOPs of `gop_len` frames each on this GPU, each ONE video coded frame after frame from its key frame on (loop
+    filter on the chunk's second stream), one host thread per chunk, every frame counted: a BASELINE config as it is written, not
+    the saturated steady state of `value`.  bitstream: every frame is also delivered as bytes (vp8drv_get_frame) into
+    frames_out[frame_base + chunk * gop_len + t].  Returns (seconds, frames, key frames, frames recoded as key, bytes)."""
+    import threading
+    leg = Leg(torch, api, W0, H0, 0, refs, -1.0, nd, device, seed)       # the synthetic frames in HBM; no drivers yet
+    src = dict(src_width=W0, src_height=H0) if tuple(leg.source_size) != (leg.W, leg.H) else {}
+    drv = [api.NativeDriver(leg.W, leg.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=-1.0,
+                            device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
+    if bitstream:      # the entropy stage allocates its scratch on first use: not inside the timed region
+        for d in drv:
+            d.encode_frame_device(*leg.ptrs[0])
+            d.get_frame()
+        for d in drv:
+            d.close()
+        drv = [api.NativeDriver(leg.W, leg.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=-1.0,
+                                device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
+    keys, nbytes = [0] * chunks, [0] * chunks
+
+    def work(k):
+        d = drv[k]
+        for t in range(gop_len):
+            d.encode_frame_device(*leg.ptrs[(3 * k + t) % leg.nd])
+            if bitstream:
+                b = d.get_frame()
+                nbytes[k] += len(b)
+                if frames_out is not None:
+                    frames_out[frame_base + k * gop_len + t] = b
+            keys[k] += int(bool(d.resolve())) if (bitstream or t == gop_len - 1) else 0
+        d.hip.synchronize()
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(chunks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = [d.stats() for d in drv]
+    out = (el, chunks * gop_len, sum(s.key_frames for s in st), sum(s.redone_as_key for s in st), sum(nbytes), leg.mbs)
+    for d in drv:
+        d.close()
+    leg.close()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
@@ -319,6 +392,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    affinity = pin_to_gpu_numa_node(torch, local)
     dist = None
     if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
         import torch.distributed as dist
@@ -445,7 +519,7 @@ def main():
                                       if CHECK_SSIM else "OFF (A/B run: not the reference's loop)"),
                        "frames_redone_as_key": redone, "frames_with_filter_update": None,
                        "batch_prep_stream": os.environ.get("VP8HIP_BATCH_PREP", "1"),
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
+                       "cpu_affinity": affinity, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
             "loop_filter_by_its_own_clock": lf_clock,
             "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}, clk_ghz if clk_n else None),
@@ -456,12 +530,52 @@ def main():
             "host_enqueue_ms_per_frame": round(enqueue_s / frames_per_gpu * 1e3, 4),
         }
     leg.profile([])
-    # ---- side legs, rank 0 at N = 1 only: they are reported next to the headline value, never as it ------------
+    # ---- side legs: reported next to the headline value, never as it ---------------------------------------------
     if rank == 0 and world == 1 and not args.no_side_legs:
         out["with_bitstream"] = bitstream_leg(torch, leg, max(16, args.steps))
     host_frames = leg.host_frames
     leg.close()
+    if not args.no_side_legs:
+        # BASELINE configs[4] as it is written, at every N: 300 frames per GPU = ONE closed GOP of 300 frames on each rank (2400 / 8),
+        # coded end to end from its key frame with finished VP8 frames out, the frames gathered to rank 0 over RCCL in frame order
+        # (gop_shard.gather_frames); the time includes the gather.  All ranks take part (collective calls).
+        from vp8oclenc_amd import gop_shard
+        GOP5 = int(os.environ.get("VP8_BENCH_GOP5", "300"))
+        local_frames = {}
+        barrier()
+        t0 = time.perf_counter()
+        el5, n5, k5, r5, b5, mbs5 = literal_gops(torch, api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
+                                                 frames_out=local_frames, frame_base=rank * GOP5)
+        gathered = gop_shard.gather_frames(local_frames, GOP5 * world, dist)
+        barrier()
+        t5 = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t5 = float(tt.item())
+        if rank == 0:
+            assert gathered is not None and len(gathered) == GOP5 * world and all(gathered)
+            out["config5_literal"] = {
+                "workload": f"{args.width}x{args.height}, {GOP5 * world} frames = one closed GOP of {GOP5} frames on each of {world} GPU(s), LAST+GOLDEN+ALTREF, check_SSIM in the loop, "
+                            "finished VP8 frames gathered to rank 0 in frame order (RCCL); the time includes the gather",
+                "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
+                "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
+                "encode_seconds_rank0": round(el5, 4), "n_gpus": world}
+        del gathered, local_frames
+        # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
+        # all_gathered, the filtered reconstruction broadcast.  Needs three ranks to mean anything; with fewer the same exchanges
+        # are walked by loopback on rank 0 (what they cost on one GPU), the other ranks only keep the collectives company.
+        rs = ref_shard_leg(torch, api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
+        if rank == 0 and rs is not None:
+            out["ref_shard"] = rs
     if rank == 0 and world == 1 and not args.no_side_legs:
+        # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
+        # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
+        el3, n3, k3, r3, _, mbs3 = literal_gops(torch, api, args.width, args.height, 2, 150, local, nd)
+        out["config3_literal"] = {"workload": f"{args.width}x{args.height}, 300 frames, -g 150: two closed GOPs of 150 frames in flight on one GPU, LAST+GOLDEN+ALTREF, "
+                                              "check_SSIM in the loop, loop filter on the GPU, every frame counted",
+                                  "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
+                                  "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
         s1 = max(200, args.steps)
         out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
@@ -480,12 +594,82 @@ def main():
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
-    if dist is not None:
-        dist.destroy_process_group()
+    import torch.distributed as td_
+    if td_.is_initialized():
+        td_.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+class _SubGroup:
+    """a process subgroup with the handful of torch.distributed names ref_shard.RefShardDriver uses"""
+
+    def __init__(self, dist, group):
+        self.dist, self.group = dist, group
+
+    def is_initialized(self):
+        return True
+
+    def get_rank(self):
+        return self.dist.get_rank(self.group)
+
+    def get_world_size(self):
+        return self.dist.get_world_size(self.group)
+
+    def get_backend(self):
+        return self.dist.get_backend(self.group)
+
+    def broadcast(self, t, src):
+        return self.dist.broadcast(t, src=src, group=self.group)
+
+    def all_gather(self, out, t):
+        return self.dist.all_gather(out, t, group=self.group)
+
+
+def ref_shard_leg(torch, api, dist, W0, H0, local, rank, world, nframes):
+    """ONE video with a frame's reference searches spread over min(world, 3) GPUs (vp8oclenc_amd/ref_shard.py): ms per frame.
+    With one rank every exchange is walked by loopback (what the exchanges cost on one GPU)."""
+    try:
+        from vp8oclenc_amd import ref_shard
+        from vp8oclenc_amd.synth import SynthSequence
+        members = min(world, 3)
+        d = dist
+        if dist is None:                       # a single plain process: a process group of one, for the loopback
+            import torch.distributed as td
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+            d = td
+        elif world > 3:
+            d = _SubGroup(dist, dist.new_group(list(range(3))))      # (every rank creates the group; only its members use it)
+            if rank >= 3:
+                return None
+        loop = members == 1
+        seq = SynthSequence(W0, H0, seed=9)
+        frames = [seq.frame(t) for t in range(6)]
+        be = ref_shard.HipRefBackend(seq.W, seq.H, device=local)
+        drv = ref_shard.RefShardDriver(be, d, seq.W, seq.H, altref_range=ALTREF_RANGE, force_collective=True, loopback=loop, download=False, device_segments=True)
+        for t in range(4):
+            drv.encode_frame(*frames[t % len(frames)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(4, 4 + nframes):
+            drv.encode_frame(*frames[t % len(frames)])
+        be.synchronize()
+        el = time.perf_counter() - t0
+        mbs = (seq.W // 16) * (seq.H // 16)
+        out = {"workload": f"{W0}x{H0}, one GOP, a frame's LAST / GOLDEN / ALTREF searches on " + (f"{members} GPUs" if not loop else "one GPU, every exchange walked by loopback"),
+               "value": round(mbs * nframes / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / nframes * 1e3, 4), "frames": nframes,
+               "bytes_all_gathered_per_frame": int(drv.bytes_gathered / (nframes + 4)), "bytes_broadcast_per_frame": int(drv.bytes_broadcast / (nframes + 4)),
+               "ranks": members, "loopback": bool(loop),
+               "what": "vp8hip_inter_search on every rank's references, one all_gather of the vector and cost nets, vp8hip_inter_finish + loop filter on rank 0, "
+                       "broadcast of the filtered reconstruction (RCCL); host planes uploaded per frame, segment data on the device"}
+        be.close()
+        return out
+    except Exception as e:      # a side leg is a report, never a reason to lose the bench line
+        return {"error": repr(e)[:300]}
 
 
 def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):

@@ -83,7 +83,7 @@ class RefShardDriver:
     encode_frame returns the frame's outputs on rank 0 ({"key": True} for a key frame) and None on the other ranks."""
 
     def __init__(self, backend, dist, width: int, height: int, gop_size: int = 150, altref_range: int = 5, qi_min: int = 0,
-                 qi_max: int = 48, force_collective: bool = False, download: bool = True, loopback: bool = False):
+                 qi_max: int = 48, force_collective: bool = False, download: bool = True, loopback: bool = False, device_segments: bool = False):
         self.be, self.dist = backend, dist
         self.W, self.H = width, height
         self.gop = api.Gop(gop_size, altref_range)
@@ -94,10 +94,20 @@ class RefShardDriver:
         self.world = dist.get_world_size() if self.collective else 1
         self.download = download
         self.loopback = loopback     # also import what this rank itself exported (a one-rank run then walks every exchange)
+        self.device_segments = device_segments   # segment data by vp8hip_auto_segments instead of the host scan (timing runs: the host
+                                                 # scan of a 1080p frame takes longer than the frame)
         self.bytes_gathered = self.bytes_broadcast = 0
 
     def owner(self, ref: int) -> int:
         return ref % self.world
+
+    def _set_segments(self, y, is_key: bool, is_altref: bool):
+        if self.device_segments:
+            self.be.auto_segments(is_key, self.altrefqi if is_altref else self.lastqi, self.qi_min)
+            return None
+        sd = self._segments(y, is_key, is_altref)
+        self.be.set_segments(sd)
+        return sd
 
     def _segments(self, y, is_key: bool, is_altref: bool):
         reductor, sharp = api.loopfilter_strength(y)
@@ -138,7 +148,7 @@ class RefShardDriver:
         self.be.upload_current(y, u, v)
         if g.current_is_key:
             if self.rank == 0:       # key frames are one raster-order wavefront: one device codes them
-                self.be.set_segments(self._segments(y, True, True))
+                self._set_segments(y, True, True)
                 self.be.intra_transform()
                 self.be.prepare_filter_mask(want_nz=False)
                 self.be.loop_filter()
@@ -146,8 +156,7 @@ class RefShardDriver:
             self._share_last()
             self.gop.frame_done()
             return {"key": True} if self.rank == 0 else None
-        sd = self._segments(y, False, bool(g.current_is_altref))
-        self.be.set_segments(sd)
+        sd = self._set_segments(y, False, bool(g.current_is_altref))
         use_golden, use_altref = self.gop.inter_flags()
         used = [0] + ([1] if use_golden else []) + ([2] if use_altref else [])
         mask = sum(1 << r for r in used if self.owner(r) == self.rank)
