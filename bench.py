@@ -104,6 +104,7 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="skip single_stream / other_configs / with_bitstream")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents in the timed region (adds packets)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1 (the N > 1 launch path)")
+    ap.add_argument("--child-legs", action="store_true", help=argparse.SUPPRESS)   # internal: the few-stream side legs in a fresh process
     return ap.parse_args()
 
 
@@ -323,7 +324,7 @@ def pin_to_gpu_numa_node(torch, local: int):
         return f"not pinned ({type(e).__name__})"
 
 
-def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream=False, seed=1, frames_out=None, frame_base=0):
+def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream=False, seed=1, frames_out=None, frame_base=0, start=None):
     """`chunks` closed GOPs of `gop_len` frames each on this GPU, each ONE video coded frame after frame from its key frame on (loop
     filter on the chunk's second stream), one host thread per chunk, every frame counted: a BASELINE config as it is written, not
     the saturated steady state of `value`.  bitstream: every frame is also delivered as bytes (vp8drv_get_frame) into
@@ -333,14 +334,9 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
     src = dict(src_width=W0, src_height=H0) if tuple(leg.source_size) != (leg.W, leg.H) else {}
     drv = [api.NativeDriver(leg.W, leg.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=-1.0,
                             device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
-    if bitstream:      # the entropy stage allocates its scratch on first use: not inside the timed region
+    if bitstream:      # the entropy stage's scratch: not inside the timed region (the reference allocates everything in init_all)
         for d in drv:
-            d.encode_frame_device(*leg.ptrs[0])
-            d.get_frame()
-        for d in drv:
-            d.close()
-        drv = [api.NativeDriver(leg.W, leg.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=-1.0,
-                                device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
+            d.hip.reserve_frame_path()
     keys, nbytes = [0] * chunks, [0] * chunks
 
     def work(k):
@@ -355,6 +351,8 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
             keys[k] += int(bool(d.resolve())) if (bitstream or t == gop_len - 1) else 0
         d.hip.synchronize()
 
+    if start is not None:
+        start()             # (all ranks begin their frame loops together)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(chunks)]
@@ -369,6 +367,58 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
     for d in drv:
         d.close()
     leg.close()
+    return out
+
+
+def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier):
+    """config5_literal (every N), ref_shard, and at N = 1 config3_literal and single_stream: legs that are one or two videos coded
+    frame after frame.  Run in a fresh process (see main()).  Returns the dict for the JSON line on rank 0."""
+    out = {}
+    if rank == 0 and world == 1:
+        # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
+        # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
+        el3, n3, k3, r3, _, mbs3 = literal_gops(torch, api, args.width, args.height, 2, 150, local, nd)
+        out["config3_literal"] = {"workload": f"{args.width}x{args.height}, 300 frames, -g 150: two closed GOPs of 150 frames in flight on one GPU, LAST+GOLDEN+ALTREF, "
+                                              "check_SSIM in the loop, loop filter on the GPU, every frame counted",
+                                  "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
+                                  "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
+        s1 = max(200, args.steps)
+        out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
+        out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
+    if True:
+        # BASELINE configs[4] as it is written, at every N: 300 frames per GPU = ONE closed GOP of 300 frames on each rank (2400 / 8),
+        # coded end to end from its key frame with finished VP8 frames out, the frames gathered to rank 0 over RCCL in frame order
+        # (gop_shard.gather_frames); the time includes the gather.  All ranks take part (collective calls).
+        from vp8oclenc_amd import gop_shard
+        GOP5 = int(os.environ.get("VP8_BENCH_GOP5", "300"))
+        local_frames = {}
+        el5, n5, k5, r5, b5, mbs5 = literal_gops(torch, api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
+                                                 frames_out=local_frames, frame_base=rank * GOP5, start=barrier)
+        # (literal_gops times its frame loop between synchronisations of its own; the clock goes on with the gather.  What is NOT in the
+        # time: making the synthetic frames and creating the encoder, which is init_all() in the reference)
+        t0 = time.perf_counter()
+        gathered = gop_shard.gather_frames(local_frames, GOP5 * world, dist)
+        barrier()
+        t5 = el5 + (time.perf_counter() - t0)
+        if dist is not None:
+            tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t5 = float(tt.item())
+        if rank == 0:
+            assert gathered is not None and len(gathered) == GOP5 * world and all(gathered)
+            out["config5_literal"] = {
+                "workload": f"{args.width}x{args.height}, {GOP5 * world} frames = one closed GOP of {GOP5} frames on each of {world} GPU(s), LAST+GOLDEN+ALTREF, check_SSIM in the loop, "
+                            "finished VP8 frames gathered to rank 0 in frame order (RCCL); the time includes the gather",
+                "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
+                "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
+                "encode_seconds_rank0": round(el5, 4), "n_gpus": world}
+        del gathered, local_frames
+        # one GOP split BY REFERENCE over up to three ranks (SURVEY 8e(i)): the searches of a frame on different GPUs, vector nets
+        # all_gathered, the filtered reconstruction broadcast.  Needs three ranks to mean anything; with fewer the same exchanges
+        # are walked by loopback on rank 0 (what they cost on one GPU), the other ranks only keep the collectives company.
+        rs = ref_shard_leg(torch, api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
+        if rank == 0 and rs is not None:
+            out["ref_shard"] = rs
     return out
 
 
@@ -405,9 +455,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    nd = max(2, args.distinct_frames)
+    if args.child_legs:      # the fresh process of the few-stream side legs: nothing else runs here
+        legs = few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier)
+        import torch.distributed as td_
+        if td_.is_initialized():
+            td_.destroy_process_group()
+        sys.stdout.flush()
+        if rank == 0:
+            os.write(json_fd, (json.dumps(legs) + "\n").encode())
+        os.close(json_fd)
+        return
     G = max(1, args.gops_per_gpu)
     B = max(1, min(8, args.batch))   # VP8HIP_MAX_BATCH
-    nd = max(2, args.distinct_frames)
     free_before = torch.cuda.mem_get_info(local)[0]
     leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
               overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")),   # experiment switch: every chunk's filter on a second stream
@@ -536,49 +596,22 @@ def main():
     host_frames = leg.host_frames
     leg.close()
     if not args.no_side_legs:
-        # BASELINE configs[4] as it is written, at every N: 300 frames per GPU = ONE closed GOP of 300 frames on each rank (2400 / 8),
-        # coded end to end from its key frame with finished VP8 frames out, the frames gathered to rank 0 over RCCL in frame order
-        # (gop_shard.gather_frames); the time includes the gather.  All ranks take part (collective calls).
-        from vp8oclenc_amd import gop_shard
-        GOP5 = int(os.environ.get("VP8_BENCH_GOP5", "300"))
-        local_frames = {}
-        barrier()
-        t0 = time.perf_counter()
-        el5, n5, k5, r5, b5, mbs5 = literal_gops(torch, api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
-                                                 frames_out=local_frames, frame_base=rank * GOP5)
-        gathered = gop_shard.gather_frames(local_frames, GOP5 * world, dist)
-        barrier()
-        t5 = time.perf_counter() - t0
+        # The legs that are ONE or TWO videos coded frame after frame run in a fresh process per rank: the HIP runtime keeps every
+        # hardware queue a process ever used, and after 48 chunks in 8 batches a lone stream shares them badly (measured: the same
+        # two-chunk leg 3 800 frames/s in a fresh process, 2 100 behind the headline's leg).  The children form their own RCCL group.
         if dist is not None:
-            tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t5 = float(tt.item())
+            dist.barrier()
+        env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
+        if not env["VP8_BENCH_CHILD"]:
+            env.pop("VP8_BENCH_CHILD")
+        argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs"]
+        child = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE)
         if rank == 0:
-            assert gathered is not None and len(gathered) == GOP5 * world and all(gathered)
-            out["config5_literal"] = {
-                "workload": f"{args.width}x{args.height}, {GOP5 * world} frames = one closed GOP of {GOP5} frames on each of {world} GPU(s), LAST+GOLDEN+ALTREF, check_SSIM in the loop, "
-                            "finished VP8 frames gathered to rank 0 in frame order (RCCL); the time includes the gather",
-                "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
-                "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
-                "encode_seconds_rank0": round(el5, 4), "n_gpus": world}
-        del gathered, local_frames
-        # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
-        # all_gathered, the filtered reconstruction broadcast.  Needs three ranks to mean anything; with fewer the same exchanges
-        # are walked by loopback on rank 0 (what they cost on one GPU), the other ranks only keep the collectives company.
-        rs = ref_shard_leg(torch, api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
-        if rank == 0 and rs is not None:
-            out["ref_shard"] = rs
+            try:
+                out.update(json.loads(child.stdout.decode().strip().splitlines()[-1]))
+            except Exception as e:
+                out["few_stream_legs_error"] = f"child exit {child.returncode}: {e!r}"[:300]
     if rank == 0 and world == 1 and not args.no_side_legs:
-        # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
-        # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
-        el3, n3, k3, r3, _, mbs3 = literal_gops(torch, api, args.width, args.height, 2, 150, local, nd)
-        out["config3_literal"] = {"workload": f"{args.width}x{args.height}, 300 frames, -g 150: two closed GOPs of 150 frames in flight on one GPU, LAST+GOLDEN+ALTREF, "
-                                              "check_SSIM in the loop, loop filter on the GPU, every frame counted",
-                                  "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
-                                  "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
-        s1 = max(200, args.steps)
-        out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
-        out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
         out["other_configs"] = {
             # 4K: sixteen chunks in eight batches of two (same-box: in batches of 4 55.0, of 2 59.7); 720p: batches of four
             # (48 chunks: twelve streams 102.8, eight streams 98.0)

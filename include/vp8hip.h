@@ -246,6 +246,11 @@ int vp8hip_encode_header(vp8hip_ctx *ctx, const vp8hip_header_params *params, ui
 int vp8hip_encode_frame(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params, uint8_t *out, size_t capacity,
                         size_t *size);
 
+/* init_all() allocates everything before the first frame (init.h:430-593); the entropy stage's scratch (about 100 MB at 1080p)
+ * and the pinned frame buffer are made when the first frame is asked for, or here -- a host that wants no allocation inside its
+ * frame loop calls this once after vp8hip_create. */
+int vp8hip_reserve_frame_path(vp8hip_ctx *ctx);
+
 /* The same in two halves, for a host thread that drives several contexts (GOP chunks): _begin enqueues the whole
  * entropy stage and the read-back on the context's stream and returns at once; _end waits for it and fills `out`.
  * Between the two no other call may be made on this context (the next frame would overwrite what a recode after a

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -506,6 +506,11 @@ class Vp8Hip:
         repl, new, mn = C.c_int32(), C.c_float(), C.c_float()
         self._chk(self.lib.vp8hip_check_ssim(self.h, C.byref(repl), C.byref(new), C.byref(mn)), "check_ssim")
         return repl.value, np.float32(new.value), np.float32(mn.value)
+
+    def reserve_frame_path(self):
+        """the entropy stage's scratch and the frame buffer now instead of at the first frame (vp8hip_reserve_frame_path)"""
+        self.lib.vp8hip_reserve_frame_path.argtypes = [C.c_void_p]
+        self._chk(self.lib.vp8hip_reserve_frame_path(self.h), "reserve_frame_path")
 
     def check_ssim_async(self, refqi, qi_min: int):
         """check_SSIM enqueued, nobody waiting (vp8hip_check_ssim_async); check_ssim_result() collects the verdict"""

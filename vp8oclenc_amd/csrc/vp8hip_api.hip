@@ -56,6 +56,7 @@ struct vp8hip_ctx {
     int32_t *h_verdict = nullptr;   // {replaced, new_SSIM, min SSIM, time-out flag, filter updated, seq}: polled, no event
     uint32_t verdict_seq = 0;       // the seq the loop filter launch that carries the verdict will write last
     bool verdict_pending = false;   // that launch is enqueued
+    hipStream_t verdict_stream = nullptr;   // ... on this stream (with vp8hip_filter_overlap not the one the context is on afterwards)
     bool chk_armed = false;         // vp8hip_check_ssim_async ran: the next loop filter launch carries the verdict
     int32_t chk_refqi[4] = {0, 0, 0, 0};
     int chk_qi_min = 0;
@@ -1131,6 +1132,7 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
         prog[n] = c->d_progress;
         launch_no[n] = c->lf_launches++;
         lf_check(c, chk[n]);
+        c->verdict_stream = b->stream;
         m[n++] = c;
     }
     if (!n) return VP8HIP_OK;
@@ -1341,7 +1343,7 @@ int vp8hip_check_ssim_result(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, 
     static const bool nowait = getenv("VP8HIP_EXPERIMENT_NOWAIT") != nullptr;   // timing experiment only: what the waiting costs
     for (unsigned spins = 0; !nowait && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
         if ((spins & 0xfff) == 0xfff) {   // every few thousand polls: is the stream still alive?
-            const hipError_t q = hipStreamQuery(c->stream);
+            const hipError_t q = hipStreamQuery(c->verdict_stream);
             if (q != hipErrorNotReady && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want) {
                 // the stream is idle (or failed) and the word never came: the launch did not run its verdict workgroup
                 c->verdict_pending = false;
@@ -1403,6 +1405,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         hipStream_t chain = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, chain));
         launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
+        c->verdict_stream = chain;
         HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
         c->stream = c->lf_stream;
         c->lf_stream = chain;
@@ -1411,6 +1414,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     } else {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
         launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
+        c->verdict_stream = c->stream;
     }
     // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401); its replicated edges are made
     // with its pyramid, in one launch, when that frame begins (pyramids())
@@ -1672,6 +1676,16 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
     HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
     return VP8HIP_OK;
+}
+
+// the entropy stage's scratch and the pinned frame buffer, which are otherwise made when the first frame is asked for
+int vp8hip_reserve_frame_path(vp8hip_ctx *c) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    vp8hip_header_params p{};
+    FrameEntropy e;
+    FrameOut fo;
+    return frame_prepare(c, 1, &p, e, fo);
 }
 
 int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p) {
