@@ -217,18 +217,22 @@ class Leg:
 
     def step(self):
         if self.batches:
-            # one frame on every group; with check_SSIM in the loop a group's next frame needs the verdict on its previous one
-            # (a few words the device writes to host memory): the groups are served as those come in, not in a fixed order
-            todo = list(self.batches)
-            while todo:
-                for i, (members, nb) in enumerate(todo):
-                    if nb.ready():
-                        self.step_group(members, nb)
-                        del todo[i]
-                        break
+            # one frame on every group, ONE call: with check_SSIM in the loop a group's next frame needs the verdict on its previous
+            # one (a few words the device writes to host memory), and the groups are served as those come in, natively
+            # (vp8drv_batches_encode_frame_device); the references searched are read from the drivers' counters afterwards
+            keys = self.api.NativeBatch.encode_frame_device_all([nb for _, nb in self.batches],
+                                                                [[self.ptrs[self.t[k] % self.nd] for k in members] for members, _ in self.batches])
+            for (members, _), kk in zip(self.batches, keys):
+                for i, k in enumerate(members):
+                    self.t[k] += 1
+                    self.keys += int(kk[i])
+            self.frames += self.G
             return
         for k in range(self.G):
             self.step_one(k)
+
+    def refs_searched(self):
+        return sum(d.stats().refs_searched for d in self.drv)
 
     def profile(self, kernels):
         for d in self.drv:
@@ -260,6 +264,7 @@ class Leg:
         """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
         sync = barrier or self.torch.cuda.synchronize
         self.frames = self.refsum = self.keys = 0
+        refs0 = self.refs_searched()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -269,6 +274,8 @@ class Leg:
         el = time.perf_counter() - t0
         for d in self.drv:
             d.hip.synchronize()   # raises if a bounded device-side wait (loop filter / intra wavefronts) expired: no number then
+        if self.batches:
+            self.refsum = self.refs_searched() - refs0
         return el, enq, self.refsum / max(self.frames - self.keys, 1)
 
     def close(self):

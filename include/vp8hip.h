@@ -320,7 +320,7 @@ const char *vp8hip_status_string(int status);
 /* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
  * layout (vp8drv_config grew in round 2: 2), MINOR when entry points are added.  A host built against an older header checks
  * it once after loading the library. */
-#define VP8HIP_ABI_VERSION 2005
+#define VP8HIP_ABI_VERSION 2006
 int vp8hip_abi_version(void);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

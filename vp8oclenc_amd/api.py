@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2005  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 2006  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
@@ -223,7 +223,7 @@ class DrvStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame_number", "inter_frames", "key_frames", "last_use_golden",
                                           "last_use_altref", "last_prev_is_golden", "last_prev_is_altref",
                                           "last_was_altref", "redone_as_key", "last_replaced")] + \
-               [("last_new_ssim", C.c_float), ("last_min_ssim", C.c_float), ("scene_changes", C.c_int32)]
+               [("last_new_ssim", C.c_float), ("last_min_ssim", C.c_float), ("scene_changes", C.c_int32), ("refs_searched", C.c_int32)]
 
 
 class NativeDriver:
@@ -391,6 +391,25 @@ class NativeBatch:
         if getattr(self, "h", None):
             self.lib.vp8drv_batch_destroy(self.h)
             self.h = None
+
+    @staticmethod
+    def encode_frame_device_all(batches, planes):
+        """one frame on every batch, each served as its verdicts come in (vp8drv_batches_encode_frame_device); planes[k][i] = member
+        i of batch k's (d_y, d_u, d_v).  Returns the per-batch lists of "was a key frame" flags."""
+        lib = batches[0].lib
+        n = len(batches)
+        for b, pl in zip(batches, planes):
+            for i, p in enumerate(pl):
+                b._ptrs[0][i], b._ptrs[1][i], b._ptrs[2][i] = p
+        PP = C.POINTER(C.c_void_p)
+        arr = lambda j: (PP * n)(*[C.cast(b._ptrs[j], PP) for b in batches])
+        keys = (C.POINTER(C.c_int) * n)(*[C.cast(b._key, C.POINTER(C.c_int)) for b in batches])
+        hs = (C.c_void_p * n)(*[b.h for b in batches])
+        lib.vp8drv_batches_encode_frame_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PP), C.POINTER(PP), C.POINTER(PP), C.POINTER(C.POINTER(C.c_int))]
+        rc = lib.vp8drv_batches_encode_frame_device(hs, n, arr(0), arr(1), arr(2), keys)
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_batches_encode_frame_device: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return [[bool(k) for k in b._key] for b in batches]
 
     def __del__(self):
         try:

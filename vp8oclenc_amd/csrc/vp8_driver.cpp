@@ -189,6 +189,7 @@ int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
     DRV_CHK(vp8hip_inter_transform(d->hip, d->gop.prev_is_golden, d->gop.prev_is_altref, use_golden, use_altref));
     d->st.last_use_golden = use_golden;
     d->st.last_use_altref = use_altref;
+    d->st.refs_searched += 1 + use_golden + use_altref;
     d->st.last_prev_is_golden = d->gop.prev_is_golden;
     d->st.last_prev_is_altref = d->gop.prev_is_altref;
     d->st.last_was_altref = d->gop.current_is_altref;
@@ -440,6 +441,7 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
         vp8drv *d = b->d[i];
         d->st.last_use_golden = ug[i];
         d->st.last_use_altref = ua[i];
+        d->st.refs_searched += 1 + ug[i] + ua[i];
         d->st.last_prev_is_golden = pg[i];
         d->st.last_prev_is_altref = pa[i];
         d->st.last_was_altref = d->gop.current_is_altref;
@@ -466,6 +468,24 @@ int vp8drv_batch_ready(const vp8drv_batch *b) {
     for (int i = 0; i < b->n; ++i)
         if (!vp8drv_ready(b->d[i])) return 0;
     return 1;
+}
+
+int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatches, const void *const *const *y, const void *const *const *u,
+                                       const void *const *const *v, int *const *was_key) {
+    if (!batches || nbatches < 1 || nbatches > 64 || !y || !u || !v) return VP8HIP_ERR_ARG;
+    bool done[64] = {};
+    for (int left = nbatches; left > 0;) {
+        bool progress = false;
+        for (int k = 0; k < nbatches; ++k) {
+            if (done[k] || !vp8drv_batch_ready(batches[k])) continue;
+            DRV_CHK(vp8drv_batch_encode_frame_device(batches[k], nullptr, y[k], u[k], v[k], nullptr, was_key ? was_key[k] : nullptr));
+            done[k] = true;
+            --left;
+            progress = true;
+        }
+        if (!progress) __builtin_ia32_pause();
+    }
+    return VP8HIP_OK;
 }
 
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
