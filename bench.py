@@ -449,7 +449,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
-    affinity = pin_to_gpu_numa_node(torch, local)
+    all_cpus = os.sched_getaffinity(0)
+    affinity = "not pinned (VP8_BENCH_NO_PIN)" if os.environ.get("VP8_BENCH_NO_PIN", "0") not in ("", "0") else pin_to_gpu_numa_node(torch, local)
     dist = None
     if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
         import torch.distributed as dist
@@ -633,6 +634,7 @@ def main():
             "1080p_conformant_stream": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, conformant=1),
         }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        os.sched_setaffinity(0, all_cpus)       # the CPU baseline gets every host core again, not the GPU's NUMA node only
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
     import torch.distributed as td_
     if td_.is_initialized():
