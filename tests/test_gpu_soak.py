@@ -68,6 +68,50 @@ def test_1080p_gop_three_references_native_loop_frames_out():
     ora.close()
 
 
+@pytest.mark.parametrize("W,H,frames,refs", [(1280, 720, 120, "last"), (1920, 1080, 300, "all")])
+def test_baseline_configs_at_their_stated_lengths(W, H, frames, refs):
+    """BASELINE configs[1] and configs[2] as long as they are written: 1280x720, 120 frames, LAST only; 1920x1080, 300 frames,
+    LAST+GOLDEN+ALTREF with the reference's default -g 150 (the key frame at frame 150 included, 60 altref periods) -- through the
+    native frame loop with check_SSIM and frames out, every frame's bytes and every filtered reconstruction (as a checksum) against
+    the reference's loop on the CPU oracle running on all host cores."""
+    import zlib
+    expected_frame = _expected_frame()
+    lib = Oracle.lib()
+    before = lib.vp8o_num_threads()
+    lib.vp8o_set_num_threads(min(128, len(os.sched_getaffinity(0))))
+    s = SynthSequence(W, H, seed=17)
+    mask = 3 if refs == "all" else 0
+    drv = api.NativeDriver(s.W, s.H, gop_size=150, num_partitions=1, check_ssim=1, ref_mask=mask)
+    ora = Oracle(s.W, s.H, -1.0)
+    do = InterPathDriver(ora, s.W, s.H, gop_size=150, ref_mask=mask)
+    keys, seen, updates = 0, set(), 0
+    try:
+        for t in range(frames):
+            y, u, v = s.frame(t)
+            drv.encode_frame_host(y, u, v)
+            got = drv.get_frame()
+            was_key = drv.resolve()
+            out = do.encode_frame(y, u, v)
+            assert was_key == (out is None), f"frame {t}: key decision differs"
+            keys += int(was_key)
+            exp = expected_frame(s.W, s.H, do.last_key if out is None else out, out is None, 1)
+            assert got == exp, f"frame {t}: {len(got)} vs {len(exp)} bytes"
+            a = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in drv.hip.download_last()]
+            b = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in ora.download_last()]
+            assert a == b, f"frame {t}: filtered reconstruction differs"
+            if out is not None:
+                seen.add((out["use_golden"], out["use_altref"]))
+                updates += int(out["min_SSIM"] > np.float32(0.95))
+    finally:
+        lib.vp8o_set_num_threads(before)
+    assert keys == (frames + 149) // 150                      # frame 0, and frame 150 of the 300
+    assert seen == ({(0, 0)} if refs == "last" else {(0, 0), (1, 0), (1, 1)}), seen
+    st = drv.stats()
+    assert (st.key_frames, st.inter_frames) == (keys, frames - keys)
+    drv.close()
+    ora.close()
+
+
 def test_4k_three_references_frame_pair():
     """BASELINE configs[3] geometry with LAST + GOLDEN + ALTREF: every stage tap against the oracle."""
     from test_gpu_parity import _compare, _frames, _one_frame

@@ -18,7 +18,7 @@ from . import api
 class InterPathDriver:
     def __init__(self, backend, width: int, height: int, gop_size: int = 150, altref_range: int = 5,
                  qi_min: int = 0, qi_max: int = 48, ssim_target: float = -1.0, download: bool = True,
-                 check_ssim: bool = True, device_intra: bool = True):
+                 check_ssim: bool = True, device_intra: bool = True, ref_mask: int = 3):
         self.be = backend
         self.W, self.H = width, height
         self.mbs = (width // 16) * (height // 16)
@@ -29,6 +29,7 @@ class InterPathDriver:
         self.download = download
         self.check = check_ssim
         self.device_intra = device_intra     # False: key frames through the old stand-in (source planes = reconstruction)
+        self.ref_mask = ref_mask             # bit 0 GOLDEN, bit 1 ALTREF may be searched (vp8drv_config.ref_mask; 0 = LAST only, BASELINE configs[1])
         self.inter_frames = 0
         self.key_frames = 0
         self.redone_as_key = 0
@@ -72,6 +73,7 @@ class InterPathDriver:
         sd = self.segments_for(y, False, bool(g.current_is_altref))             # vp8enc.cpp:419
         self.be.set_segments(sd)
         use_golden, use_altref = self.gop.inter_flags()                         # inter_part.h:103-104
+        use_golden, use_altref = use_golden & (self.ref_mask & 1), use_altref & ((self.ref_mask >> 1) & 1)
         self.be.inter_transform(g.prev_is_golden, g.prev_is_altref, use_golden, use_altref)
         out = {"segments": sd, "use_golden": use_golden, "use_altref": use_altref, "is_altref": int(g.current_is_altref)}
         if self.check:
