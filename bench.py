@@ -216,6 +216,10 @@ class Leg:
         self.refsum += 1 + st.last_use_golden + st.last_use_altref
 
     def step(self):
+        if self.batches and os.environ.get("VP8_BENCH_PYSTEP"):      # A/B: the groups advanced one by one from Python, in a fixed order
+            for members, nb in self.batches:
+                self.step_group(members, nb)
+            return
         if self.batches:
             # one frame on every group, ONE call: with check_SSIM in the loop a group's next frame needs the verdict on its previous
             # one (a few words the device writes to host memory), and the groups are served as those come in, natively
@@ -267,8 +271,27 @@ class Leg:
         refs0 = self.refs_searched()
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
+        if self.batches and not os.environ.get("VP8_BENCH_ONE_THREAD"):
+            # One host thread per group, each advancing its group by `steps` frames: with check_SSIM in the loop a group's next frame
+            # waits for the verdict on its previous one, and a single thread that serves the groups in turn couples them -- a late
+            # verdict holds up seven other streams (same box, M MB/s: one thread 55.3-58.9, a thread per group 60.3-60.4, check_SSIM
+            # off 60.7-60.9).  The calls release the interpreter lock; a native host would use eight threads the same way.
+            import threading
+
+            def work(members, nb):
+                for _ in range(steps):
+                    keys = nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members])
+                    for i, k in enumerate(members):
+                        self.t[k] += 1
+            th = [threading.Thread(target=work, args=mb) for mb in self.batches]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            self.frames += steps * self.G
+        else:
+            for _ in range(steps):
+                self.step()
         enq = time.perf_counter() - t0
         sync()
         el = time.perf_counter() - t0

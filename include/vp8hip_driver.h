@@ -115,9 +115,9 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL
 int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members);
 int vp8drv_batch_ready(const vp8drv_batch *b);
 /* One frame on EVERY batch of `batches` -- vp8drv_batch_encode_frame_device(batches[k], NULL, y[k], u[k], v[k], NULL, was_key[k])
- * (was_key may be NULL, and so may any was_key[k]) -- each batch served as soon as its members' check_SSIM verdicts are in, not in
- * the order of the array: the loop a host with many chunks in flight would otherwise write itself, without its per-call cost
- * (eight batches advanced from Python: 1.6 ms of interpreter per step against 6.3 ms of GPU work; from here: 0.1 ms). */
+ * (was_key may be NULL, and so may any was_key[k]) -- in the order of the array, each batch waiting for its own members' check_SSIM
+ * verdicts: the loop a host with many chunks in flight would otherwise write itself, in one call.  (The fixed order is on
+ * purpose: serving whichever batch is ready first lets the batches bunch up and was 3-6 % slower.) */
 int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatches, const void *const *const *y, const void *const *const *u,
                                        const void *const *const *v, int *const *was_key);
 
