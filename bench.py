@@ -272,22 +272,16 @@ class Leg:
         sync()
         t0 = time.perf_counter()
         if self.batches and not os.environ.get("VP8_BENCH_ONE_THREAD"):
-            # One host thread per group, each advancing its group by `steps` frames: with check_SSIM in the loop a group's next frame
-            # waits for the verdict on its previous one, and a single thread that serves the groups in turn couples them -- a late
-            # verdict holds up seven other streams (same box, M MB/s: one thread 55.3-58.9, a thread per group 60.3-60.4, check_SSIM
-            # off 60.7-60.9).  The calls release the interpreter lock; a native host would use eight threads the same way.
-            import threading
-
-            def work(members, nb):
-                for _ in range(steps):
-                    keys = nb.encode_frame_device([self.ptrs[self.t[k] % self.nd] for k in members])
-                    for i, k in enumerate(members):
-                        self.t[k] += 1
-            th = [threading.Thread(target=work, args=mb) for mb in self.batches]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
+            # One host thread per group, each advancing its group by `steps` frames (vp8drv_batches_encode_frames_device starts and
+            # joins them): with check_SSIM in the loop a group's next frame waits for the verdict on its previous one, and a single
+            # thread that serves the groups in turn couples them -- a late verdict holds up seven other streams (same box, M MB/s:
+            # one thread 55.3-58.9, a thread per group 60.3-60.4, check_SSIM off 60.7-60.9).
+            keys = self.api.NativeBatch.encode_frames_device_all([nb for _, nb in self.batches], steps, self.ptrs,
+                                                                 [[self.t[k] for k in members] for members, _ in self.batches])
+            for (members, _), kk in zip(self.batches, keys):
+                for i, k in enumerate(members):
+                    self.t[k] += steps
+                    self.keys += kk[i]
             self.frames += steps * self.G
         else:
             for _ in range(steps):

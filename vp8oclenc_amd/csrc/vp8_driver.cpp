@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/vp8hip_bitstream.h"
@@ -496,6 +497,32 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
         }
         if (!progress) __builtin_ia32_pause();
     }
+    return VP8HIP_OK;
+}
+
+int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                        const int *const *start, int *const *keys_out) {
+    if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start) return VP8HIP_ERR_ARG;
+    std::vector<std::thread> th;
+    std::vector<int> rc((size_t)nbatches, VP8HIP_OK);
+    for (int k = 0; k < nbatches; ++k)
+        th.emplace_back([&, k] {
+            vp8drv_batch *b = batches[k];
+            const void *y[VP8HIP_MAX_BATCH], *u[VP8HIP_MAX_BATCH], *v[VP8HIP_MAX_BATCH];
+            int key[VP8HIP_MAX_BATCH];
+            for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) {
+                for (int i = 0; i < b->n; ++i) {
+                    const void *const *f = frames[(start[k][i] + t) % nd];
+                    y[i] = f[0]; u[i] = f[1]; v[i] = f[2];
+                }
+                rc[k] = vp8drv_batch_encode_frame_device(b, nullptr, y, u, v, nullptr, key);
+                if (keys_out && keys_out[k])
+                    for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
+            }
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < nbatches; ++k)
+        if (rc[k] != VP8HIP_OK) return rc[k];
     return VP8HIP_OK;
 }
 
