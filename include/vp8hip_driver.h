@@ -125,7 +125,9 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * batch's wait from holding up the others' streams (same box, 48 chunks in 8 batches: one thread serving the batches in turn
  * 55-59 M MB/s, a thread per batch 60.3-60.4, check_SSIM off 60.7-60.9).  Frame t of member i of batch k is
  * frames[(start[k][i] + t) % nd]: `frames` = nd device-resident frames as {y, u, v} pointer triples, shared by all chunks (a
- * transcoder's ring of decoded frames; the bench's synthetic sequence).  keys_out[k][i] (may be NULL) counts member i's key frames.
+ * transcoder's ring of decoded frames; the bench's synthetic sequence).  The threads start 200 us apart: batches that start together
+ * from an idle device stay in lockstep, all their loop filters running at once with nothing wide beside them (5-8 % slower).
+ * keys_out[k][i] (may be NULL) counts member i's key frames.
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
                                         const int *const *start, int *const *keys_out);
