@@ -398,6 +398,18 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier):
     """config5_literal (every N), ref_shard, and at N = 1 config3_literal and single_stream: legs that are one or two videos coded
     frame after frame.  Run in a fresh process (see main()).  Returns the dict for the JSON line on rank 0."""
     out = {}
+    if rank == 0:
+        # every kernel of the path ALONE on the part: one chunk, one stream, nothing beside it, each launch timed by its own dispatch
+        # (HIP events) -- the launch durations the roofline fractions are made of (with 48 chunks in flight a launch shares the part)
+        solo = Leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, nd, local, seed=1)
+        solo.profile(api.K_NAMES)
+        for _ in range(4):
+            solo.step()
+        solo.profile_read()
+        el_s, _, nrefs_s = solo.run(40)
+        out["solo_kernels"] = {"refs_per_frame": round(nrefs_s, 3), "ms_per_launch": {k: round(ms / n, 5) for k, (ms, n) in solo.profile_read().items() if n},
+                               "what": "one GOP chunk on one stream, every kernel timed by its own dispatch; nothing else on the part"}
+        solo.close()
     if rank == 0 and world == 1:
         # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
         # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
@@ -550,15 +562,21 @@ def main():
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dominant, W, H)
         traffic = None if traffic is None else traffic * items   # the PMC pass ran one chunk per launch
+        path_bytes = 3000.0          # ~3.0 KB of compulsory HBM traffic per macroblock, whole inter path, 3 references
         roof = {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "chunks_per_launch": items, "launches": int(n_k),
-                "note": "longest kernel per launch; achieved = algorithmic bytes / avg_launch_ms, HIP events of its own stream over the "
-                        "timed region, all chunks.  With 16 streams on the part those events also count the time a packet waits for its "
-                        "queue (a one-chunk run and a run under rocprofv3 do not show it): kernel_clock gives the same launches by the "
-                        "kernel's own clock, which is what the rocprofv3 kernel trace under profiles/ shows.  None of this path's kernels "
-                        "is HBM-bound (integer search / transform / a serial filter chain): the binding resource is VALU issue, see "
-                        "issue_roofline"}
+                "basis": "time-shared launches (replaced by the solo launch where the side legs ran: see `solo`)",
+                "time_shared": {"avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(abytes), "chunks_per_launch": items, "launches": int(n_k),
+                                "achieved": round(achieved, 3), "frac": round(achieved / HBM_PEAK_GBS, 6),
+                                "launches_in_flight": round(n_k * avg_ms * 1e-3 / elapsed, 2),
+                                "what": "the dominant kernel's launches in the timed region by HIP events of their own dispatch, all chunks: with 48 "
+                                        "chunks in 8 batches a launch shares the part with the other batches' kernels (launches_in_flight of this "
+                                        "kernel alone), so this duration says how long a launch lasts, not how fast the kernel is"},
+                "path": {"algorithmic_bytes_per_macroblock": path_bytes, "achieved": round(value * path_bytes / 1e9, 3),
+                         "frac": round(value * path_bytes / 1e9 / HBM_PEAK_GBS, 6),
+                         "what": "the whole inter path: SURVEY 8(d)'s compulsory bytes per macroblock x macroblocks per second of `value`"},
+                "note": "None of this path's kernels is HBM-bound (integer search / transform / a serial filter chain): the binding resource is "
+                        "VALU issue, see issue_roofline.  kernel_clock: the time-shared launches by the kernel's own clock"}
         lf_clock = None
         if clk_n:
             kms = clk_ms / clk_n             # every member of a batched launch stamps its own frame: this is per chunk
@@ -636,6 +654,21 @@ def main():
                 out.update(json.loads(child.stdout.decode().strip().splitlines()[-1]))
             except Exception as e:
                 out["few_stream_legs_error"] = f"child exit {child.returncode}: {e!r}"[:300]
+            sk = out.get("solo_kernels", {}).get("ms_per_launch", {})
+            if dominant in sk:      # the roofline fraction from the kernel ALONE on the part, measured in this run (its fresh process)
+                sb = algorithmic_bytes(dominant, W, H, out["solo_kernels"]["refs_per_frame"])
+                sa = sb / (sk[dominant] * 1e-3) / 1e9
+                roof = out["roofline"]
+                roof["solo"] = {"launch_ms": sk[dominant], "algorithmic_bytes_per_launch": int(sb), "chunks_per_launch": 1, "achieved": round(sa, 3),
+                                "frac": round(sa / HBM_PEAK_GBS, 6), "refs_per_frame": out["solo_kernels"]["refs_per_frame"],
+                                "what": "the same kernel with the part to itself: one chunk per launch, HIP events of its own dispatch"}
+                roof["achieved"], roof["frac"], roof["basis"] = roof["solo"]["achieved"], roof["solo"]["frac"], "solo launch (one chunk, the part to itself)"
+                tr, _ = pmc_traffic(dominant, W, H)
+                roof["traffic"] = tr       # the PMC pass ran one chunk per launch too
+                ns = out["solo_kernels"]["refs_per_frame"]
+                out["solo_kernels"]["hbm"] = {k: {"algorithmic_bytes": int(algorithmic_bytes(k, W, H, ns)), "achieved_GBs": round(algorithmic_bytes(k, W, H, ns) / (v * 1e-3) / 1e9, 2),
+                                                  "frac": round(algorithmic_bytes(k, W, H, ns) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                              for k, v in sk.items() if algorithmic_bytes(k, W, H, ns) > 0}
     if rank == 0 and world == 1 and not args.no_side_legs:
         out["other_configs"] = {
             # 4K: sixteen chunks in eight batches of two (same-box: in batches of 4 55.0, of 2 59.7); 720p: batches of four
