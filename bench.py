@@ -830,12 +830,21 @@ def bitstream_leg(torch, leg, nb):
             leg.drv[k].get_frame()
     torch.cuda.synchronize()
     tb = time.perf_counter()
-    th = ([threading.Thread(target=group_worker, args=(m, b)) for m, b in leg.batches] if leg.batches
-          else [threading.Thread(target=worker, args=(k,)) for k in range(G)])
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    if leg.batches and not os.environ.get("VP8_BENCH_PY_BITSTREAM"):
+        # the native loop: a host thread per batch, every frame coded and delivered (vp8drv_batches_encode_frames_device with bytes_out)
+        _, nbo = leg.api.NativeBatch.encode_frames_device_all([b for _, b in leg.batches], nb, leg.ptrs, [[leg.t[k] for k in m] for m, _ in leg.batches], frames_out=True)
+        for (members, _), row in zip(leg.batches, nbo):
+            for i, k in enumerate(members):
+                leg.t[k] += nb
+                nbytes[k] += row[i]
+        th = leg.batches
+    else:
+        th = ([threading.Thread(target=group_worker, args=(m, b)) for m, b in leg.batches] if leg.batches
+              else [threading.Thread(target=worker, args=(k,)) for k in range(G)])
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     torch.cuda.synchronize()
     eb = time.perf_counter() - tb
     return {"value": round(leg.mbs * nb * G / eb, 1), "unit": "macroblocks/s", "fps": round(nb * G / eb, 1), "frames": nb * G,

@@ -127,10 +127,12 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * frames[(start[k][i] + t) % nd]: `frames` = nd device-resident frames as {y, u, v} pointer triples, shared by all chunks (a
  * transcoder's ring of decoded frames; the bench's synthetic sequence).  The threads start 200 us apart: batches that start together
  * from an idle device stay in lockstep, all their loop filters running at once with nothing wide beside them (5-8 % slower).
- * keys_out[k][i] (may be NULL) counts member i's key frames.
+ * keys_out[k][i] (may be NULL) counts member i's key frames.  bytes_out (may be NULL): with it every frame is also delivered as
+ * bytes -- vp8drv_batch_get_frame_begin for the batch, vp8drv_get_frame_end per member into a buffer of the thread -- and
+ * bytes_out[k][i] receives the sum of member i's frame sizes: the loop of a transcoder that writes the frames away.
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
-                                        const int *const *start, int *const *keys_out);
+                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

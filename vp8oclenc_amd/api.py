@@ -393,7 +393,7 @@ class NativeBatch:
             self.h = None
 
     @staticmethod
-    def encode_frames_device_all(batches, nframes, frame_ptrs, starts):
+    def encode_frames_device_all(batches, nframes, frame_ptrs, starts, frames_out=False):
         """nframes frames on every batch, one native host thread per batch (vp8drv_batches_encode_frames_device): frame t of member i of
         batch k = frame_ptrs[(starts[k][i] + t) % len(frame_ptrs)], frame_ptrs = [(d_y, d_u, d_v)].  Returns key-frame counts [k][i]."""
         lib = batches[0].lib
@@ -401,12 +401,16 @@ class NativeBatch:
         F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
         st = [(C.c_int * b.n)(*[int(x) for x in s]) for b, s in zip(batches, starts)]
         ko = [(C.c_int * b.n)() for b in batches]
-        IP = C.POINTER(C.c_int)
-        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP)]
+        bo = [(C.c_uint64 * b.n)() for b in batches]
+        IP, UP = C.POINTER(C.c_int), C.POINTER(C.c_uint64)
+        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP), C.POINTER(UP)]
         rc = lib.vp8drv_batches_encode_frames_device((C.c_void_p * n)(*[b.h for b in batches]), n, int(nframes), C.cast(F, C.c_void_p), nd,
-                                                      (IP * n)(*[C.cast(a, IP) for a in st]), (IP * n)(*[C.cast(a, IP) for a in ko]))
+                                                      (IP * n)(*[C.cast(a, IP) for a in st]), (IP * n)(*[C.cast(a, IP) for a in ko]),
+                                                      (UP * n)(*[C.cast(a, UP) for a in bo]) if frames_out else None)
         if rc < 0:
             raise Vp8HipError(f"vp8drv_batches_encode_frames_device: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+        if frames_out:
+            return [list(a) for a in ko], [list(a) for a in bo]
         return [list(a) for a in ko]
 
     @staticmethod

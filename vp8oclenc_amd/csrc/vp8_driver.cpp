@@ -502,7 +502,7 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
 }
 
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
-                                        const int *const *start, int *const *keys_out) {
+                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out) {
     if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start) return VP8HIP_ERR_ARG;
     std::vector<std::thread> th;
     std::vector<int> rc((size_t)nbatches, VP8HIP_OK);
@@ -517,6 +517,8 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
             vp8drv_batch *b = batches[k];
             const void *y[VP8HIP_MAX_BATCH], *u[VP8HIP_MAX_BATCH], *v[VP8HIP_MAX_BATCH];
             int key[VP8HIP_MAX_BATCH];
+            std::vector<uint8_t> frame;
+            if (bytes_out) frame.resize((size_t)b->d[0]->mbs * 1900 + (1u << 20));
             for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) {
                 for (int i = 0; i < b->n; ++i) {
                     const void *const *f = frames[(start[k][i] + t) % nd];
@@ -525,6 +527,14 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                 rc[k] = vp8drv_batch_encode_frame_device(b, nullptr, y, u, v, nullptr, key);
                 if (keys_out && keys_out[k])
                     for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
+                if (bytes_out && rc[k] == VP8HIP_OK) {      // the frames as bytes: one set of launches for the batch, then every member's read-back
+                    rc[k] = vp8drv_batch_get_frame_begin(b, nullptr);
+                    for (int i = 0; i < b->n && rc[k] == VP8HIP_OK; ++i) {
+                        size_t size = 0;
+                        rc[k] = vp8drv_get_frame_end(b->d[i], frame.data(), frame.size(), &size);
+                        if (bytes_out[k]) bytes_out[k][i] += size;
+                    }
+                }
             }
         });
     for (auto &t : th) t.join();
