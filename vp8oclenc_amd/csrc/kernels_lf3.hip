@@ -188,7 +188,7 @@ constexpr int SPIN_LIMIT = 1 << 22;
 // reads them, and the verdict to the host.  The sum must be the reference's -- one float accumulator over the macroblocks in
 // raster order -- so the values are staged in LDS by all threads (the strips and tiles this workgroup has no other use for)
 // and one thread adds them, four per ds_read_b128.
-__device__ __noinline__ void verdict_workgroup(const Args &a, Shared &sh, bool updated) {
+__device__ __forceinline__ void verdict_workgroup(const Args &a, Shared &sh, bool updated) {   // (inlined: a call would put the argument block into scratch memory)
     constexpr int NT = NWAVES * 64, CHUNK = 8192;
     static_assert(sizeof(sh.strip) + sizeof(sh.tile) >= CHUNK * sizeof(float), "staging area");
     float *s_val = reinterpret_cast<float *>(&sh.strip[0][0]);
