@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { sea
 // the workgroups of one (member, reference) run level 4, meet at a barrier, run level 3, meet again, run level 2: a level only
 // ever depends on its own reference's coarser level, so the barrier spans just those workgroups (170 at 1080p), which sit next
 // to each other in dispatch order.  Vector cells cross workgroups inside the launch: written and read at agent scope.
-// Generations only grow (kept by the host per reference), every wait is bounded (the error word the loop filter uses:
-// VP8HIP_ERR_TIMEOUT, nothing hangs).
+// The barrier counters only grow (`base` = their value before this launch, kept by the host per reference), every wait is
+// bounded (the error word the loop filter uses: VP8HIP_ERR_TIMEOUT, nothing hangs).
 // ------------------------------------------------------------------------------------------------
 struct CoarseLevel { uint8_t *cur, *ref[3]; int stride, w, h; };   // every surface of a context has the same layout at a level
 struct CoarseArgs {
@@ -387,32 +387,23 @@ struct CoarseArgs {
     int16_t *net[3][2];
     int refmap[3];
     int nrefs, net_width;
-    uint32_t *bar;           // [reference][2][workgroups]: the generation each workgroup has reached
-    uint32_t gen[3];         // per reference: this launch's generation (they only grow)
+    uint32_t *bar;           // [reference][2] arrival counters
+    uint32_t base[3];        // per reference: the counters' value before this launch
     int32_t *err;
 };
-constexpr int COARSE_SPIN_LIMIT = 1 << 20;
-// Barrier among the gridDim.x workgroups of one (member, reference).  No shared counter: same-address atomics from 170 workgroups
-// took 15 us per barrier on this part (a first version: one video 0.448 -> 0.512 ms per frame).  Every workgroup stores the launch's
-// generation into a word of its own; the waiters read all of them with one load per lane and poll until none is behind.
-__device__ __forceinline__ void coarse_barrier(uint32_t *flags, uint32_t gen, int32_t *err) {
+constexpr int COARSE_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ void coarse_barrier(uint32_t *counter, uint32_t base, int32_t *err) {
     __syncthreads();         // this workgroup's cells are written (agent scope stores) ...
     if (threadIdx.x == 0) {
         __threadfence();
-        __hip_atomic_store(flags + blockIdx.x, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int n = (int)gridDim.x;
-    if (threadIdx.x < 64) {
-        for (int spins = 0;; ++spins) {
-            bool behind = false;
-            for (int i = threadIdx.x; i < n; i += 64)
-                behind |= (int32_t)(__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0;
-            if (!__any(behind)) break;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t want = base + gridDim.x;
+        for (int spins = 0; (int32_t)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
             if (spins > COARSE_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                if (threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();         // ... and every other workgroup's are
@@ -446,7 +437,7 @@ __global__ __launch_bounds__(256) void k_search1_coarse_b(BatchOf<CoarseArgs> b)
         a.pbw = i > 0 ? c.lv[i - 1].w / 8 : 0;
         a.pbh = i > 0 ? c.lv[i - 1].h / 8 : 0;
         if (a.nblk > 0 && (int)blockIdx.x * S1Map<true>::BLOCKS_PER_WG < a.nblk) search1_body<true, true>(a, blockIdx.x, 0);
-        if (i < 2) coarse_barrier(c.bar + (size_t)(2 * r + i) * gridDim.x, c.gen[r], c.err);
+        if (i < 2) coarse_barrier(c.bar + 2 * r + i, c.base[r], c.err);
         src ^= 1;
     }
 }
@@ -522,7 +513,7 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         VP8_LAUNCH(k_search1_b<false>, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
 }
 
-static CoarseArgs coarse_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int net_width, uint32_t *bar, const uint32_t gen[3], int32_t *err) {
+static CoarseArgs coarse_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int net_width, uint32_t *bar, const uint32_t base[3], int32_t *err) {
     CoarseArgs a;
     for (int i = 0; i < 3; ++i) {
         const Plane &p = cur.Y[4 - i];
@@ -536,7 +527,7 @@ static CoarseArgs coarse_args(const Frame &cur, const RefSet &refs, const NetSet
     for (int r = 0; r < 3; ++r) {
         a.net[r][0] = nets.net[r][0];
         a.net[r][1] = nets.net[r][1];
-        a.gen[r] = gen[r];
+        a.base[r] = base[r];
         if (refs.use[r]) a.refmap[n++] = r;
     }
     a.nrefs = n;
@@ -551,12 +542,12 @@ int search1_coarse_workgroups(const Frame &cur) {    // workgroups per (member, 
     return nblk > 0 ? (nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG : 1;
 }
 void launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width,
-                                 uint32_t *const *bar, const uint32_t (*gen)[3], int32_t *const *err, int n) {
+                                 uint32_t *const *bar, const uint32_t (*base)[3], int32_t *const *err, int n) {
     BatchOf<CoarseArgs> b;
     b.n = n;
     int maxrefs = 0;
     for (int i = 0; i < n; ++i) {
-        b.item[i] = coarse_args(*cur[i], refs[i], *nets[i], net_width, bar[i], gen[i], err[i]);
+        b.item[i] = coarse_args(*cur[i], refs[i], *nets[i], net_width, bar[i], base[i], err[i]);
         maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
     }
     if (maxrefs == 0 || search1_skip()) return;

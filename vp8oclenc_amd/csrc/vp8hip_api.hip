@@ -61,8 +61,7 @@ struct vp8hip_ctx {
     int32_t chk_refqi[4] = {0, 0, 0, 0};
     int chk_qi_min = 0;
     unsigned intra_gen = 0;         // launches on intra_prog (its counters carry the launch number: nothing to clear)
-    uint32_t s1_gen[3] = {0, 0, 0};    // per reference: generation of the fused coarse search levels' barriers (they only grow)
-    uint32_t *s1_flags = nullptr;      // [reference][2][workgroups] generation words of those barriers; nullptr: the frame is too large to fuse
+    uint32_t s1_base[3] = {0, 0, 0};   // per reference: what the fused coarse search levels' barrier counters stand at (they only grow)
 
     NetSet nets{};
     MBOut out{};
@@ -447,14 +446,6 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
     CR(hipMemsetAsync(c->d_progress + S2_CLOCK_WORD, 0xff, 8, c->stream));   // k_search2's launch clock: "earliest start" is ~0 at rest
     CR(hipMalloc(&c->scratch, (size_t)width * height));
-    {   // the fused coarse search levels: only where a barrier group (the workgroups of level 2 for one reference) is small enough to be
-        // resident together whatever else runs -- 170 at 1080p, 675 at 4K; larger frames keep the three launches
-        const int nwg = search1_coarse_workgroups(c->cur);
-        if (nwg <= 1024) {
-            CR(hipMalloc(&c->s1_flags, (size_t)nwg * 6 * sizeof(uint32_t)));
-            CR(hipMemsetAsync(c->s1_flags, 0, (size_t)nwg * 6 * sizeof(uint32_t), c->stream));
-        }
-    }
     CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
     CR(hipMalloc(&c->ent_third, (size_t)c->mbs * 25));
     CR(hipMemsetAsync(c->ent_third, 0, (size_t)c->mbs * 25, c->stream));
@@ -530,7 +521,6 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     hipFree(c->d_stats2[0]);
     if (c->h_verdict) hipHostFree(c->h_verdict);
     hipFree(c->scratch);
-    hipFree(c->s1_flags);
     hipFree(c->ent_flags);
     hipFree(c->ent_third);
     hipFree(c->ent_counts);
@@ -750,14 +740,18 @@ static bool s1_fuse() {
 }
 static void launch_coarse(hipStream_t s, vp8hip_ctx *const *m, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n) {
     uint32_t *bar[MAX_BATCH];
-    uint32_t gen[MAX_BATCH][3];
+    uint32_t base[MAX_BATCH][3];
     int32_t *err[MAX_BATCH];
+    const uint32_t nwg = (uint32_t)search1_coarse_workgroups(*cur[0]);
     for (int i = 0; i < n; ++i) {
-        bar[i] = m[i]->s1_flags;
+        bar[i] = reinterpret_cast<uint32_t *>(m[i]->d_progress + S1_BAR_WORD);
         err[i] = m[i]->d_progress + LF_ERR_WORD;
-        for (int r = 0; r < 3; ++r) gen[i][r] = refs[i].use[r] ? ++m[i]->s1_gen[r] : m[i]->s1_gen[r];
+        for (int r = 0; r < 3; ++r) {
+            base[i][r] = m[i]->s1_base[r];
+            if (refs[i].use[r]) m[i]->s1_base[r] += nwg;      // every workgroup of that reference arrives once at each of its two barriers
+        }
     }
-    launch_search1_coarse_batch(s, cur, refs, nets, net_width, bar, gen, err, n);
+    launch_search1_coarse_batch(s, cur, refs, nets, net_width, bar, base, err, n);
 }
 
 // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
@@ -766,7 +760,7 @@ static void search_refs(vp8hip_ctx *c, const RefSet &which) {
     hipStream_t s = c->stream;
     const int net_width = c->mbw * 2;
     int src = 0, top = 4;
-    if (s1_fuse() && c->s1_flags) {
+    if (s1_fuse()) {
         Timed t(c, VP8HIP_K_SEARCH1_L4);
         const Frame *cur = &c->cur;
         const NetSet *nets = &c->nets;
@@ -1126,7 +1120,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     }
     const int net_width = c0->mbw * 2;
     int src = 0, top = 4;
-    if (s1_fuse() && c0->s1_flags) {
+    if (s1_fuse()) {
         Timed t(c0, VP8HIP_K_SEARCH1_L4);
         launch_coarse(s, m, cur, refs, nets, net_width, n);
         src = 1;
