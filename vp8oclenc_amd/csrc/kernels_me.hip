@@ -273,17 +273,15 @@ __device__ __forceinline__ void s1_subblock(const uint8_t *cp, int cstride, cons
     for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
 }
 
-// AGENT: the parent cells are read and the result is written at agent scope -- for the launch that runs several levels, where
-// the cells a workgroup reads were written by other workgroups (possibly on another XCD, behind another L2) of the SAME launch
-template <bool SPLIT, bool AGENT = false>
-__device__ __forceinline__ void search1_body(const Search1Args &a, int wg_x, int ref_idx) {
+template <bool SPLIT>
+__device__ __forceinline__ void search1_body(const Search1Args &a) {
     using M = S1Map<SPLIT>;
-    if (ref_idx >= a.nrefs) return;
-    const int r = a.refmap[ref_idx];
+    if ((int)blockIdx.y >= a.nrefs) return;
+    const int r = a.refmap[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
     const int sb0 = sub / 5, j = sub - 5 * sb0;       // SPLIT: this lane's sub-block; otherwise sb0 = 0
-    const int b_raw = (wg_x * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
+    const int b_raw = (blockIdx.x * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
     const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
     const int b = live ? b_raw : a.nblk - 1;
     const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
@@ -293,8 +291,7 @@ __device__ __forceinline__ void search1_body(const Search1Args &a, int wg_x, int
     // without the extra kernel.  vector / pixel_rate truncates toward zero (:495-500).
     const int parent = (cy >> 4) * a.net_width + (cx >> 4);
     const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
-    const uint32_t *pcell = reinterpret_cast<const uint32_t *>(a.src[r]) + parent;
-    const uint32_t pv = !parent_written ? 0u : (AGENT ? __hip_atomic_load(pcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *pcell);
+    const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
     int v0x = (int16_t)(pv & 0xffffu), v0y = (int16_t)(pv >> 16);
     const int rmask = a.pixel_rate - 1;
     v0x = (v0x + ((v0x >> 31) & rmask)) >> a.rate_shift;
@@ -359,89 +356,15 @@ __device__ __forceinline__ void search1_body(const Search1Args &a, int wg_x, int
         const uint32_t ox16 = (uint16_t)(int16_t)((int16_t)bx * (int16_t)a.pixel_rate);
         const uint32_t oy16 = (uint16_t)(int16_t)((int16_t)by * (int16_t)a.pixel_rate);
         const int cell = (cy >> 3) * a.net_width + (cx >> 3);
-        uint32_t *out = reinterpret_cast<uint32_t *>(a.dst[r]) + cell;
-        if (AGENT) __hip_atomic_store(out, ox16 | (oy16 << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *out = ox16 | (oy16 << 16);
+        reinterpret_cast<uint32_t *>(a.dst[r])[cell] = ox16 | (oy16 << 16);
     }
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_search1(Search1Args a) { search1_body<SPLIT>(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_search1(Search1Args a) { search1_body<SPLIT>(a); }
 static_assert(sizeof(BatchOf<Search1Args>) <= 4096 && sizeof(PyrArgs) <= 4096 && sizeof(BatchOf<PackItem>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z], blockIdx.x, blockIdx.y); }
-
-// ------------------------------------------------------------------------------------------------
-// The three coarsest levels (1/16, 1/8, 1/4) in ONE launch.  They are a few hundred to two thousand blocks each -- launches
-// that last as long as one wave -- and each needs the one before it, so as three launches they are three links of every
-// frame's chain (with many chunks in flight a link costs about a percent of the throughput however little work it is).  Here
-// the workgroups of one (member, reference) run level 4, meet at a barrier, run level 3, meet again, run level 2: a level only
-// ever depends on its own reference's coarser level, so the barrier spans just those workgroups (170 at 1080p), which sit next
-// to each other in dispatch order.  Vector cells cross workgroups inside the launch: written and read at agent scope.
-// The barrier counters only grow (`base` = their value before this launch, kept by the host per reference), every wait is
-// bounded (the error word the loop filter uses: VP8HIP_ERR_TIMEOUT, nothing hangs).
-// ------------------------------------------------------------------------------------------------
-struct CoarseLevel { uint8_t *cur, *ref[3]; int stride, w, h; };   // every surface of a context has the same layout at a level
-struct CoarseArgs {
-    CoarseLevel lv[3];       // [0] = level 4, [1] = level 3, [2] = level 2
-    int16_t *net[3][2];
-    int refmap[3];
-    int nrefs, net_width;
-    uint32_t *bar;           // [reference][2] arrival counters
-    uint32_t base[3];        // per reference: the counters' value before this launch
-    int32_t *err;
-};
-constexpr int COARSE_SPIN_LIMIT = 1 << 22;
-__device__ __forceinline__ void coarse_barrier(uint32_t *counter, uint32_t base, int32_t *err) {
-    __syncthreads();         // this workgroup's cells are written (agent scope stores) ...
-    if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t want = base + gridDim.x;
-        for (int spins = 0; (int32_t)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0; ++spins) {
-            __builtin_amdgcn_s_sleep(1);
-            if (spins > COARSE_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();         // ... and every other workgroup's are
-}
-__global__ __launch_bounds__(256) void k_search1_coarse_b(BatchOf<CoarseArgs> b) {
-    const CoarseArgs &c = b.item[blockIdx.z];
-    if ((int)blockIdx.y >= c.nrefs) return;
-    const int r = c.refmap[blockIdx.y];
-    int src = 0;
-#pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
-        const CoarseLevel &L = c.lv[i];
-        const int level = 4 - i;
-        // (only slot 0 of the per-reference arrays is filled, with THIS workgroup's reference: a runtime index into a local
-        // struct would put it into scratch memory; into the kernel arguments it is address arithmetic)
-        Search1Args a;
-        a.cur = Plane{L.cur, L.stride, L.w, L.h};
-        a.ref[0] = Plane{L.ref[r], L.stride, L.w, L.h};
-        a.src[0] = c.net[r][src];
-        a.dst[0] = c.net[r][src ^ 1];
-        a.refmap[0] = 0;
-        a.nrefs = 1;
-        a.net_width = c.net_width;
-        a.w = L.w;
-        a.h = L.h;
-        a.pixel_rate = 1 << level;
-        a.rate_shift = level;
-        a.bw = L.w / 8;
-        a.nblk = (L.w / 8) * (L.h / 8);
-        a.bw_inv = a.bw > 0 ? (uint32_t)(((1ull << 32) + a.bw - 1) / a.bw) : 0;
-        a.pbw = i > 0 ? c.lv[i - 1].w / 8 : 0;
-        a.pbh = i > 0 ? c.lv[i - 1].h / 8 : 0;
-        if (a.nblk > 0 && (int)blockIdx.x * S1Map<true>::BLOCKS_PER_WG < a.nblk) search1_body<true, true>(a, blockIdx.x, 0);
-        if (i < 2) coarse_barrier(c.bar + 2 * r + i, c.base[r], c.err);
-        src ^= 1;
-    }
-}
-static_assert(sizeof(BatchOf<CoarseArgs>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
+__global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z]); }
 
 static Search1Args search1_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx, int net_width) {
     Search1Args a;
@@ -511,47 +434,6 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         VP8_LAUNCH(k_search1_b<true>, dim3((nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
     else
         VP8_LAUNCH(k_search1_b<false>, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
-}
-
-static CoarseArgs coarse_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int net_width, uint32_t *bar, const uint32_t base[3], int32_t *err) {
-    CoarseArgs a;
-    for (int i = 0; i < 3; ++i) {
-        const Plane &p = cur.Y[4 - i];
-        a.lv[i].cur = p.p;
-        for (int r = 0; r < 3; ++r) a.lv[i].ref[r] = refs.ref[r].Y[4 - i].p;
-        a.lv[i].stride = p.stride;
-        a.lv[i].w = p.w;
-        a.lv[i].h = p.h;
-    }
-    int n = 0;
-    for (int r = 0; r < 3; ++r) {
-        a.net[r][0] = nets.net[r][0];
-        a.net[r][1] = nets.net[r][1];
-        a.base[r] = base[r];
-        if (refs.use[r]) a.refmap[n++] = r;
-    }
-    a.nrefs = n;
-    for (int i = n; i < 3; ++i) a.refmap[i] = 0;
-    a.net_width = net_width;
-    a.bar = bar;
-    a.err = err;
-    return a;
-}
-int search1_coarse_workgroups(const Frame &cur) {    // workgroups per (member, reference): what level 2 needs in the short-wave form
-    const int nblk = (cur.Y[2].w / 8) * (cur.Y[2].h / 8);
-    return nblk > 0 ? (nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG : 1;
-}
-void launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width,
-                                 uint32_t *const *bar, const uint32_t (*base)[3], int32_t *const *err, int n) {
-    BatchOf<CoarseArgs> b;
-    b.n = n;
-    int maxrefs = 0;
-    for (int i = 0; i < n; ++i) {
-        b.item[i] = coarse_args(*cur[i], refs[i], *nets[i], net_width, bar[i], base[i], err[i]);
-        maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
-    }
-    if (maxrefs == 0 || search1_skip()) return;
-    VP8_LAUNCH(k_search1_coarse_b, dim3(search1_coarse_workgroups(*cur[0]), maxrefs, n), dim3(256), 0, s, b);
 }
 
 // test tap: the block-match metric on caller-supplied difference blocks (n x 16 ints)

@@ -61,7 +61,6 @@ struct vp8hip_ctx {
     int32_t chk_refqi[4] = {0, 0, 0, 0};
     int chk_qi_min = 0;
     unsigned intra_gen = 0;         // launches on intra_prog (its counters carry the launch number: nothing to clear)
-    uint32_t s1_base[3] = {0, 0, 0};   // per reference: what the fused coarse search levels' barrier counters stand at (they only grow)
 
     NetSet nets{};
     MBOut out{};
@@ -732,43 +731,13 @@ static unsigned long long *s2_clock_words(const vp8hip_ctx *c) { return reinterp
 // while a host asks for it (vp8hip_profile_search2_clock; bench.py: during its warm-up steps)
 static unsigned long long *s2_clock(const vp8hip_ctx *c) { return c->s2_clock_on ? s2_clock_words(c) : nullptr; }
 
-// Levels 4, 3, 2 of the hierarchical search as one launch (kernels_me.hip, k_search1_coarse_b).  VP8HIP_S1_FUSE=0 brings the three
-// launches back (same-box A/B runs).
-static bool s1_fuse() {
-    static const bool on = [] { const char *v = getenv("VP8HIP_S1_FUSE"); return !(v && v[0] == '0'); }();
-    return on;
-}
-static void launch_coarse(hipStream_t s, vp8hip_ctx *const *m, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n) {
-    uint32_t *bar[MAX_BATCH];
-    uint32_t base[MAX_BATCH][3];
-    int32_t *err[MAX_BATCH];
-    const uint32_t nwg = (uint32_t)search1_coarse_workgroups(*cur[0]);
-    for (int i = 0; i < n; ++i) {
-        bar[i] = reinterpret_cast<uint32_t *>(m[i]->d_progress + S1_BAR_WORD);
-        err[i] = m[i]->d_progress + LF_ERR_WORD;
-        for (int r = 0; r < 3; ++r) {
-            base[i][r] = m[i]->s1_base[r];
-            if (refs[i].use[r]) m[i]->s1_base[r] += nwg;      // every workgroup of that reference arrives once at each of its two barriers
-        }
-    }
-    launch_search1_coarse_batch(s, cur, refs, nets, net_width, bar, base, err, n);
-}
-
 // hierarchical search, inter_part.h:110-236; ping-pong as bound at init.h:672-854.  One launch per level over the
 // references in `which` (the reference runs the three references on three queues, inter_part.h:122-135)
 static void search_refs(vp8hip_ctx *c, const RefSet &which) {
     hipStream_t s = c->stream;
     const int net_width = c->mbw * 2;
-    int src = 0, top = 4;
-    if (s1_fuse()) {
-        Timed t(c, VP8HIP_K_SEARCH1_L4);
-        const Frame *cur = &c->cur;
-        const NetSet *nets = &c->nets;
-        launch_coarse(s, &c, &cur, &which, &nets, net_width, 1);
-        src = 1;        // three levels: 0 -> 1 -> 0 -> 1
-        top = 1;
-    }
-    for (int l = top; l >= 0; --l) {
+    int src = 0;
+    for (int l = 4; l >= 0; --l) {
         Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
         // one video coded frame after frame (filter on its own stream): nothing else fills the chip, short waves pay
         launch_search1(s, c->cur, which, c->nets, l, src, net_width, c->lf_overlap && l > 0);
@@ -1119,14 +1088,8 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         launch_pyramid_batch(s, pyr, npyr, pyr_border);
     }
     const int net_width = c0->mbw * 2;
-    int src = 0, top = 4;
-    if (s1_fuse()) {
-        Timed t(c0, VP8HIP_K_SEARCH1_L4);
-        launch_coarse(s, m, cur, refs, nets, net_width, n);
-        src = 1;
-        top = 1;
-    }
-    for (int l = top; l >= 0; --l) {
+    int src = 0;
+    for (int l = 4; l >= 0; --l) {
         Timed t(c0, VP8HIP_K_SEARCH1_L4 + (4 - l));
         launch_search1_batch(s, cur, refs, nets, l, src, net_width, n);
         src ^= 1;

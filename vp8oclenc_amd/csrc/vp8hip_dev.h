@@ -29,7 +29,6 @@ constexpr int PAD = 32;        // allocated margin (pixels) around every plane
 constexpr int EXT = 8;         // replicated-edge width actually filled (max reach of any filter: 3)
 constexpr int LF_ERR_WORD = 1536;   // int index inside the loop filter's progress buffer of its time-out flag
 constexpr int S2_CLOCK_WORD = LF_ERR_WORD + 32;   // ... and of k_search2's launch clock (five 64-bit words, see launch_clock_end)
-constexpr int S1_BAR_WORD = LF_ERR_WORD + 64;     // ... and of the fused coarse search levels' barrier counters (six words)
 constexpr int CLOCK_SAMPLE = 64;    // every 64th workgroup of a launch stamps the clock
 constexpr int SD_INTS = 11;    // ints per segment_data, src/vp8enc.h:80-92
 enum { SD_Y_AC_I = 0, SD_Y_DC_IDELTA, SD_Y2_DC_IDELTA, SD_Y2_AC_IDELTA, SD_UV_DC_IDELTA, SD_UV_AC_IDELTA,
@@ -134,11 +133,6 @@ void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t
                                 int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
                     int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
-// levels 4, 3, 2 in one launch (barriers among the workgroups of one member and reference inside it): bar = six arrival counters
-// per context ([reference][2]) that only grow, base = their values before this launch, err = the time-out word
-int search1_coarse_workgroups(const Frame &cur);
-void launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width,
-                                 uint32_t *const *bar, const uint32_t (*base)[3], int32_t *const *err, int n);
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
                     int dbg_block = -1, unsigned long long *clk = nullptr);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
