@@ -183,7 +183,7 @@ def test_bench_launcher_starts_its_own_ranks():
     for d in (a, b):
         g, per = d["config"]["gops_per_gpu"], d["config"]["chunks_per_batched_launch"]
         assert d["n_gpus"] == 1 and d["config"]["refs_per_frame"] >= 2.7 and d["config"]["frames_per_gpu"] == 20 * g
-        assert d["roofline"]["launches"] == 20 * ((g + per - 1) // per) and d["loop_filter_by_its_own_clock"]["frames"] == 20 * g
+        assert d["roofline"]["time_shared"]["launches"] == 20 * ((g + per - 1) // per) and d["loop_filter_by_its_own_clock"]["frames"] == 20 * g
         # the process stays below the queue count at which the part's scheduler starts context-switching running waves
         assert d["loop_filter_by_its_own_clock"]["waves_context_switched"] == 0 and 1.0 < d["loop_filter_by_its_own_clock"]["shader_clock_ghz"] < 3.0
     # same work, same launcher-independent code path; run-to-run spread of a 20-step run on one box is about +-5 %
