@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--ssim-target", type=float, default=-1.0, help="SSIM_target (reference default -1 = single LQ pass; 0.93 = the 4-pass path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip single_stream / other_configs / with_bitstream")
+    ap.add_argument("--only-bitstream", action="store_true", help="of the side legs only with_bitstream (same-box A/B runs)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents in the timed region (adds packets)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1 (the N > 1 launch path)")
     ap.add_argument("--child-legs", action="store_true", help=argparse.SUPPRESS)   # internal: the few-stream side legs in a fresh process
@@ -638,6 +639,8 @@ def main():
         out["with_bitstream"] = bitstream_leg(torch, leg, max(16, args.steps))
     host_frames = leg.host_frames
     leg.close()
+    if args.only_bitstream:
+        args.no_side_legs = True
     if not args.no_side_legs:
         # The legs that are ONE or TWO videos coded frame after frame run in a fresh process per rank: the HIP runtime keeps every
         # hardware queue a process ever used, and after 48 chunks in 8 batches a lone stream shares them badly (measured: the same

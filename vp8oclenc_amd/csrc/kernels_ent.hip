@@ -895,13 +895,19 @@ static ent::CodeJob code_job(const EntBuffers &eb, int P) {
     j.P = P;
     return j;
 }
-static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs) {
+// VP8HIP_EXPERIMENT_SKIP_ENT: bit i leaves out launch i of the frame's entropy stage (the bytes are then garbage: what a launch
+// costs with the part full, measured by the throughput without it -- scripts/ab_bitstream.sh)
+unsigned ent_skip_mask() {
+    static const unsigned m = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP_ENT"); return v ? (unsigned)strtoul(v, nullptr, 0) : 0u; }();
+    return m;
+}
+static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs, unsigned skip = 0) {
     int maxP = 1;
     for (int i = 0; i < njobs; ++i) maxP = jobs.j[i].P > maxP ? jobs.j[i].P : maxP;
-    hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(ent::MAPS_THREADS), 0, s, jobs);
-    hipLaunchKernelGGL(ent::k_ent_walk, dim3(maxP, njobs), dim3(256), 0, s, jobs);
-    hipLaunchKernelGGL(ent::k_ent_encode, dim3(512, njobs), dim3(256), 0, s, jobs);
-    hipLaunchKernelGGL(ent::k_ent_finish, dim3(maxP, njobs), dim3(64 * ent::FIN_WAVES), 0, s, jobs);
+    if (!(skip & 32)) hipLaunchKernelGGL(ent::k_ent_maps, dim3(512, njobs), dim3(ent::MAPS_THREADS), 0, s, jobs);
+    if (!(skip & 64)) hipLaunchKernelGGL(ent::k_ent_walk, dim3(maxP, njobs), dim3(256), 0, s, jobs);
+    if (!(skip & 128)) hipLaunchKernelGGL(ent::k_ent_encode, dim3(512, njobs), dim3(256), 0, s, jobs);
+    if (!(skip & 256)) hipLaunchKernelGGL(ent::k_ent_finish, dim3(maxP, njobs), dim3(64 * ent::FIN_WAVES), 0, s, jobs);
 }
 void launch_bool_code(hipStream_t s, const EntBuffers &eb, int P) {
     ent::CodeJobs jobs{};
@@ -926,7 +932,7 @@ void launch_frame_code_batch(hipStream_t s, const FrameEntropy *e, const FrameOu
         jobs.head[m] = fo[m].head;
         jobs.capacity[m] = fo[m].capacity;
     }
-    bool_code(s, jobs, 2 * n);
+    bool_code(s, jobs, 2 * n, ent_skip_mask());   // (the switch acts on batched launches only: the first frames run one by one and fill every buffer)
 }
 
 static ent::Geom make_geom(const EntBuffers &eb, int mbw, int mbh, int P) {

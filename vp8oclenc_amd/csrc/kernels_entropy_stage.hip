@@ -173,9 +173,10 @@ void launch_fe_count_batch(hipStream_t s, const FrameEntropy *e, int n) {
         c.item[i] = ent::CountItem{e[i].o.coeffs, e[i].o.nz, e[i].o.parts, e[i].flags, e[i].third, e[i].counts, e[i].mbw};
         m.item[i] = mid_args(e[i]);
     }
-    hipLaunchKernelGGL(fe::k_fe_first_b, dim3(first_grid(a.item[0]), 1, n), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(ent::k_ent_count_b, dim3(e[0].mbh, ent::CNT_SPLIT, n), dim3(256), 0, s, c);
-    hipLaunchKernelGGL(fe::k_fe_mid_b, dim3(1 + ent::NCTX / 16, 1, n), dim3(256), 0, s, m);
+    const unsigned skip = ent_skip_mask();
+    if (!(skip & 1)) hipLaunchKernelGGL(fe::k_fe_first_b, dim3(first_grid(a.item[0]), 1, n), dim3(256), 0, s, a);
+    if (!(skip & 2)) hipLaunchKernelGGL(ent::k_ent_count_b, dim3(e[0].mbh, ent::CNT_SPLIT, n), dim3(256), 0, s, c);
+    if (!(skip & 4)) hipLaunchKernelGGL(fe::k_fe_mid_b, dim3(1 + ent::NCTX / 16, 1, n), dim3(256), 0, s, m);
     if (!m.item[0].defaults)
         for (int i = 0; i < n; ++i) launch_default_probs(s, e[i].probs, e[i].denom0);
 }
@@ -187,8 +188,9 @@ void launch_fe_emit_batch(hipStream_t s, const FrameEntropy *e, int n) {
         f.item[i] = hdr_frame_item(e[i]);
         a.item[i] = emit_args(e[i]);
     }
-    hipLaunchKernelGGL(hdr::k_hdr_frame_b, dim3(n), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(fe::k_fe_emit_b, dim3(a.item[0].nb_hdr + a.item[0].nb_slots, 1, n), dim3(256), 0, s, a);
+    const unsigned skip = ent_skip_mask();
+    if (!(skip & 8)) hipLaunchKernelGGL(hdr::k_hdr_frame_b, dim3(n), dim3(256), 0, s, f);
+    if (!(skip & 16)) hipLaunchKernelGGL(fe::k_fe_emit_b, dim3(a.item[0].nb_hdr + a.item[0].nb_slots, 1, n), dim3(256), 0, s, a);
 }
 
 }  // namespace vp8

@@ -28,28 +28,46 @@ namespace {
 constexpr uint32_t pk8(int a, int b, int c, int d) {
     return (uint32_t)(a & 255) | ((uint32_t)(b & 255) << 8) | ((uint32_t)(c & 255) << 16) | ((uint32_t)(d & 255) << 24);
 }
-// six taps placed at byte offset s = 0..3 of a dword stream: entries [2s], [2s+1] and, for s = 3, [8]
-#define H6(f0, f1, f2, f3, f4, f5)                                                                               \
-    {pk8(f0, f1, f2, f3), pk8(f4, f5, 0, 0), pk8(0, f0, f1, f2), pk8(f3, f4, f5, 0), pk8(0, 0, f0, f1),           \
-     pk8(f2, f3, f4, f5), pk8(0, 0, 0, f0),  pk8(f1, f2, f3, f4), pk8(f5, 0, 0, 0),  0, 0, 0}
-// seven taps at byte offset s: s=0 -> [0],[1]; s=1 -> [2],[3]; s=2 -> [4],[5],[6]; s=3 -> [7],[8],[9]
-#define V7(t0, t1, t2, t3, t4, t5, t6)                                                                           \
-    {pk8(t0, t1, t2, t3), pk8(t4, t5, t6, 0), pk8(0, t0, t1, t2), pk8(t3, t4, t5, t6), pk8(0, 0, t0, t1),         \
-     pk8(t2, t3, t4, t5), pk8(t6, 0, 0, 0),   pk8(0, 0, 0, t0),   pk8(t1, t2, t3, t4), pk8(t5, t6, 0, 0), 0, 0}
-
-// x case 0..4 = dx -2..2 quarter pels: phases 4,6,(0),2,4 of the 1/8-pel table (GPU_kernels.cl:563-572)
-static __device__ __constant__ const uint32_t K_H6[5][12] = {
-    H6(3, -16, 77, 77, -16, 3), H6(1, -8, 36, 108, -11, 2), H6(0, 0, 0, 0, 0, 0), H6(2, -11, 108, 36, -8, 1),
-    H6(3, -16, 77, 77, -16, 3)};
-// y case 0..4; dy < 0 starts one row higher (leading six taps), dy > 0 one row lower (trailing six)
-static __device__ __constant__ const uint32_t K_V7[5][12] = {
-    V7(3, -16, 77, 77, -16, 3, 0), V7(1, -8, 36, 108, -11, 2, 0), V7(0, 0, 0, 0, 0, 0, 0),
-    V7(0, 2, -11, 108, 36, -8, 1), V7(0, 3, -16, 77, 77, -16, 3)};
+// the six taps of quarter-pel offset -2..2 (phases 4, 6, (0), 2, 4 of the 1/8-pel table, GPU_kernels.cl:563-572); case 2 is the copy
+constexpr int TAPS[5][6] = {{3, -16, 77, 77, -16, 3}, {1, -8, 36, 108, -11, 2}, {0, 0, 128, 0, 0, 0}, {2, -11, 108, 36, -8, 1}, {3, -16, 77, 77, -16, 3}};
+// The two six-tap passes as products on the matrix cores (v_mfma_i32_32x32x32_i8: D[32][32] = A[32][32] . B[32][32] + C, signed bytes
+// in, int32 out -- exact; lane maps checked by scripts/ubench/mfma_i8_layout.hip).  A filter pass IS a banded matrix product:
+//   horizontal: D[window row][(x case, column)] = sum_k window[row][k] * BH[k][(x case, column)],  BH[k][n] = tap_xc[k - c - s]
+//   vertical:   D[(y case, row)][column]        = sum_k AV[(y case, row)][k] * H[k][column],       AV[m][k] = tap_yc[k - i - s]
+// (s = 1 for the positive offsets, whose six taps start one sample later).  A lane holds 16 consecutive k of one row (A) or one
+// column (B): lanes 0-31 k = 0..15, lanes 32-63 k = 16..31.
+struct OperandTable { uint32_t w[64][4]; };
+constexpr OperandTable make_bh() {   // B of the horizontal pass: lane l -> column n = l & 31 = xi * 8 + c, k = 16 * (l >> 5) + j
+    OperandTable t{};
+    for (int l = 0; l < 64; ++l) {
+        const int n = l & 31, xi = n >> 3, c = n & 7, xc = xi + (xi >> 1), s = xc >= 2 ? 1 : 0;
+        for (int j = 0; j < 16; ++j) {
+            const int k = 16 * (l >> 5) + j, tap = k - c - s;
+            const int v = (tap >= 0 && tap < 6) ? TAPS[xc][tap] : 0;
+            t.w[l][j >> 2] |= (uint32_t)(v & 255) << (8 * (j & 3));
+        }
+    }
+    return t;
+}
+constexpr OperandTable make_av() {   // A of the vertical pass: lane l -> row m = l & 31 = f * 8 + i (y case f + (f >> 1)), k = 16 * (l >> 5) + j
+    OperandTable t{};
+    for (int l = 0; l < 64; ++l) {
+        const int m = l & 31, f = m >> 3, i = m & 7, yc = f + (f >> 1), s = yc >= 2 ? 1 : 0;
+        for (int j = 0; j < 16; ++j) {
+            const int k = 16 * (l >> 5) + j, tap = k - i - s;
+            const int v = (tap >= 0 && tap < 6) ? TAPS[yc][tap] : 0;
+            t.w[l][j >> 2] |= (uint32_t)(v & 255) << (8 * (j & 3));
+        }
+    }
+    return t;
+}
+static __device__ __constant__ const OperandTable K_BH = make_bh();
+static __device__ __constant__ const OperandTable K_AV = make_av();
 
 constexpr int HT_XC = 36;            // dwords per x case in the transposed H array: 8 columns x 16 B + 16 B bank skew
-constexpr int KBIAS = 128 * 128 + 64;  // undo the -128 pixel bias (taps sum to 128) + rounding
 constexpr int V_STRIDE = 20;           // dwords per candidate in the V array: 8 columns x 8 B + 16 B so that the b128 reads of 16 lanes miss each other's banks
-// Every LDS array of the kernel is indexed by the block's slot g, and the 32 lanes of a block sit in ONE wave: the stages
+constexpr int WIN_ROW = 8;             // dwords per row of the staged window: 20 bytes loaded, 32 so that a row half is one aligned ds_read_b128
+// Every LDS array of the kernel is indexed by the block's slot g, and the two blocks of a wave sit in ITS lanes: the stages
 // hand data over inside a wave, so a wave-level "my LDS writes have landed" is all the synchronisation there is
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -77,26 +95,33 @@ __device__ __forceinline__ uint32_t halfwave_min(uint32_t key) {
     return key;
 }
 
-// sat_u8(a >> 7) in byte 0, sat_u8(b >> 7) in byte 1 (v_ashr_pk_u8_i32).  The builtin, not inline asm: a
-// VALU read of a dot4 result needs wait states on gfx950 that the compiler only inserts for instructions it
-// can see (an asm version read stale sums), and as a 16-bit value the undefined bits 31:16 stay explicit.
+// sat_i8(a >> 7) in byte 0, sat_i8(b >> 7) in byte 1 (v_ashr_pk_i8_i32; as a 16-bit value the undefined bits 31:16 stay explicit).
+// Pixels travel as signed bytes p - 128 and every tap set sums to 128, so a pass computes sum((p-128) f) = sum(p f) - 128 * 128, and
+//     sat_i8((sum(p f) - 16384 + 64) >> 7) = sat_u8((sum(p f) + 64) >> 7) - 128:
+// the signed saturation of the biased sum IS the biased byte of the reference's clamped sample; the rounding 64 is the MFMA's C input.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned short ashr7_pk_u8(int a, int b) { return __builtin_amdgcn_ashr_pk_u8_i32(a, b, 7); }
+__device__ __forceinline__ unsigned short ashr7_pk_i8(int a, int b) { return __builtin_amdgcn_ashr_pk_i8_i32(a, b, 7); }
 __device__ __forceinline__ uint32_t pack4(unsigned short lo, unsigned short hi) {
     const us2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
-// first link of a chain: the clamp bit (int32 saturation, never reached) selects the three-address VOP3P
-// form with the bias in an SGPR instead of v_mov + v_dot4c
-__device__ __forceinline__ int dot4k(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, true); }
+// four consecutive results of one lane (rows 4q .. 4q + 3 of its column) as four biased bytes
+__device__ __forceinline__ uint32_t round_pack4(const v16i &acc, int q) {
+    return pack4(ashr7_pk_i8(acc[4 * q], acc[4 * q + 1]), ashr7_pk_i8(acc[4 * q + 2], acc[4 * q + 3]));
+}
+__device__ __forceinline__ v16i mfma_round(v4i a, v4i b) {
+    const v16i c = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};   // an inline constant of the instruction
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_idx) {
     if (ref_idx >= a.nrefs) return;
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
-    uint32_t(*s_win)[25 * V_STRIDE] = s_V;   // the staged window (72 dwords) is dead once the horizontal pass has read it: same bytes
+    uint32_t(*s_win)[25 * V_STRIDE] = s_V;   // the staged window (16 rows x 32 B) is dead once the horizontal pass has read it: same bytes
     __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
     const int r = a.refmap[ref_idx];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
@@ -111,11 +136,15 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     // so that the loads stay inside the allocated margin
     const int Lx = iclamp(cx + nx, 3 - EXT, a.w + EXT - 11), Ly = iclamp(cy + ny, 3 - EXT, a.h + EXT - 11);
     const Plane rf = a.ref[r];
-    const int ax = (Lx - 3) & ~3, o = (Lx - 3) & 3;
-    for (int idx = lane; idx < 70; idx += 32) {
-        const int row = idx / 5, j = idx % 5;
-        s_win[g][idx] =
-            *reinterpret_cast<const uint32_t *>(rf.p + (ptrdiff_t)(Ly - 3 + row) * rf.stride + ax + 4 * j) ^ 0x80808080u;
+    const int wl = threadIdx.x & 63, kh = wl >> 5, gp = g & ~1;   // lane of the wave, its k half in an MFMA operand, the wave's first slot
+    // The window from its own first byte (Lx - 3: any alignment; the part's global loads need none): lane = (row, half) takes 16
+    // bytes, 16 rows of 32 bytes -- the six-tap passes need 14 x 19, the rest stays inside the planes' allocated margin (PAD) and
+    // meets zero taps.  One load and one ds_write_b128 per lane, no loop.
+    {
+        const int row = lane >> 1, half = lane & 1;
+        v4i v;
+        __builtin_memcpy(&v, rf.p + (ptrdiff_t)(Ly - 3 + row) * rf.stride + (Lx - 3) + 16 * half, 16);
+        *reinterpret_cast<v4i *>(&s_win[g][row * WIN_ROW + 4 * half]) = v ^ (int)0x80808080u;
     }
     {   // current block (lanes 0-15) and zero-MV block (16-31): one dword each, scattered as column bytes
         const int sel = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
@@ -128,43 +157,26 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
     lds_fence();
 
-    // ---- horizontal pass -------------------------------------------------------------------------
-    if (lane < 28) {
-        const int xi = lane / 7, rp = lane - xi * 7;
-        const int xc = xi + (xi >> 1);           // 0, 1, 3, 4
-        const int s0 = o + (xc >= 2);           // byte of the row holding tap 0 of column 0: o + xo + 1
-        const int j0 = s0 >> 2, sh = s0 & 3;
-        uint32_t t[9];
+    // ---- horizontal pass: ONE MFMA for the wave's two blocks ------------------------------------------------------------
+    // A = the windows (row m = 16 * block + window row; rows 14, 15 and bytes 20..31 of a row hold whatever the LDS held: they
+    // meet zero taps or land in bytes nobody reads), B = the taps of the four fractional x cases (K_BH).  A lane comes out with
+    // column n = (x case, c) and four groups of four consecutive rows: each group one dword of the TRANSPOSED H array.
+    {
+        const int m = wl & 31;
+        const v4i aw = *reinterpret_cast<const v4i *>(&s_win[gp + (m >> 4)][(m & 15) * WIN_ROW + 4 * kh]);
+        const v4i bh = *reinterpret_cast<const v4i *>(K_BH.w[wl]);
+        const v16i acc = mfma_round(aw, bh);
+        const int xi = m >> 3, c = m & 7, xc = xi + (xi >> 1);
+        uint32_t *ht = &s_HT[gp][xc * HT_XC + c * 4 + kh];   // rows 4 * kh .. of column c; + 2: rows 8 + 4 * kh ..; next slot: the other block
 #pragma unroll
-        for (int i = 0; i < 9; ++i) t[i] = K_H6[xc][i];
-        int sum[2][8];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint32_t *wr = &s_win[g][(2 * rp + rr) * 5 + j0];
-            uint32_t w[5], q[4];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) w[j] = wr[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int m = c >> 2, s = c & 3;
-                int acc = dot4k(q[m], t[2 * s], KBIAS);
-                acc = dot4(q[m + 1], t[2 * s + 1], acc);
-                if (s == 3) acc = dot4(q[m + 2], t[8], acc);
-                sum[rr][c] = acc;
-            }
-        }
-        uint16_t *ht = reinterpret_cast<uint16_t *>(s_HT[g] + xc * HT_XC) + rp;   // byte c*16 + 2*rp
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ht[c * 8] = ashr7_pk_u8(sum[0][c], sum[1][c]) ^ 0x8080u;
+        for (int q = 0; q < 4; ++q) ht[(q >> 1) * (5 * HT_XC) + 2 * (q & 1)] = round_pack4(acc, q);
     }
     {   // whole-pel x case: column c of the window, rows 4*rg..4*rg+3 (rows 14,15 only ever meet zero taps)
         const int c = lane & 7, rg = lane >> 3;
-        const uint8_t *wb = reinterpret_cast<const uint8_t *>(s_win[g]) + o + 3 + c;
+        const uint8_t *wb = reinterpret_cast<const uint8_t *>(s_win[g]) + 3 + c;
         uint32_t v = 0;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * 20] << (8 * rr);
+        for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * (4 * WIN_ROW)] << (8 * rr);
         s_HT[g][2 * HT_XC + c * 4 + rg] = v;
     }
     {   // the current block's share of the metric (vp8hip_dev.h, weight_pre_column): 16 columns x 4 quantities, two per lane.
@@ -177,40 +189,26 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
     lds_fence();
 
-    // ---- vertical pass -------------------------------------------------------------------------------
-    // Producer: the 25 candidates need, per fractional x case and column, the column filtered by four vertical filters
-    // (dy = -2, -1, +1, +2; dy = 0 is a copy).  One candidate per lane computing its own 8x8 (the first version) keeps
-    // 25 of 32 lanes busy and filters the five dy = 0 predictions for nothing: 2048 sample slots for 1000 samples.
-    // Here lane = (column c = lane >> 2, filter f = lane & 3) walks the five x cases: 5 x 8 samples per lane, every lane
-    // busy, results to LDS; the f = 0 lanes also lay down the dy = 0 copies.
+    // ---- vertical pass: three MFMAs for the wave's 2 x 5 x 8 columns ------------------------------------------------------
+    // A = the taps of the four fractional y cases (K_AV: row m = (y case, output row)), B = 32 columns of the H arrays, 16 bytes
+    // each (the lanes of the upper k half read the same column: their A entries are zero).  A lane comes out with its column and, per
+    // y case, the four rows 4 * kh .. 4 * kh + 3: one dword of the prediction [column][row half].  The whole-pel y case is a copy.
     {
-        const int f = lane & 3, c = lane >> 2, ycf = f + (f >> 1);   // y case 0, 1, 3, 4
-        uint32_t t[10];
+        const v4i av = *reinterpret_cast<const v4i *>(K_AV.w[wl]);
 #pragma unroll
-        for (int i = 0; i < 10; ++i) t[i] = K_V7[ycf][i];
+        for (int t = 0; t < 3; ++t) {
+            const int ng = 32 * t + (wl & 31);
+            const bool on = t < 2 || (wl & 31) < 16;
+            const int blk = ng >= 40 ? 1 : 0, rem = on ? ng - 40 * blk : 0, xc = rem >> 3, c = rem & 7;
+            const v4i hv = *reinterpret_cast<const v4i *>(&s_HT[gp + blk][xc * HT_XC + c * 4]);
+            const v16i acc = mfma_round(av, hv);
+            if (on) {
+                uint32_t *sv = &s_V[gp + blk][xc * V_STRIDE + c * 2 + kh];
 #pragma unroll
-        for (int xc = 0; xc < 5; ++xc) {
-            const uint4 hv = reinterpret_cast<const uint4 *>(s_HT[g] + xc * HT_XC)[c];
-            const uint32_t h[4] = {hv.x, hv.y, hv.z, hv.w};
-            int sm[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = i >> 2, si = i & 3;
-                const int tb = si == 0 ? 0 : (si == 1 ? 2 : (si == 2 ? 4 : 7));
-                int acc = dot4k(h[m], t[tb], KBIAS);
-                acc = dot4(h[m + 1], t[tb + 1], acc);
-                if (si >= 2) acc = dot4(h[m + 2], t[tb + 2], acc);
-                sm[i] = acc;
-            }
-            uint2 v;   // biased, like everything the metric reads
-            v.x = pack4(ashr7_pk_u8(sm[0], sm[1]), ashr7_pk_u8(sm[2], sm[3])) ^ 0x80808080u;
-            v.y = pack4(ashr7_pk_u8(sm[4], sm[5]), ashr7_pk_u8(sm[6], sm[7])) ^ 0x80808080u;
-            *reinterpret_cast<uint2 *>(&s_V[g][(ycf * 5 + xc) * V_STRIDE + c * 2]) = v;
-            if (f == 0) {   // whole-pel dy: rows 3..10 of the column
-                uint2 w;
-                w.x = __builtin_amdgcn_alignbyte(h[1], h[0], 3);
-                w.y = __builtin_amdgcn_alignbyte(h[2], h[1], 3);
-                *reinterpret_cast<uint2 *>(&s_V[g][(2 * 5 + xc) * V_STRIDE + c * 2]) = w;
+                for (int f = 0; f < 4; ++f) sv[(f + (f >> 1)) * 5 * V_STRIDE] = round_pack4(acc, f);
+                // whole-pel dy: rows 3..10 of the column, the lower lane half rows 3..6, the upper 7..10
+                sv[2 * 5 * V_STRIDE] = kh ? __builtin_amdgcn_alignbyte((uint32_t)hv[2], (uint32_t)hv[1], 3)
+                                          : __builtin_amdgcn_alignbyte((uint32_t)hv[1], (uint32_t)hv[0], 3);
             }
         }
     }
@@ -258,7 +256,7 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
         }
         for (int i = lane; i < 5 * HT_XC; i += 32) a.dbg[468 + i] = s_HT[g][i];
         // (the staged window is gone by now: its bytes hold vertical pass results; a.dbg[648..719] stay as the caller left them)
-        if (lane == 0) { a.dbg[730] = (uint32_t)Lx; a.dbg[731] = (uint32_t)Ly; a.dbg[732] = (uint32_t)o; }
+        if (lane == 0) { a.dbg[730] = (uint32_t)Lx; a.dbg[731] = (uint32_t)Ly; a.dbg[732] = 0; }
     }
     uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
     key = halfwave_min(key);
@@ -277,13 +275,13 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
 }
 
-__global__ __launch_bounds__(256) void k_search2(S2Args a) {
+__global__ __launch_bounds__(256, 4) void k_search2(S2Args a) {   // (a register budget of 128 also makes the MFMAs write VGPRs: no v_accvgpr_read per result)
     launch_clock_begin(a.clk);
     search2_body(a, blockIdx.x, blockIdx.y);
     launch_clock_end(a.clk);
 }
 static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
-__global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) {
+__global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
     launch_clock_begin(b.item[0].clk);
     search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y);
     launch_clock_end(b.item[0].clk);
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256) void k_search2_b(BatchOf<S2Args> b) {
 // placed -- for a grid of tens of thousands of workgroups on a full chip that is the kernel's whole duration, and the
 // pipe's other queues wait (the kernel trace of eight busy streams shows 3.6 kernels running and every stream idle half of
 // the time, ~0.26 ms between a kernel's end and its successor's start).  A grid that fits is placed at once.
-__global__ __launch_bounds__(256) void k_search2_p(BatchOf<S2Args> b, int nbx, int maxrefs, int total) {
+__global__ __launch_bounds__(256, 4) void k_search2_p(BatchOf<S2Args> b, int nbx, int maxrefs, int total) {
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int item = w / (nbx * maxrefs), rem = w - item * (nbx * maxrefs);
         const int ref_idx = rem / nbx, wg_x = rem - ref_idx * nbx;

@@ -93,6 +93,7 @@ struct vp8hip_ctx {
     bool s2_clock_on = false;          // k_search2 stamps its launches (vp8hip_profile_search2_clock)
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
     bool frame_overflowed = false;  // ... and _end found the caller's buffer too small: the coded frame waits in h_frame for a retry
+    hipEvent_t frame_event = nullptr;   // the end of the pending frame's entropy stage when it ran beside the chain (a batch's second stream)
     bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
     int frame_partitions = 0;
@@ -289,6 +290,11 @@ struct vp8hip_batch {
     hipEvent_t ev_gate2 = nullptr;       // (the two alternate: a wait never names an event that is recorded again right behind it)
     hipEvent_t ev_prep = nullptr;        // on `prep`: the head-of-frame work enqueued so far
     bool prep_pending = false;           // `stream` has not yet been told to wait for ev_prep
+    // The entropy stage of the members' frames beside their loop filter (vp8hip_batch_encode_frame_begin): a second stream, forked
+    // from `stream` right before the filter's launch (ev_ent_fork) and joined back behind the stage (ev_ent).
+    hipStream_t ent = nullptr;           // nullptr: the stage stays in the chain (VP8HIP_BATCH_ENT_STREAM=0)
+    hipEvent_t ev_ent_fork = nullptr, ev_ent = nullptr;
+    bool ent_fork_fresh = false;         // nothing was enqueued for a member since ev_ent_fork was recorded
 };
 
 static std::atomic<int> g_live_contexts{0};   // contexts that launch on a stream of their own (members of a batch share one)
@@ -343,7 +349,9 @@ static void lf_check(vp8hip_ctx *c, LfCheck &k);   // (below, with check_SSIM)
 
 // work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
 static void batch_join_prep(vp8hip_batch *b) {
-    if (!b || !b->prep || !b->prep_pending) return;
+    if (!b) return;
+    b->ent_fork_fresh = false;   // (every entry point that may enqueue passes here: the entropy stage's early fork point is stale)
+    if (!b->prep || !b->prep_pending) return;
     b->prep_pending = false;
     (void)hipEventRecord(b->ev_prep, b->prep);
     (void)hipStreamWaitEvent(b->stream, b->ev_prep, 0);
@@ -934,6 +942,24 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     return VP8HIP_OK;
 }
 
+// A batch's second stream for the entropy stage, made when the first frame is asked for as bytes (a batch that only runs the
+// inter path never has one: idle streams still take part in the runtime's stream -> hardware queue assignment).
+static bool batch_ent_stream(vp8hip_batch *b) {
+    static const int mode = [] { const char *v = getenv("VP8HIP_BATCH_ENT_STREAM"); return v && v[0] ? atoi(v) : 0; }();
+    if (!b->ev_ent && (hipEventCreateWithFlags(&b->ev_ent_fork, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&b->ev_ent, hipEventDisableTiming) != hipSuccess))
+        return false;
+    if (!mode) return false;
+    if (b->ent) return true;
+    int least = 0, greatest = 0;
+    if (mode == 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {   // A/B: in the lowest priority class
+        if (hipStreamCreateWithPriority(&b->ent, hipStreamNonBlocking, least) != hipSuccess) b->ent = nullptr;
+    } else if (hipStreamCreateWithFlags(&b->ent, hipStreamNonBlocking) != hipSuccess) {
+        b->ent = nullptr;
+    }
+    return b->ent != nullptr;
+}
+
 void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the batch before its members), each back on its own stream
     if (!b) return;
     hipSetDevice(b->c[0]->device);
@@ -944,6 +970,13 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the
     if (b->ev_gate) hipEventDestroy(b->ev_gate);
     if (b->ev_gate2) hipEventDestroy(b->ev_gate2);
     if (b->ev_prep) hipEventDestroy(b->ev_prep);
+    if (b->ent) {
+        hipStreamSynchronize(b->ent);
+        hipStreamDestroy(b->ent);
+    }
+    if (b->ev_ent_fork) hipEventDestroy(b->ev_ent_fork);
+    if (b->ev_ent) hipEventDestroy(b->ev_ent);
+    for (int i = 0; i < b->n; ++i) b->c[i]->frame_event = nullptr;
     --g_live_contexts;
     for (int i = 0; i < b->n; ++i) {
         b->c[i]->batch = nullptr;
@@ -1136,10 +1169,13 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
         m[n++] = c;
     }
     if (!n) return VP8HIP_OK;
+    // the entropy stage of these frames may start here (everything it reads has been enqueued), beside the filter
+    if (b->ent) HIPCHK(c0, hipEventRecord(b->ev_ent_fork, b->stream));
     {
         Timed t(c0, VP8HIP_K_LOOP_FILTER);
         launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n, chk);
     }
+    b->ent_fork_fresh = b->ent != nullptr;
     for (int i = 0; i < n; ++i) {   // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
         vp8hip_ctx *c = m[i];
         c->frames[c->recon].pyramid_valid = false;
@@ -1700,6 +1736,7 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
     c->frame_params = *p;
     c->frame_partitions = P;
     c->frame_pending = true;
+    c->frame_event = nullptr;
     return VP8HIP_OK;
 }
 
@@ -1712,6 +1749,7 @@ int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_
     const int P = num_partitions;
     if (P != 1 && P != 2 && P != 4 && P != 8) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
+    bool early = b->ent_fork_fresh;     // (read before USE_DEVICE, which marks it stale for whatever this call enqueues)
     USE_DEVICE(c0);
     FrameEntropy e[MAX_BATCH];
     FrameOut fo[MAX_BATCH];
@@ -1731,7 +1769,18 @@ int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_
         m[n++] = c;
     }
     if (!n) return VP8HIP_OK;
-    hipStream_t s = b->stream;
+    // Beside the loop filter, on the batch's second stream: the stage reads the frame's coefficients, modes and vectors (final
+    // before the filter's launch: ev_ent_fork) and the segment data check_SSIM may have updated INSIDE that launch -- so only a
+    // caller that has taken every member's verdict (vp8hip_check_ssim_result: the update is then in memory) gets the early
+    // start; otherwise, and whenever anything was enqueued for the batch since the filter, the stage starts behind all of it.
+    // The chain waits for the stage before it goes on (the next frame's k_mb overwrites what the stage reads).
+    const bool side = !c0->prof_mask && batch_ent_stream(b);
+    hipStream_t s = side ? b->ent : b->stream;
+    if (side) {
+        for (int i = 0; i < n; ++i) early = early && !m[i]->verdict_pending;
+        if (!early) HIPCHK(c0, hipEventRecord(b->ev_ent_fork, b->stream));
+        HIPCHK(c0, hipStreamWaitEvent(b->ent, b->ev_ent_fork, 0));
+    }
     {
         Timed t(c0, VP8HIP_K_ENT_COUNT);
         launch_fe_count_batch(s, e, n);
@@ -1753,7 +1802,10 @@ int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_
             HIPCHK(c0, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
         }
         c->frame_pending = true;
+        c->frame_event = b->ev_ent;      // the end of the stage, not of whatever the caller enqueues behind it before it takes the bytes
     }
+    if (b->ev_ent) HIPCHK(c0, hipEventRecord(b->ev_ent, s));
+    if (side) HIPCHK(c0, hipStreamWaitEvent(b->stream, b->ev_ent, 0));
     return VP8HIP_OK;
 }
 
@@ -1766,7 +1818,9 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
     hipStream_t s = c->stream;
     size_t n;
     for (;;) {
-        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->frame_event) HIPCHK(c, hipEventSynchronize(c->frame_event));   // the stage ran beside the chain: its end, not the chain's
+        else HIPCHK(c, hipStreamSynchronize(s));
+        c->frame_event = nullptr;
         n = *reinterpret_cast<const uint32_t *>(c->h_frame);
         if (n) break;
         // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
