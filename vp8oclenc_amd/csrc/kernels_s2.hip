@@ -81,18 +81,23 @@ struct S2Args {
     int nrefs;       // enabled references of this context (a batched launch is sized for the largest of its contexts)
     int w, h, nblk, bw;
     uint32_t bw_inv;   // ceil(2^32 / bw)
-    uint32_t *dbg;   // test tap: per-candidate prediction (column-major) and cost of block dbg_block, or nullptr
-    int dbg_block;
     unsigned long long *clk;   // launch clock (launch_clock_end, vp8hip_dev.h) or nullptr; a batched launch uses its first member's
 };
 
-__device__ __forceinline__ uint32_t halfwave_min(uint32_t key) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)key, m, 32);
-        key = o < key ? o : key;
-    }
-    return key;
+// minimum over the 32 lanes of a block, valid in its lanes 16..31: four DPP steps inside the 16-lane rows (the lanes a step
+// pairs hold, after it, the same value: mirrors do as well as butterflies), then lane 15 of the lower row into the upper one.
+// (__shfl_xor is a ds_bpermute_b32 with five instructions of address arithmetic around it, per step.)
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep their own value
+}
+__device__ __forceinline__ uint32_t halfwave_min_upper(uint32_t key) {
+    key = umin(key, dpp<0xb1>(key));         // quad_perm [1,0,3,2]
+    key = umin(key, dpp<0x4e>(key));         // quad_perm [2,3,0,1]
+    key = umin(key, dpp<0x141>(key));        // row_half_mirror
+    key = umin(key, dpp<0x140>(key));        // row_mirror
+    return umin(key, dpp<0x142, 0xa>(key));  // row_bcast:15 into rows 1 and 3
 }
 
 // sat_i8(a >> 7) in byte 0, sat_i8(b >> 7) in byte 1 (v_ashr_pk_i8_i32; as a 16-bit value the undefined bits 31:16 stay explicit).
@@ -247,20 +252,9 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
             diff += weight_cols_pre(pre, pp);
         }
     if (k < 25) diff += (iabs(dx) + iabs(dy)) * 32;  // :1176-1178
-    if (a.dbg && live && b == a.dbg_block) {
-        if (k < 26) {
-            uint32_t *d = a.dbg + k * 18;
-            for (int c = 0; c < 8; ++c) { d[2 * c] = P[c][0] ^ 0x80808080u; d[2 * c + 1] = P[c][1] ^ 0x80808080u; }
-            d[16] = (uint32_t)diff;
-            d[17] = valid;
-        }
-        for (int i = lane; i < 5 * HT_XC; i += 32) a.dbg[468 + i] = s_HT[g][i];
-        // (the staged window is gone by now: its bytes hold vertical pass results; a.dbg[648..719] stay as the caller left them)
-        if (lane == 0) { a.dbg[730] = (uint32_t)Lx; a.dbg[731] = (uint32_t)Ly; a.dbg[732] = 0; }
-    }
     uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
-    key = halfwave_min(key);
-    if (lane == 0 && live) {
+    key = halfwave_min_upper(key);
+    if (lane == 16 && live) {   // (every lane of the block holds the block's position and vector; this one also the minimum)
         int bqx = (int16_t)(a.w * 4 - 32), bqy = (int16_t)(a.h * 4 - 32), md = 0x7fff;  // :1136-1137
         if (key != 0xffffffffu) {
             const int kk = key & 0xff;
@@ -302,7 +296,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_p(BatchOf<S2Args> b, int nbx
 
 }  // namespace
 
-static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block, unsigned long long *clk) {
+static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk) {
     S2Args a;
     a.clk = clk;
     a.cur = cur.Y[0];
@@ -321,8 +315,6 @@ static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &n
     a.bw = a.w / 8;
     a.bw_inv = (uint32_t)(((1ull << 32) + a.bw - 1) / a.bw);
     a.nblk = a.w * a.h / 64;
-    a.dbg = dbg;
-    a.dbg_block = dbg_block;
     return a;
 }
 static bool search2_skip() {
@@ -330,8 +322,8 @@ static bool search2_skip() {
     return skip;   // timing experiment only
 }
 
-void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg, int dbg_block, unsigned long long *clk) {
-    const S2Args a = search2_args(cur, refs, nets, dbg, dbg_block, clk);
+void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk) {
+    const S2Args a = search2_args(cur, refs, nets, clk);
     if (a.nrefs == 0 || search2_skip()) return;
     VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
 }
@@ -341,7 +333,7 @@ void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
     b.n = n;
     int maxrefs = 0;
     for (int i = 0; i < n; ++i) {
-        b.item[i] = search2_args(*cur[i], refs[i], *nets[i], nullptr, -1, clk);
+        b.item[i] = search2_args(*cur[i], refs[i], *nets[i], clk);
         maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
     }
     if (maxrefs == 0 || search2_skip()) return;

@@ -753,7 +753,7 @@ static void search_refs(vp8hip_ctx *c, const RefSet &which) {
     }
     Timed t(c, VP8HIP_K_SEARCH2);
     // (the launch clock only where launches of this context cannot overlap: the one that searches LAST)
-    launch_search2(s, c->cur, which, c->nets, nullptr, -1, which.use[0] ? s2_clock(c) : nullptr);
+    launch_search2(s, c->cur, which, c->nets, which.use[0] ? s2_clock(c) : nullptr);
 }
 
 // prepare_GPU_buffers, inter_part.h:1-33 (reset_vectors is folded into k_search1's parent read)
@@ -2103,22 +2103,6 @@ int vp8hip_debug_upload_header_inputs(vp8hip_ctx *c, const int32_t *seg, const i
     if (sd) HIPCHK(c, hipMemcpyAsync(c->d_sd, sd, sizeof(SegData), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (probs || denom) c->ent_counted_partitions = 1;
-    return VP8HIP_OK;
-}
-
-int vp8hip_debug_search2_block(vp8hip_ctx *c, int ref, int block, void *out) {
-    USE_DEVICE(c);
-    JOIN_LF(c);
-    if (!c || !out || ref < 0 || ref > 2 || c->slot[ref] < 0) return VP8HIP_ERR_ARG;
-    RefSet refs;
-    for (int r = 0; r < 3; ++r) {
-        refs.use[r] = r == ref;
-        refs.ref[r] = c->frames[c->slot[r] >= 0 ? c->slot[r] : c->slot[0]].f;
-    }
-    HIPCHK(c, hipMemsetAsync(c->scratch, 0, 4096, c->stream));
-    launch_search2(c->stream, c->cur, refs, c->nets, (uint32_t *)c->scratch, block);
-    HIPCHK(c, hipMemcpyAsync(out, c->scratch, 4096, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VP8HIP_OK;
 }
 

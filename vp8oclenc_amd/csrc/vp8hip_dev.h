@@ -88,7 +88,11 @@ __device__ __forceinline__ bool launch_clock_sampled() {
     return wg % CLOCK_SAMPLE == 0;
 }
 __device__ __forceinline__ void launch_clock_begin(unsigned long long *w) {
-    if (w && threadIdx.x == 0 && launch_clock_sampled()) atomicMin(&w[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    // A SCALAR condition (the first wave of a sampled workgroup; the compiler folds the wave's atomics into one): with the per-lane
+    // "threadIdx.x == 0" here, hipcc carried the workgroup indices through the branch in VGPRs and k_search2 picked its reference's
+    // planes and nets with vector loads and 64-bit vector address arithmetic -- 49 of its 771 vector instructions.
+    if (w && launch_clock_sampled() && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0)
+        atomicMin(&w[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 __device__ __forceinline__ void launch_clock_end(unsigned long long *w) {   // every thread of the workgroup gets here
     if (!w || !launch_clock_sampled()) return;
@@ -133,8 +137,7 @@ void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t
                                 int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
                     int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
-void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, uint32_t *dbg = nullptr,
-                    int dbg_block = -1, unsigned long long *clk = nullptr);
+void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk = nullptr);
 void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh, bool conformant = false);
