@@ -11,7 +11,7 @@ wave64 instruction:
     4.2   everything else: the same opcodes with an SGPR source, SDWA or DPP; v_lshlrev_b32 (!), min/max, compares,
           v_cndmask, every VOP3 (add3, lshl_add, perm, alignbyte, sad, med3, bfe, mad, mul_lo/hi) and every VOP3P
           (v_pk_*, v_dot2, v_dot4)
-    8.2   v_ashr_pk_u8_i32, v_mad_u16
+    8.2   v_ashr_pk_u8_i32 / v_ashr_pk_i8_i32, v_mad_u16; a 32x32 MFMA is priced at the 8 cycles of vector issue it takes
 This script compiles a kernel file to assembly (hipcc -S, device only), walks every kernel's instruction stream and
 prices it.  Straight-line kernels (k_search2 is fully unrolled) are exact; for kernels with loops the static mix is
 scaled to the dynamic SQ_INSTS_VALU count of the committed PMC pass (profiles/pmc_valu.json) by bench.py.
@@ -30,13 +30,18 @@ CSRC = os.path.join(ROOT, "vp8oclenc_amd", "csrc")
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32",
         "v_mov_b32", "v_add_u16", "v_sub_u16", "v_subrev_u16", "v_max_u16", "v_max_i16", "v_min_u16", "v_min_i16", "v_lshlrev_b16",
         "v_lshrrev_b16", "v_ashrrev_i16", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32"}
-DOUBLE = {"v_ashr_pk_u8_i32", "v_mad_u16", "v_mad_i16"}
+DOUBLE = {"v_ashr_pk_u8_i32", "v_ashr_pk_i8_i32", "v_mad_u16", "v_mad_i16"}
 C_FAST, C_SLOW, C_DOUBLE = 2.31, 4.18, 8.19     # profiles/valu_cost.json
+# a 32x32 MFMA keeps the matrix pipe for 32 cycles but the SIMD's VECTOR issue for 8 of them (MI355X_MICROARCH.md, cycle constants):
+# priced as what it takes from the vector stream, in the "double" class (k_search2 issues four per wave)
+C_MFMA = 8.0
 
 
 def cost_of(mn: str, operands: str):
     """(cycles, class, why) of one VALU instruction"""
     base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
+    if base.startswith("v_mfma_"):
+        return C_MFMA, "double", "mfma"
     if base in DOUBLE:
         return C_DOUBLE, "double", ""
     if base in FAST:

@@ -127,7 +127,10 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_V[8][25 * V_STRIDE];   // vertical pass results: [y case * 5 + x case][column][row half]
     uint32_t(*s_win)[25 * V_STRIDE] = s_V;   // the staged window (16 rows x 32 B) is dead once the horizontal pass has read it: same bytes
-    __shared__ __attribute__((aligned(16))) int s_pre[8][64];   // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]
+    // the current block's share of the metric, [4x4 block][column][R0,R2,X,Y]: made after the vertical pass, in the bytes of the H array
+    // (dead by then; the LDS per workgroup decides how many workgroups a CU holds: 22.8 KB = seven, with an array of its own six --
+    // 68.9-69.1 against 68.4-68.9 M MB/s on one box, scripts/ab_build.sh; eight, with the V array's bank skew given up, adds nothing)
+    int(*s_pre)[5 * HT_XC] = reinterpret_cast<int(*)[5 * HT_XC]>(s_HT);
     const int r = a.refmap[ref_idx];
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
     const int b = imin(wg_x * 8 + g, a.nblk - 1);
@@ -184,14 +187,6 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
         for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * (4 * WIN_ROW)] << (8 * rr);
         s_HT[g][2 * HT_XC + c * 4 + rg] = v;
     }
-    {   // the current block's share of the metric (vp8hip_dev.h, weight_pre_column): 16 columns x 4 quantities, two per lane.
-        // Order = the order the cost loop below walks the 4x4 blocks: q = (m*2 + n)*4 + j  <->  column 4n+j, row half m
-        const int q = lane & 15, m = q >> 3, n = (q >> 2) & 1, j = q & 3;
-        const uint32_t ccol = s_cz[g][(4 * n + j) * 2 + m];
-        int *pre = &s_pre[g][q * 4 + (lane >> 4) * 2];
-        pre[0] = dot4s(ccol, lane < 16 ? K_W_R0 : K_W_X, 0);
-        pre[1] = dot4s(ccol, lane < 16 ? K_W_R2 : K_W_Y, 0);
-    }
     lds_fence();
 
     // ---- vertical pass: three MFMAs for the wave's 2 x 5 x 8 columns ------------------------------------------------------
@@ -216,6 +211,15 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
                                           : __builtin_amdgcn_alignbyte((uint32_t)hv[1], (uint32_t)hv[0], 3);
             }
         }
+    }
+    lds_fence();
+    {   // the current block's share of the metric (vp8hip_dev.h, weight_pre_column): 16 columns x 4 quantities, two per lane.
+        // Order = the order the cost loop below walks the 4x4 blocks: q = (m*2 + n)*4 + j  <->  column 4n+j, row half m
+        const int q = lane & 15, m = q >> 3, n = (q >> 2) & 1, j = q & 3;
+        const uint32_t ccol = s_cz[g][(4 * n + j) * 2 + m];
+        int *pre = &s_pre[g][q * 4 + (lane >> 4) * 2];
+        pre[0] = dot4s(ccol, lane < 16 ? K_W_R0 : K_W_X, 0);
+        pre[1] = dot4s(ccol, lane < 16 ? K_W_R2 : K_W_Y, 0);
     }
     lds_fence();
 

@@ -383,26 +383,12 @@ __device__ __forceinline__ void weight_pre_column(uint32_t ccol, int pre[4]) {
     pre[3] = dot4s(ccol, K_W_Y, 0);
 }
 
-// weight of (current - prediction) for one 4x4 block: pre = weight_pre_column of the four current columns,
-// p = the four prediction columns as biased bytes
-__device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t p[4]) {
-    s16x2 A[4], B[4];   // A[c] = (R0[c], R1[c]) = rows 0,1 of the column-pass output, B[c] = rows 2,3
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int R0 = dot4s(p[c], K_W_R0N, pre[4 * c + 0]);
-        const int R2 = dot4s(p[c], K_W_R2N, pre[4 * c + 1]);
-        const int X = dot4s(p[c], K_W_XN, pre[4 * c + 2]);
-        const int Y = dot4s(p[c], K_W_YN, pre[4 * c + 3]);
-        const uint32_t xy = pk16(X, Y);
-        const int t1 = dot2(xy, K_ROT16_A, 16 * 14500);
-        const int t3 = dot2(xy, K_ROT16_B, 16 * 7500);
-        A[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1, (uint32_t)R0, 0x07060100u));   // (low half of R0, high half of t1)
-        B[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3, (uint32_t)R2, 0x07060100u));
-    }
-    // Row pass.  |a| + |b| of a packed pair is one v_sad_u16 against a constant once the pair carries a bias that makes it
-    // unsigned; the biases ride on work that is done anyway: +0x8000 joins the rounding 7 of a1 (then ">> 4" is a LOGICAL
-    // shift and the pair comes out with +2048: floor((x + 32768) / 16) = floor(x / 16) + 2048), and +2^28 joins the rounding
-    // constants of the rotations (the high half comes out with +4096; |sums| < 2^28, so nothing saturates).
+// Row pass of the metric on the column pass's output: A[c] = (R0[c], R1[c]) = rows 0,1 of column c, B[c] = rows 2,3.
+// |a| + |b| of a packed pair is one v_sad_u16 against a constant once the pair carries a bias that makes it
+// unsigned; the biases ride on work that is done anyway: +0x8000 joins the rounding 7 of a1 (then ">> 4" is a LOGICAL
+// shift and the pair comes out with +2048: floor((x + 32768) / 16) = floor(x / 16) + 2048), and +2^28 joins the rounding
+// constants of the rotations (the high half comes out with +4096; |sums| < 2^28, so nothing saturates).
+__device__ __forceinline__ int weight_rows(const s16x2 A[4], const s16x2 B[4]) {
     uint32_t acc = 0;
     int o00 = 0;
 #pragma unroll
@@ -435,6 +421,30 @@ __device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t
     const int a00 = (int)__builtin_amdgcn_sad_u16((uint32_t)o00, 2048u, 0u);   // |DC| (the high halves are both zero)
     return (int)acc - (a00 - (a00 >> 2));   // DC counts a quarter (DC_UNSIGNIFICANCE, :83,:183)
 }
+
+// weight of (current - prediction) for one 4x4 block: pre = weight_pre_column of the four current columns,
+// p = the four prediction columns as biased bytes
+__device__ __forceinline__ int weight_cols_pre(const int pre[16], const uint32_t p[4]) {
+    s16x2 A[4], B[4];   // A[c] = (R0[c], R1[c]) = rows 0,1 of the column-pass output, B[c] = rows 2,3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int R0 = dot4s(p[c], K_W_R0N, pre[4 * c + 0]);
+        const int R2 = dot4s(p[c], K_W_R2N, pre[4 * c + 1]);
+        const int X = dot4s(p[c], K_W_XN, pre[4 * c + 2]);
+        const int Y = dot4s(p[c], K_W_YN, pre[4 * c + 3]);
+        const uint32_t xy = pk16(X, Y);
+        const int t1 = dot2(xy, K_ROT16_A, 16 * 14500);
+        const int t3 = dot2(xy, K_ROT16_B, 16 * 7500);
+        A[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t1, (uint32_t)R0, 0x07060100u));   // (low half of R0, high half of t1)
+        B[c] = as_s16x2(__builtin_amdgcn_perm((uint32_t)t3, (uint32_t)R2, 0x07060100u));
+    }
+    return weight_rows(A, B);
+}
+
+// (Tried for the whole-pel search, where a reference column is the prediction column of up to four candidates: the four linear
+// quantities of a column made once, as packed pairs (R0, R2) and (X, Y), and a (current, prediction) pair as two packed
+// subtractions + the rotations + two permutes.  7 % fewer instructions in k_search1, but 75-79 registers instead of 61 -- six waves per
+// SIMD instead of eight -- and the same or a lower rate with the part full: 68.1-68.5 and 67.4-67.7 against 68.4-68.7 M MB/s.)
 
 // 4x4 byte transpose: rows r[0..3] (byte k = column k) -> columns (byte r = row r); eight v_perm
 __device__ __forceinline__ void transpose4x4(const uint32_t r[4], uint32_t c[4]) {
