@@ -361,19 +361,38 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
                             device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
     if bitstream:      # the entropy stage's scratch: not inside the timed region (the reference allocates everything in init_all)
         for d in drv:
-            d.hip.reserve_frame_path()
+            d.hip.reserve_frame_path_dense()
     keys, nbytes = [0] * chunks, [0] * chunks
+    pipelined = bitstream and not os.environ.get("VP8_BENCH_NO_FRAME_PIPELINE")
 
     def work(k):
         d = drv[k]
+        pending = None
         for t in range(gop_len):
             d.encode_frame_device(*leg.ptrs[(3 * k + t) % leg.nd])
+            if pipelined:
+                # frame t is under way; NOW take frame t - 1's bytes (its entropy stage ran on the context's third stream beside
+                # frame t - 1's loop filter and frame t's side work), then enqueue frame t's stage
+                if pending is not None:
+                    b = d.get_frame_end()
+                    nbytes[k] += len(b)
+                    if frames_out is not None:
+                        frames_out[frame_base + k * gop_len + pending] = b
+                d.get_frame_begin()
+                pending = t
+                keys[k] += int(bool(d.resolve()))
+                continue
             if bitstream:
                 b = d.get_frame()
                 nbytes[k] += len(b)
                 if frames_out is not None:
                     frames_out[frame_base + k * gop_len + t] = b
             keys[k] += int(bool(d.resolve())) if (bitstream or t == gop_len - 1) else 0
+        if pending is not None:
+            b = d.get_frame_end()
+            nbytes[k] += len(b)
+            if frames_out is not None:
+                frames_out[frame_base + k * gop_len + pending] = b
         d.hip.synchronize()
 
     if start is not None:

@@ -250,11 +250,21 @@ int vp8hip_encode_frame(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header
  * and the pinned frame buffer are made when the first frame is asked for, or here -- a host that wants no allocation inside its
  * frame loop calls this once after vp8hip_create. */
 int vp8hip_reserve_frame_path(vp8hip_ctx *ctx);
+/* ... sized for the densest frame there can be (304 bools per 4x4 block instead of 64; about 270 MB at 1080p): no frame ever has to
+ * be coded a second time because the scratch was too small.  For a caller that starts the next frame before it takes the bytes of
+ * this one (vp8hip_encode_frame_begin below). */
+int vp8hip_reserve_frame_path_dense(vp8hip_ctx *ctx);
 
-/* The same in two halves, for a host thread that drives several contexts (GOP chunks): _begin enqueues the whole
- * entropy stage and the read-back on the context's stream and returns at once; _end waits for it and fills `out`.
- * Between the two no other call may be made on this context (the next frame would overwrite what a recode after a
- * scratch overflow has to read again): VP8HIP_ERR_STATE from _begin while a frame is pending, from _end when none is. */
+/* The same in two halves, for a host thread that drives several contexts (GOP chunks) or wants the next frame under way before
+ * it takes this one's bytes: _begin enqueues the whole entropy stage and the read-back and returns at once; _end waits for the
+ * stage (not for whatever was enqueued behind it) and fills `out`.  VP8HIP_ERR_STATE from _begin while a frame is pending,
+ * from _end when none is.
+ * With vp8hip_filter_overlap the stage runs on a stream of its own beside the frame's loop filter, and the NEXT frame may be
+ * started between _begin and _end (vp8hip_set_current_device ... vp8hip_loop_filter: its side work runs beside filter and stage,
+ * its macroblock kernel waits for the stage): one video then costs a frame what it costs without frames out.  Only the recode
+ * after a scratch overflow is lost that way (its input is overwritten): _end then returns VP8HIP_ERR_STATE -- call
+ * vp8hip_reserve_frame_path_dense once and it cannot happen.  Without the overlap mode no other call may be made on the context
+ * between the two. */
 int vp8hip_encode_frame_begin(vp8hip_ctx *ctx, int num_partitions, const vp8hip_header_params *params);
 int vp8hip_encode_frame_end(vp8hip_ctx *ctx, uint8_t *out, size_t capacity, size_t *size);
 
@@ -320,7 +330,7 @@ const char *vp8hip_status_string(int status);
 /* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
  * layout (vp8drv_config grew in round 2: 2), MINOR when entry points are added.  A host built against an older header checks
  * it once after loading the library. */
-#define VP8HIP_ABI_VERSION 2006
+#define VP8HIP_ABI_VERSION 2007
 int vp8hip_abi_version(void);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */

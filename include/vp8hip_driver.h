@@ -94,8 +94,10 @@ int vp8drv_ready(const vp8drv *d);
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 /* The same in two halves (device entropy stage only: VP8HIP_ERR_STATE with host_bitstream): _begin enqueues the
  * stage and returns, _end waits and fills `out`.  One host thread can thus keep many GOP chunks in flight:
- * encode_frame + get_frame_begin on every chunk, then get_frame_end on every chunk.  No other call on this driver
- * between the two. */
+ * encode_frame + get_frame_begin on every chunk, then get_frame_end on every chunk.  With cfg.overlap_filter (one video frame
+ * after frame) the NEXT frame may be started between the two -- encode(t), get_frame_begin(t), encode(t + 1), get_frame_end(t): the
+ * stage of frame t runs beside its loop filter and beside frame t + 1's input side (vp8hip_encode_frame_begin, include/vp8hip.h;
+ * call vp8hip_reserve_frame_path_dense(vp8drv_context(d)) once); without it no other call on this driver between the two. */
 int vp8drv_get_frame_begin(vp8drv *d);
 int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size);
 

@@ -21,6 +21,7 @@ int main(int argc, char **argv) {
     vp8drv_config cfg;
     vp8drv_default_config(&cfg);
     cfg.scene_detect = 1;                       // main() calls scene_change() for every would-be inter frame (vp8enc.cpp:408)
+    cfg.overlap_filter = 1;
     for (int i = 3; i < argc; ++i) {
         auto val = [&]() { return i + 1 < argc ? argv[++i] : "0"; };
         if (!strcmp(argv[i], "-g")) cfg.gop_size = atoi(val());
@@ -58,22 +59,35 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> frame(ysz + 2 * csz), bytes((size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20));
     uint32_t n = 0, keys = 0;
     size_t total = 32;
+    // One video: the loop filter of a frame runs beside the next frame's input side (vp8hip_filter_overlap), and its entropy stage
+    // beside both on a third stream -- so frame t + 1 is read and started BEFORE frame t's bytes are taken (vp8drv_get_frame_begin /
+    // _end).  The scratch is sized for the densest frame there can be: no frame is ever coded twice.
+    CK(vp8hip_reserve_frame_path_dense(vp8drv_context(drv)));
+    bool pending = false;
     for (;;) {
-        if (fread(frame.data(), 1, frame.size(), in) != frame.size()) break;                // get_yuv420_frame, encIO.h:203-254
-        uint8_t marker[6];
-        const size_t m = fread(marker, 1, 6, in);
-        if (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) { fprintf(stderr, "broken stream!\n"); return 1; }
-        CK(vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0));
-        size_t size = 0;
-        CK(vp8drv_get_frame(drv, bytes.data(), bytes.size(), &size));
+        bool got = fread(frame.data(), 1, frame.size(), in) == frame.size();                 // get_yuv420_frame, encIO.h:203-254
+        if (got) {
+            uint8_t marker[6];
+            const size_t m = fread(marker, 1, 6, in);
+            if (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) { fprintf(stderr, "broken stream!\n"); return 1; }
+            CK(vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0));
+        }
+        if (pending) {      // the previous frame's bytes
+            size_t size = 0;
+            CK(vp8drv_get_frame_end(drv, bytes.data(), bytes.size(), &size));
+            uint8_t ph[12];
+            fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)size, n), out);
+            fwrite(bytes.data(), 1, size, out);
+            total += 12 + size;
+            ++n;
+            pending = false;
+        }
+        if (!got) break;
+        CK(vp8drv_get_frame_begin(drv));
         const int key = vp8drv_resolve(drv);       // the frame's final type: check_SSIM may have sent it back to be a key frame
         CK(key);
         keys += key;
-        uint8_t ph[12];
-        fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)size, n), out);
-        fwrite(bytes.data(), 1, size, out);
-        total += 12 + size;
-        ++n;
+        pending = true;
     }
     fseek(out, 0, SEEK_SET);
     // the reference's file says one frame more than it holds: write_output_header counts from a frame number that main() has

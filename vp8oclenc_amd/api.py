@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2006  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 2007  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
@@ -551,6 +551,11 @@ class Vp8Hip:
         """the entropy stage's scratch and the frame buffer now instead of at the first frame (vp8hip_reserve_frame_path)"""
         self.lib.vp8hip_reserve_frame_path.argtypes = [C.c_void_p]
         self._chk(self.lib.vp8hip_reserve_frame_path(self.h), "reserve_frame_path")
+
+    def reserve_frame_path_dense(self):
+        """... for the densest frame there can be: a caller that starts frame n + 1 before taking frame n's bytes never loses a recode"""
+        self.lib.vp8hip_reserve_frame_path_dense.argtypes = [C.c_void_p]
+        self._chk(self.lib.vp8hip_reserve_frame_path_dense(self.h), "reserve_frame_path_dense")
 
     def check_ssim_async(self, refqi, qi_min: int):
         """check_SSIM enqueued, nobody waiting (vp8hip_check_ssim_async); check_ssim_result() collects the verdict"""

@@ -93,7 +93,14 @@ struct vp8hip_ctx {
     bool s2_clock_on = false;          // k_search2 stamps its launches (vp8hip_profile_search2_clock)
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
     bool frame_overflowed = false;  // ... and _end found the caller's buffer too small: the coded frame waits in h_frame for a retry
-    hipEvent_t frame_event = nullptr;   // the end of the pending frame's entropy stage when it ran beside the chain (a batch's second stream)
+    hipEvent_t frame_event = nullptr;   // the end of the pending frame's entropy stage when it ran beside the chain (a batch's second stream, ent_stream)
+    // vp8hip_filter_overlap: the entropy stage of a frame on a THIRD stream, beside its loop filter and beside the next frame's side
+    // work -- a caller may start the next frame between vp8hip_encode_frame_begin and _end (the chain waits for the stage before
+    // anything overwrites what it reads)
+    hipStream_t ent_stream = nullptr;
+    hipEvent_t ev_ent = nullptr;
+    bool ent_pending = false;           // the chain has not yet been told to wait for ev_ent
+    unsigned out_gen = 0, frame_gen = 0;   // frames whose results went into `out` so far / when the pending frame's stage was enqueued
     bool counted = false;           // in g_live_contexts
     vp8hip_header_params frame_params{};
     int frame_partitions = 0;
@@ -343,6 +350,10 @@ static int join_lf(vp8hip_ctx *c) {
     c->lf_stream = side;
     HIPCHK(c, hipEventRecord(c->ev_lf, side));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
+    if (c->ent_pending) {   // ... and behind the previous frame's entropy stage: what follows may overwrite the results it reads
+        c->ent_pending = false;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent, 0));
+    }
     return VP8HIP_OK;
 }
 static void lf_check(vp8hip_ctx *c, LfCheck &k);   // (below, with check_SSIM)
@@ -501,6 +512,11 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         hipStreamDestroy(c->lf_stream);
         hipEventDestroy(c->ev_fork);
         hipEventDestroy(c->ev_lf);
+        if (c->ent_stream) {
+            hipStreamSynchronize(c->ent_stream);
+            hipStreamDestroy(c->ent_stream);
+            hipEventDestroy(c->ev_ent);
+        }
     }
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->ev_created)
@@ -713,6 +729,7 @@ static int inter_begin(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref, in
     if (c->slot[0] < 0) return VP8HIP_ERR_STATE;
     c->ent_counted_partitions = 0;
     drop_overflowed_frame(c);
+    ++c->out_gen;
     // reference rotation, inter_part.h:35-50,72-83: golden/altref := the frame that is LAST now
     if (prev_is_golden) c->slot[1] = c->slot[0];
     if (prev_is_altref) c->slot[2] = c->slot[0];
@@ -1257,6 +1274,7 @@ int vp8hip_intra_transform(vp8hip_ctx *c) {
     if (rc) return rc;
     c->ent_counted_partitions = 0;
     drop_overflowed_frame(c);
+    ++c->out_gen;
     {
         Timed t(c, VP8HIP_K_INTRA);
         launch_intra(c->stream, c->cur, c->frames[c->recon].f, c->out, c->d_sd, c->intra_modes, c->intra_is_inter, c->intra_prog,
@@ -1681,7 +1699,27 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     FrameOut fo;
     const int rc = frame_prepare(c, P, p, e, fo);
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    // With the loop filter in flight (vp8hip_filter_overlap) the stage runs on a stream of its own from where the filter started:
+    // everything it reads was final then -- except the segment data check_SSIM may update INSIDE the filter's launch, so a caller that
+    // has not taken the verdict gets the stage behind the filter instead.
+    if (c->lf_pending && c->verdict_pending) { const int jr = join_lf(c); if (jr) return jr; }
+    if (c->lf_pending && !c->ent_stream && !c->prof_mask) {
+        // made with the first frame asked for, not with the overlap mode: an idle stream still takes part in the runtime's stream ->
+        // hardware queue assignment (two videos without frames out: 4 000 frames/s, with a third stream each that nothing ran on 2 600)
+        static const bool third = [] { const char *v = getenv("VP8HIP_ENT_STREAM"); return !(v && v[0] == '0'); }();
+        int least = 0, greatest = 0;
+        if (third && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&c->ent_stream, hipStreamNonBlocking, least) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess) {
+            hipStreamDestroy(c->ent_stream);
+            c->ent_stream = nullptr;
+        }
+    }
+    const bool third = c->lf_pending && c->ent_stream && !c->prof_mask;
+    hipStream_t s = third ? c->ent_stream : c->stream;
+    if (third) HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+    c->frame_event = nullptr;
+    c->frame_gen = c->out_gen;
     static const bool stepwise = [] { const char *v = getenv("VP8HIP_ENT_STEPWISE"); return v && v[0] && v[0] != '0'; }();
     if (stepwise && c->mbs * 25 <= 1024 * 1024) {   // A/B switch (the step-by-step scan stops at 2^20 blocks): the bool strings by the step-by-step kernels (15 launches instead of 5), then the same coder
         const uint8_t *defaults = hdr_default_coeff_probs();
@@ -1708,9 +1746,15 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
         launch_frame_code(s, c->ent, P, c->hdr, fo.head, fo.capacity, fo.frame);
     }
     HIPCHK(c, hipGetLastError());
-    if (frame_zero_copy()) return VP8HIP_OK;   // the coder's last kernel wrote the frame into the pinned host buffer itself
-    const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
-    HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
+    if (!frame_zero_copy()) {   // (otherwise the coder's last kernel wrote the frame into the pinned host buffer itself)
+        const size_t first = c->h_frame_cap < FRAME_FIRST_COPY ? c->h_frame_cap : FRAME_FIRST_COPY;
+        HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
+    }
+    if (third) {
+        HIPCHK(c, hipEventRecord(c->ev_ent, s));
+        c->frame_event = c->ev_ent;
+        c->ent_pending = true;
+    }
     return VP8HIP_OK;
 }
 
@@ -1722,6 +1766,22 @@ int vp8hip_reserve_frame_path(vp8hip_ctx *c) {
     FrameEntropy e;
     FrameOut fo;
     return frame_prepare(c, 1, &p, e, fo);
+}
+
+// the same for the densest frame there can be (304 bools per 4x4 block, ~270 MB at 1080p): no frame is ever coded twice, which a
+// caller that starts frame n + 1 before it takes frame n's bytes relies on
+int vp8hip_reserve_frame_path_dense(vp8hip_ctx *c) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->frame_pending) return VP8HIP_ERR_STATE;
+    if (c->ent_bools_per_block < 304) {
+        JOIN_LF(c);
+        hipStreamSynchronize(c->stream);
+        if (c->ent_stream) hipStreamSynchronize(c->ent_stream);
+        if (c->ent.offs) ent_free(c);
+        c->ent_bools_per_block = 304;
+    }
+    return vp8hip_reserve_frame_path(c);
 }
 
 int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_header_params *p) {
@@ -1736,7 +1796,6 @@ int vp8hip_encode_frame_begin(vp8hip_ctx *c, int num_partitions, const vp8hip_he
     c->frame_params = *p;
     c->frame_partitions = P;
     c->frame_pending = true;
-    c->frame_event = nullptr;
     return VP8HIP_OK;
 }
 
@@ -1823,7 +1882,10 @@ int vp8hip_encode_frame_end(vp8hip_ctx *c, uint8_t *out, size_t capacity, size_t
         c->frame_event = nullptr;
         n = *reinterpret_cast<const uint32_t *>(c->h_frame);
         if (n) break;
-        // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times)
+        // denser than the coder's scratch was sized for: enlarge it and code the frame again (at most three times) -- which needs
+        // the frame's results, gone if the caller has started the next frame in the meantime (vp8hip_reserve_frame_path_dense
+        // sizes the scratch so that this cannot happen)
+        if (c->frame_gen != c->out_gen) return VP8HIP_ERR_STATE;
         int rc = ent_grow(c);
         if (rc) return rc;
         rc = frame_enqueue(c, c->frame_partitions, p);
