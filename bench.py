@@ -14,12 +14,20 @@ N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the
 the barrier and the max-over-ranks time only -- there is no data-path collective, scaling is weak.
 
 Prints ONE JSON line on rank 0 with, besides the contract's fields,
-  roofline       the dominant kernel: algorithmic bytes per launch / hipEvent-measured launch time, vs 8 TB/s
+  roofline       the dominant kernel ALONE on the part (solo: one chunk per launch, HIP events of its own dispatch) as algorithmic
+                 bytes / time vs 8 TB/s; beside it time_shared (the launches of the timed region) and path (3.0 KB per macroblock)
   issue_roofline the resource that does bound the path: VALU issue CYCLES (per-opcode cost x PMC instruction counts)
-  single_stream  one chunk, frame after frame (what configs[2] literally is): MB/s and ms/frame      (N = 1 only)
-  other_configs  720p LAST-only (configs[1]), 4K 3-ref (configs[3]), 1080p SSIM target 0.93           (N = 1 only)
+  cpu_baseline   the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload, and the reference's own
+                 kernels compiled for x86 on one core                                                   (N = 1 only)
   with_bitstream the same frames with finished VP8 frames delivered to host memory                     (N = 1 only)
-  cpu_baseline   the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload (N = 1 only)
+  other_configs  720p LAST-only (configs[1]), 4K 3-ref (configs[3]), 1080p SSIM target 0.93, -g 150, conformant stream (N = 1 only)
+The legs that are ONE or TWO videos coded frame after frame run in a child process per rank (--child-legs; a process keeps every
+hardware queue it ever used):
+  solo_kernels, single_stream   every kernel alone / one chunk, frame after frame: MB/s and ms per frame   (N = 1 only)
+  config3_literal               configs[2] as written: 300 frames, -g 150, two chunks, every frame counted (N = 1 only)
+  config5_literal               configs[4] per rank: one 300-frame GOP with frames out (the next frame started before this one's
+                                bytes are taken), the frames gathered on rank 0 over RCCL, the gather inside the time   (every N)
+  ref_shard                     one GOP split by reference over the ranks (RCCL all_gather + broadcast per frame)     (every N)
 """
 from __future__ import annotations
 

@@ -14,10 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vp8oclenc_amd", "csrc")
 HOT = {   # file -> {kernel name fragment: max VGPRs}
     "kernels_mb.hip": {"k_mb_b": 128},
-    "kernels_s2.hip": {"k_search2E": 96, "k_search2_b": 96},
-    "kernels_me.hip": {"k_search1": 128, "k_pyramid": 128, "k_pack_b": 64},
+    "kernels_s2.hip": {"k_search2E": 72, "k_search2_b": 72},      # seven waves per SIMD ...
+    "kernels_me.hip": {"k_search1": 128, "k_search1_bILb0": 64, "k_pyramid": 128, "k_pack_b": 64},   # the loop form: eight (a form with 7 % fewer instructions and 75 registers was no faster)
     "kernels_lf3.hip": {"k_loop_filter3": 128},
 }
+LDS = {"k_search2E": 23296, "k_search2_b": 23296}   # ... and seven workgroups per CU (163 840 / 7); an MFMA result must land in VGPRs (no AGPRs)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
@@ -38,4 +39,9 @@ def test_hot_kernels_use_no_scratch_and_stay_inside_their_register_budget(src, t
                 spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
                 assert scratch == 0 and spills == 0, f"{name}: {scratch} B of scratch, {spills} spilled VGPRs"
                 assert vgprs <= max_vgprs, f"{name}: {vgprs} VGPRs (budget {max_vgprs})"
+                if frag in LDS:
+                    lds = int(re.search(r"\.amdhsa_kernel\s+" + re.escape(name.replace(".kd", "")) + r"\n(?:.*\n)*?\s+\.amdhsa_group_segment_fixed_size\s+(\d+)", text).group(1))
+                    agprs = int(re.search(r"\.set\s+" + re.escape(name.replace(".kd", "")) + r"\.num_agpr,\s*(\d+)", text).group(1))
+                    assert lds <= LDS[frag], f"{name}: {lds} B of LDS (budget {LDS[frag]})"
+                    assert agprs == 0, f"{name}: {agprs} AGPRs: every MFMA result would cost a v_accvgpr_read"
     assert seen == set(HOT[src]), f"kernels not found in {src}: {set(HOT[src]) - seen}"
