@@ -678,12 +678,19 @@ def main():
         if not env["VP8_BENCH_CHILD"]:
             env.pop("VP8_BENCH_CHILD")
         argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs"]
-        child = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE)
+        # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
+        child_out, child_rc = b"", None
+        try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+                                   timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
+            child_out, child_rc = child.stdout, child.returncode
+        except subprocess.TimeoutExpired as e:
+            child_out, child_rc = e.stdout or b"", "timeout"
         if rank == 0:
             try:
-                out.update(json.loads(child.stdout.decode().strip().splitlines()[-1]))
+                out.update(json.loads(child_out.decode().strip().splitlines()[-1]))
             except Exception as e:
-                out["few_stream_legs_error"] = f"child exit {child.returncode}: {e!r}"[:300]
+                out["few_stream_legs_error"] = f"child exit {child_rc}: {e!r}"[:300]
             sk = out.get("solo_kernels", {}).get("ms_per_launch", {})
             if dominant in sk:      # the roofline fraction from the kernel ALONE on the part, measured in this run (its fresh process)
                 sb = algorithmic_bytes(dominant, W, H, out["solo_kernels"]["refs_per_frame"])
