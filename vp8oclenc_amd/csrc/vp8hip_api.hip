@@ -969,8 +969,8 @@ static bool batch_ent_stream(vp8hip_batch *b) {
     if (!mode) return false;
     if (b->ent) return true;
     int least = 0, greatest = 0;
-    if (mode == 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {   // A/B: in the lowest priority class
-        if (hipStreamCreateWithPriority(&b->ent, hipStreamNonBlocking, least) != hipSuccess) b->ent = nullptr;
+    if (mode >= 2 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {   // A/B: 2 = in the lowest priority class, 3 = in the highest
+        if (hipStreamCreateWithPriority(&b->ent, hipStreamNonBlocking, mode == 3 ? greatest : least) != hipSuccess) b->ent = nullptr;
     } else if (hipStreamCreateWithFlags(&b->ent, hipStreamNonBlocking) != hipSuccess) {
         b->ent = nullptr;
     }
