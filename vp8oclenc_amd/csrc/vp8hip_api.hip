@@ -304,6 +304,11 @@ struct vp8hip_batch {
     bool ent_fork_fresh = false;         // nothing was enqueued for a member since ev_ent_fork was recorded
 };
 
+// The event behind which a host thread reads a finished frame out of pinned memory the stage's last kernel wrote: recorded with a
+// SYSTEM-scope release.  An event made with hipEventDisableTiming alone releases to the device only, and the host then read, once in
+// a few hundred frames, the previous frame's size word (the frame tag's first-partition size was the symptom).
+static constexpr unsigned FRAME_EVENT_FLAGS = hipEventDisableTiming | hipEventReleaseToSystem;
+
 static std::atomic<int> g_live_contexts{0};   // contexts that launch on a stream of their own (members of a batch share one)
 
 // Contexts overlap only if their streams sit on different hardware queues, and the HIP runtime multiplexes all streams
@@ -964,7 +969,7 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
 static bool batch_ent_stream(vp8hip_batch *b) {
     static const int mode = [] { const char *v = getenv("VP8HIP_BATCH_ENT_STREAM"); return v && v[0] ? atoi(v) : 0; }();
     if (!b->ev_ent && (hipEventCreateWithFlags(&b->ev_ent_fork, hipEventDisableTiming) != hipSuccess ||
-                       hipEventCreateWithFlags(&b->ev_ent, hipEventDisableTiming) != hipSuccess))
+                       hipEventCreateWithFlags(&b->ev_ent, FRAME_EVENT_FLAGS) != hipSuccess))
         return false;
     if (!mode) return false;
     if (b->ent) return true;
@@ -1594,6 +1599,7 @@ static int hdr_alloc(vp8hip_ctx *c) {
     HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
     HIPCHK(c, hipMalloc(&c->hdr_partial, HDR_STAT_WORDS * 4));   // the census of k_hdr_count: zero at rest (k_hdr_frame clears it)
     HIPCHK(c, hipMemsetAsync(c->hdr_partial, 0, HDR_STAT_WORDS * 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // once per context: the stage may run on another stream than this one (a batch's, the third)
     HIPCHK(c, hipMalloc(&c->hdr_info, 16));
     HIPCHK(c, hipMalloc(&c->hdr_sym, 64));
     return VP8HIP_OK;
@@ -1710,7 +1716,7 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
         int least = 0, greatest = 0;
         if (third && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&c->ent_stream, hipStreamNonBlocking, least) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_ent, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev_ent, FRAME_EVENT_FLAGS) != hipSuccess) {
             hipStreamDestroy(c->ent_stream);
             c->ent_stream = nullptr;
         }
@@ -1861,6 +1867,7 @@ int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_
             HIPCHK(c0, hipMemcpyAsync(c->h_frame, c->d_frame, first, hipMemcpyDeviceToHost, s));
         }
         c->frame_pending = true;
+        c->frame_gen = c->out_gen;
         c->frame_event = b->ev_ent;      // the end of the stage, not of whatever the caller enqueues behind it before it takes the bytes
     }
     if (b->ev_ent) HIPCHK(c0, hipEventRecord(b->ev_ent, s));
