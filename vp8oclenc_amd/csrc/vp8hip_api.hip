@@ -1347,6 +1347,15 @@ static void lf_check(vp8hip_ctx *c, LfCheck &k) {
     c->verdict_pending = true;
 }
 
+// With the reference's default target of -1 no macroblock can lie below it -- a macroblock's SSIM is a product of a factor in (0, 1]
+// and one that is > -1 by 2 c2 / (sum of variances + c2), four hundred float steps at the least -- so k_mb never raises the flag and
+// the fallback's launch would leave at once: it is not made.  A launch that does nothing still holds its stream for as long as its
+// workgroups wait for a place on the full chip: 4 % of the headline (VP8HIP_ALWAYS_LAUNCH_FALLBACK=1 for same-box A/B runs).
+static bool fallback_possible(float ssim_target) {
+    static const bool always = [] { const char *v = getenv("VP8HIP_ALWAYS_LAUNCH_FALLBACK"); return v && v[0] == '1'; }();
+    return always || ssim_target > -1.0f;
+}
+
 int vp8hip_check_ssim_async(vp8hip_ctx *c, const int32_t refqi[4], int qi_min) {
     USE_DEVICE(c);
     JOIN_LF(c);
@@ -1354,7 +1363,7 @@ int vp8hip_check_ssim_async(vp8hip_ctx *c, const int32_t refqi[4], int qi_min) {
     if (!c->recon_ready || c->recon < 0 || c->cur_count == 0 || c->verdict_pending || c->chk_armed) return VP8HIP_ERR_STATE;
     CheckItem it;
     check_item(c, it, refqi, qi_min);
-    {
+    if (fallback_possible(c->ssim_target)) {
         Timed t(c, VP8HIP_K_INTRA);
         launch_check_fallback(c->stream, &it, 1, c->ssim_target, c->mbw, c->mbh, c->conformant);
     }
@@ -1378,7 +1387,7 @@ int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int3
         check_item(b->c[i], it[n++], refqi[i], qi_min);
     }
     if (!n) return VP8HIP_OK;
-    {
+    if (fallback_possible(c0->ssim_target)) {
         Timed t(c0, VP8HIP_K_INTRA);
         launch_check_fallback(b->stream, it, n, c0->ssim_target, c0->mbw, c0->mbh, c0->conformant);
     }
