@@ -36,3 +36,14 @@ def reference_stages():
     if st is None:
         pytest.skip("oracle/_ref/libvp8ref.so not built (needs /root/reference)")
     return st
+
+
+def pytest_collection_modifyitems(config, items):
+    """The tests that run bench.py as a CHILD process go first: a process keeps every hardware queue it ever used, and behind two
+    hundred in-process GPU tests the parent holds enough of them that parent + child pass the 24 queues at which the part's
+    scheduler starts context-switching running waves (seen in whole-suite runs only: the child's loop filter counted switched
+    waves once, and once the child died in the runtime with `double free or corruption`; never in 100 stand-alone runs)."""
+    first = [i for i in items if "test_bench_" in i.nodeid or "gather_frames_over_rccl" in i.nodeid]
+    if first:
+        rest = [i for i in items if i not in first]
+        items[:] = first + rest
