@@ -582,15 +582,29 @@ __device__ __forceinline__ bool super_slice(const Plan *plan, int P, uint32_t su
     return false;
 }
 
-// A workgroup takes a super-chunk: one wave per chunk runs it from each possible start range -- two per lane, two
-// independent dependency chains that the scheduler interleaves (a lone chain leaves every other issue slot of its
-// SIMD empty) -- then 128 lanes compose the eight chunk maps into the super-chunk's map, which is what the serial walk
-// steps through.
+// A workgroup takes a super-chunk.  Running a chunk from each of the 128 possible start ranges was three fifths of the whole
+// entropy stage's instructions -- and most of it redundant: ranges that start apart fall together (a bool that comes out the
+// unlikely way leaves a handful of values), on coded frames 16 distinct ranges are left after 32 bools, 11 after 64, but hardly
+// ever ONE before the chunk ends.  So:
+//   1. one wave per chunk runs the first MAPS_HEAD bools from all 128 start ranges (two chains per lane, the bools wave-uniform in
+//      scalar registers: seven vector instructions per bool and chain);
+//   2. the ranges reached are counted and numbered (a 128-bit mark per chunk, ranks by popcount);
+//   3. the REST of every chunk is run once per distinct range, one (chunk, range) task per lane, the tasks of the eight chunks
+//      packed into as few waves as they need (typically two or three instead of eight; the bools per lane from LDS);
+//   4. a start range's entry = its head's shifts + the tail of the range its head reached; then 128 lanes compose the eight chunk
+//      maps into the super-chunk's map, which is what the serial walk steps through.
+// 3 584 -> about 1 300 vector instructions per chunk (the kernel alone on a 1080p frame: 45.8 -> 19.1 us, 3.4 M wave instructions);
+// the maps are the same numbers (byte-exact partitions, tests/test_gpu_entropy.py).
 constexpr int MAPS_THREADS = SUP * 64;
+constexpr int MAPS_HEAD = 32;   // (frames out on one box, scripts/ab_build_bitstream.sh: 8: 51.4-52.1, 16 / 32 / 64: 52.0-52.8, 256 = no tail: 50.6-50.8 M MB/s)
 __global__ __launch_bounds__(MAPS_THREADS) void k_ent_maps(CodeJobs jobs) {
     const CodeJob &J = jobs.j[blockIdx.y];
     __shared__ __attribute__((aligned(16))) uint16_t s_b[SUP][CHUNK];
     __shared__ uint32_t s_m[SUP][128];
+    __shared__ uint32_t s_tail[SUP][128];    // [chunk][rank of the range after the head] -> end range | tail shifts << 8
+    __shared__ uint8_t s_list[SUP][128];     // [chunk][rank] -> that range
+    __shared__ unsigned long long s_mark[SUP][2];
+    __shared__ int s_d[SUP + 1], s_n[SUP];   // distinct ranges per chunk (prefix sums), bools per chunk
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     __shared__ Plan s_plan;   // consulted several times per super-chunk: from LDS, not through chains of dependent global loads
     for (int i = tid; i < (int)(sizeof(Plan) / 4); i += MAPS_THREADS) reinterpret_cast<uint32_t *>(&s_plan)[i] = reinterpret_cast<const uint32_t *>(J.plan)[i];
@@ -607,14 +621,16 @@ __global__ __launch_bounds__(MAPS_THREADS) void k_ent_maps(CodeJobs jobs) {
             n = (int)(end - b0 < (uint32_t)CHUNK ? end - b0 : (uint32_t)CHUNK);
             for (int i = l; i < n; i += 64) s_b[w][i] = J.bools[b0 + i];
         }
+        if (l == 0) s_n[w] = n;
         __syncthreads();
+        // ---- 1: the head from every start range -------------------------------------------------------------------------
+        uint32_t r0 = 128u + l, r1 = 192u + l, Z0 = 0, Z1 = 0;
+        const int head = n < MAPS_HEAD ? n : MAPS_HEAD;
         if (w < nc) {
-            // every lane steps through the SAME bools: probability, its bias and the bit are wave-uniform and live in scalar
-            // registers (readfirstlane), which leaves seven vector instructions per bool and chain
-            uint32_t r0 = 128u + l, r1 = 192u + l, Z0 = 0, Z1 = 0;
+            // every lane steps through the SAME bools: probability, its bias and the bit are wave-uniform and live in scalar registers
             const uint4 *row = reinterpret_cast<const uint4 *>(&s_b[w][0]);   // eight bools per LDS read
             int i = 0;
-            for (; i + 8 <= n; i += 8) {
+            for (; i + 8 <= head; i += 8) {
                 const uint4 q = row[i >> 3];
                 const uint32_t e8[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)q.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y),
                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w)};
@@ -625,13 +641,69 @@ __global__ __launch_bounds__(MAPS_THREADS) void k_ent_maps(CodeJobs jobs) {
                     Z1 += range_step_z(r1, pr, bias, bit);
                 }
             }
-            for (; i < n; ++i) {
+            for (; i < head; ++i) {
                 const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_b[w][i]), pr = e & 255u, bias = 256u - pr, bit = e >> 8;
                 Z0 += range_step_z(r0, pr, bias, bit);
                 Z1 += range_step_z(r1, pr, bias, bit);
             }
-            const uint32_t S0 = Z0 - 24u * (uint32_t)n, S1 = Z1 - 24u * (uint32_t)n;
-            const uint32_t e0 = r0 | (S0 << 8), e1 = r1 | (S1 << 8);
+        }
+        // ---- 2: the ranges the heads reached, numbered ---------------------------------------------------------------------
+        if (l < 2) s_mark[w][l] = 0ull;
+        __syncthreads();
+        if (w < nc) {
+            atomicOr(&s_mark[w][(r0 - 128u) >> 6], 1ull << ((r0 - 128u) & 63u));
+            atomicOr(&s_mark[w][(r1 - 128u) >> 6], 1ull << ((r1 - 128u) & 63u));
+        }
+        __syncthreads();
+        const unsigned long long m0 = s_mark[w][0], m1 = s_mark[w][1];
+        const int d0 = __popcll(m0), dw = w < nc ? d0 + __popcll(m1) : 0;
+        if (w < nc) {   // lane l owns the values 128 + l and 192 + l: if reached, they go into the list at their rank
+            const unsigned long long below = (1ull << l) - 1ull;
+            if ((m0 >> l) & 1ull) s_list[w][__popcll(m0 & below)] = (uint8_t)(128 + l);
+            if ((m1 >> l) & 1ull) s_list[w][d0 + __popcll(m1 & below)] = (uint8_t)(192 + l);
+        }
+        if (l == 0) s_d[w + 1] = dw;
+        __syncthreads();
+        if (tid == 0) {
+            s_d[0] = 0;
+            for (int k = 0; k < SUP; ++k) s_d[k + 1] += s_d[k];
+        }
+        __syncthreads();
+        // ---- 3: the rest of each chunk once per distinct range, (chunk, range) tasks packed over the workgroup --------------------
+        const int T = s_d[SUP];
+        for (int t = tid; t < T; t += MAPS_THREADS) {
+            int cw = 0;
+#pragma unroll
+            for (int k = 1; k < SUP; ++k) cw += t >= s_d[k] ? 1 : 0;
+            const int j = t - s_d[cw], nn = s_n[cw];
+            uint32_t r = s_list[cw][j], Z = 0;
+            const int h = nn < MAPS_HEAD ? nn : MAPS_HEAD;
+            const uint16_t *bw = &s_b[cw][0];
+            int i = h;
+            for (; i + 8 <= nn; i += 8) {      // (h is a multiple of 8 unless the chunk ends inside the head: then there is no rest)
+                const uint4 q = *reinterpret_cast<const uint4 *>(bw + i);
+                const uint32_t e8[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t e = (e8[k >> 1] >> (16 * (k & 1))) & 0xffffu, pr = e & 255u;
+                    Z += range_step_z(r, pr, 256u - pr, e >> 8);
+                }
+            }
+            for (; i < nn; ++i) {
+                const uint32_t e = bw[i], pr = e & 255u;
+                Z += range_step_z(r, pr, 256u - pr, e >> 8);
+            }
+            s_tail[cw][j] = r | ((Z - 24u * (uint32_t)(nn - h)) << 8);
+        }
+        __syncthreads();
+        // ---- 4: head + tail per start range; the super-chunk's map ---------------------------------------------------------------
+        if (w < nc) {
+            const uint32_t x0 = r0 - 128u, x1 = r1 - 128u;
+            const int k0 = x0 < 64u ? __popcll(m0 & ((1ull << x0) - 1ull)) : d0 + __popcll(m1 & ((1ull << (x0 - 64u)) - 1ull));
+            const int k1 = x1 < 64u ? __popcll(m0 & ((1ull << x1) - 1ull)) : d0 + __popcll(m1 & ((1ull << (x1 - 64u)) - 1ull));
+            const uint32_t t0 = s_tail[w][k0], t1 = s_tail[w][k1];
+            const uint32_t S0 = Z0 - 24u * (uint32_t)head + (t0 >> 8), S1 = Z1 - 24u * (uint32_t)head + (t1 >> 8);
+            const uint32_t e0 = (t0 & 255u) | (S0 << 8), e1 = (t1 & 255u) | (S1 << 8);
             J.maps[(size_t)(c0 + w) * 128 + l] = e0;
             J.maps[(size_t)(c0 + w) * 128 + 64 + l] = e1;
             s_m[w][l] = e0;
