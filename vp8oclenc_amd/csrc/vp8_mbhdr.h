@@ -109,37 +109,54 @@ template <class View>
 VP8_HD Near near_mvs(const View &v, int mb) {
     const int mbw = v.mbw();
     const int row = mb / mbw, col = mb % mbw;
-    const int nb[3] = {row > 0 ? mb - mbw : -1, col > 0 ? mb - 1 : -1, row > 0 && col > 0 ? mb - mbw - 1 : -1};
-    Mv list[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    int cnt[4] = {0, 0, 0, 0};
+    // (the list of up to three distinct vectors and the four counts live in NAMED variables picked by selects: as arrays indexed by
+    // the running k they were 32 bytes of scratch memory per lane on the device, a dozen round trips per macroblock)
+    Mv l0{0, 0}, l1{0, 0}, l2{0, 0}, l3{0, 0};
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     int k = 0;   // index of the last distinct vector found
     int split = 0;
-    for (int n = 0; n < 3; ++n) {
-        if (nb[n] < 0 || !v.inter(nb[n])) continue;
-        const int weight = n == 2 ? 1 : 2;
-        const Mv m = v.vec(nb[n], 3);
-        split += (v.parts(nb[n]) != 0) * weight;
-        if (m.zero()) {
-            cnt[n == 0 ? k : 0] += weight;   // the first neighbour adds to the current slot (slot 0 then), the others to slot 0
-            continue;
-        }
-        if (n == 0 || m != list[k]) {
-            ++k;
-            list[k] = m;
-        }
-        cnt[k] += weight;
+#define VP8_NEAR_STEP(N, NBEXPR, WEIGHT)                                                            \
+    {                                                                                              \
+        const int nbn = (NBEXPR);                                                                  \
+        if (nbn >= 0 && v.inter(nbn)) {                                                            \
+            const Mv m = v.vec(nbn, 3);                                                            \
+            split += (v.parts(nbn) != 0) * (WEIGHT);                                               \
+            const Mv lk = k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));                        \
+            int slot;                                                                              \
+            if (m.zero()) {                                                                        \
+                slot = (N) == 0 ? k : 0;   /* the first neighbour adds to the current slot (slot 0 then), the others to slot 0 */ \
+            } else {                                                                               \
+                if ((N) == 0 || m != lk) {                                                         \
+                    ++k;                                                                           \
+                    if (k == 1) l1 = m; else if (k == 2) l2 = m; else l3 = m;                      \
+                }                                                                                  \
+                slot = k;                                                                          \
+            }                                                                                      \
+            c0 += slot == 0 ? (WEIGHT) : 0;                                                        \
+            c1 += slot == 1 ? (WEIGHT) : 0;                                                        \
+            c2 += slot == 2 ? (WEIGHT) : 0;                                                        \
+            c3 += slot == 3 ? (WEIGHT) : 0;                                                        \
+        }                                                                                          \
     }
-    cnt[1] += cnt[3] & (list[k] == list[1] ? 1 : 0);   // three distinct vectors: merge above-left into nearest if equal
-    cnt[3] = split;
-    if (cnt[2] > cnt[1]) {
-        const int t = cnt[1]; cnt[1] = cnt[2]; cnt[2] = t;
-        const Mv m = list[1]; list[1] = list[2]; list[2] = m;
+    VP8_NEAR_STEP(0, row > 0 ? mb - mbw : -1, 2)
+    VP8_NEAR_STEP(1, col > 0 ? mb - 1 : -1, 2)
+    VP8_NEAR_STEP(2, (row > 0 && col > 0) ? mb - mbw - 1 : -1, 1)
+#undef VP8_NEAR_STEP
+    const Mv lk = k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));
+    c1 += c3 & (lk == l1 ? 1 : 0);   // three distinct vectors: merge above-left into nearest if equal
+    c3 = split;
+    if (c2 > c1) {
+        const int t = c1; c1 = c2; c2 = t;
+        const Mv m = l1; l1 = l2; l2 = m;
     }
     Near r;
-    r.best = cnt[1] >= cnt[0] ? list[1] : list[0];
-    r.nearest = list[1];
-    r.near = list[2];
-    for (int i = 0; i < 4; ++i) r.p[i] = P_MODE_CONTEXTS[cnt[i]][i];
+    r.best = c1 >= c0 ? l1 : l0;
+    r.nearest = l1;
+    r.near = l2;
+    r.p[0] = P_MODE_CONTEXTS[c0][0];
+    r.p[1] = P_MODE_CONTEXTS[c1][1];
+    r.p[2] = P_MODE_CONTEXTS[c2][2];
+    r.p[3] = P_MODE_CONTEXTS[c3][3];
     return r;
 }
 
