@@ -130,7 +130,8 @@ int vp8hip_intra_transform(vp8hip_ctx *ctx);
 int vp8hip_check_ssim(vp8hip_ctx *ctx, int32_t *replaced, float *new_ssim, float *min_ssim);
 /* The same without the host in the middle -- what a frame loop at thousands of frames per second needs.  The call enqueues
  * check_SSIM's fallback (a launch whose workgroups leave at once unless the transform has flagged a macroblock below the
- * target; it also renews the filter mask and non-zero count of what it replaces: no vp8hip_prepare_filter_mask needed) and
+ * target -- not made at all when the context's target is -1 or lower, which no macroblock's SSIM can lie below; it also renews
+ * the filter mask and non-zero count of what it replaces: no vp8hip_prepare_filter_mask needed) and
  * arms the NEXT vp8hip_loop_filter / vp8hip_batch_loop_filter call, whose launch then carries the rest: every band of the
  * filter takes the frame's minimum SSIM and, above 0.95, filters with the segment data `prepare_segments_data(1, 7)` gives
  * (:260-261; from the strength pair vp8hip_auto_segments left on the device, so the frame's segment data must come from that
