@@ -677,6 +677,12 @@ def main():
         env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
         if not env["VP8_BENCH_CHILD"]:
             env.pop("VP8_BENCH_CHILD")
+        # Under torchrun the ranks inherit TORCHELASTIC_USE_AGENT_STORE: init_process_group then CONNECTS to the launcher's store at
+        # MASTER_PORT instead of making one -- and at MASTER_PORT + 1, where the children meet, nobody listens (found by running the
+        # driver's multi-GPU command with one rank: the children sat in the rendezvous until the time-out).  The children are a
+        # group of their own: rank 0's child makes the store.
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)
         argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs"]
         # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
         child_out, child_rc = b"", None

@@ -193,6 +193,21 @@ def test_bench_launcher_starts_its_own_ranks():
     assert abs(a["value"] - b["value"]) / a["value"] < 0.25, (a["value"], b["value"])
 
 
+def test_bench_under_torchrun_runs_its_child_legs():
+    """The driver's multi-GPU command, with one rank: `python -m torch.distributed.run ... bench.py --gpus N`.  The ranks inherit the
+    launcher's TORCHELASTIC_* variables, with which a process group CONNECTS to the launcher's store instead of making one -- the
+    child processes of the one- and two-video legs, which meet at MASTER_PORT + 1, once sat in that rendezvous until their time-out."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29557", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, VP8_BENCH_CHILD_TIMEOUT="300"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "few_stream_legs_error" not in d, d["few_stream_legs_error"]
+    assert d["config5_literal"]["frames"] == 300 and d["ref_shard"]["value"] > 0 and d["single_stream"]["ms_per_frame"] > 0
+
+
 def test_bench_last_only_config():
     d = _bench("--refs", "last", "--width", "1280", "--height", "720")
     assert d["config"]["refs_per_frame"] == 1.0 and d["config"]["macroblocks_per_frame"] == 3600
