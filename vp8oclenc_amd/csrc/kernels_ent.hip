@@ -28,6 +28,31 @@ __device__ __constant__ const uint8_t k_path_bits[12] = {   // branch bits, LSB 
     0x01, 0x03, 0x07, 0x17, 0x37, 0x0f, 0x2f, 0x1f, 0x5f, 0x3f, 0x7f, 0x00};
 __device__ __constant__ const uint8_t k_path_len[12] = {2, 3, 5, 6, 6, 6, 6, 7, 7, 7, 7, 1};
 __device__ __constant__ const uint8_t k_band[16] = {0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7};   // :200
+// extra-bit categories (src/CPU_kernels.cl:194-199)
+__device__ __constant__ const int k_cat_base[6] = {5, 7, 11, 19, 35, 67};
+__device__ __constant__ const int k_cat_bits[6] = {1, 2, 3, 4, 5, 11};
+__device__ __constant__ const uint8_t k_cat_prob[6][11] = {
+    {159}, {165, 145}, {173, 148, 140}, {176, 155, 140, 135}, {180, 157, 141, 134, 130},
+    {254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129}};
+
+// The token tables in LDS, one 64-bit entry per token: path nodes (bits 0-27), branch bits (32-39), path length (40-43), extra
+// bits (44-47) and base (48-54) of the categories.  As arrays in constant memory every lookup was a vector load from the cache
+// hierarchy on the walk's serial chain -- k_fe_emit alone held 154 of them behind 205 waits; a workgroup copies them once.
+struct WalkTab {
+    unsigned long long tok[12];
+    uint8_t catp[6][12];
+};
+__device__ __forceinline__ void walk_tab_fill(WalkTab &T) {   // by the first 84 threads of a workgroup; the caller synchronises
+    const int t = threadIdx.x;
+    if (t < 12) {
+        unsigned long long e = (unsigned long long)k_path_nodes[t] | ((unsigned long long)k_path_bits[t] << 32) | ((unsigned long long)k_path_len[t] << 40);
+        if (t >= T_CAT1 && t < T_EOB) e |= ((unsigned long long)k_cat_bits[t - T_CAT1] << 44) | ((unsigned long long)k_cat_base[t - T_CAT1] << 48);
+        T.tok[t] = e;
+    } else if (t < 12 + 72) {
+        const int i = t - 12, c = i / 12, j = i % 12;
+        T.catp[c][j] = j < 11 ? k_cat_prob[c][j] : 0;
+    }
+}
 
 __device__ __forceinline__ int classify(int mag) {   // tokenize_block, :263-345
     return mag <= 4 ? mag : (mag <= 6 ? T_CAT1 : (mag <= 10 ? T_CAT2 : (mag <= 18 ? T_CAT3 : (mag <= 34 ? T_CAT4 : (mag <= 66 ? T_CAT5 : T_CAT6)))));
@@ -99,6 +124,8 @@ struct CountItem {
 __device__ __forceinline__ void count_body(int mb_row, int quarter, const int16_t *coeffs, const int32_t *nzc, const int32_t *parts,
                                            const uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, int mbw) {
     __shared__ uint32_t s_h[NCTX * 2];
+    __shared__ WalkTab s_tab;
+    walk_tab_fill(s_tab);
     for (int i = threadIdx.x; i < NCTX * 2; i += 256) s_h[i] = 0;
     __syncthreads();
     const int per = (mbw * 25 + CNT_SPLIT - 1) / CNT_SPLIT, i0 = quarter * per;
@@ -127,8 +154,9 @@ __device__ __forceinline__ void count_body(int mb_row, int quarter, const int16_
                 if (i < first) continue;
                 const int c = (int16_t)(w[i >> 1] >> (16 * (i & 1)));
                 const int t = i > last ? T_EOB : classify(c < 0 ? -c : c);   // every position past the end is an EOB, counted too
-                const uint32_t nodes = k_path_nodes[t];
-                const int bits = k_path_bits[t], len = k_path_len[t];
+                const unsigned long long e = s_tab.tok[t];
+                const uint32_t nodes = (uint32_t)e;
+                const int bits = (int)(e >> 32) & 255, len = (int)(e >> 40) & 15;
                 const int base = ((ctx1 * 8 + k_band[i]) * 3 + ctx3) * 11;
                 for (int s = after_zero ? 1 : 0; s < len; ++s) {   // after a ZERO the first branch is implied
                     const int at = (base + ((nodes >> (4 * s)) & 15)) * 2;
@@ -221,11 +249,7 @@ namespace ent {
 constexpr int CHUNK = 256;        // bools per chunk
 constexpr int SCAN_TILE = 1024;   // slots per scan tile (256 threads x 4)
 
-__device__ __constant__ const int k_cat_base[6] = {5, 7, 11, 19, 35, 67};
-__device__ __constant__ const int k_cat_bits[6] = {1, 2, 3, 4, 5, 11};
-__device__ __constant__ const uint8_t k_cat_prob[6][11] = {   // :194-199
-    {159}, {165, 145}, {173, 148, 140}, {176, 155, 140, 135}, {180, 157, 141, 134, 130},
-    {254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129}};
+
 
 struct Geom {
     int mbw, mbh, P;
@@ -242,8 +266,21 @@ __device__ __forceinline__ int block_of_k(int k) { return k == 0 ? 24 : k - 1; }
 
 // the bools of one block in coding order (encode_block, :202-261): ctx(index into coeff_probs, bit) for tree
 // branches, lit(probability, bit) for extra bits and signs
-template <class Sink>
-__device__ __forceinline__ void walk_block(const int16_t *blk, int ctx1, int ctx3, Sink &sink) {
+struct ConstTab {   // the step-by-step kernels: straight from constant memory
+    __device__ __forceinline__ unsigned long long tok(int t) const {
+        unsigned long long e = (unsigned long long)k_path_nodes[t] | ((unsigned long long)k_path_bits[t] << 32) | ((unsigned long long)k_path_len[t] << 40);
+        if (t >= T_CAT1 && t < T_EOB) e |= ((unsigned long long)k_cat_bits[t - T_CAT1] << 44) | ((unsigned long long)k_cat_base[t - T_CAT1] << 48);
+        return e;
+    }
+    __device__ __forceinline__ int catp(int c, int j) const { return k_cat_prob[c][j]; }
+};
+struct LdsTab {     // the frame path: the workgroup's copy
+    const WalkTab &T;
+    __device__ __forceinline__ unsigned long long tok(int t) const { return T.tok[t]; }
+    __device__ __forceinline__ int catp(int c, int j) const { return T.catp[c][j]; }
+};
+template <class Sink, class Tab = ConstTab>
+__device__ __forceinline__ void walk_block(const int16_t *blk, int ctx1, int ctx3, Sink &sink, const Tab tab = Tab()) {
     const uint4 *p = reinterpret_cast<const uint4 *>(blk);
     const uint4 q0 = p[0], q1 = p[1];
     const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -261,14 +298,15 @@ __device__ __forceinline__ void walk_block(const int16_t *blk, int ctx1, int ctx
         const int c = (int16_t)(w[i >> 1] >> (16 * (i & 1)));
         const int mag = c < 0 ? -c : c;
         const int t = i > last ? T_EOB : classify(mag);
-        const uint32_t nodes = k_path_nodes[t];
-        const int bits = k_path_bits[t], len = k_path_len[t];
+        const unsigned long long e = tab.tok(t);
+        const uint32_t nodes = (uint32_t)e;
+        const int bits = (int)(e >> 32) & 255, len = (int)(e >> 40) & 15;
         const int base = ((ctx1 * 8 + k_band[i]) * 3 + ctx3) * 11;
         for (int s = after_zero ? 1 : 0; s < len; ++s) sink.ctx(base + ((nodes >> (4 * s)) & 15), (bits >> s) & 1);
         if (t == T_EOB) break;
         if (t >= T_CAT1) {
-            const int cat = t - T_CAT1, nb = k_cat_bits[cat], extra = mag - k_cat_base[cat];
-            for (int j = 0; j < nb; ++j) sink.lit(k_cat_prob[cat][j], (extra >> (nb - 1 - j)) & 1);
+            const int cat = t - T_CAT1, nb = (int)(e >> 44) & 15, extra = mag - ((int)(e >> 48) & 127);
+            for (int j = 0; j < nb; ++j) sink.lit(tab.catp(cat, j), (extra >> (nb - 1 - j)) & 1);
         }
         if (t != T_ZERO) sink.lit(128, c < 0);
         after_zero = t == T_ZERO;
@@ -285,6 +323,12 @@ struct EmitSink {
     uint16_t *out;
     const uint32_t *probs;
     __device__ __forceinline__ void ctx(int idx, int bit) { *out++ = (uint16_t)((probs[idx] & 255u) | (bit << 8)); }
+    __device__ __forceinline__ void lit(int prob, int bit) { *out++ = (uint16_t)(prob | (bit << 8)); }
+};
+struct EmitSinkLds {   // the frame path: the 1 056 probabilities as bytes in LDS
+    uint16_t *out;
+    const uint8_t *probs8;
+    __device__ __forceinline__ void ctx(int idx, int bit) { *out++ = (uint16_t)(probs8[idx] | (bit << 8)); }
     __device__ __forceinline__ void lit(int prob, int bit) { *out++ = (uint16_t)(prob | (bit << 8)); }
 };
 
@@ -435,13 +479,16 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *s_w, uint32
 __device__ __forceinline__ void boolcount_slots_body(int vb, const int16_t *coeffs, const int32_t *nzc, const int32_t *parts, const Geom &g,
                                                      uint32_t *cnt, uint32_t *tile_sum) {
     __shared__ uint32_t s_w[4];
+    __shared__ WalkTab s_tab;
+    walk_tab_fill(s_tab);
+    __syncthreads();
     const uint32_t s = (uint32_t)vb * 256u + threadIdx.x;
     int mb, k;
     CountSink sink;
     if (slot_to_block(g, s, mb, k)) {
         bool has_y2;
         const int b = block_of_k(k);
-        if (slot_live(nzc, parts, mb, k, has_y2)) walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), 0, sink);
+        if (slot_live(nzc, parts, mb, k, has_y2)) walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), 0, sink, LdsTab{s_tab});
         cnt[s] = sink.n;
     }
     uint32_t total;
@@ -499,8 +546,12 @@ __device__ __forceinline__ void emit_slots_body(int vb, int nvb, const int16_t *
                                                 const uint32_t *tile_pre, const Plan *plan, const Geom &g, uint16_t *bools,
                                                 unsigned long long *acc) {
     __shared__ uint32_t s_w[4];
+    __shared__ WalkTab s_tab;
+    __shared__ uint8_t s_probs[NCTX];
     for (uint32_t i = (uint32_t)vb * 256u + threadIdx.x, n = plan->word_base[g.P]; i < n; i += (uint32_t)nvb * 256u) acc[i] = 0ull;   // the coder's accumulators
     if (plan->overflow) return;
+    walk_tab_fill(s_tab);
+    for (int i = threadIdx.x; i < NCTX; i += 256) s_probs[i] = (uint8_t)probs[i];   // (read below behind wg_scan256's barriers)
     const uint32_t s = (uint32_t)vb * 256u + threadIdx.x;
     int mb = 0, k = 0;
     const bool valid = slot_to_block(g, s, mb, k);
@@ -510,8 +561,8 @@ __device__ __forceinline__ void emit_slots_body(int vb, int nvb, const int16_t *
     if (!n) return;   // dead slot (a live one has at least its end-of-block)
     const int b = block_of_k(k);
     const bool has_y2 = parts[mb] == 0;
-    EmitSink sink{bools + off, probs};
-    walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), third_ctx[mb * 25 + b], sink);
+    EmitSinkLds sink{bools + off, s_probs};
+    walk_block(coeffs + ((size_t)mb * 25 + b) * 16, plane_ctx(b, has_y2), third_ctx[mb * 25 + b], sink, LdsTab{s_tab});
 }
 
 // chunk -> its partition and its slice of the bool string
