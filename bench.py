@@ -663,7 +663,9 @@ def main():
     leg.profile([])
     # ---- side legs: reported next to the headline value, never as it ---------------------------------------------
     if rank == 0 and world == 1 and not args.no_side_legs:
-        out["with_bitstream"] = bitstream_leg(torch, leg, max(16, args.steps))
+        # (at least 40 frames per chunk: the leg starts from an idle part with its threads 200 us apart, and over 20 frames that start
+        # is 3 % of the rate -- 52.9 against 54.3 M MB/s at 40 and 54.8 at 120 on one box)
+        out["with_bitstream"] = bitstream_leg(torch, leg, max(40, args.steps))
     host_frames = leg.host_frames
     leg.close()
     if args.only_bitstream:
