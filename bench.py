@@ -20,9 +20,11 @@ Prints ONE JSON line on rank 0 with, besides the contract's fields,
   cpu_baseline   the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload, and the reference's own
                  kernels compiled for x86 on one core                                                   (N = 1 only)
   with_bitstream the same frames with finished VP8 frames delivered to host memory                     (N = 1 only)
-  other_configs  720p LAST-only (configs[1]), 4K 3-ref (configs[3]), 1080p SSIM target 0.93, -g 150, conformant stream (N = 1 only)
-The legs that are ONE or TWO videos coded frame after frame run in a child process per rank (--child-legs; a process keeps every
-hardware queue it ever used):
+The legs that are ONE or TWO videos coded frame after frame, and the other geometries, run in a child process per rank (--child-legs;
+a process keeps every hardware queue it ever used; and a leg that dies -- destroying dozens of contexts has, rarely,
+ended a process inside the runtime -- takes only itself along: the child hands every finished leg over at once, the parent keeps
+the headline's contexts until the line is out and leaves without tearing anything down):
+  other_configs                 720p LAST-only (configs[1]), 4K 3-ref (configs[3]), 1080p SSIM target 0.93, -g 150, conformant stream (N = 1 only)
   solo_kernels, single_stream   every kernel alone / one chunk, frame after frame: MB/s and ms per frame   (N = 1 only)
   config3_literal               configs[2] as written: 300 frames, -g 150, two chunks, every frame counted (N = 1 only)
   config5_literal               configs[4] per rank: one 300-frame GOP with frames out (the next frame started before this one's
@@ -422,10 +424,16 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
     return out
 
 
-def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier):
-    """config5_literal (every N), ref_shard, and at N = 1 config3_literal and single_stream: legs that are one or two videos coded
-    frame after frame.  Run in a fresh process (see main()).  Returns the dict for the JSON line on rank 0."""
-    out = {}
+def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emit=None):
+    """config5_literal (every N), ref_shard, and at N = 1 config3_literal, single_stream and other_configs: the legs that are one or two
+    videos coded frame after frame, and the other geometries.  Run in a fresh process (see main()).  Returns the dict for the JSON line
+    on rank 0; `emit` (if given) is also handed every finished leg at once, so that a leg that dies takes only itself along."""
+    class _Out(dict):
+        def __setitem__(self, k, v):
+            dict.__setitem__(self, k, v)
+            if emit is not None:
+                emit({k: v})
+    out = _Out()
     if rank == 0:
         # every kernel of the path ALONE on the part: one chunk, one stream, nothing beside it, each launch timed by its own dispatch
         # (HIP events) -- the launch durations the roofline fractions are made of (with 48 chunks in flight a launch shares the part)
@@ -447,8 +455,9 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier):
                                   "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
                                   "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
         s1 = max(200, args.steps)
-        out["single_stream"] = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
-        out["single_stream"]["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
+        ss = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
+        ss["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
+        out["single_stream"] = ss
     if True:
         # BASELINE configs[4] as it is written, at every N: 300 frames per GPU = ONE closed GOP of 300 frames on each rank (2400 / 8),
         # coded end to end from its key frame with finished VP8 frames out, the frames gathered to rank 0 over RCCL in frame order
@@ -483,7 +492,24 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier):
         rs = ref_shard_leg(torch, api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
         if rank == 0 and rs is not None:
             out["ref_shard"] = rs
-    return out
+    if rank == 0 and world == 1 and not args.only_bitstream:
+        G, B = max(1, args.gops_per_gpu), max(1, min(8, args.batch))
+        oc = {}
+        for name, leg_args, kw in (
+                # 4K: sixteen chunks in eight batches of two (same-box: in batches of 4 55.0, of 2 59.7); 720p: batches of four
+                # (48 chunks: twelve streams 102.8, eight streams 98.0)
+                ("720p_last_only", (1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5), dict(batch=min(B, 4))),
+                ("4k_3refs", (3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3), dict(batch=min(B, 2))),
+                ("1080p_ssim93", (1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5), dict(batch=B)),
+                # the reference's default GOP of 150: key frames (a raster-order wavefront each, 1.5 ms alone) among the inter frames;
+                # value counts every frame
+                ("1080p_gop150", (1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5), dict(batch=B, gop=150)),
+                # vp8hip_conformant_stream (NOT the reference's bytes: the format's predictor, so that the stream decodes to the
+                # encoder's own reconstruction): what the opt-in costs
+                ("1080p_conformant_stream", (1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5), dict(batch=B, conformant=1))):
+            oc[name] = side_leg(torch, api, *leg_args, local, **kw)
+            out["other_configs"] = dict(oc)      # (handed on after every geometry)
+    return dict(out)
 
 
 def main():
@@ -522,15 +548,16 @@ def main():
 
     nd = max(2, args.distinct_frames)
     if args.child_legs:      # the fresh process of the few-stream side legs: nothing else runs here
-        legs = few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier)
+        def emit(part):      # one line per finished leg: what is done is on its way before the next leg starts
+            if rank == 0:
+                os.write(json_fd, (json.dumps(part) + "\n").encode())
+        few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emit)
         import torch.distributed as td_
         if td_.is_initialized():
             td_.destroy_process_group()
         sys.stdout.flush()
-        if rank == 0:
-            os.write(json_fd, (json.dumps(legs) + "\n").encode())
         os.close(json_fd)
-        return
+        os._exit(0)          # (no interpreter teardown over a process that has created and destroyed hundreds of contexts)
     G = max(1, args.gops_per_gpu)
     B = max(1, min(8, args.batch))   # VP8HIP_MAX_BATCH
     free_before = torch.cuda.mem_get_info(local)[0]
@@ -667,7 +694,8 @@ def main():
         # is 3 % of the rate -- 52.9 against 54.3 M MB/s at 40 and 54.8 at 120 on one box)
         out["with_bitstream"] = bitstream_leg(torch, leg, max(40, args.steps))
     host_frames = leg.host_frames
-    leg.close()
+    # (the headline's contexts stay as they are until the line is out: destroying 48 contexts has, once in some twenty runs of this
+    # program, ended the process inside the runtime -- the side legs run in a child process anyway and the line is what matters)
     if args.only_bitstream:
         args.no_side_legs = True
     if not args.no_side_legs:
@@ -695,10 +723,17 @@ def main():
         except subprocess.TimeoutExpired as e:
             child_out, child_rc = e.stdout or b"", "timeout"
         if rank == 0:
-            try:
-                out.update(json.loads(child_out.decode().strip().splitlines()[-1]))
-            except Exception as e:
-                out["few_stream_legs_error"] = f"child exit {child_rc}: {e!r}"[:300]
+            got = 0
+            for line in child_out.decode(errors="replace").splitlines():      # one line per finished leg
+                try:
+                    part = json.loads(line)
+                except Exception:
+                    continue
+                if isinstance(part, dict):
+                    out.update(part)
+                    got += 1
+            if child_rc != 0 or not got:
+                out["few_stream_legs_error"] = f"child exit {child_rc} after {got} legs"
             sk = out.get("solo_kernels", {}).get("ms_per_launch", {})
             if dominant in sk:      # the roofline fraction from the kernel ALONE on the part, measured in this run (its fresh process)
                 sb = algorithmic_bytes(dominant, W, H, out["solo_kernels"]["refs_per_frame"])
@@ -714,20 +749,6 @@ def main():
                 out["solo_kernels"]["hbm"] = {k: {"algorithmic_bytes": int(algorithmic_bytes(k, W, H, ns)), "achieved_GBs": round(algorithmic_bytes(k, W, H, ns) / (v * 1e-3) / 1e9, 2),
                                                   "frac": round(algorithmic_bytes(k, W, H, ns) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
                                               for k, v in sk.items() if algorithmic_bytes(k, W, H, ns) > 0}
-    if rank == 0 and world == 1 and not args.no_side_legs:
-        out["other_configs"] = {
-            # 4K: sixteen chunks in eight batches of two (same-box: in batches of 4 55.0, of 2 59.7); 720p: batches of four
-            # (48 chunks: twelve streams 102.8, eight streams 98.0)
-            "720p_last_only": side_leg(torch, api, 1280, 720, G, "last", -1.0, max(20, args.steps // 2), 5, local, batch=min(B, 4)),
-            "4k_3refs": side_leg(torch, api, 3840, 2160, min(G, 16), "all", -1.0, max(10, args.steps // 4), 3, local, batch=min(B, 2)),
-            "1080p_ssim93": side_leg(torch, api, 1920, 1080, G, "all", 0.93, max(20, args.steps // 2), 5, local, batch=B),
-            # the reference's default GOP of 150: key frames (a raster-order wavefront each, 1.5 ms alone) among the inter frames;
-            # value counts every frame
-            "1080p_gop150": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, gop=150),
-            # vp8hip_conformant_stream (NOT the reference's bytes: the format's predictor, so that the stream decodes to the
-            # encoder's own reconstruction): what the opt-in costs
-            "1080p_conformant_stream": side_leg(torch, api, 1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5, local, batch=B, conformant=1),
-        }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         os.sched_setaffinity(0, all_cpus)       # the CPU baseline gets every host core again, not the GPU's NUMA node only
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
@@ -738,6 +759,8 @@ def main():
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+    sys.stderr.flush()
+    os._exit(0)              # the line is out: no teardown of the contexts (see above)
 
 
 class _SubGroup:
