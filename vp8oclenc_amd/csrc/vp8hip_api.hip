@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <new>
 
 #include "../../include/vp8hip.h"
@@ -119,7 +121,7 @@ struct vp8hip_ctx {
     hipEvent_t ev[MAX_EVENTS];
     int ev_kernel[MAX_EVENTS / 2];
     int ev_used = 0;
-    bool ev_created = false;
+    int ev_made = 0;                // ev[0 .. ev_made) are taken from the process's pool so far (event_pool_get)
     double prof_ms[VP8HIP_K_COUNT] = {0};
     int64_t prof_n[VP8HIP_K_COUNT] = {0};
 };
@@ -176,12 +178,41 @@ uint8_t *carve_frame(uint8_t *cursor, int W, int H, Frame *f) {
 constexpr uint32_t SINGLE_LAUNCH_STAGES = (1u << VP8HIP_K_PACK) | (1u << VP8HIP_K_DOWNSAMPLE) | (1u << VP8HIP_K_SEARCH1_L4) | (1u << VP8HIP_K_SEARCH1_L3) |
                                           (1u << VP8HIP_K_SEARCH1_L2) | (1u << VP8HIP_K_SEARCH1_L1) | (1u << VP8HIP_K_SEARCH1_L0) | (1u << VP8HIP_K_SEARCH2) |
                                           (1u << VP8HIP_K_MB) | (1u << VP8HIP_K_LOOP_FILTER) | (1u << VP8HIP_K_BORDER);
+// The timing events come from a pool of the process (per device) and go back to it: they are never destroyed.  Every context used
+// to create 4 096 of them and destroy them with itself -- 200 000 per bench leg -- and a process that had TIMED kernels with them
+// (hipExtLaunchKernel's start / stop events) ended inside the runtime in hipEventDestroy once in some twenty legs (segmentation
+// fault or `double free or corruption`; scripts/stress_headline_flow.py: cycle 19 of 40 with events, none in 60 without).
+static std::mutex g_event_mutex;
+static std::vector<hipEvent_t> g_event_pool[64];
+static hipEvent_t event_pool_get(int device) {
+    std::lock_guard<std::mutex> lock(g_event_mutex);
+    std::vector<hipEvent_t> &pool = g_event_pool[device & 63];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+static void event_pool_put(int device, hipEvent_t *ev, int n) {
+    std::lock_guard<std::mutex> lock(g_event_mutex);
+    std::vector<hipEvent_t> &pool = g_event_pool[device & 63];
+    for (int i = 0; i < n; ++i)
+        if (ev[i]) pool.push_back(ev[i]);
+}
+
 struct Timed {
     vp8hip_ctx *c;
     int slot = -1;
     bool by_dispatch = false;
     Timed(vp8hip_ctx *ctx, int kernel) : c(ctx) {
         if (!(c->prof_mask & (1u << kernel)) || c->ev_used + 2 > MAX_EVENTS) return;
+        while (c->ev_made < c->ev_used + 2) {   // taken when first needed: a context that times nothing holds none
+            hipEvent_t e = event_pool_get(c->device);
+            if (!e) return;
+            c->ev[c->ev_made++] = e;
+        }
         slot = c->ev_used;
         c->ev_kernel[slot / 2] = kernel;
         c->ev_used += 2;
@@ -491,8 +522,6 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipMemsetAsync(c->out.vec, 0, (size_t)c->mbs * 16, c->stream));
     CR(hipMemsetAsync(c->out.coeffs, 0, (size_t)c->mbs * 800, c->stream));
     CR(hipMemsetAsync(c->d_sd2[0], 0, 2 * sizeof(SegData), c->stream));
-    for (int i = 0; i < MAX_EVENTS; ++i) CR(hipEventCreate(&c->ev[i]));
-    c->ev_created = true;
     c->recon = 0;
     CR(hipStreamSynchronize(c->stream));
 #undef CR
@@ -524,8 +553,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         }
     }
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->ev_created)
-        for (int i = 0; i < MAX_EVENTS; ++i) hipEventDestroy(c->ev[i]);
+    event_pool_put(c->device, c->ev, c->ev_made);
     hipFree(c->pixel_pool);
     for (int r = 0; r < 3; ++r) {
         hipFree(c->nets.net[r][0]);
