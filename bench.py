@@ -717,7 +717,7 @@ def main():
         # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
         child_out, child_rc = b"", None
         try:
-            child = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+            child = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,   # (a leg that dies says where, on stderr)
                                    timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
             child_out, child_rc = child.stdout, child.returncode
         except subprocess.TimeoutExpired as e:
