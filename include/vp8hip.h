@@ -307,10 +307,11 @@ int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
  * in ONE kernel launch per stage (same kernels, blockIdx.z = member), on one stream that the members share from then on --
  * so a member's own calls (vp8hip_intra_transform for a chunk's key frame, vp8hip_encode_frame, downloads) stay ordered
  * with the batched stages.  Arrays are indexed by member; `active` (may be NULL = all) leaves members out of a stage.
- * A batch has a second, low-priority stream for the head of a frame -- vp8hip_batch_set_current_device,
- * vp8hip_batch_auto_segments and the new frame's pyramid run there, beside the PREVIOUS frame's chain, because none of them
- * depends on the previous frame's reconstruction; the chain that does (LAST's pyramid, the searches, the transform, the
- * loop filter) waits for them where it starts (VP8HIP_BATCH_PREP=0 in the environment keeps everything on one stream).
+ * Everything of a batch runs on that one stream by default.  VP8HIP_BATCH_PREP in the environment (read once per process) gives
+ * the head of a frame -- vp8hip_batch_set_current_device, vp8hip_batch_auto_segments and the new frame's pyramid, none of which
+ * depends on the previous frame's reconstruction -- a second, low-priority stream beside the PREVIOUS frame's chain, which
+ * waits for it where it starts: 1 = a stream per batch, 2 = one stream for all batches.  Off (0) by default: it measured 2-4 %
+ * slower with the part full; vp8hip_batch_prep_mode() reports the mode in force.
  * No reference counterpart: the reference codes one video on one in-order queue set. */
 #define VP8HIP_MAX_BATCH 8
 typedef struct vp8hip_batch vp8hip_batch;
@@ -329,10 +330,36 @@ int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int3
 int vp8hip_batch_encode_frame_begin(vp8hip_batch *b, const int *active, int num_partitions, const vp8hip_header_params *params);
 const char *vp8hip_status_string(int status);
 /* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
- * layout (vp8drv_config grew in round 2: 2), MINOR when entry points are added.  A host built against an older header checks
- * it once after loading the library. */
-#define VP8HIP_ABI_VERSION 2007
+ * layout (vp8drv_config grew in round 2: 2; vp8drv_stats grew by refs_searched and vp8drv_default_config turned check_ssim on
+ * -- return values and counters provisional until vp8drv_resolve -- in round 3: 3), MINOR when entry points are added.  A host
+ * built against an older header checks it once after loading the library. */
+#define VP8HIP_ABI_VERSION 3001
 int vp8hip_abi_version(void);
+/* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
+ * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with
+ * -DVP8HIP_EXPERIMENTS, results are then garbage on purpose); 0 for the shipped build, in which they are constants and no
+ * environment can take work out of a run.  bench.py refuses to print a line from a build that answers 1. */
+int vp8hip_experiments_compiled_in(void);
+/* the head-of-frame stream mode of batches in force in this process: 0 none (default), 1 per batch, 2 one for all (VP8HIP_BATCH_PREP) */
+int vp8hip_batch_prep_mode(void);
+
+/* ---- device memory for a caller that has none of its own ---------------------------------------------------------------
+ * vp8hip_set_current_device / vp8hip_set_last_device / the batched forms take planes that are already in this device's memory.
+ * A host that is not a GPU program itself (the reference's main(), bench.py, the tests) gets such memory here, so that the process
+ * needs no second GPU runtime beside the one this library was built for (PyTorch ships its own copy of the HIP runtime; both in
+ * one process was where a one-in-twenty teardown crash of round 3 lived).  Plain hipMalloc / hipMemcpy / hipDeviceSynchronize
+ * on device_ordinal; the copies block. */
+int vp8hip_device_count(void);
+int vp8hip_device_alloc(int device_ordinal, size_t bytes, void **out);
+int vp8hip_device_free(int device_ordinal, void *p);
+int vp8hip_device_upload(int device_ordinal, void *dst, const void *src, size_t bytes);
+int vp8hip_device_download(int device_ordinal, void *dst, const void *src, size_t bytes);
+int vp8hip_device_synchronize(int device_ordinal);
+int vp8hip_device_mem_info(int device_ordinal, size_t *free_bytes, size_t *total_bytes);
+/* "dddd:bb:dd.f" of the device (for pinning the host threads to its NUMA node); len >= 16 */
+int vp8hip_device_pci_bus_id(int device_ordinal, char *out, int len);
+/* version of the HIP runtime this process's library calls land in (hipRuntimeGetVersion), e.g. 70226015 */
+int vp8hip_runtime_version(void);
 
 /* ---- measurement taps (bench.py / tests; not part of the reference boundary) -------------- */
 typedef enum {

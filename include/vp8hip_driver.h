@@ -38,7 +38,11 @@ typedef struct {
                                 host's -- redo as key frame -- is taken when the verdict is next needed: at the start of the next
                                 vp8drv_encode_frame_* / vp8drv_batch_encode_frame_device, in vp8drv_get_frame[_begin], or in
                                 vp8drv_resolve.  Until then the return value "inter frame" and the counters of vp8drv_get_stats
-                                are provisional.  With device_params == 0 the host sits in the middle, as in the reference.
+                                are provisional.  (A bounded device-side wait of the SAME frame's loop filter that expires is
+                                reported one step later still: the verdict workgroup samples the error word when the filter's
+                                launch starts, so a time-out inside that launch shows in the next verdict or in
+                                vp8hip_synchronize / vp8drv_get_frame, whichever comes first.)  With device_params == 0 the
+                                host sits in the middle, as in the reference.
                                 0: skip it (the reference's loop minus the filter update; kept for A/B runs) */
     int32_t num_partitions;  /* -partitions: 1, 2, 4 or 8 coefficient partitions (init.h:1451-1469, default 1) */
     int32_t display_width, display_height;   /* video.dst_width/height written into key frames; 0 = the coded size */

@@ -274,7 +274,6 @@ def test_gpu_conformant_stream_on_hard_edges(W, H, frames, P, cfg):
 @pytest.mark.gpu
 def test_gpu_conformant_stream_in_a_batch():
     """the batched launch takes the same switch (all members must agree): frames of a batch of two == the single contexts'"""
-    import torch
     from hard_edges import HardEdgeSequence
     from vp8oclenc_amd import api
     seqs = [HardEdgeSequence(320, 192, seed=s) for s in (1, 2)]
@@ -285,7 +284,7 @@ def test_gpu_conformant_stream_in_a_batch():
     batch = api.NativeBatch(members)
     changed = 0
     for t in range(7):
-        dev = [tuple(torch.from_numpy(p).cuda() for p in s.frame(t)) for s in seqs]
+        dev = [tuple(api.to_device(p) for p in s.frame(t)) for s in seqs]
         ptr = [tuple(p.data_ptr() for p in f) for f in dev]
         batch.encode_frame_device(ptr)
         batch.get_frames_begin()
@@ -295,7 +294,7 @@ def test_gpu_conformant_stream_in_a_batch():
             frame = members[i].get_frame_end()
             assert d.get_frame() == frame, (t, i)
             changed += plain[i].get_frame() != frame
-        torch.cuda.synchronize()
+        api.device_synchronize()
     assert changed > 0
     batch.close()
     with pytest.raises(api.Vp8HipError):      # one launch, one predictor

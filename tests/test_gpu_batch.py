@@ -20,7 +20,6 @@ pytestmark = pytest.mark.gpu
                                                      (640, 352, 3, 8, 5, dict(check_ssim=1, qi_min=50, qi_max=110, ssim_target=0.9)),
                                                      (1920, 1080, 3, 4, 150, dict(check_ssim=1, ssim_target=0.93))])
 def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop, extra):
-    import torch
     seqs = [SynthSequence(W, H, seed=40 + i) for i in range(n)]
     Wp, Hp = seqs[0].W, seqs[0].H
     cfg = dict(gop_size=gop, altref_range=3, num_partitions=2, device_params=1, check_ssim=0)
@@ -29,7 +28,7 @@ def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop, e
     # already coded i frames on its own when the batch takes over
     single = [api.NativeDriver(Wp, Hp, **cfg) for _ in range(n)]
     batched = [api.NativeDriver(Wp, Hp, **cfg) for _ in range(n)]
-    dev = [[tuple(torch.from_numpy(p).cuda() for p in s.frame(t)) for t in range(frames + n)] for s in seqs]
+    dev = [[tuple(api.to_device(p) for p in s.frame(t)) for t in range(frames + n)] for s in seqs]
     ptr = [[tuple(p.data_ptr() for p in f) for f in d] for d in dev]
     pos = [0] * n
     for i in range(n):
@@ -74,10 +73,9 @@ def test_batched_chunks_emit_the_frames_of_single_chunks(W, H, n, frames, gop, e
 def test_batches_on_a_host_thread_each_give_the_frames_of_single_chunks():
     """vp8drv_batches_encode_frames_device: N frames on every batch, one native host thread per batch, check_SSIM's verdicts waited for
     inside each thread -- the chunks end where the same chunks end when they are coded one by one"""
-    import torch
     W, H, nd, frames = 320, 192, 6, 9
     seq = SynthSequence(W, H, seed=71)
-    dev = [tuple(torch.from_numpy(p).cuda() for p in seq.frame(t)) for t in range(nd)]
+    dev = [tuple(api.to_device(p) for p in seq.frame(t)) for t in range(nd)]
     ptr = [tuple(p.data_ptr() for p in f) for f in dev]
     cfg = dict(gop_size=5, altref_range=2, num_partitions=2, device_params=1, check_ssim=1, qi_min=40, qi_max=110, ssim_target=0.92)
     starts = [[0, 2, 4], [1, 3, 5]]

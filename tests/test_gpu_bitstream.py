@@ -63,7 +63,6 @@ def test_bitstream_with_intra_fallback_and_scene_cut(host_bitstream):
 
 def test_bitstream_from_device_resident_frames_and_device_parameters():
     """vp8drv_encode_frame_device: planes already in HBM, segment data computed on the device."""
-    import torch
     W, H = 176, 144
     s = SynthSequence(W, H, seed=61)
     drv = api.NativeDriver(W, H, check_ssim=1, device_params=1)
@@ -71,8 +70,8 @@ def test_bitstream_from_device_resident_frames_and_device_parameters():
     do = InterPathDriver(ora, W, H)
     for t in range(4):
         y, u, v = s.frame(t)
-        d = [torch.from_numpy(p).cuda() for p in (y, u, v)]
-        torch.cuda.synchronize()
+        d = [api.to_device(p) for p in (y, u, v)]
+        api.device_synchronize()
         drv.encode_frame_device(*(x.data_ptr() for x in d))
         got = drv.get_frame()
         out = do.encode_frame(y, u, v)
@@ -234,10 +233,9 @@ def test_overlap_three_references_device_frames(frames_out):
     on the device, LAST + GOLDEN + ALTREF.  The context trades streams at every filter (the next frame's pack, parameter scan
     and GOLDEN / ALTREF searches run beside it, the LAST search behind it on the filter's own stream): same frames, same
     reconstructions, with the entropy stage beside the filter or without one."""
-    import torch
     W, H = 640, 352
     s = SynthSequence(W, H, seed=73)
-    dev = [tuple(torch.from_numpy(p).cuda() for p in s.frame(t)) for t in range(16)]
+    dev = [tuple(api.to_device(p) for p in s.frame(t)) for t in range(16)]
     outs = []
     for overlap in (0, 1):
         d = api.NativeDriver(s.W, s.H, num_partitions=4, check_ssim=0, gop_size=150, altref_range=3, device_params=1, overlap_filter=overlap)

@@ -99,7 +99,6 @@ def test_async_check_equals_the_host_driven_sequence(W, H, qi, target, want):
 def test_native_loop_with_async_check_emits_the_oracle_loops_bytes(W, H, qi, target, gop):
     """frames on which the worst macroblock is above 0.95 (low quantizers: the filter update), frames with replaced macroblocks, and
     frames sent back to be key frames -- the native loop's bytes against the reference's loop on the CPU oracle"""
-    import torch
     a, b = SynthSequence(W, H, seed=41), SynthSequence(W, H, seed=97)
     frames = [a.frame(t) for t in range(4)] + [b.frame(t) for t in range(4)]      # the cut hits an ordinary P frame
     drv = api.NativeDriver(W, H, num_partitions=2, check_ssim=1, device_params=1, gop_size=gop, qi_min=qi[0], qi_max=qi[1], ssim_target=target)
@@ -107,8 +106,8 @@ def test_native_loop_with_async_check_emits_the_oracle_loops_bytes(W, H, qi, tar
     do = InterPathDriver(ora, W, H, gop_size=gop, qi_min=qi[0], qi_max=qi[1], ssim_target=target)
     updates = 0
     for t, (y, u, v) in enumerate(frames):
-        d = [torch.from_numpy(p).cuda() for p in (y, u, v)]
-        torch.cuda.synchronize()
+        d = [api.to_device(p) for p in (y, u, v)]
+        api.device_synchronize()
         drv.encode_frame_device(*(x.data_ptr() for x in d))
         got = drv.get_frame() if t % 3 else None     # without a bitstream request the verdict is taken by the next call
         out = do.encode_frame(y, u, v)

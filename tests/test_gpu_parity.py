@@ -271,7 +271,6 @@ def test_block_match_metric_device_vs_oracle():
 
 def test_device_resident_inputs_match_host_upload():
     """vp8hip_set_current_device / vp8hip_set_last_device (planes already in HBM, what bench.py uses)."""
-    import torch
     W, H = 208, 112
     f = _frames(W, H, 19)
     sd = default_segments()
@@ -282,8 +281,8 @@ def test_device_resident_inputs_match_host_upload():
         keep = []
         for t in range(1, 4):
             if dev:
-                last = [torch.from_numpy(p).cuda() for p in f[t - 1]] if t == 1 else None
-                cur = [torch.from_numpy(p).cuda() for p in f[t]]
+                last = [api.to_device(p) for p in f[t - 1]] if t == 1 else None
+                cur = [api.to_device(p) for p in f[t]]
                 keep += [last, cur]
                 if last:
                     hip.set_last_device(*[x.data_ptr() for x in last])

@@ -70,7 +70,6 @@ def test_restatement_against_the_reference_function(sw, sh, W, H):
 @pytest.mark.gpu
 @pytest.mark.parametrize("sw,sh,W,H", SIZES)
 def test_device_padding_matches_the_restatement(sw, sh, W, H):
-    import torch
     from vp8oclenc_amd import api
     hip = api.Vp8Hip(W, H)
     hip.set_source_size(sw, sh)
@@ -81,9 +80,9 @@ def test_device_padding_matches_the_restatement(sw, sh, W, H):
             hip.upload_current(*src)
         else:
             off = 3 if how.endswith("unaligned") else 0     # source planes at an odd address: the byte-wise path
-            dev = [torch.zeros(p.size + 8, dtype=torch.uint8, device="cuda") for p in src]
+            dev = [api.DeviceBuffer(p.size + 8) for p in src]
             for d, p in zip(dev, src):
-                d[off:off + p.size] = torch.from_numpy(p.reshape(-1)).cuda()
+                d.upload(p.reshape(-1), offset=off)
             hip.set_current_device(*[d.data_ptr() + off for d in dev])
         got = [hip.debug(api.DBG_PYRAMID, 3, 0), hip.debug(api.DBG_CURRENT_CHROMA, 0), hip.debug(api.DBG_CURRENT_CHROMA, 1)]
         for name, g, e in zip("YUV", got, exp):
@@ -104,7 +103,6 @@ def test_device_padding_matches_the_restatement(sw, sh, W, H):
 def test_native_loop_and_batch_with_a_source_size(sw, sh, W, H):
     """vp8drv_config.src_width/height: frames of the source size in == frames padded by the restatement in, byte for byte
     (host planes, device planes, and two chunks in a batch); key frames carry the source size as display size"""
-    import torch
     import vp8_parse as vp
     from vp8oclenc_amd import api
     rng = np.random.default_rng(3)
@@ -128,7 +126,7 @@ def test_native_loop_and_batch_with_a_source_size(sw, sh, W, H):
         k = padded.encode_frame_host(*exp[0])
         want = padded.get_frame()
         assert host.encode_frame_host(*src[0]) == k and host.get_frame() == want, t
-        d = [[torch.from_numpy(p).cuda() for p in s] for s in src]
+        d = [[api.to_device(p) for p in s] for s in src]
         ptr = [tuple(p.data_ptr() for p in f) for f in d]
         assert dev.encode_frame_device(*ptr[0]) == k and dev.get_frame() == want, t
         batch.encode_frame_device(ptr)
@@ -139,7 +137,7 @@ def test_native_loop_and_batch_with_a_source_size(sw, sh, W, H):
         if k:
             f = vp.parse_frame(want, vp.StreamState())
             assert (f.width, f.height) == (sw, sh) and (f.mbw, f.mbh) == (W // 16, H // 16)
-        torch.cuda.synchronize()
+        api.device_synchronize()
     batch.close()
     with pytest.raises(api.Vp8HipError):
         api.NativeDriver(W, H, src_width=sw, src_height=sh, device_params=0)

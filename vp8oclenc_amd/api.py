@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_experiments_compiled_in", "vp8hip_batch_prep_mode", "vp8hip_device_count", "vp8hip_device_alloc", "vp8hip_device_free", "vp8hip_device_upload", "vp8hip_device_download", "vp8hip_device_synchronize", "vp8hip_device_mem_info", "vp8hip_device_pci_bus_id", "vp8hip_runtime_version", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2007  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 3001  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 
@@ -130,9 +130,91 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.vp8host_gop_init.restype = None
     lib.vp8host_gop_inter_flags.argtypes = [C.POINTER(GopState), i32p, i32p]
     lib.vp8host_gop_inter_flags.restype = None
+    lib.vp8hip_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.vp8hip_device_free.argtypes = [C.c_int, C.c_void_p]
+    lib.vp8hip_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.vp8hip_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.vp8hip_device_synchronize.argtypes = [C.c_int]
+    lib.vp8hip_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.vp8hip_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     if path is None:
         _lib = lib
     return lib
+
+
+class DeviceBuffer:
+    """Device memory from the library's own runtime (vp8hip_device_alloc): what a host without a GPU framework of its own
+    hands to vp8hip_set_current_device & co.  `data_ptr()` like a torch tensor, so call sites read the same."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.lib, self.device, self.nbytes = load_library(), device, int(nbytes)
+        p = C.c_void_p()
+        rc = self.lib.vp8hip_device_alloc(device, self.nbytes, C.byref(p))
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_device_alloc({self.nbytes}): {self.lib.vp8hip_status_string(rc).decode()}")
+        self.ptr = p.value
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        rc = self.lib.vp8hip_device_upload(self.device, self.ptr + offset, a.ctypes.data, a.nbytes)
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_device_upload: {self.lib.vp8hip_status_string(rc).decode()}")
+        return self
+
+    def download(self, dtype=np.uint8, shape=None) -> np.ndarray:
+        out = np.empty(self.nbytes, np.uint8)
+        rc = self.lib.vp8hip_device_download(self.device, out.ctypes.data, self.ptr, self.nbytes)
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_device_download: {self.lib.vp8hip_status_string(rc).decode()}")
+        out = out.view(dtype)
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.vp8hip_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def to_device(a: np.ndarray, device: int = 0) -> DeviceBuffer:
+    """a copy of the array in the device's memory (blocking)"""
+    a = np.ascontiguousarray(a)
+    return DeviceBuffer(a.nbytes, device).upload(a)
+
+
+def device_synchronize(device: int = 0) -> None:
+    rc = load_library().vp8hip_device_synchronize(device)
+    if rc != 0:
+        raise Vp8HipError(f"vp8hip_device_synchronize: {load_library().vp8hip_status_string(rc).decode()}")
+
+
+def device_count() -> int:
+    return int(load_library().vp8hip_device_count())
+
+
+def device_mem_info(device: int = 0):
+    f, t = C.c_size_t(), C.c_size_t()
+    rc = load_library().vp8hip_device_mem_info(device, C.byref(f), C.byref(t))
+    if rc != 0:
+        raise Vp8HipError("vp8hip_device_mem_info failed")
+    return int(f.value), int(t.value)
+
+
+def device_pci_bus_id(device: int = 0) -> str:
+    buf = C.create_string_buffer(32)
+    rc = load_library().vp8hip_device_pci_bus_id(device, buf, 32)
+    if rc != 0:
+        raise Vp8HipError("vp8hip_device_pci_bus_id failed")
+    return buf.value.decode().lower()
 
 
 def _ptr(a):
@@ -141,6 +223,8 @@ def _ptr(a):
     if isinstance(a, np.ndarray):
         assert a.flags["C_CONTIGUOUS"]
         return a.ctypes.data
+    if isinstance(a, DeviceBuffer):
+        return a.ptr
     return int(a)  # raw device/host address (e.g. torch tensor.data_ptr())
 
 

@@ -1021,7 +1021,7 @@ static ent::CodeJob code_job(const EntBuffers &eb, int P) {
 // VP8HIP_EXPERIMENT_SKIP_ENT: bit i leaves out launch i of the frame's entropy stage (the bytes are then garbage: what a launch
 // costs with the part full, measured by the throughput without it -- scripts/ab_bitstream.sh)
 unsigned ent_skip_mask() {
-    static const unsigned m = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP_ENT"); return v ? (unsigned)strtoul(v, nullptr, 0) : 0u; }();
+    static const unsigned m = [] { const char *v = experiment_env("VP8HIP_EXPERIMENT_SKIP_ENT"); return v ? (unsigned)strtoul(v, nullptr, 0) : 0u; }();
     return m;
 }
 static void bool_code(hipStream_t s, const ent::CodeJobs &jobs, int njobs, unsigned skip = 0) {

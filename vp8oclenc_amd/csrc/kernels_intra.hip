@@ -500,7 +500,12 @@ __device__ __forceinline__ void intra_check3_body(const IntraArgs &a) {
     const LaneK k = lane_consts(lane);
     const int mb_row0 = r * mbw;
     if (a.stall_test && r == 0) return;
-    if (a.flagged && __builtin_nontemporal_load(a.flagged) == 0) return;   // (is_inter / modes are then not read either: replaced == 0)
+    if (a.flagged && __builtin_nontemporal_load(a.flagged) == 0) {   // (is_inter / modes are then not read either: replaced == 0)
+        // the row's counter still gets this launch's number: counters carry the launch number modulo 2^22, and a row left
+        // unstamped for that many launches (long GOPs with nothing below the target) would read as complete in a later one
+        if (threadIdx.x == 0) prog_store(a, r, mbw);
+        return;
+    }
     for (int i = threadIdx.x; i < mbw; i += 192) a.is_inter[mb_row0 + i] = 1;
     for (int i = threadIdx.x; i < mbw * 16; i += 192) a.modes[(size_t)mb_row0 * 16 + i] = 0;
     if (threadIdx.x == 0) s_abort = 0;

@@ -620,7 +620,7 @@ static lf3::Args loop_filter3_args(hipStream_t s, const Frame &recon, const MBOu
     return a;
 }
 static bool lf_skip() {
-    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "lf") != nullptr; }();
+    static const bool skip = experiment_skip("lf");
     return skip;   // timing experiment only
 }
 

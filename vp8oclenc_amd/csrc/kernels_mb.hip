@@ -549,7 +549,7 @@ static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, 
     return a;
 }
 static bool mb_skip() {
-    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "mb") != nullptr; }();
+    static const bool skip = experiment_skip("mb");
     return skip;   // timing experiment only (what the frame costs without this kernel); never set in production
 }
 

@@ -208,7 +208,7 @@ void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *
     b.n = n;
     for (int i = 0; i < n; ++i) b.item[i] = pack_item(*f[i], y[i], u[i], v[i], sw, sh, 0, 0);
     const int units = (f[0]->Y[0].w >> 3) * f[0]->Y[0].h + 2 * ((f[0]->U.w >> 3) * f[0]->U.h);
-    static const bool skip = [] { const char *e = getenv("VP8HIP_EXPERIMENT_SKIP"); return e && strstr(e, "pack") != nullptr; }();
+    static const bool skip = experiment_skip("pack");
     if (skip) return;   // timing experiment only
     const int per = pack_units_per_thread();
     VP8_LAUNCH(k_pack_b, dim3((units + 256 * per - 1) / (256 * per), 1, n), dim3(256), 0, s, b, per);
@@ -397,7 +397,7 @@ int persistent_workgroups() {
 }
 
 static bool search1_skip() {
-    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s1") != nullptr; }();
+    static const bool skip = experiment_skip("s1");
     return skip;   // timing experiment only
 }
 // fewer waves than the chip has SIMDs: the launch is as long as one wave whatever else runs -> the short-wave form.

@@ -181,7 +181,7 @@ void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t
         const SegArgs g{y.w * y.h, (y.h - 1) * (y.w - 1), is_key[i], refqi[i][0], refqi[i][1], refqi[i][2], refqi[i][3], qi_min};
         b.item[i] = StrengthItem{y, partial[i], partial[i] + 2 * MAX_PARTIALS, stats[i], sd[i], strength_out[i], g};
     }
-    static const bool skip = [] { const char *e = getenv("VP8HIP_EXPERIMENT_SKIP"); return e && strstr(e, "scan") != nullptr; }();
+    static const bool skip = experiment_skip("scan");
     if (skip) return;   // timing experiment only
     hipLaunchKernelGGL(k_strength_segments_b, dim3(nb, 1, n), dim3(256), 0, s, b);
 }

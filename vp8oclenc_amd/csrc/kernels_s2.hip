@@ -322,7 +322,7 @@ static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &n
     return a;
 }
 static bool search2_skip() {
-    static const bool skip = [] { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, "s2") != nullptr; }();
+    static const bool skip = experiment_skip("s2");
     return skip;   // timing experiment only
 }
 

@@ -480,7 +480,11 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
     // In the order of the array, each batch waiting for its own verdicts.  (Serving whichever batch is ready first was tried
     // and is slower -- 55-58.8 against 58.8-59.5 M MB/s on the same box: a fixed order keeps the batches evenly staggered, and it
     // is the staggering that lets one batch's latency-bound loop filter run beside the others' searches.)
+#ifdef VP8HIP_EXPERIMENTS
     static const bool ready_first = getenv("VP8DRV_EXPERIMENT_READY_FIRST") != nullptr;
+#else
+    constexpr bool ready_first = false;
+#endif
     if (!ready_first) {
         for (int k = 0; k < nbatches; ++k)
             DRV_CHK(vp8drv_batch_encode_frame_device(batches[k], nullptr, y[k], u[k], v[k], nullptr, was_key ? was_key[k] : nullptr));
@@ -504,6 +508,8 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
                                         const int *const *start, int *const *keys_out, uint64_t *const *bytes_out) {
     if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start) return VP8HIP_ERR_ARG;
+    for (int k = 0; k < nbatches; ++k)
+        if (!batches[k] || batches[k]->n < 1 || !batches[k]->d[0] || !start[k]) return VP8HIP_ERR_ARG;
     std::vector<std::thread> th;
     std::vector<int> rc((size_t)nbatches, VP8HIP_OK);
     // Thread k starts k * 200 us after thread 0.  Batches that start together from an idle device stay in lockstep -- every verdict
@@ -516,7 +522,7 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
             if (stagger_us > 0) std::this_thread::sleep_for(std::chrono::microseconds((long)k * stagger_us));
             vp8drv_batch *b = batches[k];
             const void *y[VP8HIP_MAX_BATCH], *u[VP8HIP_MAX_BATCH], *v[VP8HIP_MAX_BATCH];
-            int key[VP8HIP_MAX_BATCH];
+            int key[VP8HIP_MAX_BATCH] = {};
             std::vector<uint8_t> frame;
             if (bytes_out) frame.resize((size_t)b->d[0]->mbs * 1900 + (1u << 20));
             for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) {
@@ -525,7 +531,7 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                     y[i] = f[0]; u[i] = f[1]; v[i] = f[2];
                 }
                 rc[k] = vp8drv_batch_encode_frame_device(b, nullptr, y, u, v, nullptr, key);
-                if (keys_out && keys_out[k])
+                if (rc[k] == VP8HIP_OK && keys_out && keys_out[k])   // (a failed call may not have filled key[])
                     for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
                 if (bytes_out && rc[k] == VP8HIP_OK) {      // the frames as bytes: one set of launches for the batch, then every member's read-back
                     // (taking frame t's bytes only after frame t + 1 is enqueued changes nothing -- 45.8 M MB/s either way on one

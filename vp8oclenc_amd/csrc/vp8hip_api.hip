@@ -72,6 +72,7 @@ struct vp8hip_ctx {
     SegData *h_sd_ring = nullptr;   // pinned staging for vp8hip_set_segments
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
+    void *d_lf_handoff = nullptr;   // loop filter form 4: a band's bottom rows on their way to the next band (tagged granules)
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
     int src_w = 0, src_h = 0;       // vp8hip_set_source_size: size of the planes handed over as current frames (0 = coded size)
     int conformant = 0;             // vp8hip_conformant_stream (NOT the reference; off by default)
@@ -498,6 +499,8 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
     CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
     CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
+    CR(hipMalloc(&c->d_lf_handoff, loop_filter4_handoff_bytes(c->mbw, c->mbh)));
+    CR(hipMemsetAsync(c->d_lf_handoff, 0, loop_filter4_handoff_bytes(c->mbw, c->mbh), c->stream));
     CR(hipMemsetAsync(c->d_progress + S2_CLOCK_WORD, 0xff, 8, c->stream));   // k_search2's launch clock: "earliest start" is ~0 at rest
     CR(hipMalloc(&c->scratch, (size_t)width * height));
     CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
@@ -574,6 +577,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     if (c->h_frame) hipHostFree(c->h_frame);
     hipFree(c->d_frame);
     hipFree(c->d_progress);
+    hipFree(c->d_lf_handoff);
     hipFree(c->d_stats2[0]);
     if (c->h_verdict) hipHostFree(c->h_verdict);
     hipFree(c->scratch);
@@ -964,7 +968,7 @@ int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n) {
     // 1 = one per batch, in the lowest priority class; 2 = one for all batches of the process.  Measured on MI355X, 48 chunks
     // in 8 batches, same box: 62.2 M MB/s without, 59.5 with one per batch (59.9 in the default priority class), 60.9 with one
     // for all -- the second set of queues costs more than the shorter chains win, so it is off unless asked for.
-    static const int prep_mode = [] { const char *v = getenv("VP8HIP_BATCH_PREP"); return v && v[0] ? atoi(v) : 0; }();
+    const int prep_mode = vp8hip_batch_prep_mode();
     bool ok = true;
     if (prep_mode) {
         ok = hipEventCreateWithFlags(&b->ev_gate, hipEventDisableTiming) == hipSuccess &&
@@ -1199,6 +1203,7 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
     const MBOut *outs[MAX_BATCH];
     SegData *sds[MAX_BATCH];
     int32_t *prog[MAX_BATCH];
+    void *hand[MAX_BATCH];
     unsigned launch_no[MAX_BATCH];
     LfCheck chk[MAX_BATCH];
     int n = 0;
@@ -1213,6 +1218,7 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
         outs[n] = &c->out;
         sds[n] = c->d_sd;
         prog[n] = c->d_progress;
+        hand[n] = c->d_lf_handoff;
         launch_no[n] = c->lf_launches++;
         lf_check(c, chk[n]);
         c->verdict_stream = b->stream;
@@ -1223,7 +1229,10 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
     if (b->ent) HIPCHK(c0, hipEventRecord(b->ev_ent_fork, b->stream));
     {
         Timed t(c0, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n, chk);
+        // (form 3 for batches: with the part full a launch's instructions and LDS count, not its latency; VP8HIP_LF_BATCH_FORM=4 for A/B runs)
+        static const bool form4 = [] { const char *v = getenv("VP8HIP_LF_BATCH_FORM"); return v && atoi(v) == 4; }();
+        if (form4) launch_loop_filter4_batch(b->stream, recon, outs, sds, prog, hand, c0->mbw, c0->mbh, launch_no, n, chk);
+        else launch_loop_filter3_batch(b->stream, recon, outs, sds, prog, c0->mbw, c0->mbh, launch_no, n, chk);
     }
     b->ent_fork_fresh = b->ent != nullptr;
     for (int i = 0; i < n; ++i) {   // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401)
@@ -1436,7 +1445,7 @@ int vp8hip_check_ssim_result(vp8hip_ctx *c, int32_t *replaced, float *new_ssim, 
     // host memory the device sees: it is there a few microseconds into that launch, long before the launch ends.
     volatile int32_t *v = c->h_verdict;
     const uint32_t want = c->verdict_seq;
-    static const bool nowait = getenv("VP8HIP_EXPERIMENT_NOWAIT") != nullptr;   // timing experiment only: what the waiting costs
+    static const bool nowait = experiment_env("VP8HIP_EXPERIMENT_NOWAIT") != nullptr;   // timing experiment only: what the waiting costs
     for (unsigned spins = 0; !nowait && (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
         if ((spins & 0xfff) == 0xfff) {   // every few thousand polls: is the stream still alive?
             const hipError_t q = hipStreamQuery(c->verdict_stream);
@@ -1500,7 +1509,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     if (c->lf_overlap && !c->prof_mask) {   // (the per-kernel timers bracket launches on the context's stream only)
         hipStream_t chain = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, chain));
-        launch_loop_filter3(chain, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
+        launch_loop_filter4(chain, f, c->out, c->d_sd, c->d_progress, c->d_lf_handoff, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
         c->verdict_stream = chain;
         HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
         c->stream = c->lf_stream;
@@ -1509,7 +1518,7 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
         c->lf_sd = c->d_sd;
     } else {
         Timed t(c, VP8HIP_K_LOOP_FILTER);
-        launch_loop_filter3(c->stream, f, c->out, c->d_sd, c->d_progress, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
+        launch_loop_filter4(c->stream, f, c->out, c->d_sd, c->d_progress, c->d_lf_handoff, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
         c->verdict_stream = c->stream;
     }
     // the filtered reconstruction is the LAST reference of the next frame (vp8enc.cpp:395-401); its replicated edges are made
@@ -2159,6 +2168,71 @@ int vp8hip_debug_weight(vp8hip_ctx *c, const int32_t *d, int n, int32_t *out) {
 }
 
 int vp8hip_abi_version(void) { return VP8HIP_ABI_VERSION; }
+// ---- device memory for a caller that has none of its own (include/vp8hip.h) ------------------------------------------------
+int vp8hip_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+#define DEVCHK(call) do { if ((call) != hipSuccess) return VP8HIP_ERR_HIP; } while (0)
+int vp8hip_device_alloc(int device_ordinal, size_t bytes, void **out) {
+    if (!out) return VP8HIP_ERR_ARG;
+    *out = nullptr;
+    if (device_ordinal < 0 || device_ordinal >= vp8hip_device_count()) return VP8HIP_ERR_NO_DEVICE;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipMalloc(out, bytes ? bytes : 1));
+    return VP8HIP_OK;
+}
+int vp8hip_device_free(int device_ordinal, void *p) {
+    if (!p) return VP8HIP_OK;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipFree(p));
+    return VP8HIP_OK;
+}
+int vp8hip_device_upload(int device_ordinal, void *dst, const void *src, size_t bytes) {
+    if (!dst || !src) return VP8HIP_ERR_ARG;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return VP8HIP_OK;
+}
+int vp8hip_device_download(int device_ordinal, void *dst, const void *src, size_t bytes) {
+    if (!dst || !src) return VP8HIP_ERR_ARG;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return VP8HIP_OK;
+}
+int vp8hip_device_synchronize(int device_ordinal) {
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipDeviceSynchronize());
+    return VP8HIP_OK;
+}
+int vp8hip_device_mem_info(int device_ordinal, size_t *free_bytes, size_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return VP8HIP_ERR_ARG;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return VP8HIP_OK;
+}
+int vp8hip_device_pci_bus_id(int device_ordinal, char *out, int len) {
+    if (!out || len < 16) return VP8HIP_ERR_ARG;
+    DEVCHK(hipDeviceGetPCIBusId(out, len, device_ordinal));
+    return VP8HIP_OK;
+}
+int vp8hip_runtime_version(void) {
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+}
+#undef DEVCHK
+
+int vp8hip_batch_prep_mode(void) {
+    static const int prep_mode = [] { const char *v = getenv("VP8HIP_BATCH_PREP"); const int m = v && v[0] ? atoi(v) : 0; return m < 0 || m > 2 ? 0 : m; }();
+    return prep_mode;
+}
+int vp8hip_experiments_compiled_in(void) {
+#ifdef VP8HIP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int vp8hip_conformant_stream(vp8hip_ctx *c, int on) {
     if (!c) return VP8HIP_ERR_ARG;

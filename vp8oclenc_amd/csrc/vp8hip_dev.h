@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace vp8 {
 
@@ -110,6 +112,16 @@ __device__ __forceinline__ void launch_clock_end(unsigned long long *w) {   // e
     }
 }
 #endif
+// Switches that LEAVE WORK OUT of a launch or a wait (the results are then garbage) exist for same-box timing runs only: they
+// are compiled in with -DVP8HIP_EXPERIMENTS (scripts/ab_*.sh build that way) and are constants otherwise, so no environment
+// can take work out of a run of the shipped library.  vp8hip_experiments_compiled_in() tells a caller which build it has.
+#ifdef VP8HIP_EXPERIMENTS
+inline bool experiment_skip(const char *what) { const char *v = getenv("VP8HIP_EXPERIMENT_SKIP"); return v && strstr(v, what) != nullptr; }
+inline const char *experiment_env(const char *name) { return getenv(name); }
+#else
+inline bool experiment_skip(const char *) { return false; }
+inline const char *experiment_env(const char *) { return nullptr; }
+#endif
 // workgroups of a persistent launch (0 = launch the full grid); VP8HIP_PERSIST overrides (same-box A/B runs)
 int persistent_workgroups();
 
@@ -133,6 +145,9 @@ void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs,
 struct LfCheck;
 void launch_loop_filter3_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, SegData *const *d_sd,
                                int32_t *const *progress, int mbw, int mbh, const unsigned *launch_no, int n, const LfCheck *chk = nullptr);
+void launch_loop_filter4_batch(hipStream_t s, const Frame *const *recon, const MBOut *const *o, SegData *const *d_sd,
+                               int32_t *const *progress, void *const *handoff, int mbw, int mbh, const unsigned *launch_no, int n,
+                               const LfCheck *chk = nullptr);
 void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
                                 int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
@@ -142,8 +157,15 @@ void launch_weight_tap(hipStream_t s, const int32_t *d, int n, int32_t *out);
 void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon,
                const MBOut &o, const SegData *d_sd, float ssim_target, int mbw, int mbh, bool conformant = false);
 void launch_filter_mask(hipStream_t s, const MBOut &o, const SegData *d_sd, int mbs);
+// The loop filter exists in two forms with the same results.  Form 3: byte tiles and strips in 46 KB of LDS,
+// the worker wave does everything itself -- what batches of GOP chunks launch (with the part full what counts is the
+// instructions and the LDS a launch takes from the other kernels, not its latency).  Form 4: a band-tall plane of dwords in
+// 112 KB of LDS, the workers only filter, porter waves feed and drain -- the short dependency chain of ONE video.
 void launch_loop_filter3(hipStream_t s, const Frame &recon, const MBOut &o, SegData *d_sd, int32_t *progress,
-                         int mbw, int mbh, unsigned launch_no, int stall_test = 0, const LfCheck *chk = nullptr);  // banded wavefront in LDS, one-step row lag
+                         int mbw, int mbh, unsigned launch_no, int stall_test = 0, const LfCheck *chk = nullptr);
+void launch_loop_filter4(hipStream_t s, const Frame &recon, const MBOut &o, SegData *d_sd, int32_t *progress, void *handoff,
+                         int mbw, int mbh, unsigned launch_no, int stall_test = 0, const LfCheck *chk = nullptr);
+size_t loop_filter4_handoff_bytes(int mbw, int mbh);   // the HBM buffer form 4 hands a band's bottom rows to the next band through
 
 // per-frame parameter scans on the device copy of the current frame (kernels_rc.hip); stats = 4 uint32
 size_t rc_partial_words();   // uint32 words of per-workgroup partial sums the three launchers below need
