@@ -144,9 +144,10 @@ def spawn_ranks(args) -> int:
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
-    def __init__(self, torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None, conformant=0):
+    def __init__(self, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None, conformant=0):
         from vp8oclenc_amd.synth import SynthSequence
-        self.torch, self.api = torch, api
+        self.api, self.device = api, device
+        self.overlap_filter, self.ssim_target, self.gop, self.conformant, self.seed0 = overlap_filter, ssim_target, gop, conformant, seed
         seq = SynthSequence(W0, H0, seed=seed)
         self.W, self.H = seq.W, seq.H
         self.mbs = (self.W // 16) * (self.H // 16)
@@ -165,7 +166,8 @@ class Leg:
         else:
             source = self.host_frames
         self.source_size = (W0, H0) if src else (self.W, self.H)
-        self.dev_frames = [tuple(torch.from_numpy(p).cuda() for p in f) for f in source]
+        self.src_kw = src
+        self.dev_frames = [tuple(api.to_device(p, device) for p in f) for f in source]     # (the library's own allocator: no second GPU runtime in the process)
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
         self.drv, self.t, self.batches = [], [], []
         self.frames = self.refsum = self.keys = 0
@@ -179,6 +181,7 @@ class Leg:
             assert d.encode_frame_device(*self.ptrs[t % nd])   # frame 0 of the chunk: key frame
             self.drv.append(d)
             self.t.append(t + 1)
+            self.t_key = getattr(self, "t_key", []) + [t]
             # batched launches: groups of `batch` chunks advance together, one launch per stage for the group (vp8drv_batch_*).
             # A group is formed as soon as its members exist: their own streams go and the group gets a new one, so the
             # process never holds more than batch + G / batch streams and every group ends up on a hardware queue of its own
@@ -199,7 +202,7 @@ class Leg:
             for k in range(G):
                 for _ in range(pre[k]):
                     self.step_one(k)
-        torch.cuda.synchronize()
+        api.device_synchronize(device)
         self.frames = self.refsum = self.keys = 0
 
     def step_group(self, members, nb, on=None):
@@ -277,7 +280,7 @@ class Leg:
 
     def run(self, steps, barrier=None):
         """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
-        sync = barrier or self.torch.cuda.synchronize
+        sync = barrier or (lambda: self.api.device_synchronize(self.device))
         self.frames = self.refsum = self.keys = 0
         refs0 = self.refs_searched()
         sync()
@@ -313,12 +316,34 @@ class Leg:
         for d in self.drv:
             d.close()
         self.drv = []
+        for f in self.dev_frames:
+            for p in f:
+                p.free()
         self.dev_frames = []
 
+    def replay_chunk(self, k):
+        """Chunk k coded AGAIN, from its key frame to where it stands now, on a fresh driver of its own -- no batch, no other chunk
+        beside it, one frame at a time: the filtered reconstruction it ends with must be the chunk's, byte for byte (a closed GOP
+        depends on nothing but its own frames).  The self-check of a bench line: outside every timed region."""
+        import zlib
+        d = self.api.NativeDriver(self.W, self.H, device=self.device, gop_size=self.gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
+                                  ssim_target=self.ssim_target, device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if self.refs == "all" else 0,
+                                  overlap_filter=0, conformant_stream=self.conformant, **self.src_kw)
+        for t in range(self.t_key[k], self.t[k]):
+            d.encode_frame_device(*self.ptrs[t % self.nd])
+        d.resolve()
+        crc = lambda planes: [zlib.crc32(p.tobytes()) for p in planes]
+        self.drv[k].resolve()
+        a, b = crc(self.drv[k].hip.download_last()), crc(d.hip.download_last())
+        sa, sb = self.drv[k].stats(), d.stats()
+        d.close()
+        return {"chunk": k, "frames_recoded": self.t[k] - self.t_key[k], "crc32_yuv_batched": a, "crc32_yuv_alone": b,
+                "key_frames": [sa.key_frames, sb.key_frames], "identical": a == b and sa.key_frames == sb.key_frames}
 
-def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1, gop=None, conformant=0):
+
+def side_leg(api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=1, batch=1, gop=None, conformant=0):
     # one chunk = one video coded frame after frame: the loop filter on its own stream, GOLDEN/ALTREF searched beside it
-    leg = Leg(torch, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1, gop=gop,
+    leg = Leg(api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=1 if G == 1 else 0, batch=batch if G > 1 else 1, gop=gop,
               conformant=conformant)
     for _ in range(warm):
         leg.step()
@@ -338,11 +363,10 @@ def side_leg(torch, api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4
     return out
 
 
-def pin_to_gpu_numa_node(torch, local: int):
+def pin_to_gpu_numa_node(api, local: int):
     """this rank's host threads onto the CPUs of its GPU's NUMA node (best effort; returns what was done, for the JSON line)"""
     try:
-        p = torch.cuda.get_device_properties(local)
-        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        bdf = api.device_pci_bus_id(local)
         node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
         if node < 0:
             return f"{bdf}: no NUMA node reported"
@@ -359,13 +383,13 @@ def pin_to_gpu_numa_node(torch, local: int):
         return f"not pinned ({type(e).__name__})"
 
 
-def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream=False, seed=1, frames_out=None, frame_base=0, start=None):
+def literal_gops(api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream=False, seed=1, frames_out=None, frame_base=0, start=None):
     """`chunks` closed GOPs of `gop_len` frames each on this GPU, each ONE video coded frame after frame from its key frame on (loop
     filter on the chunk's second stream), one host thread per chunk, every frame counted: a BASELINE config as it is written, not
     the saturated steady state of `value`.  bitstream: every frame is also delivered as bytes (vp8drv_get_frame) into
     frames_out[frame_base + chunk * gop_len + t].  Returns (seconds, frames, key frames, frames recoded as key, bytes)."""
     import threading
-    leg = Leg(torch, api, W0, H0, 0, refs, -1.0, nd, device, seed)       # the synthetic frames in HBM; no drivers yet
+    leg = Leg(api, W0, H0, 0, refs, -1.0, nd, device, seed)       # the synthetic frames in HBM; no drivers yet
     src = dict(src_width=W0, src_height=H0) if tuple(leg.source_size) != (leg.W, leg.H) else {}
     drv = [api.NativeDriver(leg.W, leg.H, device=device, gop_size=1 << 30, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=-1.0,
                             device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if refs == "all" else 0, overlap_filter=1, **src) for _ in range(chunks)]
@@ -407,14 +431,14 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
 
     if start is not None:
         start()             # (all ranks begin their frame loops together)
-    torch.cuda.synchronize()
+    api.device_synchronize(device)
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(chunks)]
     for t in th:
         t.start()
     for t in th:
         t.join()
-    torch.cuda.synchronize()
+    api.device_synchronize(device)
     el = time.perf_counter() - t0
     st = [d.stats() for d in drv]
     out = (el, chunks * gop_len, sum(s.key_frames for s in st), sum(s.redone_as_key for s in st), sum(nbytes), leg.mbs)
@@ -424,7 +448,7 @@ def literal_gops(torch, api, W0, H0, chunks, gop_len, device, nd, refs="all", bi
     return out
 
 
-def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emit=None):
+def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None):
     """config5_literal (every N), ref_shard, and at N = 1 config3_literal, single_stream and other_configs: the legs that are one or two
     videos coded frame after frame, and the other geometries.  Run in a fresh process (see main()).  Returns the dict for the JSON line
     on rank 0; `emit` (if given) is also handed every finished leg at once, so that a leg that dies takes only itself along."""
@@ -437,7 +461,7 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
     if rank == 0:
         # every kernel of the path ALONE on the part: one chunk, one stream, nothing beside it, each launch timed by its own dispatch
         # (HIP events) -- the launch durations the roofline fractions are made of (with 48 chunks in flight a launch shares the part)
-        solo = Leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, nd, local, seed=1)
+        solo = Leg(api, args.width, args.height, 1, args.refs, args.ssim_target, nd, local, seed=1)
         solo.profile(api.K_NAMES)
         for _ in range(4):
             solo.step()
@@ -449,13 +473,13 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
     if rank == 0 and world == 1:
         # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
         # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
-        el3, n3, k3, r3, _, mbs3 = literal_gops(torch, api, args.width, args.height, 2, 150, local, nd)
+        el3, n3, k3, r3, _, mbs3 = literal_gops(api, args.width, args.height, 2, 150, local, nd)
         out["config3_literal"] = {"workload": f"{args.width}x{args.height}, 300 frames, -g 150: two closed GOPs of 150 frames in flight on one GPU, LAST+GOLDEN+ALTREF, "
                                               "check_SSIM in the loop, loop filter on the GPU, every frame counted",
                                   "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
                                   "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
         s1 = max(200, args.steps)
-        ss = side_leg(torch, api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
+        ss = side_leg(api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         ss["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
         out["single_stream"] = ss
     if True:
@@ -465,7 +489,7 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
         from vp8oclenc_amd import gop_shard
         GOP5 = int(os.environ.get("VP8_BENCH_GOP5", "300"))
         local_frames = {}
-        el5, n5, k5, r5, b5, mbs5 = literal_gops(torch, api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
+        el5, n5, k5, r5, b5, mbs5 = literal_gops(api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
                                                  frames_out=local_frames, frame_base=rank * GOP5, start=barrier)
         # (literal_gops times its frame loop between synchronisations of its own; the clock goes on with the gather.  What is NOT in the
         # time: making the synthetic frames and creating the encoder, which is init_all() in the reference)
@@ -474,6 +498,7 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
         barrier()
         t5 = el5 + (time.perf_counter() - t0)
         if dist is not None:
+            import torch
             tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t5 = float(tt.item())
@@ -489,7 +514,7 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
         # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
         # all_gathered, the filtered reconstruction broadcast.  Needs three ranks to mean anything; with fewer the same exchanges
         # are walked by loopback on rank 0 (what they cost on one GPU), the other ranks only keep the collectives company.
-        rs = ref_shard_leg(torch, api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
+        rs = ref_shard_leg(api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
         if rank == 0 and rs is not None:
             out["ref_shard"] = rs
     if rank == 0 and world == 1 and not args.only_bitstream:
@@ -507,7 +532,7 @@ def few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emi
                 # vp8hip_conformant_stream (NOT the reference's bytes: the format's predictor, so that the stream decodes to the
                 # encoder's own reconstruction): what the opt-in costs
                 ("1080p_conformant_stream", (1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5), dict(batch=B, conformant=1))):
-            oc[name] = side_leg(torch, api, *leg_args, local, **kw)
+            oc[name] = side_leg(api, *leg_args, local, **kw)
             out["other_configs"] = dict(oc)      # (handed on after every geometry)
     return dict(out)
 
@@ -521,52 +546,61 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    import torch
-    from vp8oclenc_amd import api
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
-    all_cpus = os.sched_getaffinity(0)
-    affinity = "not pinned (VP8_BENCH_NO_PIN)" if os.environ.get("VP8_BENCH_NO_PIN", "0") not in ("", "0") else pin_to_gpu_numa_node(torch, local)
-    dist = None
+    # ONE GPU runtime per process.  With one rank nothing here needs PyTorch: the synthetic frames live in memory the library
+    # allocates (vp8hip_device_alloc) and the process runs on the HIP runtime libvp8hip.so was built for.  With several ranks
+    # torch.distributed (backend nccl = RCCL) carries the barrier, the max-over-ranks time and the gathering of frames: torch is
+    # imported FIRST then, and the library's calls land in the runtime torch brings -- still one runtime in the process.
+    dist = torch = None
     if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
+        import torch
         import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from vp8oclenc_amd import api
+    lib = api.load_library()
+    if api.device_count() <= local:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # a build with the timing-experiment switches compiled in (they leave work out of launches) never prints a line
+    if lib.vp8hip_experiments_compiled_in():
+        raise SystemExit("bench.py: libvp8hip.so was built with -DVP8HIP_EXPERIMENTS (switches that leave work out of a launch): "
+                         "rebuild it without (python -m vp8oclenc_amd.build) -- no number from this build")
+    all_cpus = os.sched_getaffinity(0)
+    affinity = "not pinned (VP8_BENCH_NO_PIN)" if os.environ.get("VP8_BENCH_NO_PIN", "0") not in ("", "0") else pin_to_gpu_numa_node(api, local)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        api.device_synchronize(local)
 
     nd = max(2, args.distinct_frames)
     if args.child_legs:      # the fresh process of the few-stream side legs: nothing else runs here
         def emit(part):      # one line per finished leg: what is done is on its way before the next leg starts
             if rank == 0:
                 os.write(json_fd, (json.dumps(part) + "\n").encode())
-        few_stream_legs(args, torch, api, dist, rank, world, local, nd, barrier, emit)
-        import torch.distributed as td_
-        if td_.is_initialized():
-            td_.destroy_process_group()
+        few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit)
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
         sys.stdout.flush()
         os.close(json_fd)
-        os._exit(0)          # (no interpreter teardown over a process that has created and destroyed hundreds of contexts)
+        sys.exit(0)          # (through the ordinary teardown: every context of every leg has been destroyed by now)
     G = max(1, args.gops_per_gpu)
     B = max(1, min(8, args.batch))   # VP8HIP_MAX_BATCH
-    free_before = torch.cuda.mem_get_info(local)[0]
-    leg = Leg(torch, api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
+    free_before = api.device_mem_info(local)[0]
+    leg = Leg(api, args.width, args.height, G, args.refs, args.ssim_target, nd, local, seed=1 + rank,
               overlap_filter=int(os.environ.get("VP8_BENCH_OVERLAP", "0")),   # experiment switch: every chunk's filter on a second stream
               batch=B)
     W, H, mbs = leg.W, leg.H, leg.mbs
-    torch.cuda.synchronize()
-    hbm_used = free_before - torch.cuda.mem_get_info(local)[0]      # contexts (surfaces, nets, coefficient buffers) + the synthetic frames
+    api.device_synchronize(local)
+    hbm_used = free_before - api.device_mem_info(local)[0]      # contexts (surfaces, nets, coefficient buffers) + the synthetic frames
 
     # ---- warmup; every kernel of chunk 0 timed to find the dominant one --------------------------------------
     leg.drv[0].hip.profile_enable(api.K_NAMES)
@@ -575,7 +609,7 @@ def main():
     leg.clock_read()
     for _ in range(max(args.warmup, 1)):
         leg.step()
-    torch.cuda.synchronize()
+    api.device_synchronize(local)
     warm = leg.drv[0].hip.profile_read()
     for d in leg.drv:
         d.hip.profile_search2_clock(False)
@@ -601,6 +635,12 @@ def main():
     for d in leg.drv:
         d.resolve()
     redone = sum(d.stats().redone_as_key for d in leg.drv)
+    # ---- self-check, outside the timed region: ONE chunk of the timed run coded again from its key frame on a driver of its own
+    # (no batch, no other chunk in flight); the reconstruction it ends with must be the timed chunk's.  A run whose timed frames
+    # are not the frames a single un-batched encoder produces prints no line.
+    verify = leg.replay_chunk((7 * (rank + 1)) % G)
+    if not verify["identical"]:
+        raise SystemExit(f"bench.py: self-check FAILED -- the timed region's chunk {verify['chunk']} does not end where the same frames coded alone end: {verify}")
     frames_per_gpu = args.steps * G
     if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:
         raise SystemExit(f"bench.py: the timed frames averaged {nrefs_avg:.2f} references per frame; LAST+GOLDEN+ALTREF in GOP "
@@ -676,7 +716,9 @@ def main():
                        "check_ssim": ("on the device inside the step: intra fallback, filter update at min SSIM > 0.95, verdict read one call later"
                                       if CHECK_SSIM else "OFF (A/B run: not the reference's loop)"),
                        "frames_redone_as_key": redone, "frames_with_filter_update": None,
-                       "batch_prep_stream": os.environ.get("VP8HIP_BATCH_PREP", "1"),
+                       "batch_prep_stream": int(lib.vp8hip_batch_prep_mode()),     # 0 = none (default), 1 = per batch, 2 = one for all
+                       "experiment_switches": "compiled out",
+                       "hip_runtime_version": int(lib.vp8hip_runtime_version()), "gpu_framework_in_process": "torch (several ranks)" if torch is not None else "none",
                        "cpu_affinity": affinity, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
             "roofline": roof,
             "loop_filter_by_its_own_clock": lf_clock,
@@ -685,6 +727,8 @@ def main():
             "other_kernels": others,
             "fps": round(frames_per_gpu * world / elapsed, 2),
             "timed_region_s": round(elapsed, 4),
+            "self_check": dict(verify, what="one chunk of the timed region coded again from its key frame on an un-batched driver of its own: "
+                                            "CRC-32 of the final filtered reconstruction (Y, U, V), key frames; the run aborts on a mismatch"),
             "host_enqueue_ms_per_frame": round(enqueue_s / frames_per_gpu * 1e3, 4),
         }
     leg.profile([])
@@ -692,10 +736,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_side_legs:
         # (at least 40 frames per chunk: the leg starts from an idle part with its threads 200 us apart, and over 20 frames that start
         # is 3 % of the rate -- 52.9 against 54.3 M MB/s at 40 and 54.8 at 120 on one box)
-        out["with_bitstream"] = bitstream_leg(torch, leg, max(40, args.steps))
+        out["with_bitstream"] = bitstream_leg(leg, max(40, args.steps))
     host_frames = leg.host_frames
-    # (the headline's contexts stay as they are until the line is out: destroying 48 contexts has, once in some twenty runs of this
-    # program, ended the process inside the runtime -- the side legs run in a child process anyway and the line is what matters)
     if args.only_bitstream:
         args.no_side_legs = True
     if not args.no_side_legs:
@@ -752,80 +794,52 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         os.sched_setaffinity(0, all_cpus)       # the CPU baseline gets every host core again, not the GPU's NUMA node only
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
-    import torch.distributed as td_
-    if td_.is_initialized():
-        td_.destroy_process_group()
+    leg.close()              # every context destroyed (vp8drv_batch_destroy, vp8drv_destroy -> vp8hip_destroy): the exit code is real
+    if dist is not None and dist.is_initialized():
+        dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
     sys.stderr.flush()
-    os._exit(0)              # the line is out: no teardown of the contexts (see above)
 
 
-class _SubGroup:
-    """a process subgroup with the handful of torch.distributed names ref_shard.RefShardDriver uses"""
-
-    def __init__(self, dist, group):
-        self.dist, self.group = dist, group
-
-    def is_initialized(self):
-        return True
-
-    def get_rank(self):
-        return self.dist.get_rank(self.group)
-
-    def get_world_size(self):
-        return self.dist.get_world_size(self.group)
-
-    def get_backend(self):
-        return self.dist.get_backend(self.group)
-
-    def broadcast(self, t, src):
-        return self.dist.broadcast(t, src=src, group=self.group)
-
-    def all_gather(self, out, t):
-        return self.dist.all_gather(out, t, group=self.group)
-
-
-def ref_shard_leg(torch, api, dist, W0, H0, local, rank, world, nframes):
-    """ONE video with a frame's reference searches spread over min(world, 3) GPUs (vp8oclenc_amd/ref_shard.py): ms per frame.
-    With one rank every exchange is walked by loopback (what the exchanges cost on one GPU)."""
+def ref_shard_leg(api, dist, W0, H0, local, rank, world, nframes):
+    """ONE video with a frame's reference searches spread over min(world, 3) GPUs (vp8oclenc_amd/ref_shard.py; the exchanges are the
+    library's: vp8hip_shard_share_search / vp8hip_shard_share_last, RCCL on the context's stream, no host synchronisation per
+    frame): ms per frame.  With one rank the communicator has one member (what the calls cost on one GPU)."""
     try:
         from vp8oclenc_amd import ref_shard
         from vp8oclenc_amd.synth import SynthSequence
         members = min(world, 3)
-        d = dist
-        if dist is None:                       # a single plain process: a process group of one, for the loopback
-            import torch.distributed as td
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
-            d = td
-        elif world > 3:
-            d = _SubGroup(dist, dist.new_group(list(range(3))))      # (every rank creates the group; only its members use it)
-            if rank >= 3:
-                return None
-        loop = members == 1
+        uid = [ref_shard.shard_unique_id() if rank == 0 else None]
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(uid, src=0)     # (every rank takes part in the broadcast; the first three form the communicator)
+        if rank >= members:
+            return None
         seq = SynthSequence(W0, H0, seed=9)
         frames = [seq.frame(t) for t in range(6)]
         be = ref_shard.HipRefBackend(seq.W, seq.H, device=local)
-        drv = ref_shard.RefShardDriver(be, d, seq.W, seq.H, altref_range=ALTREF_RANGE, force_collective=True, loopback=loop, download=False, device_segments=True)
+        be.shard_init(uid[0], rank, members)
+        drv = ref_shard.RefShardDriver(be, None, seq.W, seq.H, altref_range=ALTREF_RANGE, download=False, device_segments=True)
         for t in range(4):
             drv.encode_frame(*frames[t % len(frames)])
-        torch.cuda.synchronize()
+        be.synchronize()
+        be.shard_max(0.0)          # (barrier)
         t0 = time.perf_counter()
         for t in range(4, 4 + nframes):
             drv.encode_frame(*frames[t % len(frames)])
         be.synchronize()
-        el = time.perf_counter() - t0
+        el = be.shard_max(time.perf_counter() - t0)
         mbs = (seq.W // 16) * (seq.H // 16)
-        out = {"workload": f"{W0}x{H0}, one GOP, a frame's LAST / GOLDEN / ALTREF searches on " + (f"{members} GPUs" if not loop else "one GPU, every exchange walked by loopback"),
+        out = {"workload": f"{W0}x{H0}, one GOP, a frame's LAST / GOLDEN / ALTREF searches on " + (f"{members} GPUs" if members > 1 else "one GPU (a communicator of one rank)"),
                "value": round(mbs * nframes / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / nframes * 1e3, 4), "frames": nframes,
-               "bytes_all_gathered_per_frame": int(drv.bytes_gathered / (nframes + 4)), "bytes_broadcast_per_frame": int(drv.bytes_broadcast / (nframes + 4)),
-               "ranks": members, "loopback": bool(loop),
-               "what": "vp8hip_inter_search on every rank's references, one all_gather of the vector and cost nets, vp8hip_inter_finish + loop filter on rank 0, "
-                       "broadcast of the filtered reconstruction (RCCL); host planes uploaded per frame, segment data on the device"}
+               "bytes_of_nets_shared_per_frame": int(drv.bytes_gathered / (nframes + 4)), "bytes_broadcast_per_frame": int(drv.bytes_broadcast / (nframes + 4)),
+               "ranks": members,
+               "what": "vp8hip_inter_search on every rank's references, vp8hip_shard_share_search (one group of RCCL broadcasts, in place in the "
+                       "context's nets), vp8hip_inter_finish + loop filter on rank 0, vp8hip_shard_share_last (the padded planes out of rank 0's "
+                       "frame pool into the others'): all on the context's stream, no host synchronisation per frame; host planes uploaded per "
+                       "frame, segment data on the device"}
         be.close()
         return out
     except Exception as e:      # a side leg is a report, never a reason to lose the bench line
@@ -866,12 +880,13 @@ def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):
     return out
 
 
-def bitstream_leg(torch, leg, nb):
+def bitstream_leg(leg, nb):
     """the same chunks with finished VP8 frames delivered to host memory (vp8drv_get_frame: the whole entropy stage on the
     device), one host thread per GOP chunk"""
     import threading
     G = leg.G
     nbytes = [0] * G
+    checks, t_before = [None] * G, None
 
     def worker(k):
         d = leg.drv[k]
@@ -896,15 +911,17 @@ def bitstream_leg(torch, leg, nb):
             leg.drv[k].encode_frame_device(*leg.ptrs[leg.t[k] % leg.nd])
             leg.t[k] += 1
             leg.drv[k].get_frame()
-    torch.cuda.synchronize()
+    leg.api.device_synchronize(leg.device)
     tb = time.perf_counter()
     if leg.batches and not os.environ.get("VP8_BENCH_PY_BITSTREAM"):
         # the native loop: a host thread per batch, every frame coded and delivered (vp8drv_batches_encode_frames_device with bytes_out)
-        _, nbo = leg.api.NativeBatch.encode_frames_device_all([b for _, b in leg.batches], nb, leg.ptrs, [[leg.t[k] for k in m] for m, _ in leg.batches], frames_out=True)
-        for (members, _), row in zip(leg.batches, nbo):
+        t_before = list(leg.t)
+        _, nbo, chk = leg.api.NativeBatch.encode_frames_device_all([b for _, b in leg.batches], nb, leg.ptrs, [[leg.t[k] for k in m] for m, _ in leg.batches], frames_out="check")
+        for (members, _), row, crow in zip(leg.batches, nbo, chk):
             for i, k in enumerate(members):
                 leg.t[k] += nb
                 nbytes[k] += row[i]
+                checks[k] = crow[i]
         th = leg.batches
     else:
         th = ([threading.Thread(target=group_worker, args=(m, b)) for m, b in leg.batches] if leg.batches
@@ -913,10 +930,30 @@ def bitstream_leg(torch, leg, nb):
             t.start()
         for t in th:
             t.join()
-    torch.cuda.synchronize()
+    leg.api.device_synchronize(leg.device)
     eb = time.perf_counter() - tb
+    self_check = None
+    if t_before is not None:
+        # self-check, outside the timed region: chunk k coded again from its key frame on a driver of its own, one frame at a time; the
+        # frames it delivers over the leg's span must be the leg's, byte for byte (vp8drv_frame_check folded over every frame)
+        k = 5 % G
+        d = leg.api.NativeDriver(leg.W, leg.H, device=leg.device, gop_size=leg.gop or (1 << 30), altref_range=ALTREF_RANGE, qi_min=0, qi_max=48,
+                                 ssim_target=leg.ssim_target, device_params=1, check_ssim=CHECK_SSIM, ref_mask=3 if leg.refs == "all" else 0,
+                                 conformant_stream=leg.conformant, **leg.src_kw)
+        h = size = 0
+        for t in range(leg.t_key[k], leg.t[k]):
+            d.encode_frame_device(*leg.ptrs[t % leg.nd])
+            if t >= t_before[k]:
+                f = d.get_frame()
+                h, size = leg.api.frame_check(h, f), size + len(f)
+        d.close()
+        self_check = {"chunk": k, "frames": nb, "bytes": [int(nbytes[k]), int(size)], "frame_check": [int(checks[k]), int(h)],
+                      "identical": int(checks[k]) == int(h) and int(nbytes[k]) == int(size),
+                      "what": "the leg's frames of one chunk against the same frames delivered by an un-batched driver of its own (every byte, in order)"}
+        if not self_check["identical"]:
+            raise SystemExit(f"bench.py: self-check of the frames-out leg FAILED: {self_check}")
     return {"value": round(leg.mbs * nb * G / eb, 1), "unit": "macroblocks/s", "fps": round(nb * G / eb, 1), "frames": nb * G,
-            "host_threads_per_gpu": len(th), "avg_frame_bytes": int(sum(nbytes) / (nb * G)),
+            "host_threads_per_gpu": len(th), "avg_frame_bytes": int(sum(nbytes) / (nb * G)), "self_check": self_check,
             "what": "native frame loop + vp8drv_get_frame: coefficient partitions and first partition coded on the device, finished "
                     "frames in host memory (byte-identical to the reference's output)"}
 

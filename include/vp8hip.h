@@ -300,6 +300,28 @@ int vp8hip_export_search(vp8hip_ctx *ctx, int ref, void *d_vectors, void *d_cost
 int vp8hip_import_search(vp8hip_ctx *ctx, int ref, const void *d_vectors, const void *d_costs);
 int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
 
+/* The same exchanges made by the library itself: RCCL (ncclBroadcast groups) on the context's stream, event-ordered with the
+ * kernels around them, NO host synchronisation per frame -- what stands where the reference's three queues meet
+ * (inter_part.h:122-135, 201-236, 263-266).  One context per process and device takes part:
+ *   vp8hip_shard_unique_id   on ONE rank: 128 opaque bytes (ncclGetUniqueId) that the host hands to the other ranks by its own means
+ *                            (a TCP store, MPI, a file);
+ *   vp8hip_shard_init        every rank, the same id: the context's communicator (ncclCommInitRank; world <= 3, collective);
+ *   vp8hip_shard_share_search  after vp8hip_inter_search: the vector and cost nets of every reference in used_mask (bit r) from
+ *                            the rank that searched it (reference r belongs to rank r mod world) to all ranks, in place in the
+ *                            nets vp8hip_inter_finish reads;
+ *   vp8hip_shard_share_last  after rank root's vp8hip_loop_filter: root's filtered reconstruction becomes every rank's LAST;
+ *   vp8hip_shard_max         barrier + maximum of one double over the ranks (a wall time); blocks.
+ * The frame-type state machine runs identically on every rank (RefShardDriver in vp8oclenc_amd/ref_shard.py), so the GOLDEN /
+ * ALTREF rotation needs no message.  VP8HIP_ERR_STATE before vp8hip_shard_init or for a member of a batch. */
+#define VP8HIP_SHARD_ID_BYTES 128
+int vp8hip_shard_unique_id(uint8_t id[VP8HIP_SHARD_ID_BYTES]);
+int vp8hip_shard_init(vp8hip_ctx *ctx, const uint8_t id[VP8HIP_SHARD_ID_BYTES], int rank, int world);
+int vp8hip_shard_rank(const vp8hip_ctx *ctx);    /* -1 before vp8hip_shard_init */
+int vp8hip_shard_world(const vp8hip_ctx *ctx);   /*  0 before vp8hip_shard_init */
+int vp8hip_shard_share_search(vp8hip_ctx *ctx, int used_mask);
+int vp8hip_shard_share_last(vp8hip_ctx *ctx, int root);
+int vp8hip_shard_max(vp8hip_ctx *ctx, double *value);
+
 /* ---- batched contexts: one launch per stage for up to four GOP chunks ---------------------------------------------------
  * The MI355X runs four to five kernels at once however many streams offer work, so sixteen contexts
  * that each launch their own kernels leave most of the part idle.  A batch groups up to VP8HIP_MAX_BATCH contexts of one

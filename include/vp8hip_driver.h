@@ -136,9 +136,14 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * keys_out[k][i] (may be NULL) counts member i's key frames.  bytes_out (may be NULL): with it every frame is also delivered as
  * bytes -- vp8drv_batch_get_frame_begin for the batch, vp8drv_get_frame_end per member into a buffer of the thread -- and
  * bytes_out[k][i] receives the sum of member i's frame sizes: the loop of a transcoder that writes the frames away.
+ * check_out (may be NULL; needs bytes_out): check_out[k][i] is folded with a checksum of every frame of member i as it is
+ * delivered, in order -- vp8drv_frame_check(previous value, frame, size); start it at 0 -- so that a caller can hold the bytes of
+ * a whole run against a second coding of the same frames without keeping them (bench.py's self-check).
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
-                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out);
+                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out);
+/* the fold above: h' = (h * 0x9E3779B97F4A7C15 + size) ^ (sum of the frame's little-endian 64-bit words, the tail zero-padded) */
+uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */
 typedef struct {

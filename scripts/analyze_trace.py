@@ -9,7 +9,7 @@ for r in rows:
     m = re.search(r"(k_[a-z0-9_]+)", n)
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else n[:20], r.get("Stream_Id", r.get("Queue_Id", "")), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)))
 ev.sort()
-lf = [i for i, e in enumerate(ev) if e[2] == "k_loop_filter3"]
+lf = [i for i, e in enumerate(ev) if e[2].startswith("k_loop_filter")]
 nshow = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for a, b in list(zip(lf, lf[1:]))[-nshow - 1:-1]:
     t0 = ev[a][0]

@@ -8,7 +8,7 @@ for r in rows:
     m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"]); n = m.group(1) if m else r["Kernel_Name"][:16]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, int(r.get("Grid_Size", 0) or 0)))
 ev.sort()
-lf = [e for e in ev if e[2].startswith("k_loop_filter3")]
+lf = [e for e in ev if e[2].startswith("k_loop_filter")]
 t0, t1 = lf[-min(nlf, len(lf))][0], lf[-1][1]
 sel = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 print("window %.1f ms, %d kernels" % ((t1 - t0) / 1e6, len(sel)))

@@ -6,7 +6,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch
 from vp8oclenc_amd import api
 from vp8oclenc_amd.synth import SynthSequence
 
@@ -27,8 +26,8 @@ seq = SynthSequence(a.width, a.height, seed=1)
 W, H = seq.W, seq.H
 mbs = (W // 16) * (H // 16)
 nd = 8
-dev = [tuple(torch.from_numpy(p).cuda() for p in seq.frame(t)) for t in range(nd)]
-torch.cuda.synchronize()
+dev = [tuple(api.to_device(p) for p in seq.frame(t)) for t in range(nd)]
+api.device_synchronize()
 drvs = [api.NativeDriver(W, H, gop_size=1 << 30, num_partitions=a.partitions, check_ssim=a.check_ssim) for _ in range(a.streams)]
 sizes = [0] * a.streams
 

@@ -2,16 +2,15 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import bench
 from vp8oclenc_amd import api
 
 def single(tag, n=200):
-    r = bench.side_leg(torch, api, 1920, 1080, 1, "all", -1.0, n, 20, 0, nd=8)
+    r = bench.side_leg(api, 1920, 1080, 1, "all", -1.0, n, 20, 0, nd=8)
     print(tag, r["ms_per_frame"], "lf", r["loop_filter_ms_by_its_own_clock"], "clock", r["shader_clock_ghz"], flush=True)
 
 single("fresh")
-leg = bench.Leg(torch, api, 1920, 1080, 32, "all", -1.0, 8, 0, 1, batch=4)
+leg = bench.Leg(api, 1920, 1080, 32, "all", -1.0, 8, 0, 1, batch=4)
 for _ in range(10): leg.step()
 el, enq, nrefs = leg.run(int(os.environ.get("LOAD_STEPS", "120")))
 print("32 chunks: %.2f M MB/s" % (leg.mbs * int(os.environ.get("LOAD_STEPS", "120")) * 32 / el / 1e6), flush=True)

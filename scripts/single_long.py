@@ -2,10 +2,9 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import bench
 from vp8oclenc_amd import api
-leg = bench.Leg(torch, api, 1920, 1080, 1, "all", -1.0, 8, 0, 1, overlap_filter=1)
+leg = bench.Leg(api, 1920, 1080, 1, "all", -1.0, 8, 0, 1, overlap_filter=1)
 for _ in range(20): leg.step()
 for i in range(8):
     el, enq, nrefs = leg.run(2000)

@@ -5,7 +5,6 @@ import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
 from vp8oclenc_amd import api
 from vp8oclenc_amd.synth import SynthSequence
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -14,7 +13,7 @@ gop = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 G = int(sys.argv[5]) if len(sys.argv) > 5 else 48
 B = int(sys.argv[6]) if len(sys.argv) > 6 else 6
 seq = SynthSequence(W, H, seed=1)
-dev = [tuple(torch.from_numpy(p).cuda() for p in seq.frame(t)) for t in range(4)]
+dev = [tuple(api.to_device(p) for p in seq.frame(t)) for t in range(4)]
 ptrs = [tuple(p.data_ptr() for p in f) for f in dev]
 t0 = time.time()
 for c in range(cycles):
@@ -24,7 +23,7 @@ for c in range(cycles):
     api.NativeBatch.encode_frames_device_all(batches, 6, ptrs, [[(3 * k) % 4 for k in m] for m in groups])
     for d in drv:
         d.resolve()
-    torch.cuda.synchronize()
+    api.device_synchronize()
     for b in batches:
         b.close()
     for d in drv:

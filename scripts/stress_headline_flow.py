@@ -5,14 +5,13 @@ import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import bench
 from vp8oclenc_amd import api
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 noprof, nobits = "noprof" in sys.argv, "nobits" in sys.argv
 t0 = time.time()
 for c in range(cycles):
-    leg = bench.Leg(torch, api, 1920, 1080, 48, "all", -1.0, 4, 0, seed=1, batch=6)
+    leg = bench.Leg(api, 1920, 1080, 48, "all", -1.0, 4, 0, seed=1, batch=6)
     if not noprof:
         leg.drv[0].hip.profile_enable(api.K_NAMES)
         for d in leg.drv:
@@ -20,7 +19,7 @@ for c in range(cycles):
     leg.clock_read()
     for _ in range(5):
         leg.step()
-    torch.cuda.synchronize()
+    api.device_synchronize()
     if not noprof:
         leg.drv[0].hip.profile_read()
         for d in leg.drv:
@@ -31,7 +30,7 @@ for c in range(cycles):
     if not noprof:
         leg.profile_read()
         leg.profile([])
-    bs = None if nobits else bench.bitstream_leg(torch, leg, 20)["value"]
+    bs = None if nobits else bench.bitstream_leg(leg, 20)["value"]
     leg.close()
     print(f"cycle {c}: {leg.mbs * 20 * 48 / el / 1e6:.1f} M, frames out {(bs or 0) / 1e6:.1f} M ({time.time() - t0:.0f} s)", flush=True)
 print("done")

@@ -5,7 +5,6 @@ import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
 import bench
 from vp8oclenc_amd import api
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -20,6 +19,6 @@ for c in range(cycles):
     for name, (a, kw) in legs.items():
         if which != "all" and which != name:
             continue
-        r = bench.side_leg(torch, api, *a, 0, **kw)
+        r = bench.side_leg(api, *a, 0, **kw)
         print(f"cycle {c} {name}: {r['value'] / 1e6:.1f} M  ({time.time() - t0:.0f} s)", flush=True)
 print("done")

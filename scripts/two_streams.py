@@ -3,11 +3,10 @@ import os, sys, threading, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
 from vp8oclenc_amd import api
 from vp8oclenc_amd.synth import SynthSequence
 seq = SynthSequence(1920, 1080, seed=1)
-dev = [tuple(torch.from_numpy(p).cuda() for p in seq.frame(t)) for t in range(8)]
+dev = [tuple(api.to_device(p) for p in seq.frame(t)) for t in range(8)]
 ptr = [tuple(p.data_ptr() for p in f) for f in dev]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 def run(chunks, check, bits, overlap=1, label=""):
@@ -20,10 +19,10 @@ def run(chunks, check, bits, overlap=1, label=""):
             d.encode_frame_device(*ptr[(3 * k + t) % 8])
             if bits: d.get_frame()
         d.resolve(); d.hip.synchronize()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    api.device_synchronize(); t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(chunks)]
     [t.start() for t in th]; [t.join() for t in th]
-    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    api.device_synchronize(); el = time.perf_counter() - t0
     print(f"{label or ''} chunks {chunks} check {check} frames_out {bits} overlap {overlap}: {el / N * 1e3:.4f} ms per frame-step, {chunks * N / el:.0f} fps total", flush=True)
     for d in drv: d.close()
 for chunks in (1, 2):

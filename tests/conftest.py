@@ -11,15 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # PyTorch ships its own copy of the HIP runtime.  If libvp8hip.so (linked against /opt/rocm) is the
-    # first to initialise HIP in a process, torch later reports "No HIP GPUs are available"; the other
-    # order works (bench.py also initialises torch first).  Only one test hands torch tensors to the ABI.
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
+    # ONE GPU runtime per test process: the tests hold their frames in memory the library allocates (api.to_device) and never
+    # import PyTorch in-process on the GPU box; the few tests that need torch.distributed over RCCL run it in a child process.
 
 
 @pytest.fixture(scope="session")

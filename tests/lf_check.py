@@ -41,7 +41,7 @@ def run(W, H, seed, levels=(6, 10, 14, 20), reps=1):
         st = np.zeros(64, np.uint64)
         hip.lib.vp8hip_debug_download(hip.h, 100, 0, 0, C.c_void_p(st.ctypes.data), 512)
         steps = W // 16 + 8      # library built with VP8HIP_EXTRA_FLAGS=-DLF_STAMPS
-        print("   stamps (cycles/step: poll p1 p2 spins) per band,wave:", (st.reshape(16, 4)[:8] / steps).astype(int).tolist(), "feeder band 0 (wait vm work):", (st.reshape(16, 4)[8] / steps).astype(int).tolist())
+        print("   stamps (cycles/step: poll p1 p2 spins) per band,wave:", (st.reshape(16, 4)[:8] / steps).astype(int).tolist(), "\n   band timelines (us: step 0, step 64, end of wave 0):", (st[32:32 + 27].reshape(9, 3) / 100.0).round(1).tolist())
     bad = ""
     if not all(ok):
         d = np.argwhere(hy != fo["recon_Y"])

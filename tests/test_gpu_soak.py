@@ -244,8 +244,7 @@ def test_gather_frames_over_rccl(tmp_path):
 
 def test_two_contexts_on_two_devices_from_worker_threads():
     """entry points select the context's device themselves (HIP's current device is per thread)."""
-    import torch
-    if torch.cuda.device_count() < 2:
+    if api.device_count() < 2:
         pytest.skip("needs two GPUs")
     import threading
     s = SynthSequence(128, 96, seed=3)
@@ -263,20 +262,21 @@ def test_two_contexts_on_two_devices_from_worker_threads():
     assert out[0] == out[1] and len(out[0]) == 4
 
 
-REF_WORKER = textwrap.dedent("""
-    import os, sys
-    sys.path.insert(0, {root!r})
-    import numpy as np, torch, torch.distributed as dist
-    from vp8oclenc_amd import api, ref_shard
-    from vp8oclenc_amd.driver import InterPathDriver
+def test_reference_split_exchanges_inside_the_library():
+    """SURVEY 8e(i) on hardware, through the C ABI: vp8hip_shard_init (a communicator of one rank: ncclCommInitRank from
+    vp8hip_shard_unique_id), vp8hip_inter_search -> vp8hip_shard_share_search (RCCL broadcasts, in place in the context's nets) ->
+    vp8hip_inter_finish, loop filter, vp8hip_shard_share_last -- every exchange enqueued on the context's stream with no host
+    synchronisation -- and every frame compared with the plain vp8hip_inter_transform path.  The three-rank split itself:
+    tests/test_ref_shard.py over gloo with the CPU oracle as the backend."""
+    from vp8oclenc_amd import ref_shard
     from vp8oclenc_amd.gop_shard import frame_digest
-    from vp8oclenc_amd.synth import SynthSequence
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     for (W, H, frames) in ((320, 192, 12), (1920, 1080, 4)):
         seq = SynthSequence(W, H, seed=9)
         be = ref_shard.HipRefBackend(seq.W, seq.H)
-        drv = ref_shard.RefShardDriver(be, dist, seq.W, seq.H, altref_range=3, force_collective=True, loopback=True)
+        be.shard_init(ref_shard.shard_unique_id(), 0, 1)
+        assert (be.shard_rank(), be.shard_world()) == (0, 1)
+        drv = ref_shard.RefShardDriver(be, None, seq.W, seq.H, altref_range=3)
+        assert drv.native and drv.collective
         plain = api.Vp8Hip(seq.W, seq.H)
         pdrv = InterPathDriver(plain, seq.W, seq.H, altref_range=3, check_ssim=False)
         for t in range(frames):
@@ -288,21 +288,8 @@ REF_WORKER = textwrap.dedent("""
             db = frame_digest(b, plain.download_last())
             assert da == db, (W, H, t)
         assert drv.bytes_broadcast == frames * seq.W * seq.H * 3 // 2 and drv.bytes_gathered > 0
+        assert abs(be.shard_max(1.25) - 1.25) < 1e-12
         be.close(); plain.close()
-    dist.destroy_process_group()
-    print("ref shard over rccl ok")
-""")
-
-
-def test_reference_split_exchanges_over_rccl(tmp_path):
-    """SURVEY 8e(i) on hardware: vp8hip_inter_search / export_search -> RCCL all_gather -> import_search / inter_finish, loop
-    filter, export_last -> RCCL broadcast -> set_last_device, every exchange walked by one rank (loopback) and every frame
-    compared with the plain vp8hip_inter_transform path.  The three-rank split itself: tests/test_ref_shard.py over gloo."""
-    script = tmp_path / "w.py"
-    script.write_text(REF_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ref shard over rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_contexts_driven_from_worker_threads_at_once():

@@ -30,13 +30,13 @@ ABI_SYMBOLS = [
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
     "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
-    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_experiments_compiled_in", "vp8hip_batch_prep_mode", "vp8hip_device_count", "vp8hip_device_alloc", "vp8hip_device_free", "vp8hip_device_upload", "vp8hip_device_download", "vp8hip_device_synchronize", "vp8hip_device_mem_info", "vp8hip_device_pci_bus_id", "vp8hip_runtime_version", "vp8hip_encode_header", "vp8hip_encode_frame",
+    "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_experiments_compiled_in", "vp8hip_batch_prep_mode", "vp8hip_device_count", "vp8hip_device_alloc", "vp8hip_device_free", "vp8hip_device_upload", "vp8hip_device_download", "vp8hip_device_synchronize", "vp8hip_device_mem_info", "vp8hip_device_pci_bus_id", "vp8hip_runtime_version", "vp8hip_shard_unique_id", "vp8hip_shard_init", "vp8hip_shard_rank", "vp8hip_shard_world", "vp8hip_shard_share_search", "vp8hip_shard_share_last", "vp8hip_shard_max", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_frame_check", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -215,6 +215,14 @@ def device_pci_bus_id(device: int = 0) -> str:
     if rc != 0:
         raise Vp8HipError("vp8hip_device_pci_bus_id failed")
     return buf.value.decode().lower()
+
+
+def frame_check(h: int, frame: bytes) -> int:
+    """vp8drv_frame_check (include/vp8hip_driver.h): the fold bench.py holds a run's frames against a second coding with"""
+    lib = load_library()
+    lib.vp8drv_frame_check.argtypes = [C.c_uint64, C.c_char_p, C.c_size_t]
+    lib.vp8drv_frame_check.restype = C.c_uint64
+    return int(lib.vp8drv_frame_check(h, frame, len(frame)))
 
 
 def _ptr(a):
@@ -486,13 +494,17 @@ class NativeBatch:
         st = [(C.c_int * b.n)(*[int(x) for x in s]) for b, s in zip(batches, starts)]
         ko = [(C.c_int * b.n)() for b in batches]
         bo = [(C.c_uint64 * b.n)() for b in batches]
+        co = [(C.c_uint64 * b.n)() for b in batches]       # vp8drv_frame_check folded over every delivered frame, per member
         IP, UP = C.POINTER(C.c_int), C.POINTER(C.c_uint64)
-        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP), C.POINTER(UP)]
+        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP), C.POINTER(UP), C.POINTER(UP)]
         rc = lib.vp8drv_batches_encode_frames_device((C.c_void_p * n)(*[b.h for b in batches]), n, int(nframes), C.cast(F, C.c_void_p), nd,
                                                       (IP * n)(*[C.cast(a, IP) for a in st]), (IP * n)(*[C.cast(a, IP) for a in ko]),
-                                                      (UP * n)(*[C.cast(a, UP) for a in bo]) if frames_out else None)
+                                                      (UP * n)(*[C.cast(a, UP) for a in bo]) if frames_out else None,
+                                                      (UP * n)(*[C.cast(a, UP) for a in co]) if frames_out else None)
         if rc < 0:
             raise Vp8HipError(f"vp8drv_batches_encode_frames_device: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+        if frames_out == "check":
+            return [list(a) for a in ko], [list(a) for a in bo], [list(a) for a in co]
         if frames_out:
             return [list(a) for a in ko], [list(a) for a in bo]
         return [list(a) for a in ko]

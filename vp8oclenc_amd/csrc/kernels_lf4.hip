@@ -599,8 +599,25 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
         asm volatile("" ::: "memory");
     }
 #ifdef LF_STAMPS
-    unsigned long long st_p1 = 0, st_wait = 0, st_p2 = 0, st_spins = 0, st_t0, st_t1;
+    unsigned long long st_p1 = 0, st_wait = 0, st_p2 = 0, st_spins = 0, st_t0, st_t1, tl0 = 0, tl64 = 0;
 #endif
+    // What P1 of a step reads of its own macroblock -- the parameter record and the sixteen fresh samples of the lane's pixel row --
+    // is requested half a step early, behind the poll that has just seen the porter's progress: the reads return during P2.
+    // (Only the four samples to the left, which P2 of this very step writes, are read when P1 starts.)
+    int4 n_pa = make_int4(0, 0, 0, 0), n_v1 = n_pa, n_v2 = n_pa, n_v3 = n_pa, n_v4 = n_pa;
+    int2 n_pb = make_int2(0, 0);
+#define P1_REQUEST(S_)                                                                        \
+    {                                                                                         \
+        const int xn = (S_) - r;                                                              \
+        if (row_real & (xn >= 0) & (xn < mbw)) {                                              \
+            const uint32_t sl = (uint32_t)xn & (RING - 1);                                    \
+            const uint32_t sn = p1_base + (sl << mb_shift), pn = par_base + sl * PAR_BYTES;   \
+            n_pa = ld128(pn); n_pb = ld64(pn + 16);                                           \
+            n_v1 = ld128(sn); n_v2 = ld128(sn + 16); n_v3 = ld128(sn + 32); n_v4 = ld128(sn + 48); \
+        }                                                                                     \
+    }
+    P1_REQUEST(0)
+    const int up = imax(wave - 1, 0);
     for (int S = 0; S < steps; ++S) {
         STAMP(st_t0);
         const int x = S - r;
@@ -608,22 +625,19 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
         const bool on = row_real & (x >= 0) & (x < mbw);
         const uint32_t slot = (uint32_t)x & (RING - 1);
         const uint32_t colB = slot << mb_shift, colA = (colB - 16) & ringmask;
-        const uint32_t pa_ = par_base + slot * PAR_BYTES;
         Limits L;
         int il_p1 = -1, il_in = -1, il_p2 = -1;
         // ---- P1: vertical edges, lane = pixel row -------------------------------------------------
         if (on) {
-            const int4 pa = ld128(pa_);
-            const int2 pb = ld64(pa_ + 16);
             const uint32_t s = p1_base + colB;
-            const int4 v0 = ld128(p1_base + colA), v1 = ld128(s), v2 = ld128(s + 16), v3 = ld128(s + 32), v4 = ld128(s + 48);
-            il_p1 = pa.x; il_in = pa.y; il_p2 = pa.z;
-            L.hev_thr = pa.w; L.mb_delta = pb.x; L.b_delta = pb.y;
+            const int4 v0 = ld128(p1_base + colA), v1 = n_v1, v2 = n_v2, v3 = n_v3, v4 = n_v4;
+            il_p1 = n_pa.x; il_in = n_pa.y; il_p2 = n_pa.z;
+            L.hev_thr = n_pa.w; L.mb_delta = n_pb.x; L.b_delta = n_pb.y;
             int t[20] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
             filter_line(t, L, il_p1, il_in, il_in | chroma_m1);
 #pragma unroll
             for (int k = 1; k < 18; ++k) t[k] = satb(t[k]);
-            // macroblock 0 has nothing to its left (the slot belongs to a macroblock the feeder may be bringing in); chroma
+            // macroblock 0 has nothing to its left (the slot belongs to a macroblock the porter may be bringing in); chroma
             // lanes own eight columns
             st128(x > 0 ? p1_base + colA : dummy, make_int4(t[0], t[1], t[2], t[3]));
             st128(s, make_int4(t[4], t[5], t[6], t[7]));
@@ -632,23 +646,34 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
             st128(sh_ + 32, make_int4(t[12], t[13], t[14], t[15]));
             st128(sh_ + 48, make_int4(t[16], t[17], t[18], t[19]));
         }
+        // ---- the one poll of the step ------------------------------------------------------------
+        // Its first reads are issued before this wave's own writes have landed (LDS operations of a wave complete in order): in the
+        // steady state the wave above and the porter are a hand-off ahead, and the poll costs the instructions, not a round trip.
+        const int need_up = 2 * S + 1;                           // P1 of the rows above (their macroblock x+1)
+        const int need_feed = imin(S + 2, mbw + 2 * wave + 1);   // the macroblocks of the next step's P1 (this wave's porter)
+        const int need_top = imin(S + 1, mbw);                   // the rows above the band over this step's macroblock of row 0
+        int f_up = need_up, f_top = need_top;
+        if (wave > 0) f_up = flag[up];
+        if (top_wave) f_top = flag[F_TOP];
+        int f_feed = flag[F_FEED + wave];
         lds_fence();
         flag[wave] = 2 * S + 1;   // (every lane, the same word: no exec mask to set up and restore)
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p1 += st_t1 - st_t0; st_t0 = st_t1;
 #endif
-        // ---- the one poll of the step ------------------------------------------------------------
-        {
-            const int need_up = 2 * S + 1;                       // P1 of the rows above (their macroblock x+1)
-            const int need_feed = imin(S + 2, mbw + 2 * wave + 1);   // the macroblocks of the next step's P1 (this wave's porter)
-            const int need_top = top_wave ? imin(S + 1, mbw) : 0;   // the rows above the band over this step's macroblock of row 0
-            const int up = imax(wave - 1, 0);
+        // Everything the poll compares is the same in all lanes; readfirstlane says so to the compiler, which otherwise
+        // builds the loop out of exec-mask bookkeeping.
+        if (!__builtin_amdgcn_readfirstlane((int)((f_up >= need_up) & (f_feed >= need_feed) & (f_top >= need_top)))) {
+            // What this wave waits for is the work of a wave that shares its SIMD (its porter) or of the wave above: a polling
+            // wave at high priority takes the issue slots its own supplier needs.
+            __builtin_amdgcn_s_setprio(0);
             for (int spins = 0;; ++spins) {
-                const int f_up = flag[up], f_feed = flag[F_FEED + wave], f_top = flag[F_TOP], f_abort = flag[F_ABORT];
-                const bool ok = (wave == 0 || f_up >= need_up) && f_feed >= need_feed && f_top >= need_top;
-                // Everything the poll compares is the same in all lanes; readfirstlane says so to the compiler, which otherwise
-                // builds the loop out of exec-mask bookkeeping.
+                if (wave > 0) f_up = flag[up];
+                if (top_wave) f_top = flag[F_TOP];
+                f_feed = flag[F_FEED + wave];
+                const int f_abort = flag[F_ABORT];
+                const bool ok = (f_up >= need_up) & (f_feed >= need_feed) & (f_top >= need_top);
                 const int state = __builtin_amdgcn_readfirstlane(f_abort ? 2 : (ok ? 1 : 0));
                 if (state == 1) break;
                 if (state == 2) return;
@@ -656,14 +681,15 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
                 st_spins += (f_feed < need_feed) ? 1000 : 1;
 #endif
                 if (spins > SPIN_LIMIT) { flag[F_ABORT] = 1; *a.err = 1; }
-                // What this wave waits for is the work of a wave that shares its SIMD (a helper) or of the wave above: a polling
-                // wave at high priority takes the issue slots its own supplier needs.
-                if (spins == 0) __builtin_amdgcn_s_setprio(0);
                 if (spins < 32) asm volatile("s_nop 3"); else __builtin_amdgcn_s_sleep(1);   // the flag is usually a few hundred cycles away: a tight poll first, naps when it is not
             }
             __builtin_amdgcn_s_setprio(LF_PRIO);
-            asm volatile("" ::: "memory");
         }
+        asm volatile("" ::: "memory");
+#ifdef LF_STAMPS
+        if (wave == 0 && (S == 0 || S == 64)) { unsigned long long tt = __builtin_amdgcn_s_memrealtime(); if (S == 0) tl0 = tt; else tl64 = tt; }
+#endif
+        P1_REQUEST(S + 1)
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_wait += st_t1 - st_t0; st_t0 = st_t1;
@@ -696,6 +722,11 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
     if (lane == 0 && band < 2) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(a.gprog + 1024) + (band * WORKERS + wave) * 4;
         o[0] = st_wait; o[1] = st_p1; o[2] = st_p2; o[3] = st_spins;
+    }
+    if (lane == 0 && wave == 0 && band < 16) {   // the band's timeline, 100 MHz ticks since the launch's start
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.gprog + 1024) + 8 * 4 + band * 3;
+        const unsigned long long t0 = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o[0] = tl0 - t0; o[1] = tl64 - t0; o[2] = __builtin_amdgcn_s_memrealtime() - t0;
     }
 #endif
 }

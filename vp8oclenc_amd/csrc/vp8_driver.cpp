@@ -5,6 +5,7 @@
 
 #include <new>
 #include <chrono>
+#include <string.h>
 #include <thread>
 #include <vector>
 
@@ -505,9 +506,25 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
     return VP8HIP_OK;
 }
 
+uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size) {
+    uint64_t sum = 0;
+    size_t i = 0;
+    for (; i + 8 <= size; i += 8) {
+        uint64_t w;
+        memcpy(&w, frame + i, 8);
+        sum += w;
+    }
+    if (i < size) {
+        uint64_t w = 0;
+        memcpy(&w, frame + i, size - i);
+        sum += w;
+    }
+    return (h * 0x9E3779B97F4A7C15ull + (uint64_t)size) ^ sum;
+}
+
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
-                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out) {
-    if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start) return VP8HIP_ERR_ARG;
+                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out) {
+    if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start || (check_out && !bytes_out)) return VP8HIP_ERR_ARG;
     for (int k = 0; k < nbatches; ++k)
         if (!batches[k] || batches[k]->n < 1 || !batches[k]->d[0] || !start[k]) return VP8HIP_ERR_ARG;
     std::vector<std::thread> th;
@@ -541,6 +558,7 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                         size_t size = 0;
                         rc[k] = vp8drv_get_frame_end(b->d[i], frame.data(), frame.size(), &size);
                         if (bytes_out[k]) bytes_out[k][i] += size;
+                        if (check_out && check_out[k] && rc[k] == VP8HIP_OK) check_out[k][i] = vp8drv_frame_check(check_out[k][i], frame.data(), size);
                     }
                 }
             }

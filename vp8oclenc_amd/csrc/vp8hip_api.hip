@@ -15,6 +15,8 @@
 #include <vector>
 #include <new>
 
+#include <rccl/rccl.h>
+
 #include "../../include/vp8hip.h"
 #include "vp8hip_dev.h"
 
@@ -72,6 +74,9 @@ struct vp8hip_ctx {
     SegData *h_sd_ring = nullptr;   // pinned staging for vp8hip_set_segments
     unsigned sd_ring_pos = 0;
     int32_t *d_progress = nullptr;
+    // a frame's reference searches on several devices (vp8hip_shard_*): this context's communicator
+    ncclComm_t shard_comm = nullptr;
+    int shard_rank = 0, shard_world = 1;
     void *d_lf_handoff = nullptr;   // loop filter form 4: a band's bottom rows on their way to the next band (tagged granules)
     unsigned lf_launches = 0;       // window index of the loop filter's never-reset band counters
     int src_w = 0, src_h = 0;       // vp8hip_set_source_size: size of the planes handed over as current frames (0 = coded size)
@@ -556,6 +561,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         }
     }
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->shard_comm) ncclCommDestroy(c->shard_comm);
     event_pool_put(c->device, c->ev, c->ev_made);
     hipFree(c->pixel_pool);
     for (int r = 0; r < 3; ++r) {
@@ -915,6 +921,103 @@ int vp8hip_export_last(vp8hip_ctx *c, void *d_y, void *d_u, void *d_v) {
     void *dst[3] = {d_y, d_u, d_v};
     for (int i = 0; i < 3; ++i)
         HIPCHK(c, hipMemcpy2DAsync(dst[i], pl[i]->w, pl[i]->p, pl[i]->stride, pl[i]->w, pl[i]->h, hipMemcpyDeviceToDevice, c->stream));
+    return VP8HIP_OK;
+}
+
+// ---- the exchanges of a frame split by reference, inside the library: RCCL on the context's stream, no host synchronisation ----
+// (the reference runs the three searches of a frame on three command queues that share only the current frame,
+// inter_part.h:122-135, 201-236, and reads the results back at :263-266.)
+int vp8hip_shard_unique_id(uint8_t id[VP8HIP_SHARD_ID_BYTES]) {
+    static_assert(VP8HIP_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id travels as opaque bytes");
+    if (!id) return VP8HIP_ERR_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return VP8HIP_ERR_HIP;
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return VP8HIP_OK;
+}
+
+int vp8hip_shard_init(vp8hip_ctx *c, const uint8_t id[VP8HIP_SHARD_ID_BYTES], int rank, int world) {
+    USE_DEVICE(c);
+    if (!c || !id || world < 1 || world > 3 || rank < 0 || rank >= world) return VP8HIP_ERR_ARG;
+    if (c->shard_comm || c->batch) return VP8HIP_ERR_STATE;
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    if (ncclCommInitRank(&c->shard_comm, world, u, rank) != ncclSuccess) {
+        c->shard_comm = nullptr;
+        return VP8HIP_ERR_HIP;
+    }
+    c->shard_rank = rank;
+    c->shard_world = world;
+    return VP8HIP_OK;
+}
+
+int vp8hip_shard_rank(const vp8hip_ctx *c) { return c && c->shard_comm ? c->shard_rank : -1; }
+int vp8hip_shard_world(const vp8hip_ctx *c) { return c && c->shard_comm ? c->shard_world : 0; }
+
+// Every searched reference's quarter-pel vector net and cost net (8 bytes per 8x8 block) from the rank that searched it
+// (reference r: rank r mod world) to all ranks, IN PLACE in the nets the searches wrote and vp8hip_inter_finish reads: one
+// group of broadcasts = one RCCL launch on the context's stream.
+int vp8hip_shard_share_search(vp8hip_ctx *c, int used_mask) {
+    USE_DEVICE(c);
+    if (!c || (used_mask & ~7)) return VP8HIP_ERR_ARG;
+    if (!c->shard_comm) return VP8HIP_ERR_STATE;
+    JOIN_LF(c);
+    bool ok = ncclGroupStart() == ncclSuccess;
+    for (int r = 0; r < 3 && ok; ++r) {
+        if (!(used_mask & (1 << r))) continue;
+        const int root = r % c->shard_world;
+        ok = ncclBroadcast(c->nets.net[r][0], c->nets.net[r][0], (size_t)c->b8, ncclInt32, root, c->shard_comm, c->stream) == ncclSuccess &&
+             ncclBroadcast(c->nets.bdiff[r], c->nets.bdiff[r], (size_t)c->b8, ncclInt32, root, c->shard_comm, c->stream) == ncclSuccess;
+    }
+    ok = (ncclGroupEnd() == ncclSuccess) && ok;
+    return ok ? VP8HIP_OK : VP8HIP_ERR_HIP;
+}
+
+// The filtered reconstruction of rank `root` (its LAST after vp8hip_loop_filter) becomes every rank's LAST: the three padded
+// planes straight out of root's frame pool into a free surface of the others' pools (vp8enc.cpp:395-401 is what the
+// reference does with it on one device).  Replicated edges and pyramid are made where the next frame begins, as after a
+// loop filter of this context's own.
+int vp8hip_shard_share_last(vp8hip_ctx *c, int root) {
+    USE_DEVICE(c);
+    if (!c || root < 0) return VP8HIP_ERR_ARG;
+    if (!c->shard_comm || root >= c->shard_world) return VP8HIP_ERR_STATE;
+    JOIN_LF(c);
+    int idx;
+    if (c->shard_rank == root) {
+        idx = c->slot[0];
+        if (idx < 0) return VP8HIP_ERR_STATE;
+    } else {
+        idx = pick_free_frame(c);
+        if (idx < 0) return VP8HIP_ERR_STATE;
+    }
+    const Frame &f = c->frames[idx].f;
+    const Plane *pl[3] = {&f.Y[0], &f.U, &f.V};
+    bool ok = ncclGroupStart() == ncclSuccess;
+    for (int i = 0; i < 3 && ok; ++i) {
+        uint8_t *base = pl[i]->p - (size_t)PAD * pl[i]->stride - PAD;       // the plane with its margins: one contiguous piece
+        const size_t bytes = (size_t)pl[i]->stride * (pl[i]->h + 2 * PAD);
+        ok = ncclBroadcast(base, base, bytes, ncclUint8, root, c->shard_comm, c->stream) == ncclSuccess;
+    }
+    ok = (ncclGroupEnd() == ncclSuccess) && ok;
+    if (!ok) return VP8HIP_ERR_HIP;
+    if (c->shard_rank != root) {
+        c->frames[idx].pyramid_valid = false;
+        c->frames[idx].border_valid = false;
+        c->slot[0] = idx;
+    }
+    return VP8HIP_OK;
+}
+
+// barrier + maximum over the ranks of one double (a time), on the context's stream; blocks
+int vp8hip_shard_max(vp8hip_ctx *c, double *value) {
+    USE_DEVICE(c);
+    if (!c || !value) return VP8HIP_ERR_ARG;
+    if (!c->shard_comm) return VP8HIP_ERR_STATE;
+    double *d = reinterpret_cast<double *>(c->scratch);
+    HIPCHK(c, hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (ncclAllReduce(d, d, 1, ncclDouble, ncclMax, c->shard_comm, c->stream) != ncclSuccess) return VP8HIP_ERR_HIP;
+    HIPCHK(c, hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return VP8HIP_OK;
 }
 

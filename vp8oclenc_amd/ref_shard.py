@@ -13,68 +13,77 @@ This is the only data-path collective of the package; GOP-level sharding (gop_sh
 -- a 3 MB exchange per 0.5 ms frame is latency-bound -- so this path is for ONE live stream that must be coded faster
 than one GPU codes it.  The loop is InterPathDriver's (driver.py) without check_SSIM.
 
-A backend is an encoder context with the C ABI's method names (vp8oclenc_amd.api.Vp8Hip through HipRefBackend below; the
-CPU oracle through tests/refshard_cpu.py) plus four exchanges in torch tensors on the backend's device:
+A backend is an encoder context with the C ABI's method names.  The MI355X backend (HipRefBackend over vp8oclenc_amd.api.Vp8Hip)
+makes both exchanges INSIDE the library -- vp8hip_shard_share_search / vp8hip_shard_share_last: RCCL broadcasts on the context's
+stream, in place in the context's own buffers, no host synchronisation per frame -- and this file keeps only the frame-type state
+machine.  A backend without those calls (the CPU oracle, tests/refshard_cpu.py) gets the same exchanges made here over a
+torch.distributed group (gloo), through four methods in torch tensors on the backend's device:
     export_search(ref) -> int32 [2, b8]   (vectors, costs)      import_search(ref, tensor)
     export_last()      -> uint8 [W*H*3/2] (Y, U, V tight)       import_last(tensor)
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import api
 
+SHARD_ID_BYTES = 128     # VP8HIP_SHARD_ID_BYTES
+
+
+def shard_unique_id() -> bytes:
+    """vp8hip_shard_unique_id: on ONE rank; hand the bytes to the others (a store, a broadcast of the launcher's)"""
+    buf = (C.c_uint8 * SHARD_ID_BYTES)()
+    rc = api.load_library().vp8hip_shard_unique_id(buf)
+    if rc != 0:
+        raise api.Vp8HipError(f"vp8hip_shard_unique_id: {rc}")
+    return bytes(buf)
+
 
 class HipRefBackend(api.Vp8Hip):
-    """Vp8Hip + the device-memory exchanges of include/vp8hip.h (vp8hip_inter_search ... vp8hip_export_last)."""
+    """Vp8Hip + vp8hip_inter_search / vp8hip_inter_finish and the library's own exchanges (vp8hip_shard_*, include/vp8hip.h)."""
 
     def __init__(self, width: int, height: int, ssim_target: float = -1.0, device: int = 0):
         super().__init__(width, height, ssim_target, device)
-        import ctypes as C
-        import torch
-        self.torch = torch
-        self.dev = torch.device("cuda", device)
         vp = C.c_void_p
         self.lib.vp8hip_inter_search.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         self.lib.vp8hip_inter_finish.argtypes = [vp, C.c_int, C.c_int]
-        self.lib.vp8hip_export_search.argtypes = [vp, C.c_int, vp, vp]
-        self.lib.vp8hip_import_search.argtypes = [vp, C.c_int, vp, vp]
-        self.lib.vp8hip_export_last.argtypes = [vp, vp, vp, vp]
+        self.lib.vp8hip_shard_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        self.lib.vp8hip_shard_share_search.argtypes = [vp, C.c_int]
+        self.lib.vp8hip_shard_share_last.argtypes = [vp, C.c_int]
+        self.lib.vp8hip_shard_max.argtypes = [vp, C.POINTER(C.c_double)]
+        self.lib.vp8hip_shard_rank.argtypes = [vp]
+        self.lib.vp8hip_shard_world.argtypes = [vp]
+        self.native_shard = False
+
+    def shard_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == SHARD_ID_BYTES
+        self._chk(self.lib.vp8hip_shard_init(self.h, unique_id, rank, world), "shard_init")
+        self.native_shard = True
+
+    def shard_rank(self) -> int:
+        return int(self.lib.vp8hip_shard_rank(self.h))
+
+    def shard_world(self) -> int:
+        return int(self.lib.vp8hip_shard_world(self.h))
+
+    def shard_share_search(self, used_mask: int):
+        self._chk(self.lib.vp8hip_shard_share_search(self.h, int(used_mask)), "shard_share_search")
+
+    def shard_share_last(self, root: int = 0):
+        self._chk(self.lib.vp8hip_shard_share_last(self.h, int(root)), "shard_share_last")
+
+    def shard_max(self, value: float) -> float:
+        v = C.c_double(value)
+        self._chk(self.lib.vp8hip_shard_max(self.h, C.byref(v)), "shard_max")
+        return float(v.value)
 
     def inter_search(self, prev_is_golden, prev_is_altref, use_golden, use_altref, mask):
         self._chk(self.lib.vp8hip_inter_search(self.h, int(prev_is_golden), int(prev_is_altref), int(use_golden), int(use_altref), int(mask)), "inter_search")
 
     def inter_finish(self, use_golden, use_altref):
         self._chk(self.lib.vp8hip_inter_finish(self.h, int(use_golden), int(use_altref)), "inter_finish")
-
-    def export_search(self, ref: int):
-        t = self.torch.empty((2, self.b8), dtype=self.torch.int32, device=self.dev)
-        self._chk(self.lib.vp8hip_export_search(self.h, ref, t[0].data_ptr(), t[1].data_ptr()), "export_search")
-        self.synchronize()          # the copies ran on the context's stream; the collective runs on torch's
-        return t
-
-    def import_search(self, ref: int, t):
-        t = t.contiguous()
-        self.torch.cuda.current_stream(self.dev).synchronize()
-        self._chk(self.lib.vp8hip_import_search(self.h, ref, t[0].data_ptr(), t[1].data_ptr()), "import_search")
-        self.synchronize()          # t may be freed by the caller
-
-    def _plane_split(self, t):
-        n = self.W * self.H
-        return t[:n], t[n:n + n // 4], t[n + n // 4:]
-
-    def export_last(self):
-        t = self.torch.empty(self.W * self.H * 3 // 2, dtype=self.torch.uint8, device=self.dev)
-        y, u, v = self._plane_split(t)
-        self._chk(self.lib.vp8hip_export_last(self.h, y.data_ptr(), u.data_ptr(), v.data_ptr()), "export_last")
-        self.synchronize()
-        return t
-
-    def import_last(self, t):
-        self.torch.cuda.current_stream(self.dev).synchronize()
-        y, u, v = self._plane_split(t.contiguous())
-        self.set_last_device(y.data_ptr(), u.data_ptr(), v.data_ptr())
-        self.synchronize()
 
 
 class RefShardDriver:
@@ -89,9 +98,14 @@ class RefShardDriver:
         self.gop = api.Gop(gop_size, altref_range)
         self.qi_min = min(qi_min, qi_max)
         self.lastqi, self.altrefqi = api.quantizer_ladders(qi_min, qi_max)
-        self.collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
-        self.rank = dist.get_rank() if self.collective else 0
-        self.world = dist.get_world_size() if self.collective else 1
+        self.native = bool(getattr(backend, "native_shard", False))    # the exchanges are the library's (vp8hip_shard_*)
+        if self.native:
+            self.collective = True
+            self.rank, self.world = backend.shard_rank(), backend.shard_world()
+        else:
+            self.collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+            self.rank = dist.get_rank() if self.collective else 0
+            self.world = dist.get_world_size() if self.collective else 1
         self.download = download
         self.loopback = loopback     # also import what this rank itself exported (a one-rank run then walks every exchange)
         self.device_segments = device_segments   # segment data by vp8hip_auto_segments instead of the host scan (timing runs: the host
@@ -117,6 +131,10 @@ class RefShardDriver:
         """rank 0's filtered reconstruction becomes every rank's LAST (broadcast; RCCL on the GPUs)"""
         if not self.collective:
             return
+        if self.native:
+            self.be.shard_share_last(0)
+            self.bytes_broadcast += self.W * self.H * 3 // 2
+            return
         if self.rank == 0:
             t = self.be.export_last()
         else:
@@ -130,6 +148,10 @@ class RefShardDriver:
     def _share_search(self, used):
         """every used reference's vectors and costs from its owner to every rank (one all_gather)"""
         if not self.collective:
+            return
+        if self.native:
+            self.be.shard_share_search(sum(1 << r for r in used))
+            self.bytes_gathered += len(used) * 8 * self.be.b8
             return
         import torch
         mine = torch.zeros((3, 2, self.be.b8), dtype=torch.int32, device=self.be.dev)
