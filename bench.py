@@ -818,7 +818,7 @@ def ref_shard_leg(api, dist, W0, H0, local, rank, world, nframes):
         if rank >= members:
             return None
         seq = SynthSequence(W0, H0, seed=9)
-        frames = [seq.frame(t) for t in range(6)]
+        frames = [tuple(api.to_device(p, local) for p in seq.frame(t)) for t in range(6)]     # resident in HBM, like every leg's frames
         be = ref_shard.HipRefBackend(seq.W, seq.H, device=local)
         be.shard_init(uid[0], rank, members)
         drv = ref_shard.RefShardDriver(be, None, seq.W, seq.H, altref_range=ALTREF_RANGE, download=False, device_segments=True)
@@ -838,8 +838,8 @@ def ref_shard_leg(api, dist, W0, H0, local, rank, world, nframes):
                "ranks": members,
                "what": "vp8hip_inter_search on every rank's references, vp8hip_shard_share_search (one group of RCCL broadcasts, in place in the "
                        "context's nets), vp8hip_inter_finish + loop filter on rank 0, vp8hip_shard_share_last (the padded planes out of rank 0's "
-                       "frame pool into the others'): all on the context's stream, no host synchronisation per frame; host planes uploaded per "
-                       "frame, segment data on the device"}
+                       "frame pool into the others'): all on the context's stream, no host synchronisation per frame; frames resident in HBM, "
+                       "segment data on the device"}
         be.close()
         return out
     except Exception as e:      # a side leg is a report, never a reason to lose the bench line

@@ -112,6 +112,112 @@ def test_baseline_configs_at_their_stated_lengths(W, H, frames, refs):
     ora.close()
 
 
+def test_4k_sequence_three_references_frames_out():
+    """BASELINE configs[3] as a SEQUENCE: 3840x2160, 30 frames of one GOP -- key frame, golden refresh, altref periods of 5 and the
+    filter's feedback from frame to frame (vp8enc.cpp:351-488) -- through the native loop with check_SSIM, frames out in 8
+    partitions; every frame's bytes and every filtered reconstruction against the reference's loop on the CPU oracle."""
+    import zlib
+    expected_frame = _expected_frame()
+    lib = Oracle.lib()
+    before = lib.vp8o_num_threads()
+    lib.vp8o_set_num_threads(min(128, len(os.sched_getaffinity(0))))
+    s = SynthSequence(3840, 2160, seed=29)
+    P = 8
+    drv = api.NativeDriver(s.W, s.H, gop_size=150, num_partitions=P, check_ssim=1)
+    ora = Oracle(s.W, s.H, -1.0)
+    do = InterPathDriver(ora, s.W, s.H, gop_size=150)
+    seen = set()
+    try:
+        for t in range(30):
+            y, u, v = s.frame(t)
+            drv.encode_frame_host(y, u, v)
+            got = drv.get_frame()
+            was_key = drv.resolve()
+            out = do.encode_frame(y, u, v)
+            assert was_key == (out is None), f"frame {t}: key decision differs"
+            exp = expected_frame(s.W, s.H, do.last_key if out is None else out, out is None, P)
+            assert got == exp, f"frame {t}: {len(got)} vs {len(exp)} bytes"
+            a = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in drv.hip.download_last()]
+            b = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in ora.download_last()]
+            assert a == b, f"frame {t}: filtered reconstruction differs"
+            if out is not None:
+                seen.add((out["use_golden"], out["use_altref"]))
+    finally:
+        lib.vp8o_set_num_threads(before)
+    assert seen == {(0, 0), (1, 0), (1, 1)}, seen       # LAST only, LAST + GOLDEN, all three
+    st = drv.stats()
+    assert (st.key_frames, st.inter_frames) == (1, 29)
+    drv.close()
+    ora.close()
+
+
+def test_headline_shape_48_chunks_in_8_batches_a_thread_each_against_the_oracle():
+    """What bench.py times, as it times it: 1920x1080 sources in 1920x1088 contexts, 48 closed-GOP chunks in 8 batches of 6, the
+    native loop with ONE HOST THREAD PER BATCH (vp8drv_batches_encode_frames_device), check_SSIM on the device, three references,
+    five inter frames per chunk with frames out.  Four of the chunks -- one in each of four different batches, at four different
+    member positions -- are held against the reference's loop on the CPU oracle: the fold of every delivered frame's bytes
+    (vp8drv_frame_check) and the filtered reconstruction they end with; every other chunk against the same chunk coded alone on
+    an un-batched driver (the single path is what the other tests hold against the oracle)."""
+    import zlib
+    expected_frame = _expected_frame()
+    lib = Oracle.lib()
+    before = lib.vp8o_num_threads()
+    lib.vp8o_set_num_threads(min(128, len(os.sched_getaffinity(0))))
+    W0, H0, G, B, ND, FR = 1920, 1080, 48, 6, 8, 5
+    seq = SynthSequence(W0, H0, seed=1)
+    W, H = seq.W, seq.H
+    src = [tuple(np.ascontiguousarray(p[:H0 // k, :W0 // k]) for p, k in zip(seq.frame(t), (1, 2, 2))) for t in range(ND)]
+    padded = [tuple(np.pad(p, ((0, (H // k) - p.shape[0]), (0, 0)), mode="edge") for p, k in zip(f, (1, 2, 2))) for f in src]   # copy_with_padding
+    dev = [tuple(api.to_device(p) for p in f) for f in src]
+    ptrs = [tuple(p.data_ptr() for p in f) for f in dev]
+    cfg = dict(gop_size=1 << 30, altref_range=2, qi_min=0, qi_max=48, device_params=1, check_ssim=1, src_width=W0, src_height=H0)
+    drv = [api.NativeDriver(W, H, **cfg) for _ in range(G)]
+    start = [(3 * k) % ND for k in range(G)]
+    for k, d in enumerate(drv):
+        assert d.encode_frame_device(*ptrs[start[k]])          # the chunk's key frame
+    groups = [list(range(i, i + B)) for i in range(0, G, B)]
+    batches = [api.NativeBatch([drv[k] for k in m]) for m in groups]
+    try:
+        _, nbytes, chk = api.NativeBatch.encode_frames_device_all(batches, FR, ptrs, [[start[k] + 1 for k in m] for m in groups], frames_out="check")
+        for d in drv:
+            d.resolve()
+        against_oracle = [0 * B + 0, 2 * B + 3, 5 * B + 5, 7 * B + 1]
+        for g, m in enumerate(groups):
+            for i, k in enumerate(m):
+                got_recon = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in drv[k].hip.download_last()]
+                if k in against_oracle:
+                    ora = Oracle(W, H, -1.0)
+                    do = InterPathDriver(ora, W, H, gop_size=1 << 30, altref_range=2)
+                    h = size = 0
+                    for t in range(FR + 1):
+                        out = do.encode_frame(*padded[(start[k] + t) % ND])
+                        assert (out is None) == (t == 0)
+                        if t:
+                            f = expected_frame(W, H, out, False, 1)
+                            h, size = api.frame_check(h, f), size + len(f)
+                    exp_recon = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in ora.download_last()]
+                    ora.close()
+                else:
+                    d = api.NativeDriver(W, H, **cfg)
+                    h = size = 0
+                    for t in range(FR + 1):
+                        d.encode_frame_device(*ptrs[(start[k] + t) % ND])
+                        if t:
+                            f = d.get_frame()
+                            h, size = api.frame_check(h, f), size + len(f)
+                    d.resolve()
+                    exp_recon = [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in d.hip.download_last()]
+                    d.close()
+                assert (nbytes[g][i], chk[g][i]) == (size, h), f"chunk {k}: the bytes of its {FR} frames differ"
+                assert got_recon == exp_recon, f"chunk {k}: filtered reconstruction differs"
+    finally:
+        lib.vp8o_set_num_threads(before)
+        for b in batches:
+            b.close()
+        for d in drv:
+            d.close()
+
+
 def test_4k_three_references_frame_pair():
     """BASELINE configs[3] geometry with LAST + GOLDEN + ALTREF: every stage tap against the oracle."""
     from test_gpu_parity import _compare, _frames, _one_frame

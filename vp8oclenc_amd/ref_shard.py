@@ -167,7 +167,10 @@ class RefShardDriver:
 
     def encode_frame(self, y: np.ndarray, u: np.ndarray, v: np.ndarray):
         g = self.gop.next()
-        self.be.upload_current(y, u, v)
+        if isinstance(y, np.ndarray):
+            self.be.upload_current(y, u, v)
+        else:                                   # planes already in this device's memory (api.DeviceBuffer / addresses)
+            self.be.set_current_device(y, u, v)
         if g.current_is_key:
             if self.rank == 0:       # key frames are one raster-order wavefront: one device codes them
                 self._set_segments(y, True, True)
