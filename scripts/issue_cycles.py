@@ -129,15 +129,22 @@ def price(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--files", nargs="*", default=["kernels_s2.hip", "kernels_me.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_rc.hip"])
+    ap.add_argument("--files", nargs="*", default=["kernels_s2.hip", "kernels_me.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_lf4.hip", "kernels_rc.hip"])
     ap.add_argument("--kernel", default=None, help="substring of the kernel name to print the opcode table for")
     ap.add_argument("--json", default=None, help="write {kernel: {valu, cycles, cycles_per_instr}} here")
+    ap.add_argument("--opcode-json", default=None, help="write the per-opcode table of every kernel (count x price, by cycles) here")
     a = ap.parse_args()
     out = {}
+    tables = {}
     for f in a.files:
         for name, body in kernels_of(compile_asm(f)):
             short = short_name(name)
             n, cyc, by, avoidable = price(body)
+            price_of = {"fast": C_FAST, "slow": C_SLOW, "double": C_DOUBLE}
+            tables[short] = {"file": f, "valu_instructions": n, "issue_cycles": round(cyc, 1), "cycles_per_instruction": round(cyc / max(n, 1), 3),
+                             "by_opcode": [{"opcode": mn, "class": cls, "count": k, "cycles": round(k * (C_MFMA if mn.startswith("v_mfma") else price_of[cls]), 1),
+                                            "share_of_cycles": round(k * (C_MFMA if mn.startswith("v_mfma") else price_of[cls]) / max(cyc, 1), 4)}
+                                           for (mn, cls), k in sorted(by.items(), key=lambda kv: -kv[1] * (C_MFMA if kv[0][0].startswith("v_mfma") else price_of[kv[0][1]]))]}
             out[short] = {"file": f, "static_valu": n, "static_cycles": round(cyc, 1), "cycles_per_instr": round(cyc / max(n, 1), 3),
                           "fast_opcodes_made_slow_by_an_sgpr_source": int(sum(avoidable.values()))}
             print(f"{short:28s} {f:18s} VALU {n:5d}  cycles {cyc:9.0f}  {cyc / max(n, 1):.2f} cyc/instr   fast-ops slowed by an SGPR source: {sum(avoidable.values())}")
@@ -147,6 +154,11 @@ def main():
                     print(f"      {mn:28s} {cls:6s} x{k:4d} = {k * c:7.0f} cycles")
                 if avoidable:
                     print("      slowed by an SGPR source:", dict(avoidable))
+    if a.opcode_json:
+        with open(a.opcode_json, "w") as fjs:
+            json.dump({"what": "static (k_search1<loop>: dynamic, loop x4) VALU instruction stream of every kernel by opcode, priced with the per-class issue "
+                               "costs measured on the part (profiles/valu_cost.json): count x price, sorted by cycles",
+                       "costs": {"fast": C_FAST, "slow": C_SLOW, "double": C_DOUBLE, "mfma_32x32": C_MFMA}, "kernels": tables}, fjs, indent=1)
     if a.json:
         with open(a.json, "w") as fjs:
             json.dump({"costs": {"fast": C_FAST, "slow": C_SLOW, "double": C_DOUBLE, "source": "profiles/valu_cost.json"}, "kernels": out}, fjs, indent=1)

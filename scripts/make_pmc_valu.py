@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import issue_cycles as ic  # noqa: E402
 
-FILES = ["kernels_s2.hip", "kernels_me.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_rc.hip"]
+FILES = ["kernels_s2.hip", "kernels_me.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_lf4.hip", "kernels_rc.hip"]
 
 
 def cycles_per_instruction():

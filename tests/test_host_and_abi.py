@@ -209,3 +209,11 @@ def test_status_strings_and_bad_arguments():
     assert lib.vp8hip_create(C.byref(h), 100, 64, -1.0, 0) == -1          # not a multiple of 16
     assert lib.vp8hip_inter_transform(None, 0, 0, 0, 0) == -1
     assert lib.vp8hip_loop_filter(None) == -1
+
+
+def test_integration_section_2_is_what_the_drop_in_script_does():
+    """INTEGRATION.md section 2 is generated from oracle/ref_main/build.sh + vp8hip_drop_in.h (the patch tests/test_ref_main.py
+    builds and runs): the prose cannot deviate from the script"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_integration_section2.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,21 +1,25 @@
-// kernels_s2.hip -- quarter-pel refinement (luma_search_2step, src/GPU_kernels.cl:1094-1203) on dot4.
+// kernels_s2.hip -- quarter-pel refinement (luma_search_2step, src/GPU_kernels.cl:1094-1203): the two six-tap passes as int8
+// products on the matrix cores, the block match on the vector ALUs, lane = candidate.
 //
-// The search kernels are VALU-issue bound on gfx950 (scripts/ubench/valu_rates.hip), so this version is
-// built around instruction count.  Pixels are kept as signed bytes (p-128) so that both six-tap passes run
-// on v_dot4_i32_i8: sum(p*f) = sum((p-128)*f) + 128*128 because every tap set sums to 128.
+// The search kernels are VALU-issue bound on gfx950 (scripts/ubench/valu_cost.hip, profiles/r04_issue_cycles_by_opcode.json), so
+// the kernel is built around what the vector pipe has to issue.  Pixels travel as signed bytes p - 128: every tap set sums to 128,
+// so a filter pass computes sum((p - 128) * f) = sum(p * f) - 128 * 128 and sat_i8((sum + 64) >> 7) IS the biased byte of the
+// reference's clamped sample (v_ashr_pk_i8_i32: no bias to undo).
 //   * 32 lanes per 8x8 block (2 blocks per wave, 8 per workgroup), one reference per blockIdx.y.
-//   * The 14x20-byte window around the 1x winner is staged in LDS once (biased).
-//   * Horizontal pass: 28 lanes = (4 fractional x cases) x (7 row pairs); 8 columns x 2 rows each, 2.25
-//     dot4 per sample (the taps are pre-shifted into the 4 possible byte alignments, K_H6), the saturated
-//     pair goes to LDS TRANSPOSED (column-major, 16 B per column) with one ds_write_b16.  The whole-pel x
-//     case is a transposing byte copy done by all 32 lanes.
-//   * Vertical pass: lane k = candidate (dx,dy); a column is one ds_read_b128 and the six taps run down its
-//     bytes: 2.5 dot4 per sample with 7-tap pre-shifted constants (K_V7; the 7th slot absorbs the one-row
-//     offset between dy<0 and dy>=0), v_ashr_pk_u8_i32 saturates two samples at a time.
-//   * The current block and the zero-MV block are transposed through LDS so the metric sees columns too; the current
-//     block's share of the metric's column pass is computed once per block into LDS (weight_pre_column) and every
-//     candidate adds its own with one dot4 per quantity (weight_cols_pre, vp8hip_dev.h).
-// First version (32-bit multiply-adds, row-major H array; git history): 0.156 ms per 1080p frame, this one 0.091.
+//   * The 16 x 32-byte window around the 1x winner is staged in LDS by ONE unaligned 16-byte global load per lane (the window
+//     starts at its own first byte).
+//   * Horizontal pass = one v_mfma_i32_32x32x32_i8: A = the two blocks' window rows, B = the taps of the four fractional x cases
+//     x 8 columns (a constant operand table, make_bh below), C = the rounding 64 as an inline constant.  A lane comes out with a
+//     column and four groups of four consecutive rows = four dwords of the TRANSPOSED H array, which go to LDS.
+//   * Vertical pass = three MFMAs over the wave's 2 x 5 x 8 columns: A = the taps of the four y cases (make_av), B = 32 columns of
+//     16 bytes, one ds_read_b128 each; a lane comes out with, per y case, one dword of the prediction [column][row half].  The
+//     whole-pel cases are copies.
+//   * Then lane k = candidate (dx, dy) of the 25 (+ the zero-vector candidate): the block-match metric on four 4x4 blocks, the
+//     current block's share of its column pass made once per block into LDS (weight_pre_column) and added by every candidate with
+//     one dot4 per quantity (weight_cols_pre, vp8hip_dev.h); the minimum over the 32 lanes by four DPP steps + row_bcast.
+// The operand and result lane maps of the MFMA are pinned by scripts/ubench/mfma_i8_layout.hip, the results by the whole parity
+// suite.  History per 1080p frame and reference: 32-bit multiply-adds 0.156 ms; both passes on v_dot4_i32_i8 0.091 (892 vector
+// instructions per wave; git history, ae32ece^); this form 681 instructions, 56 us per chunk of three references.
 #include <stdlib.h>
 #include <string.h>
 
