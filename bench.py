@@ -858,7 +858,7 @@ def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):
         return None
     cm = t["cycle_model"]
     simd_cycles_per_ns = cm["simds"] * cm["clock_ghz"]
-    path_keys = [k for k in g if k != "_meta"]
+    path_keys = [k for k in g if k not in ("_meta", "loop_filter4")]     # (batches launch the loop filter's form 3; form 4 is the one-video kernel)
     insts = {k: (g[k]["per_ref"] * nrefs if "per_ref" in g[k] else g[k]["fixed"]) for k in path_keys}
     cycles = {k: (g[k].get("cycles_per_ref", 0) * nrefs if "per_ref" in g[k] else g[k].get("cycles_fixed", 0)) for k in path_keys}
     tot_i, tot_c = sum(insts.values()), sum(cycles.values())

@@ -72,7 +72,7 @@ def main():
                 if (nblk + 7) // 8 * 256 * refs == grid:
                     per_level["s2"].append((v / refs, "k_search2", len(vals)))
         else:
-            for short, key in (("k_mb", "mb"), ("k_loop_filter", "loop_filter"), ("k_pyramid", "downsample"), ("k_pack", "pack"), ("k_border", "border"),
+            for short, key in (("k_mb", "mb"), ("k_loop_filter3", "loop_filter"), ("k_loop_filter4", "loop_filter4"), ("k_pyramid", "downsample"), ("k_pack", "pack"), ("k_border", "border"),
                                ("k_strength_segments", "lf_strength")):
                 if short + "(" in name or name.endswith(short) or (short in name and "k_mbhdr" not in name):
                     if key in ("downsample", "border") and key in table and table[key]["fixed"] > v:

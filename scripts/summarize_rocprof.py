@@ -13,7 +13,7 @@ are kept next to the corrected sum so the correction stays visible."""
 import argparse, collections, csv, json, os, shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHORT = {"k_loop_filter3": "loop_filter", "k_loop_filter4": "loop_filter", "k_loop_filter2": "loop_filter", "k_search2": "search2", "k_mb": "mb",
+SHORT = {"k_loop_filter3": "loop_filter", "k_loop_filter4": "loop_filter4", "k_loop_filter2": "loop_filter", "k_search2": "search2", "k_mb": "mb",
          "k_search1": "search1", "k_border": "border", "k_pack": "pack", "k_pyramid": "downsample"}
 
 
