@@ -392,6 +392,7 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
     // The order is fixed, so the slot a feed overwrites (macroblock x - RING) was drained RING - LAG iterations ago, and the
     // compiler can count the loads and stores in flight (a wait for a load never waits for a younger store).
     // ---------------------------------------------------------------------------------------------
+    if (wave >= W_PORTER) __builtin_amdgcn_s_setprio(1);   // helpers: ahead of other kernels' waves on the SIMD (a video's other streams), behind the workers
     if (wave >= W_PORTER && wave < W_PORTER + WORKERS) {
         const int pi = wave - W_PORTER;
         const int r = 2 * pi + half, gr = band_row0 + r;

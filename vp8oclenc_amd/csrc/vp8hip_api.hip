@@ -382,8 +382,15 @@ static void next_params(vp8hip_ctx *c) {
 }
 
 // work enqueued on the context's stream from here on sees the filtered reconstruction
-static int join_lf(vp8hip_ctx *c) {
-    if (!c->lf_pending) return VP8HIP_OK;
+// work enqueued on the context's stream from here on may overwrite what the previous frame's entropy stage (on its own stream) reads
+static int join_ent(vp8hip_ctx *c) {
+    if (!c->ent_pending) return VP8HIP_OK;
+    c->ent_pending = false;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent, 0));
+    return VP8HIP_OK;
+}
+static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
+    if (!c->lf_pending) return defer_ent ? VP8HIP_OK : join_ent(c);
     c->lf_pending = false;
     // back to the stream the filter is on, behind it and behind everything that ran beside it.  The streams trade places
     // first: whatever the two calls below return, `stream` is the one vp8hip_create made again (vp8hip_destroy relies on it)
@@ -392,11 +399,9 @@ static int join_lf(vp8hip_ctx *c) {
     c->lf_stream = side;
     HIPCHK(c, hipEventRecord(c->ev_lf, side));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
-    if (c->ent_pending) {   // ... and behind the previous frame's entropy stage: what follows may overwrite the results it reads
-        c->ent_pending = false;
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent, 0));
-    }
-    return VP8HIP_OK;
+    // ... and behind the previous frame's entropy stage: what follows may overwrite the results it reads.  vp8hip_inter_transform
+    // defers that wait to the one kernel of its chain that does (k_mb): the LAST search does not have to stand behind the stage.
+    return defer_ent ? VP8HIP_OK : join_ent(c);
 }
 static void lf_check(vp8hip_ctx *c, LfCheck &k);   // (below, with check_SSIM)
 
@@ -851,9 +856,10 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         c->cur_pyramid_valid = true;
         search_refs(c, ref_set(c, 0, use_golden, use_altref));
     }
-    JOIN_LF(c);
+    { const int jr = join_lf(c, /*defer_ent=*/true); if (jr) return jr; }
     pyramids(c);
     search_refs(c, split ? ref_set(c, 1, 0, 0) : refs);
+    { const int jr = join_ent(c); if (jr) return jr; }      // (the previous frame's coefficients, vectors and modes are the stage's until here)
     {
         Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
         launch_mb(c->stream, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh, c->conformant != 0);
