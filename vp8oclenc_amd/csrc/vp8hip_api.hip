@@ -97,6 +97,8 @@ struct vp8hip_ctx {
     hipStream_t lf_stream = nullptr;   // the stream `stream` is not
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     bool lf_overlap = false, lf_pending = false;
+    bool fork_by_verdict = false;      // the pending filter's launch has no fork event in front of it: see side_stream_ordered()
+    bool fork_by_verdict_at_launch = false;   // ... as it was launched (fork_by_verdict is cleared once the ordering is established)
     int64_t lf_context_switches = 0;   // see vp8hip_profile_context_switches
     bool s2_clock_on = false;          // k_search2 stamps its launches (vp8hip_profile_search2_clock)
     bool frame_pending = false;     // between vp8hip_encode_frame_begin and _end
@@ -392,6 +394,7 @@ static int join_ent(vp8hip_ctx *c) {
 static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
     if (!c->lf_pending) return defer_ent ? VP8HIP_OK : join_ent(c);
     c->lf_pending = false;
+    c->fork_by_verdict = false;
     // back to the stream the filter is on, behind it and behind everything that ran beside it.  The streams trade places
     // first: whatever the two calls below return, `stream` is the one vp8hip_create made again (vp8hip_destroy relies on it)
     hipStream_t side = c->stream;
@@ -417,7 +420,23 @@ static void batch_join_prep(vp8hip_batch *b) {
 // HIP's current device is per host thread: a context may be driven from a thread other than its creator's, or two contexts
 // on two GPUs from one thread -- every entry point that may allocate or use the null stream selects the context's device.
 // A member of a batch launches on the batch's stream: whatever it does there comes after the batch's head-of-frame work.
-#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); } } while (0)
+// vp8hip_filter_overlap: the side stream's work must start behind everything the frame's chain enqueued BEFORE the filter (the next
+// frame's GOLDEN / ALTREF searches overwrite nets the frame's k_mb reads).  An event recorded in front of the filter's launch says
+// so on the device -- and costs the chain 12 us per frame: a marker packet with a completion signal between k_mb and the filter
+// (0.375 -> 0.362 ms per 1080p frame without it).  When the filter's launch carries check_SSIM's verdict, the verdict itself is
+// the proof: its sequence number arrives in host memory from INSIDE that launch, and a launch starts when everything before it on
+// its stream has completed.  So no event is recorded then, and the first entry point that would enqueue on the side stream makes
+// sure the number is there (the native frame loop has taken the verdict by then anyway: nothing waits).
+static void side_stream_ordered(vp8hip_ctx *c) {
+    if (!c->lf_pending || !c->fork_by_verdict) return;
+    const uint32_t want = c->verdict_seq;
+    for (unsigned spins = 0; (uint32_t)__atomic_load_n(&c->h_verdict[5], __ATOMIC_ACQUIRE) != want; ++spins) {
+        if ((spins & 0xfff) == 0xfff && hipStreamQuery(c->lf_stream) != hipErrorNotReady) break;   // the filter's stream is idle: it has run (or failed; the next call says so)
+        __builtin_ia32_pause();
+    }
+    c->fork_by_verdict = false;
+}
+#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); side_stream_ordered(c); } } while (0)
 #define USE_DEVICE_ONLY(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
 #define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
 
@@ -1617,10 +1636,12 @@ int vp8hip_loop_filter(vp8hip_ctx *c) {
     lf_check(c, chk);
     if (c->lf_overlap && !c->prof_mask) {   // (the per-kernel timers bracket launches on the context's stream only)
         hipStream_t chain = c->stream;
-        HIPCHK(c, hipEventRecord(c->ev_fork, chain));
+        const bool by_verdict = chk.on != 0;      // (see side_stream_ordered)
+        if (!by_verdict) HIPCHK(c, hipEventRecord(c->ev_fork, chain));
         launch_loop_filter4(chain, f, c->out, c->d_sd, c->d_progress, c->d_lf_handoff, c->mbw, c->mbh, c->lf_launches++, c->lf_stall_test, &chk);
         c->verdict_stream = chain;
-        HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
+        if (!by_verdict) HIPCHK(c, hipStreamWaitEvent(c->lf_stream, c->ev_fork, 0));   // the side work starts where the filter starts
+        c->fork_by_verdict = c->fork_by_verdict_at_launch = by_verdict;
         c->stream = c->lf_stream;
         c->lf_stream = chain;
         c->lf_pending = true;
@@ -1878,7 +1899,9 @@ static int frame_enqueue(vp8hip_ctx *c, int P, const vp8hip_header_params *p) {
     }
     const bool third = c->lf_pending && c->ent_stream && !c->prof_mask;
     hipStream_t s = third ? c->ent_stream : c->stream;
-    if (third) HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+    // (behind the fork event where one was recorded; otherwise the caller has taken the verdict -- see above -- and the filter's
+    // launch, behind which everything the stage reads was final, is under way)
+    if (third && !c->fork_by_verdict_at_launch) HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     c->frame_event = nullptr;
     c->frame_gen = c->out_gen;
     static const bool stepwise = [] { const char *v = getenv("VP8HIP_ENT_STEPWISE"); return v && v[0] && v[0] != '0'; }();
