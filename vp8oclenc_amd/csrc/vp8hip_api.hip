@@ -391,17 +391,30 @@ static int join_ent(vp8hip_ctx *c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ent, 0));
     return VP8HIP_OK;
 }
-static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
-    if (!c->lf_pending) return defer_ent ? VP8HIP_OK : join_ent(c);
+// The join in two halves: the context goes back to the stream the filter is on (what is enqueued from then on runs behind the
+// FILTER), and later that stream is told to wait for everything that ran beside the filter.  vp8hip_inter_transform puts the new
+// LAST's pyramid and replicated edges -- which need the filter's output and nothing of the side work -- between the two: the
+// barrier packet of the wait is then evaluated while that kernel runs instead of between the filter and it (11 us per frame).
+static hipStream_t join_lf_swap(vp8hip_ctx *c) {
     c->lf_pending = false;
     c->fork_by_verdict = false;
-    // back to the stream the filter is on, behind it and behind everything that ran beside it.  The streams trade places
-    // first: whatever the two calls below return, `stream` is the one vp8hip_create made again (vp8hip_destroy relies on it)
+    // The streams trade places first: whatever the calls after this return, `stream` is the one vp8hip_create made again
+    // (vp8hip_destroy relies on it)
     hipStream_t side = c->stream;
     c->stream = c->lf_stream;
     c->lf_stream = side;
+    return side;
+}
+static int join_lf_wait(vp8hip_ctx *c, hipStream_t side) {
     HIPCHK(c, hipEventRecord(c->ev_lf, side));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
+    return VP8HIP_OK;
+}
+static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
+    if (!c->lf_pending) return defer_ent ? VP8HIP_OK : join_ent(c);
+    // back to the stream the filter is on, behind it and behind everything that ran beside it
+    hipStream_t side = join_lf_swap(c);
+    { const int wr = join_lf_wait(c, side); if (wr) return wr; }
     // ... and behind the previous frame's entropy stage: what follows may overwrite the results it reads.  vp8hip_inter_transform
     // defers that wait to the one kernel of its chain that does (k_mb): the LAST search does not have to stand behind the stage.
     return defer_ent ? VP8HIP_OK : join_ent(c);
@@ -875,7 +888,17 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
         c->cur_pyramid_valid = true;
         search_refs(c, ref_set(c, 0, use_golden, use_altref));
     }
-    { const int jr = join_lf(c, /*defer_ent=*/true); if (jr) return jr; }
+    if (c->lf_pending && c->cur_pyramid_valid && c->slot[0] >= 0 && !c->frames[c->slot[0]].pyramid_valid) {
+        hipStream_t side = join_lf_swap(c);
+        FrameSurf &last = c->frames[c->slot[0]];
+        build_pyramid(c, &last.f, nullptr, last.border_valid ? 0u : 1u);     // behind the filter, beside whatever the side stream still runs
+        last.pyramid_valid = last.border_valid = true;
+        const int wr = join_lf_wait(c, side);
+        if (wr) return wr;
+    } else {
+        const int jr = join_lf(c, /*defer_ent=*/true);
+        if (jr) return jr;
+    }
     pyramids(c);
     search_refs(c, split ? ref_set(c, 1, 0, 0) : refs);
     { const int jr = join_ent(c); if (jr) return jr; }      // (the previous frame's coefficients, vectors and modes are the stage's until here)
