@@ -607,15 +607,14 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
     // (Only the four samples to the left, which P2 of this very step writes, are read when P1 starts.)
     int4 n_pa = make_int4(0, 0, 0, 0), n_v1 = n_pa, n_v2 = n_pa, n_v3 = n_pa, n_v4 = n_pa;
     int2 n_pb = make_int2(0, 0);
+// (Unconditional: an LDS read of a slot that holds nothing yet is harmless -- the values are used under `on` only -- and reads under a
+// predicate cost a register move per destination to merge the two paths.)
 #define P1_REQUEST(S_)                                                                        \
     {                                                                                         \
-        const int xn = (S_) - r;                                                              \
-        if (row_real & (xn >= 0) & (xn < mbw)) {                                              \
-            const uint32_t sl = (uint32_t)xn & (RING - 1);                                    \
-            const uint32_t sn = p1_base + (sl << mb_shift), pn = par_base + sl * PAR_BYTES;   \
-            n_pa = ld128(pn); n_pb = ld64(pn + 16);                                           \
-            n_v1 = ld128(sn); n_v2 = ld128(sn + 16); n_v3 = ld128(sn + 32); n_v4 = ld128(sn + 48); \
-        }                                                                                     \
+        const uint32_t sl = (uint32_t)((S_) - r) & (RING - 1);                                \
+        const uint32_t sn = p1_base + (sl << mb_shift), pn = par_base + sl * PAR_BYTES;       \
+        n_pa = ld128(pn); n_pb = ld64(pn + 16);                                               \
+        n_v1 = ld128(sn); n_v2 = ld128(sn + 16); n_v3 = ld128(sn + 32); n_v4 = ld128(sn + 48); \
     }
     P1_REQUEST(0)
     const int up = imax(wave - 1, 0);
