@@ -906,7 +906,8 @@ def bitstream_leg(leg, nb):
             for k in members:
                 nbytes[k] += len(leg.drv[k].get_frame_end())
 
-    for k in range(G):   # untimed: the entropy stage allocates its scratch on first use
+    for k in range(G):   # untimed: the entropy stage allocates its scratch on first use (sized for the densest frame: the native loop
+        leg.drv[k].hip.reserve_frame_path_dense()      # starts frame t + 1 before it takes frame t's bytes, so no frame may need a second coding)
         for _ in range(2):
             leg.drv[k].encode_frame_device(*leg.ptrs[leg.t[k] % leg.nd])
             leg.t[k] += 1

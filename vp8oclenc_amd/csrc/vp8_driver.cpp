@@ -542,7 +542,7 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
             int key[VP8HIP_MAX_BATCH] = {};
             std::vector<uint8_t> frame;
             if (bytes_out) frame.resize((size_t)b->d[0]->mbs * 1900 + (1u << 20));
-            for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) {
+            auto encode = [&](int t) {
                 for (int i = 0; i < b->n; ++i) {
                     const void *const *f = frames[(start[k][i] + t) % nd];
                     y[i] = f[0]; u[i] = f[1]; v[i] = f[2];
@@ -550,16 +550,27 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                 rc[k] = vp8drv_batch_encode_frame_device(b, nullptr, y, u, v, nullptr, key);
                 if (rc[k] == VP8HIP_OK && keys_out && keys_out[k])   // (a failed call may not have filled key[])
                     for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
-                if (bytes_out && rc[k] == VP8HIP_OK) {      // the frames as bytes: one set of launches for the batch, then every member's read-back
-                    // (taking frame t's bytes only after frame t + 1 is enqueued changes nothing -- 45.8 M MB/s either way on one
-                    // box -- and would leave a frame denser than the coder's scratch with nothing to be coded again from)
-                    rc[k] = vp8drv_batch_get_frame_begin(b, nullptr);
-                    for (int i = 0; i < b->n && rc[k] == VP8HIP_OK; ++i) {
-                        size_t size = 0;
-                        rc[k] = vp8drv_get_frame_end(b->d[i], frame.data(), frame.size(), &size);
-                        if (bytes_out[k]) bytes_out[k][i] += size;
-                        if (check_out && check_out[k] && rc[k] == VP8HIP_OK) check_out[k][i] = vp8drv_frame_check(check_out[k][i], frame.data(), size);
-                    }
+            };
+            if (!bytes_out) {
+                for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) encode(t);
+                return;
+            }
+            // The frames as bytes: one set of launches for the batch's entropy stage, then every member's read-back -- with frame t + 1
+            // ENQUEUED before frame t's bytes are waited for: the stage is a link of the batch's chain (same stream), so frame t + 1's
+            // kernels queue up behind it and the stream never runs dry while this thread sleeps on the stage's event, copies six
+            // frames and comes back (in the old order -- encode, begin, end, encode -- it did, once per frame and batch).  A frame
+            // denser than the coder's scratch could not be coded again once the next frame has overwritten its coefficients, so the
+            // scratch is sized for the densest frame there can be (a no-op when the caller has done it: vp8hip_reserve_frame_path_dense).
+            for (int i = 0; i < b->n && rc[k] == VP8HIP_OK; ++i) rc[k] = vp8hip_reserve_frame_path_dense(b->d[i]->hip);
+            if (nframes > 0 && rc[k] == VP8HIP_OK) encode(0);
+            for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) {
+                rc[k] = vp8drv_batch_get_frame_begin(b, nullptr);                       // frame t's type is final here (its verdict is in)
+                if (rc[k] == VP8HIP_OK && t + 1 < nframes) encode(t + 1);
+                for (int i = 0; i < b->n && rc[k] == VP8HIP_OK; ++i) {
+                    size_t size = 0;
+                    rc[k] = vp8drv_get_frame_end(b->d[i], frame.data(), frame.size(), &size);
+                    if (bytes_out[k]) bytes_out[k][i] += size;
+                    if (check_out && check_out[k] && rc[k] == VP8HIP_OK) check_out[k][i] = vp8drv_frame_check(check_out[k][i], frame.data(), size);
                 }
             }
         });
