@@ -402,6 +402,18 @@ def literal_gops(api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream
     def work(k):
         d = drv[k]
         pending = None
+        if pipelined and not os.environ.get("VP8_BENCH_PY_VIDEO_LOOP"):
+            # the whole loop natively (vp8drv_encode_video_device: encode(t), frame t - 1's bytes, frame t's stage, frame t's verdict):
+            # the host's reaction times are on the path -- the later a frame's stage is enqueued behind its verdict, the further it
+            # reaches under the next frame's LAST search
+            fr, kk = d.encode_video_device(gop_len, leg.ptrs, start=3 * k)
+            keys[k] += kk
+            nbytes[k] += sum(len(b) for b in fr)
+            if frames_out is not None:
+                for t, b in enumerate(fr):
+                    frames_out[frame_base + k * gop_len + t] = b
+            d.hip.synchronize()
+            return
         for t in range(gop_len):
             d.encode_frame_device(*leg.ptrs[(3 * k + t) % leg.nd])
             if pipelined:

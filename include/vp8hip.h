@@ -227,10 +227,14 @@ int vp8hip_encode_coefficients(vp8hip_ctx *ctx, const uint32_t *coeff_probs, int
  * encode_header derives them.  Writes the partition with its 3- or 10-byte uncompressed chunk to `out`; *size = its
  * size (frames.encoded_frame_size after encode_header).  Blocks.  The host implementation of the same function is
  * vp8bs_encode_header (include/vp8hip_bitstream.h); vp8bs_gather_frame appends the coefficient partitions. */
+#define VP8HIP_SHARPNESS_ON_DEVICE INT32_MIN
 typedef struct {
     int32_t is_key, is_golden, is_altref;    /* frames.current_is_{key,golden,altref}_frame */
     int32_t loop_filter_type;                /* video.loop_filter_type (0) */
-    int32_t loop_filter_sharpness;           /* video.loop_filter_sharpness; -1 = the value vp8hip_auto_segments computed */
+    int32_t loop_filter_sharpness;           /* video.loop_filter_sharpness; VP8HIP_SHARPNESS_ON_DEVICE = the value vp8hip_auto_segments
+                                                computed.  (Not -1: get_loopfilter_strength's `int` accumulator overflows on large noisy
+                                                frames, vp8enc.cpp:112-126, and the sharpness it then leaves is NEGATIVE -- -1 on a 1080p
+                                                frame of noise; the reference writes its low three bits into the header, and so must this.) */
     int32_t partitions_log2;                 /* video.number_of_partitions_ind */
     int32_t width, height;                   /* video.dst_width/height for key frames; 0 = the coded size */
     int32_t use_intra_info;                  /* inter frames: 1 = vp8hip_check_ssim ran on this frame */

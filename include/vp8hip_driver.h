@@ -142,6 +142,16 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
                                         const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out);
+/* ONE video, `nframes` frames, frame after frame with the frames out -- the loop of scripts/native/y4m_to_ivf.cpp for frames that are
+ * already in device memory: encode(t), take frame t - 1's bytes, enqueue frame t's entropy stage, take frame t's verdict; frame t
+ * is frames[(start + t) % nd].  With overlap_filter the stage of a frame runs on a stream of its own beside its loop filter and the
+ * next frame's side work (vp8hip_encode_frame_begin); call vp8hip_reserve_frame_path_dense(vp8drv_context(d)) first.  The frames
+ * are laid end to end into `out` (capacity bytes), sizes[t] = frame t's size; keys (may be NULL) counts the key frames, frames sent
+ * back by check_SSIM included.  A native loop because the host's reaction times are on the path: every microsecond between a
+ * frame's verdict and the enqueue of its stage moves the stage further under the next frame's LAST search (one video with frames
+ * out, 1080p: 0.383 ms per frame from Python). */
+int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frames)[3], int nd, int start, uint8_t *out, size_t capacity,
+                               uint32_t *sizes, int *keys);
 /* the fold above: h' = (h * 0x9E3779B97F4A7C15 + size) ^ (sum of the frame's little-endian 64-bit words, the tail zero-padded) */
 uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size);
 

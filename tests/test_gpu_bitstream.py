@@ -52,6 +52,20 @@ def test_bitstream_of_a_gop_with_golden_and_altref(P, host_bitstream):
     assert ivf[:4] == b"DKIF" and len(ivf) == 32 + sum(12 + len(f) for f in stream)
 
 
+@pytest.mark.parametrize("device_params,host_bitstream", [(0, 0), (1, 0), (0, 1)])
+def test_negative_sharpness_of_the_overflowed_strength_accumulator(device_params, host_bitstream):
+    """get_loopfilter_strength's second `int` accumulator (vp8enc.cpp:112-126) overflows on a large frame of noise and leaves a
+    NEGATIVE sharpness; the reference writes its low three bits into every frame header and derives the interior limits from it.
+    (Found by the fuzz run once it drew 1080p: the header took "negative" for "still on the device".)"""
+    W, H = 1024, 512
+    rng = np.random.default_rng(9559)
+    frames = [(rng.integers(0, 256, (H, W)).astype(np.uint8), rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8),
+               rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)) for _ in range(3)]
+    red, sharp = api.loopfilter_strength(frames[0][0])
+    assert sharp < 0, sharp
+    run_sequence(W, H, frames, P=2, qi_min=27, qi_max=50, device_params=device_params, host_bitstream=host_bitstream)
+
+
 @pytest.mark.parametrize("host_bitstream", [0, 1])
 def test_bitstream_with_intra_fallback_and_scene_cut(host_bitstream):
     W, H = 320, 192

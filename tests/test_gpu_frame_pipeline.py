@@ -69,3 +69,33 @@ def test_a_recode_whose_input_is_gone_is_refused_not_garbled():
     with pytest.raises(api.Vp8HipError, match=r"\(-4\)"):
         d.get_frame_end()
     d.close()
+
+
+def test_native_video_loop_delivers_the_frames_of_the_call_by_call_loop():
+    """vp8drv_encode_video_device (one video, frames out, the whole loop natively) against encode / get_frame call by call: the same
+    bytes frame by frame -- with the filter-overlap mode (the stage on its third stream, the next frame started before a frame's bytes
+    are taken) and without, key frames inside the run, check_SSIM replacing macroblocks and sending frames back"""
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H, ND, N = 320, 192, 7, 23
+    seq = SynthSequence(W, H, seed=33)
+    dev = [tuple(api.to_device(p) for p in seq.frame(t)) for t in range(ND)]
+    ptrs = [tuple(p.data_ptr() for p in f) for f in dev]
+    for cfg in (dict(overlap_filter=1, gop_size=150), dict(overlap_filter=0, gop_size=6, num_partitions=4),
+                dict(overlap_filter=1, gop_size=9, ssim_target=0.92, qi_min=40, qi_max=110)):
+        kw = dict(device_params=1, check_ssim=1, altref_range=3)
+        kw.update(cfg)
+        a = api.NativeDriver(seq.W, seq.H, **kw)
+        want = []
+        for t in range(N):
+            a.encode_frame_device(*ptrs[(2 + t) % ND])
+            want.append(a.get_frame())
+        a.resolve()
+        b = api.NativeDriver(seq.W, seq.H, **kw)
+        b.hip.reserve_frame_path_dense()
+        got, keys = b.encode_video_device(N, ptrs, start=2)
+        assert got == want, [i for i, (x, y) in enumerate(zip(got, want)) if x != y][:4]
+        sa, sb = a.stats(), b.stats()
+        assert (sa.key_frames, sa.inter_frames, sa.redone_as_key) == (sb.key_frames, sb.inter_frames, sb.redone_as_key) and keys == sa.key_frames
+        for p_, q_ in zip(a.hip.download_last(), b.hip.download_last()):
+            assert np.array_equal(p_, q_)
+        a.close(); b.close()

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_frame_check", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_frame_check", "vp8drv_encode_video_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -48,6 +48,7 @@ class Vp8HipError(RuntimeError):
 ABI_VERSION = 3001  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
+SHARPNESS_ON_DEVICE = -2 ** 31   # VP8HIP_SHARPNESS_ON_DEVICE
 
 
 class _Results(C.Structure):
@@ -410,6 +411,26 @@ class NativeDriver:
             raise Vp8HipError(f"vp8drv_get_frame_end: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return self._frame_buf[:n.value].tobytes()
 
+    def encode_video_device(self, nframes: int, frame_ptrs, start: int = 0, capacity: int | None = None):
+        """vp8drv_encode_video_device: `nframes` frames of one video with the frames out, natively (frame t =
+        frame_ptrs[(start + t) % len]); returns (list of frames as bytes, key-frame count)"""
+        nd = len(frame_ptrs)
+        F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
+        cap = capacity or nframes * (self.hip.mbs * 64 + (1 << 16))      # (twenty times a dense frame at the reference's default quantisers)
+        out = np.empty(cap, np.uint8)
+        sizes = (C.c_uint32 * max(nframes, 1))()
+        keys = C.c_int(0)
+        self.lib.vp8drv_encode_video_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        rc = self.lib.vp8drv_encode_video_device(self.h, int(nframes), C.cast(F, C.c_void_p), nd, int(start), out.ctypes.data, cap, sizes, C.byref(keys))
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_encode_video_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+        frames, o = [], 0
+        for t in range(nframes):
+            frames.append(out[o:o + sizes[t]].tobytes())
+            o += sizes[t]
+        return frames, int(keys.value)
+
     def stats(self) -> DrvStats:
         s = DrvStats()
         self.lib.vp8drv_get_stats(self.h, C.byref(s))
@@ -672,7 +693,7 @@ class Vp8Hip:
         self._chk(self.lib.vp8hip_download_intra(self.h, modes.ctypes.data, is_inter.ctypes.data), "download_intra")
         return modes, is_inter
 
-    def encode_header(self, is_key, is_golden=0, is_altref=0, sharpness=-1, partitions_log2=0, use_intra_info=False,
+    def encode_header(self, is_key, is_golden=0, is_altref=0, sharpness=SHARPNESS_ON_DEVICE, partitions_log2=0, use_intra_info=False,
                       loop_filter_type=0, width=0, height=0) -> np.ndarray:
         """encode_header (entropy_host.cpp:709-1256) on the device: the first partition with its frame tag."""
         class P(C.Structure):

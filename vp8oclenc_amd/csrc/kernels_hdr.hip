@@ -66,7 +66,7 @@ struct EmitSink {
 struct Params {
     View v;
     int mbs, key;
-    int is_golden, is_altref, loop_filter_type, sharpness, partitions_log2;   // sharpness < 0: take it from `strength`
+    int is_golden, is_altref, loop_filter_type, sharpness, partitions_log2;   // sharpness == INT32_MIN (VP8HIP_SHARPNESS_ON_DEVICE): take it from `strength`
     const SegData *sd;
     const int32_t *strength;      // {reductor, sharpness, sharpness in force} of vp8hip_auto_segments / the check_SSIM verdict
     const uint32_t *probs, *denom0;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void hdr_frame_body(const Params &a, uint32_t *partia
     const int mbs = a.mbs;
     const bool key = a.key != 0;
     const int32_t *sd = s_sd;
-    const int sharpness = a.sharpness >= 0 ? a.sharpness : a.strength[2];
+    const int sharpness = a.sharpness != INT32_MIN ? a.sharpness : a.strength[2];   // (a negative sharpness is a value: the reference's overflowed accumulator)
     const int replaced = key ? 0 : (int)s_tot[ST_REPLACED];
     if (t == 0) {
         // ---- the probability table of this frame (what the macroblock headers refer to symbolically) ----

@@ -24,7 +24,7 @@ struct vp8drv {
     vp8drv_stats st{};
     // what vp8drv_get_frame needs to know about the frame just coded
     bool have_frame = false, last_key = false, last_altref = false, checked = false;
-    int sharpness = -1;              // video.loop_filter_sharpness in force; -1 = still on the device (vp8hip_get_segments)
+    int sharpness = VP8HIP_SHARPNESS_ON_DEVICE;   // video.loop_filter_sharpness in force, or: still on the device (vp8hip_get_segments).  May be NEGATIVE (vp8hip.h)
     int replaced = 0;
     bool verdict_pending = false;    // check_SSIM's verdict on the frame just coded is still on its way (resolve())
     // read-back buffers of vp8drv_get_frame
@@ -112,7 +112,7 @@ namespace {
 
 // segment data of the current frame: on the device, or from the host mirror on the caller's luma plane
 int segments(vp8drv *d, const uint8_t *host_y, bool key, const int32_t *refqi) {
-    d->sharpness = -1;
+    d->sharpness = VP8HIP_SHARPNESS_ON_DEVICE;
     if (d->cfg.device_params || !host_y) return vp8hip_auto_segments(d->hip, key ? 1 : 0, refqi, d->qi_min);
     int32_t red = 0, sharp = 0, sd[VP8HIP_SD_INTS];
     vp8host_loopfilter_strength(host_y, d->W, d->H, &red, &sharp);
@@ -256,7 +256,7 @@ vp8hip_header_params header_params(const vp8drv *d) {
     hp.is_golden = d->last_key;                 // current_is_golden_frame = current_is_key_frame (vp8enc.cpp:369)
     hp.is_altref = d->last_altref;
     hp.loop_filter_type = 0;                    // init.h:1583
-    hp.loop_filter_sharpness = d->sharpness;    // -1: still on the device
+    hp.loop_filter_sharpness = d->sharpness;    // or VP8HIP_SHARPNESS_ON_DEVICE
     hp.width = d->cfg.display_width;
     hp.height = d->cfg.display_height;
     hp.use_intra_info = d->checked;
@@ -302,7 +302,7 @@ int get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     }
     int32_t sd[VP8HIP_SD_INTS], red = 0, sharp = 0;
     DRV_CHK(vp8hip_get_segments(d->hip, sd, &red, &sharp));
-    if (d->sharpness >= 0) sharp = d->sharpness;
+    if (d->sharpness != VP8HIP_SHARPNESS_ON_DEVICE) sharp = d->sharpness;
     vp8bs_frame f{};
     f.width = d->cfg.display_width > 0 ? d->cfg.display_width : d->W;
     f.height = d->cfg.display_height > 0 ? d->cfg.display_height : d->H;
@@ -433,7 +433,7 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
         ua[i] = a & ((d->cfg.ref_mask >> 1) & 1);
         pg[i] = d->gop.prev_is_golden;
         pa[i] = d->gop.prev_is_altref;
-        d->sharpness = -1;
+        d->sharpness = VP8HIP_SHARPNESS_ON_DEVICE;
     }
     if (!n_inter) return VP8HIP_OK;
     DRV_CHK(vp8hip_batch_auto_segments(b->hb, active, zero, refqi, b->d[0]->qi_min));   // vp8enc.cpp:390, 419
@@ -621,6 +621,38 @@ int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members) {
 int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {
     if (!d || !out || !size) return VP8HIP_ERR_ARG;
     return vp8hip_encode_frame_end(d->hip, out, capacity, size);
+}
+
+int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frames)[3], int nd, int start, uint8_t *out, size_t capacity,
+                               uint32_t *sizes, int *keys) {
+    if (!d || nframes < 0 || !frames || nd < 1 || start < 0 || !out || !sizes) return VP8HIP_ERR_ARG;
+    size_t used = 0;
+    int nkeys = 0;
+    for (int t = 0; t < nframes; ++t) {
+        const void *const *f = frames[(start + t) % nd];
+        int rc = vp8drv_encode_frame_device(d, f[0], f[1], f[2], 0);          // frame t under way ...
+        if (rc < 0) return rc;
+        if (t > 0) {                                                          // ... now frame t - 1's bytes
+            size_t n = 0;
+            rc = vp8drv_get_frame_end(d, out + used, capacity - used, &n);
+            if (rc < 0) return rc;
+            sizes[t - 1] = (uint32_t)n;
+            used += n;
+        }
+        rc = vp8drv_get_frame_begin(d);                                       // frame t's type is final (the verdict is in): its stage
+        if (rc < 0) return rc;
+        rc = vp8drv_resolve(d);
+        if (rc < 0) return rc;
+        nkeys += rc > 0;
+    }
+    if (nframes > 0) {
+        size_t n = 0;
+        const int rc = vp8drv_get_frame_end(d, out + used, capacity - used, &n);
+        if (rc < 0) return rc;
+        sizes[nframes - 1] = (uint32_t)n;
+    }
+    if (keys) *keys = nkeys;
+    return VP8HIP_OK;
 }
 
 }  // extern "C"

@@ -209,7 +209,7 @@ void launch_frame_code(hipStream_t s, const EntBuffers &coef, int P, const EntBu
 inline size_t ent_maps_entries(uint32_t cap_chunks) { return ((size_t)cap_chunks + cap_chunks / 8 + 2 * ENT_MAX_PARTITIONS) * 128; }
 
 // first partition on the device (kernels_hdr.hip): encode_header, src/entropy_host.cpp:709-1256
-struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* < 0: the device's */, partitions_log2; };
+struct HdrFrame { int is_key, is_golden, is_altref, loop_filter_type, sharpness /* INT32_MIN: the device's */, partitions_log2; };
 void launch_default_probs(hipStream_t s, uint32_t *probs, const uint32_t *denom0);   // vp8enc.cpp:69-76
 const uint8_t *hdr_default_coeff_probs();   // device address of the default coefficient probabilities [4][8][3][11] (RFC 6386 13.5)
 constexpr int HDR_STAT_WORDS = 84;   // per-workgroup partial sums of k_hdr_count
