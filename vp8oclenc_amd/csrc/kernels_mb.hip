@@ -280,7 +280,7 @@ __device__ __forceinline__ float sum4(float acc, int lane) {   // (((c0 + c1) + 
 template <bool CONFORMANT>
 __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const int mb_raw = blockIdx.x * 8 + g;
+    const int mb_raw = xcd_band(blockIdx.x, gridDim.x) * 8 + g;   // an XCD's workgroups on one band of the frame (vp8hip_dev.h)
     const bool live = mb_raw < a.mbs;
     const int mb = live ? mb_raw : a.mbs - 1;
     const int mbx = mb % a.mbw, mby = mb / a.mbw;

@@ -281,7 +281,7 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
     const int sb0 = sub / 5, j = sub - 5 * sb0;       // SPLIT: this lane's sub-block; otherwise sb0 = 0
-    const int b_raw = (blockIdx.x * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
+    const int b_raw = (xcd_band(blockIdx.x, gridDim.x) * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
     const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
     const int b = live ? b_raw : a.nblk - 1;
     const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32

@@ -279,13 +279,13 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
 
 __global__ __launch_bounds__(256, 4) void k_search2(S2Args a) {   // (a register budget of 128 also makes the MFMAs write VGPRs: no v_accvgpr_read per result)
     launch_clock_begin(a.clk);
-    search2_body(a, blockIdx.x, blockIdx.y);
+    search2_body(a, xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(a.clk);
 }
 static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
     launch_clock_begin(b.item[0].clk);
-    search2_body(b.item[blockIdx.z], blockIdx.x, blockIdx.y);
+    search2_body(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,

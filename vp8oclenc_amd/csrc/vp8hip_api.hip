@@ -96,6 +96,7 @@ struct vp8hip_ctx {
     // side work's path, which has 0.25 ms of slack.  Every entry point that needs the filtered frame joins first (join_lf).
     hipStream_t lf_stream = nullptr;   // the stream `stream` is not
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
+    hipEvent_t ev_src = nullptr;       // behind the current frame's pack / parameter scan / pyramid on the side stream: see side_sources_done()
     bool lf_overlap = false, lf_pending = false;
     bool fork_by_verdict = false;      // the pending filter's launch has no fork event in front of it: see side_stream_ordered()
     bool fork_by_verdict_at_launch = false;   // ... as it was launched (fork_by_verdict is cleared once the ordering is established)
@@ -410,6 +411,20 @@ static int join_lf_wait(vp8hip_ctx *c, hipStream_t side) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lf, 0));
     return VP8HIP_OK;
 }
+// The LAST search needs of the side stream's work only the head: the current frame packed, scanned and downsampled.  The host
+// is far ahead of the device there (it enqueues the chain while the filter still has 0.1 ms to run), so it can simply LOOK: once
+// the event behind the head has been seen complete, launches enqueued from then on start after it whatever their stream, and the
+// chain needs no barrier packet between the new LAST's pyramid and the LAST search (10 us per 1080p frame; the GOLDEN / ALTREF
+// searches are waited for in front of k_mb, by the one barrier packet that is there anyway).  Gives up after 20 us.
+static bool side_sources_done(vp8hip_ctx *c) {
+    for (int spins = 0; spins < 64; ++spins) {
+        const hipError_t q = hipEventQuery(c->ev_src);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        for (int i = 0; i < 16; ++i) __builtin_ia32_pause();
+    }
+    return false;
+}
 static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
     if (!c->lf_pending) return defer_ent ? VP8HIP_OK : join_ent(c);
     // back to the stream the filter is on, behind it and behind everything that ran beside it
@@ -467,6 +482,7 @@ int vp8hip_filter_overlap(vp8hip_ctx *c, int on) {
         HIPCHK(c, hipStreamCreateWithPriority(&c->lf_stream, hipStreamNonBlocking, least));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_lf, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
     }
     c->lf_overlap = on != 0;
     return VP8HIP_OK;
@@ -591,6 +607,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         hipStreamDestroy(c->lf_stream);
         hipEventDestroy(c->ev_fork);
         hipEventDestroy(c->ev_lf);
+        hipEventDestroy(c->ev_src);
         if (c->ent_stream) {
             hipStreamSynchronize(c->ent_stream);
             hipStreamDestroy(c->ent_stream);
@@ -883,25 +900,43 @@ int vp8hip_inter_transform(vp8hip_ctx *c, int prev_is_golden, int prev_is_altref
     // chain (0.36 ms of a 0.60 ms frame at 1080p); this takes 1.8 of the 2.8 reference searches out of the chain.
     const bool split = c->lf_pending && (use_golden || use_altref) && (!use_golden || c->slot[1] != c->slot[0]) &&
                        (!use_altref || c->slot[2] != c->slot[0]);
+    bool src_marked = false;
     if (split) {
         if (!c->cur_pyramid_valid) build_pyramid(c, &c->cur, nullptr);
         c->cur_pyramid_valid = true;
+        src_marked = hipEventRecord(c->ev_src, c->stream) == hipSuccess;   // (`stream` is the side stream while the filter is pending)
         search_refs(c, ref_set(c, 0, use_golden, use_altref));
     }
+    hipStream_t late_side = nullptr;   // the side stream, when its GOLDEN / ALTREF searches are joined in front of k_mb only
     if (c->lf_pending && c->cur_pyramid_valid && c->slot[0] >= 0 && !c->frames[c->slot[0]].pyramid_valid) {
         hipStream_t side = join_lf_swap(c);
         FrameSurf &last = c->frames[c->slot[0]];
         build_pyramid(c, &last.f, nullptr, last.border_valid ? 0u : 1u);     // behind the filter, beside whatever the side stream still runs
         last.pyramid_valid = last.border_valid = true;
-        const int wr = join_lf_wait(c, side);
-        if (wr) return wr;
+        if (src_marked && side_sources_done(c)) late_side = side;
+        else {
+            const int wr = join_lf_wait(c, side);
+            if (wr) return wr;
+        }
     } else {
         const int jr = join_lf(c, /*defer_ent=*/true);
         if (jr) return jr;
     }
     pyramids(c);
     search_refs(c, split ? ref_set(c, 1, 0, 0) : refs);
-    { const int jr = join_ent(c); if (jr) return jr; }      // (the previous frame's coefficients, vectors and modes are the stage's until here)
+    if (late_side) {
+        // ONE barrier packet in front of k_mb: the side stream waits for the previous frame's entropy stage itself (its barrier
+        // costs the chain nothing), and the chain for the side stream
+        if (c->ent_pending) {
+            c->ent_pending = false;
+            HIPCHK(c, hipStreamWaitEvent(late_side, c->ev_ent, 0));
+        }
+        const int wr = join_lf_wait(c, late_side);
+        if (wr) return wr;
+    } else {
+        const int jr = join_ent(c);      // (the previous frame's coefficients, vectors and modes are the stage's until here)
+        if (jr) return jr;
+    }
     {
         Timed t(c, VP8HIP_K_MB);   // select_reference + pack_8x8_into_16x16 run inside
         launch_mb(c->stream, c->cur, refs, c->nets, c->frames[c->recon].f, c->out, c->d_sd, c->ssim_target, c->mbw, c->mbh, c->conformant != 0);

@@ -282,6 +282,22 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int byte_of(uint32_t w, int k) { return (int)((w >> (8 * k)) & 0xffu); }
 
+// The workgroups of a launch go to the part's eight XCDs round-robin by their linear index, and every XCD has an L2 of its own.  A
+// kernel whose workgroup x works on tile x therefore spreads every neighbourhood of the frame over all eight L2s: the reference rows
+// two vertically adjacent search windows share, the 128-byte line two horizontally adjacent tiles share, are fetched once per XCD
+// that meets them (k_search2: 3.5 x its algorithmic bytes, profiles/pmc_traffic.json of round 3).  With this map the workgroups an
+// XCD is given (x = k mod 8) work on ONE contiguous run of tiles -- a band of the frame -- so a line is fetched by the one L2 whose
+// band it lies in (and by a neighbour's at a band's edge).  A bijection of [0, n) for any n.
+__device__ __forceinline__ int xcd_band(int x, int n) {
+#if defined(VP8HIP_NO_XCD_BANDS)
+    (void)n;
+    return x;
+#else
+    const int k = x & 7, chunk = n >> 3, rem = n & 7;
+    return k * chunk + (k < rem ? k : rem) + (x >> 3);
+#endif
+}
+
 // VP8 quantiser index -> step tables (RFC 6386 14.1; the reference keeps them at GPU_kernels.cl:58-80)
 static __device__ __constant__ const int k_dc_q[128] = {
     4,   5,   6,   7,   8,   9,   10,  10,  11,  12,  13,  14,  15,  16,  17,  17,  18,  19,  20,  20,  21,  21,
