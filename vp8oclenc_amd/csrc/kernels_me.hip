@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const Plane &P0 = f.Y[0];
     const int tiles_y = (P0.h + 63) / 64;
+    // A tile is 64 bytes wide, a line of memory 128: horizontal neighbours share every line they read, and the rows they write in
+    // the levels below are 32, 16, 8 and 4 bytes of one line.  Tiles are therefore handed out so that an XCD gets a run of
+    // consecutive tiles (xcd_band, vp8hip_dev.h): the two halves of a line meet in ONE L2.
+    const int tile = xcd_band((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, tiles_y * (int)gridDim.x);
+    const int bx = tile % (int)gridDim.x, by = tile / (int)gridDim.x;
     if ((int)blockIdx.y >= tiles_y) {
         if (!((a.border_mask >> blockIdx.z) & 1)) return;
         int job = (((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x) * 4 + (t >> 6);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
         return;
     }
     // 4x4 source pixels -> 2x2 of level 1 -> 1 of level 2
-    const int sx = imin(blockIdx.x * 64 + 4 * tx, P0.w - 4), sy0 = blockIdx.y * 64 + 4 * ty;
+    const int sx = imin(bx * 64 + 4 * tx, P0.w - 4), sy0 = by * 64 + 4 * ty;
     uint32_t r[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
             l1[j][i] = (byte_of(r[2 * j], 2 * i) + byte_of(r[2 * j], 2 * i + 1) + byte_of(r[2 * j + 1], 2 * i) +
                         byte_of(r[2 * j + 1], 2 * i + 1) + 2) >> 2;
     const Plane &P1 = f.Y[1];
-    const int x1 = blockIdx.x * 32 + 2 * tx, y1 = blockIdx.y * 32 + 2 * ty;
+    const int x1 = bx * 32 + 2 * tx, y1 = by * 32 + 2 * ty;
     if (x1 < P1.w) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     }
     const int l2 = (l1[0][0] + l1[0][1] + l1[1][0] + l1[1][1] + 2) >> 2;
     const Plane &P2 = f.Y[2];
-    const int x2 = blockIdx.x * 16 + tx, y2 = blockIdx.y * 16 + ty;
+    const int x2 = bx * 16 + tx, y2 = by * 16 + ty;
     if (x2 < P2.w && y2 < P2.h) P2.p[(ptrdiff_t)y2 * P2.stride + x2] = (uint8_t)l2;
     s2[ty][tx] = (uint8_t)l2;
     __syncthreads();
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
         const int ux = t & 7, uy = t >> 3;
         const int l3 = (s2[2 * uy][2 * ux] + s2[2 * uy][2 * ux + 1] + s2[2 * uy + 1][2 * ux] + s2[2 * uy + 1][2 * ux + 1] + 2) >> 2;
         const Plane &P3 = f.Y[3];
-        const int x3 = blockIdx.x * 8 + ux, y3 = blockIdx.y * 8 + uy;
+        const int x3 = bx * 8 + ux, y3 = by * 8 + uy;
         if (x3 < P3.w && y3 < P3.h) P3.p[(ptrdiff_t)y3 * P3.stride + x3] = (uint8_t)l3;
         s3[uy][ux] = (uint8_t)l3;
     }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
         const int ux = t & 3, uy = t >> 2;
         const int l4 = (s3[2 * uy][2 * ux] + s3[2 * uy][2 * ux + 1] + s3[2 * uy + 1][2 * ux] + s3[2 * uy + 1][2 * ux + 1] + 2) >> 2;
         const Plane &P4 = f.Y[4];
-        const int x4 = blockIdx.x * 4 + ux, y4 = blockIdx.y * 4 + uy;
+        const int x4 = bx * 4 + ux, y4 = by * 4 + uy;
         if (x4 < P4.w && y4 < P4.h) P4.p[(ptrdiff_t)y4 * P4.stride + x4] = (uint8_t)l4;
     }
 }
