@@ -398,15 +398,18 @@ def literal_gops(api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream
             d.hip.reserve_frame_path_dense()
     keys, nbytes = [0] * chunks, [0] * chunks
     pipelined = bitstream and not os.environ.get("VP8_BENCH_NO_FRAME_PIPELINE")
+    native_loop = pipelined and not os.environ.get("VP8_BENCH_PY_VIDEO_LOOP")
+    # where the frames land: host memory allocated and touched before the clock starts (the reference's output buffers are init_all()'s)
+    video_out = [d.video_out_buffer(gop_len) for d in drv] if native_loop else None
 
     def work(k):
         d = drv[k]
         pending = None
-        if pipelined and not os.environ.get("VP8_BENCH_PY_VIDEO_LOOP"):
+        if native_loop:
             # the whole loop natively (vp8drv_encode_video_device: encode(t), frame t - 1's bytes, frame t's stage, frame t's verdict):
             # the host's reaction times are on the path -- the later a frame's stage is enqueued behind its verdict, the further it
             # reaches under the next frame's LAST search
-            fr, kk = d.encode_video_device(gop_len, leg.ptrs, start=3 * k)
+            fr, kk = d.encode_video_device(gop_len, leg.ptrs, start=3 * k, out=video_out[k], views=True)
             keys[k] += kk
             nbytes[k] += sum(len(b) for b in fr)
             if frames_out is not None:

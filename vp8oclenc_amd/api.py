@@ -411,13 +411,22 @@ class NativeDriver:
             raise Vp8HipError(f"vp8drv_get_frame_end: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return self._frame_buf[:n.value].tobytes()
 
-    def encode_video_device(self, nframes: int, frame_ptrs, start: int = 0, capacity: int | None = None):
+    def video_out_buffer(self, nframes: int) -> np.ndarray:
+        """host memory for the frames of `nframes` calls' worth of video (twenty times a dense frame at the reference's default
+        quantisers), every page touched: what a caller allocates ONCE, before its clock starts, and hands to encode_video_device"""
+        out = np.empty(nframes * (self.hip.mbs * 64 + (1 << 16)), np.uint8)
+        out.fill(0)
+        return out
+
+    def encode_video_device(self, nframes: int, frame_ptrs, start: int = 0, out: np.ndarray | None = None, views: bool = False):
         """vp8drv_encode_video_device: `nframes` frames of one video with the frames out, natively (frame t =
-        frame_ptrs[(start + t) % len]); returns (list of frames as bytes, key-frame count)"""
+        frame_ptrs[(start + t) % len]); returns (list of frames, key-frame count).  The frames land back to back in `out`
+        (video_out_buffer(); allocated here when None); views=True returns them as memoryviews into it instead of copies."""
         nd = len(frame_ptrs)
         F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
-        cap = capacity or nframes * (self.hip.mbs * 64 + (1 << 16))      # (twenty times a dense frame at the reference's default quantisers)
-        out = np.empty(cap, np.uint8)
+        if out is None:
+            out = np.empty(nframes * (self.hip.mbs * 64 + (1 << 16)), np.uint8)
+        cap = int(out.size)
         sizes = (C.c_uint32 * max(nframes, 1))()
         keys = C.c_int(0)
         self.lib.vp8drv_encode_video_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
@@ -426,9 +435,11 @@ class NativeDriver:
         if rc < 0:
             raise Vp8HipError(f"vp8drv_encode_video_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         frames, o = [], 0
+        mv = memoryview(out)
         for t in range(nframes):
-            frames.append(out[o:o + sizes[t]].tobytes())
-            o += sizes[t]
+            n = int(sizes[t])
+            frames.append(mv[o:o + n] if views else mv[o:o + n].tobytes())
+            o += n
         return frames, int(keys.value)
 
     def stats(self) -> DrvStats:
