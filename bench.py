@@ -417,6 +417,10 @@ def literal_gops(api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream
                     frames_out[frame_base + k * gop_len + t] = b
             d.hip.synchronize()
             return
+        if not bitstream and not os.environ.get("VP8_BENCH_PY_VIDEO_LOOP"):
+            d.encode_video_device_no_frames(gop_len, leg.ptrs, start=3 * k)     # (the same calls from C: no interpreter lock between two videos' threads)
+            d.hip.synchronize()
+            return
         for t in range(gop_len):
             d.encode_frame_device(*leg.ptrs[(3 * k + t) % leg.nd])
             if pipelined:

@@ -147,7 +147,9 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
  * is frames[(start + t) % nd].  With overlap_filter the stage of a frame runs on a stream of its own beside its loop filter and the
  * next frame's side work (vp8hip_encode_frame_begin); call vp8hip_reserve_frame_path_dense(vp8drv_context(d)) first.  The frames
  * are laid end to end into `out` (capacity bytes), sizes[t] = frame t's size; keys (may be NULL) counts the key frames, frames sent
- * back by check_SSIM included.  A native loop because the host's reaction times are on the path: every microsecond between a
+ * back by check_SSIM included.  out == NULL (sizes is then not used): the same video WITHOUT frames out -- encode after encode, the
+ * last verdict taken at the end -- for callers that code several videos side by side from a thread each and want no interpreter in
+ * the loop (bench.py's config3_literal).  A native loop because the host's reaction times are on the path: every microsecond between a
  * frame's verdict and the enqueue of its stage moves the stage further under the next frame's LAST search (one video with frames
  * out, 1080p: 0.383 ms per frame from Python). */
 int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frames)[3], int nd, int start, uint8_t *out, size_t capacity,

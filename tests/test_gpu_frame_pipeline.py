@@ -98,4 +98,17 @@ def test_native_video_loop_delivers_the_frames_of_the_call_by_call_loop():
         assert (sa.key_frames, sa.inter_frames, sa.redone_as_key) == (sb.key_frames, sb.inter_frames, sb.redone_as_key) and keys == sa.key_frames
         for p_, q_ in zip(a.hip.download_last(), b.hip.download_last()):
             assert np.array_equal(p_, q_)
-        a.close(); b.close()
+        # ... and with out = NULL (no frames out, no interpreter in the loop): the same video, views into a caller's buffer the same bytes
+        c = api.NativeDriver(seq.W, seq.H, **kw)
+        c.encode_video_device_no_frames(N, ptrs, start=2)
+        sc = c.stats()
+        assert (sa.key_frames, sa.inter_frames, sa.redone_as_key) == (sc.key_frames, sc.inter_frames, sc.redone_as_key)
+        for p_, q_ in zip(a.hip.download_last(), c.hip.download_last()):
+            assert np.array_equal(p_, q_)
+        c.hip.reserve_frame_path_dense()
+        buf = c.video_out_buffer(3)
+        more, _ = c.encode_video_device(3, ptrs, start=2 + N, out=buf, views=True)
+        for t in range(3):
+            a.encode_frame_device(*ptrs[(2 + N + t) % ND])
+            assert bytes(more[t]) == a.get_frame()
+        a.close(); b.close(); c.close()

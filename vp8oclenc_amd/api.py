@@ -442,6 +442,16 @@ class NativeDriver:
             o += n
         return frames, int(keys.value)
 
+    def encode_video_device_no_frames(self, nframes: int, frame_ptrs, start: int = 0):
+        """vp8drv_encode_video_device with out = NULL: `nframes` frames of one video, no frames out, no interpreter in the loop"""
+        nd = len(frame_ptrs)
+        F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
+        self.lib.vp8drv_encode_video_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        rc = self.lib.vp8drv_encode_video_device(self.h, int(nframes), C.cast(F, C.c_void_p), nd, int(start), None, 0, None, None)
+        if rc < 0:
+            raise Vp8HipError(f"vp8drv_encode_video_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+
     def stats(self) -> DrvStats:
         s = DrvStats()
         self.lib.vp8drv_get_stats(self.h, C.byref(s))

@@ -625,9 +625,20 @@ int vp8drv_get_frame_end(vp8drv *d, uint8_t *out, size_t capacity, size_t *size)
 
 int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frames)[3], int nd, int start, uint8_t *out, size_t capacity,
                                uint32_t *sizes, int *keys) {
-    if (!d || nframes < 0 || !frames || nd < 1 || start < 0 || !out || !sizes) return VP8HIP_ERR_ARG;
+    if (!d || nframes < 0 || !frames || nd < 1 || start < 0 || (out && !sizes)) return VP8HIP_ERR_ARG;
     size_t used = 0;
     int nkeys = 0;
+    if (!out) {      // no frames out: a frame's verdict is taken by the next call (resolve() at its head), the last one's here
+        for (int t = 0; t < nframes; ++t) {
+            const void *const *f = frames[(start + t) % nd];
+            const int rc = vp8drv_encode_frame_device(d, f[0], f[1], f[2], 0);
+            if (rc < 0) return rc;
+        }
+        const int rc = vp8drv_resolve(d);
+        if (rc < 0) return rc;
+        if (keys) *keys = -1;     // (not counted here: vp8drv_get_stats has key_frames and redone_as_key)
+        return VP8HIP_OK;
+    }
     for (int t = 0; t < nframes; ++t) {
         const void *const *f = frames[(start + t) % nd];
         int rc = vp8drv_encode_frame_device(d, f[0], f[1], f[2], 0);          // frame t under way ...
