@@ -358,8 +358,9 @@ const char *vp8hip_status_string(int status);
 /* The ABI of this header as MAJOR * 1000 + MINOR: MAJOR changes when an existing entry point or struct changes its meaning or
  * layout (vp8drv_config grew in round 2: 2; vp8drv_stats grew by refs_searched and vp8drv_default_config turned check_ssim on
  * -- return values and counters provisional until vp8drv_resolve -- in round 3: 3), MINOR when entry points are added.  A host
- * built against an older header checks it once after loading the library. */
-#define VP8HIP_ABI_VERSION 3001
+ * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
+ * 3002: vp8drv_encode_video_device. */
+#define VP8HIP_ABI_VERSION 3002
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

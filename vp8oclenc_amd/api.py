@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3001  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 3002  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 SHARPNESS_ON_DEVICE = -2 ** 31   # VP8HIP_SHARPNESS_ON_DEVICE
