@@ -17,18 +17,20 @@ namespace vp8 {
 // GPU_kernels.cl:562).  grid = (max rows + 2*EXT, 3 planes), block = 64.
 // ------------------------------------------------------------------------------------------------
 struct BorderItem { Plane y, u, v; };
-// one row (-EXT .. h + EXT - 1) of one plane by the 64 lanes of a wave
+// one row (-EXT .. h + EXT - 1) of one plane by the 64 lanes of a wave.  Rows start 32-byte aligned and plane widths are multiples
+// of 8 (vp8hip_create: frame sizes are multiples of 16), so a row above or below the plane is copied eight bytes per lane and step
+// and either margin is ONE eight-byte store of the edge sample (byte by byte a full 1080p row was 30 dependent rounds per lane, and
+// the 48 such rows of a frame made the pyramid-and-edges launch twice as long as the pyramid alone).
+static_assert(EXT == 8, "border_row stores a margin as one eight-byte word");
 __device__ __forceinline__ void border_row(const Plane &pl, int row, int lane) {
     if (row >= pl.h + EXT) return;
     uint8_t *dst = pl.p + (ptrdiff_t)row * pl.stride;
-    if (row >= 0 && row < pl.h) {
-        for (int t = lane; t < 2 * EXT; t += 64) {
-            const int x = t < EXT ? t - EXT : pl.w + (t - EXT);
-            dst[x] = dst[t < EXT ? 0 : pl.w - 1];
-        }
-    } else {
-        const uint8_t *src = pl.p + (ptrdiff_t)iclamp(row, 0, pl.h - 1) * pl.stride;
-        for (int x = -EXT + lane; x < pl.w + EXT; x += 64) dst[x] = src[iclamp(x, 0, pl.w - 1)];
+    const uint8_t *src = pl.p + (ptrdiff_t)iclamp(row, 0, pl.h - 1) * pl.stride;
+    if (row < 0 || row >= pl.h)
+        for (int x = lane * 8; x < pl.w; x += 512) *reinterpret_cast<uint2 *>(dst + x) = *reinterpret_cast<const uint2 *>(src + x);
+    if (lane < 2) {
+        const uint32_t s4 = (uint32_t)src[lane ? pl.w - 1 : 0] * 0x01010101u;
+        *reinterpret_cast<uint2 *>(dst + (lane ? pl.w : -EXT)) = make_uint2(s4, s4);
     }
 }
 __device__ __forceinline__ void border_body(const BorderItem &a) {
