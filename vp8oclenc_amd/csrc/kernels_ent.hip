@@ -246,7 +246,7 @@ void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *th
 // ====================================================================================================
 namespace ent {
 
-constexpr int CHUNK = 256;        // bools per chunk
+constexpr int CHUNK = ENT_CHUNK;  // bools per chunk
 constexpr int SCAN_TILE = 1024;   // slots per scan tile (256 threads x 4)
 
 

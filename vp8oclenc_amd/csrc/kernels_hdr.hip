@@ -278,7 +278,7 @@ __device__ __forceinline__ void hdr_frame_body(const Params &a, uint32_t *partia
             }
         }
         const uint32_t H = s_n1 + n2 + w.n, total = H + s_total;
-        const uint32_t chunks = (total + 255) / 256, words = (total * 7 + 31) / 32 + 4;
+        const uint32_t chunks = (total + ENT_CHUNK - 1) / ENT_CHUNK, words = (total * 7 + 31) / 32 + 4;
         const bool over = total > a.cap_bools || chunks > a.cap_chunks || words > a.cap_words;
         for (int p = 0; p <= ENT_MAX_PARTITIONS; ++p) plan->bool_base[p] = plan->chunk_base[p] = plan->word_base[p] = 0;
         for (int p = 0; p < ENT_MAX_PARTITIONS; ++p) plan->nbools[p] = plan->w_end[p] = plan->nbytes[p] = 0;

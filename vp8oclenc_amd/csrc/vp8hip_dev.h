@@ -177,6 +177,10 @@ void launch_auto_segments(hipStream_t s, const Frame &cur, uint32_t *partial, ui
 // coefficient entropy stage (kernels_ent.hip): flags + third context + token histogram + probabilities
 constexpr int ENT_NCTX = 4 * 8 * 3 * 11;
 constexpr int ENT_MAX_PARTITIONS = 8;
+#if !defined(VP8HIP_ENT_CHUNK)
+#define VP8HIP_ENT_CHUNK 256
+#endif
+constexpr int ENT_CHUNK = VP8HIP_ENT_CHUNK;   // bools per chunk of the parallel boolean coder (kernels_ent.hip)
 void launch_ent_count(hipStream_t s, const MBOut &o, uint8_t *flags, uint8_t *third_ctx, uint32_t *counts, uint32_t *probs,
                       uint32_t *denom0, int mbw, int mbh, int num_partitions, const uint8_t *defaults = nullptr);   // defaults: see hdr_default_coeff_probs
 // layout of one frame's bool strings / chunks / output words per partition; written by the device, read by the host
