@@ -660,7 +660,7 @@ def main():
     # (no batch, no other chunk in flight); the reconstruction it ends with must be the timed chunk's.  A run whose timed frames
     # are not the frames a single un-batched encoder produces prints no line.
     verify = leg.replay_chunk((7 * (rank + 1)) % G)
-    if not verify["identical"]:
+    if not verify["identical"] and not experiment_build:      # (an experiment build leaves work out of launches: its line says INVALID)
         raise SystemExit(f"bench.py: self-check FAILED -- the timed region's chunk {verify['chunk']} does not end where the same frames coded alone end: {verify}")
     frames_per_gpu = args.steps * G
     if args.refs == "all" and args.steps * G >= 2 * ALTREF_RANGE and nrefs_avg < 2.7:

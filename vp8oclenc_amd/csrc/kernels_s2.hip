@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "vp8hip_dev.h"
+#include "kernels_rc_dev.h"
 
 namespace vp8 {
 
@@ -288,6 +289,24 @@ __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
     search2_body(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
+// The same launch carrying the loop-filter strength scans of its members' NEW frames (kernels_rc_dev.h): the workgroups behind the
+// nbx block groups of reference 0.  With the part full a launch of the scan's own holds the batch's stream for 0.4-0.7 ms where its
+// work is 15 us (every workgroup waits for a place) -- the headline without that launch: +4 %, scripts/ab_flags_experiments.sh -- and
+// the shorter launches of the chain cannot absorb it either (in the pyramid's launch it made THAT link the long one: -2 %).  This is
+// the frame's longest launch, the scan's result is wanted by k_mb, which comes next, and the scan's 136 workgroups per frame are
+// spread through the launch's 12 000 per member.
+struct S2Scans { rc::ScanCore item[MAX_BATCH]; uint32_t mask; int nbx, wgs; };
+static_assert(sizeof(BatchOf<S2Args>) + sizeof(S2Scans) <= 4096, "the kernel-argument segment");
+__global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scans sc) {
+    if ((int)blockIdx.x >= sc.nbx) {
+        const int wg = (int)blockIdx.x - sc.nbx;
+        if (blockIdx.y == 0 && ((sc.mask >> blockIdx.z) & 1) && wg < sc.wgs) rc::strength_segments_body(b.item[blockIdx.z].cur, sc.item[blockIdx.z], wg, sc.wgs);
+        return;
+    }
+    launch_clock_begin(b.item[0].clk);
+    search2_body(b.item[blockIdx.z], xcd_band(blockIdx.x, sc.nbx), blockIdx.y);
+    launch_clock_end(b.item[0].clk);
+}
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
 // block group) space with a stride.  A command-processor pipe stays busy with a launch until its last workgroup is
 // placed -- for a grid of tens of thousands of workgroups on a full chip that is the kernel's whole duration, and the
@@ -336,7 +355,8 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
 }
 
-void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n, unsigned long long *clk) {
+bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n, unsigned long long *clk,
+                          const ScanRequest *const *scan) {
     BatchOf<S2Args> b;
     b.n = n;
     int maxrefs = 0;
@@ -344,14 +364,31 @@ void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         b.item[i] = search2_args(*cur[i], refs[i], *nets[i], clk);
         maxrefs = b.item[i].nrefs > maxrefs ? b.item[i].nrefs : maxrefs;
     }
-    if (maxrefs == 0 || search2_skip()) return;
+    if (maxrefs == 0 || search2_skip()) return false;
     const int nbx = (b.item[0].nblk + 7) / 8;
     const int persist = persistent_workgroups();
     if (persist > 0 && nbx * maxrefs * n > persist) {
         VP8_LAUNCH(k_search2_p, dim3(persist), dim3(256), 0, s, b, nbx, maxrefs, nbx * maxrefs * n);
-        return;
+        return false;
     }
-    VP8_LAUNCH(k_search2_b, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+    S2Scans sc;
+    sc.mask = 0;
+    for (int i = 0; scan && i < n; ++i) {
+        if (!scan[i]) continue;
+        const ScanRequest &q = *scan[i];
+        const Plane &y = b.item[i].cur;
+        sc.mask |= 1u << i;
+        sc.item[i] = rc::ScanCore{q.partial, q.partial + 2 * rc::MAX_PARTIALS, q.stats, q.sd, q.strength_out,
+                                  rc::SegArgs{y.w * y.h, (y.h - 1) * (y.w - 1), q.is_key, q.refqi[0], q.refqi[1], q.refqi[2], q.refqi[3], q.qi_min}};
+    }
+    if (!sc.mask) {
+        VP8_LAUNCH(k_search2_b, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+        return false;
+    }
+    sc.nbx = nbx;
+    sc.wgs = (b.item[0].h + rc::ROWS_PER_BLOCK - 1) / rc::ROWS_PER_BLOCK;
+    VP8_LAUNCH(k_search2_bs, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    return true;
 }
 
 }  // namespace vp8

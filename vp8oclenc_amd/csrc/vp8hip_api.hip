@@ -97,6 +97,10 @@ struct vp8hip_ctx {
     hipStream_t lf_stream = nullptr;   // the stream `stream` is not
     hipEvent_t ev_fork = nullptr, ev_lf = nullptr;
     hipEvent_t ev_src = nullptr;       // behind the current frame's pack / parameter scan / pyramid on the side stream: see side_sources_done()
+    // A batch member's parameter scan (vp8hip_batch_auto_segments) waits here for the frame's longest launch, k_search2's, and rides in it
+    // (launch_search2_batch); whoever needs the segment data earlier launches it on its own first (flush_scan).
+    bool scan_deferred = false;
+    ScanRequest scan_req{};
     bool lf_overlap = false, lf_pending = false;
     bool fork_by_verdict = false;      // the pending filter's launch has no fork event in front of it: see side_stream_ordered()
     bool fork_by_verdict_at_launch = false;   // ... as it was launched (fork_by_verdict is cleared once the ordering is established)
@@ -436,9 +440,11 @@ static int join_lf(vp8hip_ctx *c, bool defer_ent = false) {
 }
 static void lf_check(vp8hip_ctx *c, LfCheck &k);   // (below, with check_SSIM)
 
+static void flush_scan(vp8hip_ctx *c);
 // work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
 static void batch_join_prep(vp8hip_batch *b) {
     if (!b) return;
+    for (int i = 0; i < b->n; ++i) flush_scan(b->c[i]);   // (a member's parameter scan still waiting for its pyramid launch: ahead of whatever comes now)
     b->ent_fork_fresh = false;   // (every entry point that may enqueue passes here: the entropy stage's early fork point is stale)
     if (!b->prep || !b->prep_pending) return;
     b->prep_pending = false;
@@ -464,7 +470,13 @@ static void side_stream_ordered(vp8hip_ctx *c) {
     }
     c->fork_by_verdict = false;
 }
-#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); side_stream_ordered(c); } } while (0)
+static void flush_scan(vp8hip_ctx *c) {
+    if (!c->scan_deferred) return;
+    c->scan_deferred = false;
+    const ScanRequest &q = c->scan_req;
+    launch_auto_segments(c->stream, c->cur, q.partial, q.stats, q.sd, q.strength_out, q.is_key, q.refqi, q.qi_min);
+}
+#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); side_stream_ordered(c); flush_scan(c); } } while (0)
 #define USE_DEVICE_ONLY(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
 #define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
 
@@ -1291,6 +1303,20 @@ int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is
         for (int k = 0; k < 4; ++k) qi[n][k] = refqi[i][k];
         ++n;
     }
+    // The scan rides in k_search2's launch of the same frame (vp8hip_batch_inter_transform, next; kernels_s2.hip says why): with the part
+    // full a launch of its own holds the batch's stream for half a millisecond where its work is 15 us (VP8HIP_BATCH_SCAN_LAUNCH=1: as it was)
+    static const bool own_launch = [] { const char *v = getenv("VP8HIP_BATCH_SCAN_LAUNCH"); return v && v[0] == '1'; }();
+    if (n && !b->prep && !own_launch) {
+        int k = 0;
+        for (int i = 0; i < b->n; ++i) {
+            if (active && !active[i]) continue;
+            vp8hip_ctx *c = b->c[i];
+            c->scan_req = ScanRequest{partial[k], stats[k], sd[k], strength[k], key[k], {qi[k][0], qi[k][1], qi[k][2], qi[k][3]}, qi_min};
+            c->scan_deferred = true;
+            ++k;
+        }
+        return VP8HIP_OK;
+    }
     if (n && b->prep) b->prep_pending = true;
     if (n) launch_auto_segments_batch(b->prep ? b->prep : b->stream, cur, partial, stats, sd, strength, key, qi, qi_min, n);
     HIPCHK(c0, hipGetLastError());
@@ -1305,6 +1331,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     vp8hip_ctx *m[MAX_BATCH];
     RefSet refs[MAX_BATCH];
     const Frame *cur[MAX_BATCH], *recon[MAX_BATCH], *pyr[2 * MAX_BATCH], *pyr_cur[MAX_BATCH];
+    const ScanRequest *scans[MAX_BATCH] = {};   // the members' parameter scans still waiting for a launch to ride in (vp8hip_batch_auto_segments)
     int npyr_cur = 0;
     const NetSet *nets[MAX_BATCH];
     const MBOut *outs[MAX_BATCH];
@@ -1347,6 +1374,10 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         nets[n] = &c->nets;
         outs[n] = &c->out;
         sds[n] = c->d_sd;
+        if (c->scan_deferred) {
+            scans[n] = &c->scan_req;
+            c->scan_deferred = false;      // (this call launches it: in k_search2's launch, or on its own right behind it)
+        }
         m[n++] = c;
     }
     if (!n) return VP8HIP_OK;
@@ -1367,10 +1398,14 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         launch_search1_batch(s, cur, refs, nets, l, src, net_width, n);
         src ^= 1;
     }
+    bool carried;
     {
         Timed t(c0, VP8HIP_K_SEARCH2);
-        launch_search2_batch(s, cur, refs, nets, n, s2_clock(c0));
+        carried = launch_search2_batch(s, cur, refs, nets, n, s2_clock(c0), scans);
     }
+    for (int i = 0; i < n && !carried; ++i)
+        if (scans[i]) launch_auto_segments(s, m[i]->cur, scans[i]->partial, scans[i]->stats, scans[i]->sd, scans[i]->strength_out, scans[i]->is_key,
+                                           scans[i]->refqi, scans[i]->qi_min);
     {
         Timed t(c0, VP8HIP_K_MB);
         launch_mb_batch(s, cur, refs, nets, recon, outs, sds, c0->ssim_target, c0->mbw, c0->mbh, n, c0->conformant != 0);

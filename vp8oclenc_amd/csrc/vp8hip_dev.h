@@ -133,12 +133,16 @@ void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t bord
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v, int sw = 0, int sh = 0, int ssy = 0, int ssc = 0);
 // batched forms: n <= MAX_BATCH contexts (pyramid: nframes <= 2 * MAX_BATCH surfaces)
 void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask = 0);
+// launch_auto_segments' work (same arguments) for a launch that lets it ride along (launch_search2_batch)
+struct ScanRequest { uint32_t *partial, *stats; SegData *sd; int32_t *strength_out; int is_key; int32_t refqi[4]; int qi_min; };
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n,
                        int sw = 0, int sh = 0);
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
                           int net_width, int n);
-void launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n,
-                          unsigned long long *clk = nullptr);   // clk: launch clock words (launch_clock_end) or nullptr
+// scan[i] (may be nullptr, as may scan): member i's new frame gets its loop-filter strength scan + segment data in this launch.
+// Returns false if the scans were NOT carried (nothing to search, or the persistent form): the caller launches them on their own.
+bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n,
+                          unsigned long long *clk = nullptr, const ScanRequest *const *scan = nullptr);   // clk: launch clock words (launch_clock_end) or nullptr
 void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, const Frame *const *recon,
                      const MBOut *const *o, const SegData *const *d_sd, float ssim_target, int mbw, int mbh, int n,
                      bool conformant = false);
