@@ -338,6 +338,9 @@ int vp8hip_shard_max(vp8hip_ctx *ctx, double *value);
  * depends on the previous frame's reconstruction -- a second, low-priority stream beside the PREVIOUS frame's chain, which
  * waits for it where it starts: 1 = a stream per batch, 2 = one stream for all batches.  Off (0) by default: it measured 2-4 %
  * slower with the part full; vp8hip_batch_prep_mode() reports the mode in force.
+ * vp8hip_batch_auto_segments launches nothing by itself: the scan rides in the quarter-pel search launch that
+ * vp8hip_batch_inter_transform makes for the same frame (a launch of its own cost 4 % with the part full), and any
+ * entry point that needs the segment data earlier launches it on its own first; VP8HIP_BATCH_SCAN_LAUNCH=1 = always on its own.
  * No reference counterpart: the reference codes one video on one in-order queue set. */
 #define VP8HIP_MAX_BATCH 8
 typedef struct vp8hip_batch vp8hip_batch;
