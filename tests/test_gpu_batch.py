@@ -103,3 +103,42 @@ def test_batches_on_a_host_thread_each_give_the_frames_of_single_chunks():
     for row in single + batched:
         for d in row:
             d.close()
+
+
+def test_a_batch_members_parameter_scan_is_there_when_somebody_asks_before_the_search_launch():
+    """vp8hip_batch_auto_segments leaves the scan to the frame's quarter-pel search launch; an entry point that needs the segment data
+    before that launch exists (here: vp8hip_get_segments of one member, then a second frame set without any search in between) gets
+    the scan launched on its own first -- the numbers of vp8hip_auto_segments on a context of its own"""
+    import ctypes as C
+    from vp8oclenc_amd.synth import SynthSequence
+    W, H, n = 320, 192, 3
+    seqs = [SynthSequence(W, H, seed=90 + i) for i in range(n)]
+    lib = api.load_library()
+    members = [api.Vp8Hip(seqs[0].W, seqs[0].H) for _ in range(n)]
+    alone = [api.Vp8Hip(seqs[0].W, seqs[0].H) for _ in range(n)]
+    hb = C.c_void_p()
+    lib.vp8hip_batch_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
+    assert lib.vp8hip_batch_create(C.byref(hb), (C.c_void_p * n)(*[m.h for m in members]), n) == 0
+    lib.vp8hip_batch_set_current_device.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.vp8hip_batch_auto_segments.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32 * 4), C.c_int]
+    lib.vp8hip_batch_destroy.argtypes = [C.c_void_p]
+    lib.vp8hip_batch_destroy.restype = None
+    refqi = [(20 + 3 * i, 30, 40, 50 + i) for i in range(n)]
+    for t in range(2):       # the second round replaces frames whose scan was asked for and (members 1, 2) never looked at
+        dev = [tuple(api.to_device(p) for p in seqs[i].frame(t)) for i in range(n)]
+        ptr = [[C.c_void_p(dev[i][k].data_ptr()) for i in range(n)] for k in range(3)]
+        arrs = [(C.c_void_p * n)(*ptr[k]) for k in range(3)]
+        assert lib.vp8hip_batch_set_current_device(hb, None, arrs[0], arrs[1], arrs[2]) == 0
+        q = ((C.c_int32 * 4) * n)(*[(C.c_int32 * 4)(*r) for r in refqi])
+        assert lib.vp8hip_batch_auto_segments(hb, None, (C.c_int * n)(*([0] * n)), q, 4) == 0
+        for i in range(n):
+            alone[i].set_current_device(*[p.data_ptr() for p in dev[i]])
+            alone[i].auto_segments(False, refqi[i], 4)
+        for i in ([0] if t == 0 else range(n)):
+            sa, ra, ha = alone[i].get_segments()
+            sb, rb, hb_ = members[i].get_segments()
+            assert np.array_equal(sa, sb) and (ra, ha) == (rb, hb_), (t, i)
+        api.device_synchronize()
+    lib.vp8hip_batch_destroy(hb)
+    for m in members + alone:
+        m.close()

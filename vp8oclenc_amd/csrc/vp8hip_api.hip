@@ -444,7 +444,7 @@ static void flush_scan(vp8hip_ctx *c);
 // work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
 static void batch_join_prep(vp8hip_batch *b) {
     if (!b) return;
-    for (int i = 0; i < b->n; ++i) flush_scan(b->c[i]);   // (a member's parameter scan still waiting for its pyramid launch: ahead of whatever comes now)
+    for (int i = 0; i < b->n; ++i) flush_scan(b->c[i]);   // (a member's parameter scan still waiting for its search launch: ahead of whatever comes now)
     b->ent_fork_fresh = false;   // (every entry point that may enqueue passes here: the entropy stage's early fork point is stale)
     if (!b->prep || !b->prep_pending) return;
     b->prep_pending = false;
@@ -1251,6 +1251,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
         if (active && !active[i]) continue;
         if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
         if (b->c[i]->src_w != c0->src_w || b->c[i]->src_h != c0->src_h) return VP8HIP_ERR_ARG;   // one launch, one source size
+        flush_scan(b->c[i]);      // (a parameter scan of the frame that is being replaced, asked for and never used: on that frame, now)
         next_current(b->c[i]);
         f[n] = &b->c[i]->cur;
         py[n] = y[i]; pu[n] = u[i]; pv[n] = v[i];
