@@ -9,9 +9,12 @@ device, vp8hip_inter_transform, vp8hip_loop_filter).  A rank keeps G independent
 (>= 2*altref_range + 2 frames, chunk phases staggered), so the timed frames carry the real reference mix
 (2.8 references per frame on average); the run fails if they do not.
 
-N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the environment; started plainly with
---gpus N > 1 (or --spawn) this process starts the N rank processes itself, before it touches the GPU.  RCCL carries
-the barrier and the max-over-ranks time only -- there is no data-path collective, scaling is weak.
+N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the environment (RANK, WORLD_SIZE, LOCAL_RANK,
+MASTER_PORT; the launcher is the only thing of PyTorch involved: no rank imports it); started plainly with --gpus N > 1 (or --spawn)
+this process starts the N rank processes itself, before it touches the GPU.  The ranks form the library's own process group
+(vp8hip_group_*: RCCL inside libvp8hip.so, the id handed over through a file): it carries the barrier, the max-over-ranks time and
+the gathering of finished frames -- there is no data-path collective, scaling is weak.  `rccl_ranks` (ncclCommCount) and
+`per_rank` in the line show that N ranks met and what each measured.
 
 Prints ONE JSON line on rank 0 with, besides the contract's fields,
   roofline       the dominant kernel ALONE on the part (solo: one chunk per launch, HIP events of its own dispatch) as algorithmic
@@ -41,14 +44,9 @@ import subprocess
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue
-# serialise; the workload is many independent GOP chunks.  But the part's hardware scheduler holds 24 queues of a process at
-# once: with more (the runtime keeps every queue it ever made, torch and RCCL bring their own) it rotates them and
-# CONTEXT-SWITCHES running waves -- the loop filter's waves change hardware slots mid-launch (`waves_context_switched` in the
-# JSON line) and one GOP coded frame after frame takes 0.51 instead of 0.445 ms per frame.  16 leaves room (measured, 32 chunks
-# in 8 batches: 4 -> 37, 8 -> 48, 12 -> 50, 16 -> 55, 20 -> 54, 24 -> 53 M MB/s).
-# Must be set before the first HIP call of the process; the library notes on stderr when a host's contexts outnumber the queues.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# GPU_MAX_HW_QUEUES (the hardware queues the HIP runtime multiplexes its streams onto; default 4, streams that share a queue serialise)
+# is NOT set here: libvp8hip.so sets it itself when it is loaded (16 unless the environment says otherwise; csrc/api_context.hip,
+# include/vp8hip.h vp8hip_hw_queues) -- this program loads the library before anything touches the GPU, like any host that links it.
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -115,7 +113,7 @@ def parse():
     ap.add_argument("--only-bitstream", action="store_true", help="of the side legs only with_bitstream (same-box A/B runs)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel with hipEvents in the timed region (adds packets)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from here even for --gpus 1 (the N > 1 launch path)")
-    ap.add_argument("--child-legs", action="store_true", help=argparse.SUPPRESS)   # internal: the few-stream side legs in a fresh process
+    ap.add_argument("--child-legs", choices=["few", "other"], default=None, help=argparse.SUPPRESS)   # internal: side legs in a fresh process
     return ap.parse_args()
 
 
@@ -130,7 +128,7 @@ def spawn_ranks(args) -> int:
     argv = [a for a in sys.argv[1:] if a != "--spawn"]
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), VP8_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), VP8_BENCH_CHILD="1", VP8_BENCH_RDZV_KEY=f"bench-{os.getpid()}-{port}", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
@@ -467,7 +465,7 @@ def literal_gops(api, W0, H0, chunks, gop_len, device, nd, refs="all", bitstream
     return out
 
 
-def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None):
+def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None, which="few"):
     """config5_literal (every N), ref_shard, and at N = 1 config3_literal, single_stream and other_configs: the legs that are one or two
     videos coded frame after frame, and the other geometries.  Run in a fresh process (see main()).  Returns the dict for the JSON line
     on rank 0; `emit` (if given) is also handed every finished leg at once, so that a leg that dies takes only itself along."""
@@ -477,7 +475,8 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None)
             if emit is not None:
                 emit({k: v})
     out = _Out()
-    if rank == 0:
+    few, other = which == "few", which == "other"
+    if rank == 0 and few:
         # every kernel of the path ALONE on the part: one chunk, one stream, nothing beside it, each launch timed by its own dispatch
         # (HIP events) -- the launch durations the roofline fractions are made of (with 48 chunks in flight a launch shares the part)
         solo = Leg(api, args.width, args.height, 1, args.refs, args.ssim_target, nd, local, seed=1)
@@ -489,7 +488,7 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None)
         out["solo_kernels"] = {"refs_per_frame": round(nrefs_s, 3), "ms_per_launch": {k: round(ms / n, 5) for k, (ms, n) in solo.profile_read().items() if n},
                                "what": "one GOP chunk on one stream, every kernel timed by its own dispatch; nothing else on the part"}
         solo.close()
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and few:
         # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
         # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
         el3, n3, k3, r3, _, mbs3 = literal_gops(api, args.width, args.height, 2, 150, local, nd)
@@ -501,7 +500,7 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None)
         ss = side_leg(api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         ss["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
         out["single_stream"] = ss
-    if True:
+    if few:
         # BASELINE configs[4] as it is written, at every N: 300 frames per GPU = ONE closed GOP of 300 frames on each rank (2400 / 8),
         # coded end to end from its key frame with finished VP8 frames out, the frames gathered to rank 0 over RCCL in frame order
         # (gop_shard.gather_frames); the time includes the gather.  All ranks take part (collective calls).
@@ -517,18 +516,16 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None)
         barrier()
         t5 = el5 + (time.perf_counter() - t0)
         if dist is not None:
-            import torch
-            tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t5 = float(tt.item())
+            t5 = dist.max(t5)
         if rank == 0:
             assert gathered is not None and len(gathered) == GOP5 * world and all(gathered)
             out["config5_literal"] = {
                 "workload": f"{args.width}x{args.height}, {GOP5 * world} frames = one closed GOP of {GOP5} frames on each of {world} GPU(s), LAST+GOLDEN+ALTREF, check_SSIM in the loop, "
-                            "finished VP8 frames gathered to rank 0 in frame order (RCCL); the time includes the gather",
+                            "finished VP8 frames gathered to rank 0 in frame order (vp8hip_group_gather_bytes: ncclSend / ncclRecv inside the library); the time includes the gather",
                 "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
                 "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
-                "encode_seconds_rank0": round(el5, 4), "n_gpus": world}
+                "encode_seconds_rank0": round(el5, 4), "n_gpus": world, "rccl_ranks": None if dist is None else int(dist.count()),
+                "gpu_framework_in_process": "torch" if "torch" in sys.modules else "none"}
         del gathered, local_frames
         # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
         # all_gathered, the filtered reconstruction broadcast.  Needs three ranks to mean anything; with fewer the same exchanges
@@ -536,7 +533,11 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None)
         rs = ref_shard_leg(api, dist, args.width, args.height, local, rank, world, int(os.environ.get("VP8_BENCH_REFSHARD_FRAMES", "60")))
         if rank == 0 and rs is not None:
             out["ref_shard"] = rs
-    if rank == 0 and world == 1 and not args.only_bitstream:
+    # The other geometries run in a child of their own: the one-video legs above make low-priority streams (the side stream of
+    # vp8hip_filter_overlap, the entropy stage's) and RCCL brings queues too -- a process keeps every hardware queue it ever used, the
+    # priority classes have queue sets of their own, and past 24 queues per process the part's scheduler rotates them and
+    # context-switches running waves (`waves_context_switched` was 20-47 per leg here while these legs shared the few-stream child).
+    if rank == 0 and world == 1 and other and not args.only_bitstream:
         G, B = max(1, args.gops_per_gpu), max(1, min(8, args.batch))
         oc = {}
         for name, leg_args, kw in (
@@ -570,24 +571,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # ONE GPU runtime per process.  With one rank nothing here needs PyTorch: the synthetic frames live in memory the library
-    # allocates (vp8hip_device_alloc) and the process runs on the HIP runtime libvp8hip.so was built for.  With several ranks
-    # torch.distributed (backend nccl = RCCL) carries the barrier, the max-over-ranks time and the gathering of frames: torch is
-    # imported FIRST then, and the library's calls land in the runtime torch brings -- still one runtime in the process.
-    dist = torch = None
-    if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
-        import torch
-        import torch.distributed as dist
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-        torch.cuda.set_device(local)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    # ONE GPU runtime per process and NO GPU framework in it, at every N: the synthetic frames live in memory the library allocates
+    # (vp8hip_device_alloc), and with several ranks the process group is the library's own (vp8hip_group_*, RCCL resolved by the
+    # library from the ROCm it was built for).  Under torchrun only the LAUNCHER is PyTorch; the ranks never import it.
     from vp8oclenc_amd import api
     lib = api.load_library()
     if api.device_count() <= local:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    dist = None
+    # the rendezvous key: the same on every rank of this run, different for any other run alive on the node (the launcher's pid is the
+    # ranks' common parent under torchrun; bench.py's own launcher and the parents of the child legs hand a key down)
+    rdzv_key = os.environ.get("VP8_BENCH_RDZV_KEY") or f"bench-{os.getppid()}-{os.environ.get('MASTER_PORT', '0')}-{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}-{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+    if world > 1 or os.environ.get("VP8_BENCH_CHILD") or os.environ.get("VP8_BENCH_FORCE_DIST"):
+        dist = api.Group.from_env(local, rdzv_key + (f"-{args.child_legs}" if args.child_legs else ""), timeout_s=float(os.environ.get("VP8_BENCH_RDZV_TIMEOUT", "180")))
+        if dist.count() != world:
+            raise SystemExit(f"bench.py: RCCL counts {dist.count()} ranks in the group, WORLD_SIZE is {world}")
     # a build with the timing-experiment switches compiled in (they leave work out of launches) never prints a line
     experiment_build = bool(lib.vp8hip_experiments_compiled_in())
     if experiment_build and os.environ.get("VP8_BENCH_EXPERIMENT_BUILD", "") != "prints-an-invalid-line":
@@ -607,9 +605,9 @@ def main():
         def emit(part):      # one line per finished leg: what is done is on its way before the next leg starts
             if rank == 0:
                 os.write(json_fd, (json.dumps(part) + "\n").encode())
-        few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit)
-        if dist is not None and dist.is_initialized():
-            dist.destroy_process_group()
+        few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit, which=args.child_legs)
+        if dist is not None:
+            dist.close()
         sys.stdout.flush()
         os.close(json_fd)
         sys.exit(0)          # (through the ordinary teardown: every context of every leg has been destroyed by now)
@@ -647,10 +645,12 @@ def main():
 
     # ---- timed region: exactly --steps steps, barrier + synchronize on both sides, max over ranks -------------
     elapsed, enqueue_s, nrefs_avg = leg.run(args.steps, barrier)
+    own_elapsed = elapsed
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = dist.max(elapsed)          # the contract: the slowest rank's time
+        import numpy as _np
+        per_rank = dist.all_gather(_np.array([own_elapsed, float(nrefs_avg)], _np.float64))     # [world, 2] on every rank
     prof = leg.profile_read()
     clk_ms, clk_n, clk_ghz = leg.clock_read()
     for d in leg.drv:
@@ -740,8 +740,9 @@ def main():
                        "frames_redone_as_key": redone, "frames_with_filter_update": None,
                        "batch_prep_stream": int(lib.vp8hip_batch_prep_mode()),     # 0 = none (default), 1 = per batch, 2 = one for all
                        "experiment_switches": "COMPILED IN" if experiment_build else "compiled out",
-                       "hip_runtime_version": int(lib.vp8hip_runtime_version()), "gpu_framework_in_process": "torch (several ranks)" if torch is not None else "none",
-                       "cpu_affinity": affinity, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun" if world > 1 else "single process")},
+                       "hip_runtime_version": int(lib.vp8hip_runtime_version()), "gpu_framework_in_process": "torch" if "torch" in sys.modules else "none",
+                       "process_group": None if dist is None else "vp8hip_group_* (RCCL inside libvp8hip.so; id by file rendezvous)",
+                       "cpu_affinity": affinity, "hw_queues": int(lib.vp8hip_hw_queues()), "hw_queues_set_by": "the environment" if os.environ.get("GPU_MAX_HW_QUEUES") else "libvp8hip.so at load time", "launcher": "self-spawned ranks" if os.environ.get("VP8_BENCH_CHILD") else ("torchrun (launcher only)" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")},
             "roofline": roof,
             "loop_filter_by_its_own_clock": lf_clock,
             "issue_roofline": issue_roofline(W, H, nrefs_avg, ms_frame, {**warm, **prof}, clk_ghz if clk_n else None),
@@ -749,6 +750,11 @@ def main():
             "other_kernels": others,
             "fps": round(frames_per_gpu * world / elapsed, 2),
             "timed_region_s": round(elapsed, 4),
+            # N ranks were seen: RCCL's own count of the communicator, and what every rank measured on its own clock
+            "rccl_ranks": None if dist is None else int(dist.count()),
+            "per_rank": None if per_rank is None else [{"rank": r, "timed_region_s": round(float(per_rank[r][0]), 4),
+                                                        "value": round(mbs * frames_per_gpu / float(per_rank[r][0]), 1),
+                                                        "refs_per_frame": round(float(per_rank[r][1]), 3)} for r in range(world)],
             "self_check": dict(verify, what="one chunk of the timed region coded again from its key frame on an un-batched driver of its own: "
                                             "CRC-32 of the final filtered reconstruction (Y, U, V), key frames; the run aborts on a mismatch"),
             "host_enqueue_ms_per_frame": round(enqueue_s / frames_per_gpu * 1e3, 4),
@@ -768,24 +774,20 @@ def main():
         # two-chunk leg 3 800 frames/s in a fresh process, 2 100 behind the headline's leg).  The children form their own RCCL group.
         if dist is not None:
             dist.barrier()
-        env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
+        # the children are a group of their own; they meet through a file named by this run's key + "-legs" (no port, no store)
+        env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", VP8_BENCH_RDZV_KEY=rdzv_key)
         if not env["VP8_BENCH_CHILD"]:
             env.pop("VP8_BENCH_CHILD")
-        # Under torchrun the ranks inherit TORCHELASTIC_USE_AGENT_STORE: init_process_group then CONNECTS to the launcher's store at
-        # MASTER_PORT instead of making one -- and at MASTER_PORT + 1, where the children meet, nobody listens (found by running the
-        # driver's multi-GPU command with one rank: the children sat in the rendezvous until the time-out).  The children are a
-        # group of their own: rank 0's child makes the store.
-        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
-            env.pop(k)
-        argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs"]
         # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
-        child_out, child_rc = b"", None
-        try:
-            child = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,   # (a leg that dies says where, on stderr)
-                                   timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
-            child_out, child_rc = child.stdout, child.returncode
-        except subprocess.TimeoutExpired as e:
-            child_out, child_rc = e.stdout or b"", "timeout"
+        child_out, child_rc = b"", 0
+        for which in (["few"] + (["other"] if world == 1 and not args.only_bitstream else [])):
+            argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs", which]
+            try:
+                child = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,   # (a leg that dies says where, on stderr)
+                                       timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
+                child_out, child_rc = child_out + child.stdout, child_rc or child.returncode
+            except subprocess.TimeoutExpired as e:
+                child_out, child_rc = child_out + (e.stdout or b""), "timeout"
         if rank == 0:
             got = 0
             for line in child_out.decode(errors="replace").splitlines():      # one line per finished leg
@@ -817,8 +819,8 @@ def main():
         os.sched_setaffinity(0, all_cpus)       # the CPU baseline gets every host core again, not the GPU's NUMA node only
         out["cpu_baseline"] = cpu_baseline(args, api, host_frames, W, H, mbs)
     leg.close()              # every context destroyed (vp8drv_batch_destroy, vp8drv_destroy -> vp8hip_destroy): the exit code is real
-    if dist is not None and dist.is_initialized():
-        dist.destroy_process_group()
+    if dist is not None:
+        dist.close()
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -836,7 +838,7 @@ def ref_shard_leg(api, dist, W0, H0, local, rank, world, nframes):
         members = min(world, 3)
         uid = [ref_shard.shard_unique_id() if rank == 0 else None]
         if dist is not None and world > 1:
-            dist.broadcast_object_list(uid, src=0)     # (every rank takes part in the broadcast; the first three form the communicator)
+            uid = [dist.broadcast_bytes(uid[0], ref_shard.SHARD_ID_BYTES, root=0)]     # (every rank takes part; the first three form the communicator)
         if rank >= members:
             return None
         seq = SynthSequence(W0, H0, seed=9)
@@ -1011,10 +1013,25 @@ def cpu_baseline(args, api, host_frames, W, H, mbs):
         el = time.perf_counter() - t0
         if el >= args.cpu_seconds or n >= 64:   # a bounded sample: ~12 s of host time
             break
-    ora.close()
     out = {"value": round(mbs * n / el, 1), "unit": "macroblocks/s", "cores": threads, "kind": "port",
+           "value_per_core": round(mbs * n / el / max(threads, 1), 1),
            "sample": f"{n} inter frames {W}x{H}, 3 references, oracle/vp8_oracle.c with OpenMP on {threads} threads, "
                      f"{el:.1f} s"}
+    # the same restatement on ONE thread (what a core does when it does not wait for 255 others at every kernel's barrier)
+    if args.cpu_seconds >= 5:
+        lib = Oracle.lib()
+        lib.vp8o_set_num_threads(1)
+        t1 = time.perf_counter()
+        ora.set_segments(segs[2 % len(segs)])
+        ora.upload_current(*host_frames[2 % len(host_frames)])
+        ora.inter_transform(0, 0, 1, 1)
+        ora.loop_filter()
+        e1 = time.perf_counter() - t1
+        lib.vp8o_set_num_threads(threads)
+        out["port_on_one_thread"] = {"value": round(mbs / e1, 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
+                                     "sample": f"1 inter frame {W}x{H}, 3 references + loop filter, {e1:.1f} s",
+                                     "parallel_efficiency_of_the_full_run": round((mbs * n / el) / (mbs / e1) / max(threads, 1), 3)}
+    ora.close()
     # beside it, where oracle/_ref travelled: the REFERENCE'S OWN kernels (GPU_kernels.cl + CPU_kernels.cl compiled for x86,
     # oracle/build_ref.sh) through the same frame -- work-item loops on one core, the way oracle/ref_driver.c drives them
     try:

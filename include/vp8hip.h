@@ -280,12 +280,15 @@ int vp8hip_synchronize(vp8hip_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller) */
 void *vp8hip_stream(vp8hip_ctx *ctx);
 int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
-/* Hardware queues the HIP runtime of this process multiplexes its streams onto: GPU_MAX_HW_QUEUES as exported when the
- * process started (default 4).  Contexts whose streams share a queue serialise; a host that keeps many GOP chunks in
- * flight exports GPU_MAX_HW_QUEUES=24 before its first HIP call, or advances them in batches
- * (vp8hip_batch_create below) -- vp8hip_inter_transform prints one line to stderr when more contexts launch on streams of
- * their own than there are queues (VP8HIP_QUIET=1 silences it).  No reference counterpart: the
- * reference has one in-order OpenCL queue per reference frame (init.h:210-228). */
+/* Hardware queues the HIP runtime of this process multiplexes its streams onto.  The runtime reads GPU_MAX_HW_QUEUES once, at the
+ * process's first HIP call (default 4), and streams that share a queue serialise -- so the LIBRARY sets it when it is loaded (a
+ * constructor: setenv("GPU_MAX_HW_QUEUES", "16", 0), i.e. unless the host exported a value of its own): a host that links or dlopens
+ * libvp8hip.so before it touches the GPU runs on 16 queues without knowing any of this (the reference creates the queues it needs
+ * itself, init.h:1162-1165).  16: measured optimum; beyond 24 queues per process the hardware scheduler rotates them and
+ * context-switches running waves.  Returns the value in force as far as the library can tell: what the environment said when the
+ * runtime initialised.  If the runtime was ALREADY initialised when the library was loaded (a host that made HIP calls first) the
+ * constructor changes nothing, says so on stderr once (VP8HIP_QUIET=1 silences it) and this returns what the environment held then
+ * (4 if nothing).  vp8hip_inter_transform prints one line when more contexts launch on streams of their own than there are queues. */
 int vp8hip_hw_queues(void);
 
 /* ---- one frame's reference searches on different devices (reference: the three searches of a frame run
@@ -303,6 +306,10 @@ int vp8hip_inter_finish(vp8hip_ctx *ctx, int use_golden, int use_altref);
 int vp8hip_export_search(vp8hip_ctx *ctx, int ref, void *d_vectors, void *d_costs);
 int vp8hip_import_search(vp8hip_ctx *ctx, int ref, const void *d_vectors, const void *d_costs);
 int vp8hip_export_last(vp8hip_ctx *ctx, void *d_y, void *d_u, void *d_v);
+/* The other end of vp8hip_export_last: tight planes in this device's memory become LAST exactly the way a receiving rank of
+ * vp8hip_shard_share_last gets it (the same code: a free surface of the pool, adopted without touching GOLDEN / ALTREF; edges and
+ * pyramid when the next frame begins).  vp8enc.cpp:395-401.  VP8HIP_ERR_STATE if no surface is free. */
+int vp8hip_import_last(vp8hip_ctx *ctx, const void *d_y, const void *d_u, const void *d_v);
 
 /* The same exchanges made by the library itself: RCCL (ncclBroadcast groups) on the context's stream, event-ordered with the
  * kernels around them, NO host synchronisation per frame -- what stands where the reference's three queues meet
@@ -325,6 +332,38 @@ int vp8hip_shard_world(const vp8hip_ctx *ctx);   /*  0 before vp8hip_shard_init 
 int vp8hip_shard_share_search(vp8hip_ctx *ctx, int used_mask);
 int vp8hip_shard_share_last(vp8hip_ctx *ctx, int root);
 int vp8hip_shard_max(vp8hip_ctx *ctx, double *value);
+
+/* ---- the process group of a GOP-sharded run: one process per GPU, no data-path collective -------------------
+ * GOP chunks are independent (intra_part.h:1091-1098).  What the ranks of a node still need from each other -- starting together,
+ * the slowest rank's time, the finished frames in the hands of the one writer (the reference's single output file, encIO.h:1-30,
+ * vp8enc.cpp:476-481) -- is here, over RCCL on a stream of the group's own, so that a host needs no GPU framework of its own for it:
+ *   vp8hip_group_rendezvous   the 128 id bytes from rank 0 to the other ranks of ONE node through a file
+ *                             ($VP8HIP_RENDEZVOUS_DIR or /tmp)/vp8hip-rdzv-<uid>-<key>: rank 0 makes the id (vp8hip_shard_unique_id) and
+ *                             writes the file atomically, the others poll for it up to timeout_s (VP8HIP_ERR_TIMEOUT).  `key` names the
+ *                             run: the same string on every rank, different for runs alive on the node at the same time.  A host with a
+ *                             store of its own (MPI, TCP) hands the id over itself and skips this call;
+ *   vp8hip_group_create       every rank, the same id (ncclCommInitRank: collective); key (may be NULL): rank 0 removes the rendezvous file;
+ *   vp8hip_group_count        the ranks RCCL counts in the communicator (ncclCommCount);
+ *   vp8hip_group_barrier / _max (maximum of one double: a wall time) / _all_gather (<= 4 KB per rank, in rank order, on every rank) /
+ *   _broadcast (host memory of rank root to every rank);
+ *   vp8hip_group_gather_bytes every rank's `bytes` of host memory (counts[] = every rank's size, from _all_gather, the same on all
+ *                             ranks) end to end in rank order into dst on root.  One code path at every world size: every rank, root
+ *                             included, sends (ncclSend), root receives from every rank, itself included (ncclRecv).
+ * All calls are collective (every rank, same order) and block.  RCCL is loaded (dlopen) by the first call that needs it:
+ * $VP8HIP_RCCL_LIBRARY, librccl.so.1 on the process's search path, $ROCM_PATH/lib, /opt/rocm/lib. */
+typedef struct vp8hip_group vp8hip_group;
+int vp8hip_group_rendezvous(const char *key, int rank, double timeout_s, uint8_t id[VP8HIP_SHARD_ID_BYTES]);
+int vp8hip_group_create(vp8hip_group **out, int device_ordinal, const uint8_t id[VP8HIP_SHARD_ID_BYTES], int rank, int world, const char *key);
+void vp8hip_group_destroy(vp8hip_group *g);
+int vp8hip_group_rank(const vp8hip_group *g);
+int vp8hip_group_world(const vp8hip_group *g);
+int vp8hip_group_count(const vp8hip_group *g);
+int vp8hip_group_barrier(vp8hip_group *g);
+int vp8hip_group_max(vp8hip_group *g, double *value);
+int vp8hip_group_all_gather(vp8hip_group *g, const void *mine, size_t bytes, void *all);
+int vp8hip_group_broadcast(vp8hip_group *g, int root, void *buf, size_t bytes);
+int vp8hip_group_gather_bytes(vp8hip_group *g, int root, const void *src, size_t bytes, void *dst, const uint64_t *counts);
+int vp8hip_group_last_hip_error(const vp8hip_group *g);
 
 /* ---- batched contexts: one launch per stage for up to four GOP chunks ---------------------------------------------------
  * The MI355X runs four to five kernels at once however many streams offer work, so sixteen contexts
@@ -362,8 +401,9 @@ const char *vp8hip_status_string(int status);
  * layout (vp8drv_config grew in round 2: 2; vp8drv_stats grew by refs_searched and vp8drv_default_config turned check_ssim on
  * -- return values and counters provisional until vp8drv_resolve -- in round 3: 3), MINOR when entry points are added.  A host
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
- * 3002: vp8drv_encode_video_device. */
-#define VP8HIP_ABI_VERSION 3002
+ * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
+ * vp8drv_frame_check folds position in (4: its values change). */
+#define VP8HIP_ABI_VERSION 4003
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

@@ -145,16 +145,21 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
 /* ONE video, `nframes` frames, frame after frame with the frames out -- the loop of scripts/native/y4m_to_ivf.cpp for frames that are
  * already in device memory: encode(t), take frame t - 1's bytes, enqueue frame t's entropy stage, take frame t's verdict; frame t
  * is frames[(start + t) % nd].  With overlap_filter the stage of a frame runs on a stream of its own beside its loop filter and the
- * next frame's side work (vp8hip_encode_frame_begin); call vp8hip_reserve_frame_path_dense(vp8drv_context(d)) first.  The frames
+ * next frame's side work (vp8hip_encode_frame_begin).  Because frame t + 1 is under way before frame t's bytes are taken, a frame denser
+ * than the coder's scratch could not be coded again: the call sizes the scratch for the densest frame there can be
+ * (vp8hip_reserve_frame_path_dense; a no-op when the caller has done it) -- about 270 MB per context at 1080p and four times that at
+ * 4K, allocated behind a stream synchronisation, so a caller that times this call reserves beforehand.  The frames
  * are laid end to end into `out` (capacity bytes), sizes[t] = frame t's size; keys (may be NULL) counts the key frames, frames sent
  * back by check_SSIM included.  out == NULL (sizes is then not used): the same video WITHOUT frames out -- encode after encode, the
- * last verdict taken at the end -- for callers that code several videos side by side from a thread each and want no interpreter in
+ * last verdict taken at the end and the context synchronised (vp8hip_synchronize: a bounded device-side wait that expired inside the last
+ * frame's loop filter is reported by THIS call, VP8HIP_ERR_TIMEOUT) -- for callers that code several videos side by side from a thread each and want no interpreter in
  * the loop (bench.py's config3_literal).  A native loop because the host's reaction times are on the path: every microsecond between a
  * frame's verdict and the enqueue of its stage moves the stage further under the next frame's LAST search (one video with frames
  * out, 1080p: 0.383 ms per frame from Python). */
 int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frames)[3], int nd, int start, uint8_t *out, size_t capacity,
                                uint32_t *sizes, int *keys);
-/* the fold above: h' = (h * 0x9E3779B97F4A7C15 + size) ^ (sum of the frame's little-endian 64-bit words, the tail zero-padded) */
+/* the fold above: f = h * 0x9E3779B97F4A7C15 + size; for every little-endian 64-bit word w of the frame, in order (the tail
+ * zero-padded): f = (rotl(f, 5) ^ w) * 0x100000001B3; h' = f.  Position-dependent: words that trade places change the value. */
 uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size);
 
 /* counters and the flags inter_transform was given for the last inter frame (tests, logs) */

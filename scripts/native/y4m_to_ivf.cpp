@@ -99,7 +99,7 @@ int main(int argc, char **argv) {
     vp8drv_stats st;
     vp8drv_get_stats(drv, &st);
     vp8drv_destroy(drv);
-    printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes\n", argv[2], n, W, H, Wc, Hc, keys,
-           st.scene_changes, st.redone_as_key, total);
+    printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes; %d hardware queues\n", argv[2], n, W, H, Wc, Hc, keys,
+           st.scene_changes, st.redone_as_key, total, vp8hip_hw_queues());
     return 0;
 }

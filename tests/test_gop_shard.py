@@ -129,3 +129,35 @@ def test_two_gloo_ranks_write_the_same_ivf_as_one_process(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert open(two, "rb").read() == data
+
+
+def test_gather_frames_through_a_group_of_the_librarys_shape():
+    """gop_shard.gather_frames_group: the frame bookkeeping around vp8hip_group_gather_bytes (api.Group on the GPU box), here with
+    three thread ranks and a stand-in group that concatenates the blobs the way the library does (rank order, counts on every rank)."""
+    import threading
+    world, total = 3, 11
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, int(rng.integers(0, 400)), dtype=np.uint8).tobytes() for _ in range(total)]
+    owner = [int(rng.integers(0, world)) for _ in range(total)]
+    owner[4] = owner[5] = 2
+    bar, slots, results = threading.Barrier(world), [None] * world, [None] * world
+
+    class Group:
+        def __init__(self, rank):
+            self.rank, self.world = rank, world
+
+        def gather_bytes(self, data, root=0):
+            slots[self.rank] = bytes(data)
+            bar.wait()
+            counts = np.array([len(b) for b in slots], np.uint64)
+            out = np.frombuffer(b"".join(slots), np.uint8).copy() if self.rank == root else None
+            bar.wait()
+            return out, counts
+
+    def run(r):
+        results[r] = gop_shard.gather_frames({t: frames[t] for t in range(total) if owner[t] == r}, total, Group(r), dst=1)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert results[0] is None and results[2] is None and results[1] == frames

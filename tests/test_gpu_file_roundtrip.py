@@ -111,8 +111,10 @@ def test_native_y4m_to_ivf_program(tmp_path):
                 np.ascontiguousarray(v[:H // 2, :W // 2]))
     src = [crop(a.frame(t)) for t in range(6)] + [crop(b.frame(t), 45) for t in range(6)]      # a cut at frame 6
     y4m.write_y4m(str(tmp_path / "in.y4m"), src, framerate=24)
-    r = subprocess.run([exe, str(tmp_path / "in.y4m"), str(tmp_path / "out.ivf"), "-g", "9", "-partitions", "2", "-scene-detect"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(tmp_path / "in.y4m"), str(tmp_path / "out.ivf"), "-g", "9", "-partitions", "2", "-scene-detect"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})      # a C++ host that knows nothing of hardware queues
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "16 hardware queues" in r.stdout, r.stdout       # the library set them when it was loaded (csrc/api_context.hip)
     assert "12 frames 360x200 (coded 368x208)" in r.stdout and "(1 by scene change" in r.stdout, r.stdout
     Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(tmp_path / "out.ivf"))
     assert (Wf, Hf, rate, len(packets)) == (W, H, 24, 12)

@@ -1,0 +1,60 @@
+"""The hardware-queue setting is the library's (a load-time constructor, csrc/api_context.hip), not the host's environment's:
+a host that exports nothing runs as fast as one that exports GPU_MAX_HW_QUEUES=16, and faster than one held to 4 queues.
+Reference: the command queues init_all() creates itself, src/init.h:1162-1165."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent("""
+    import json, os, sys, threading, time
+    sys.path.insert(0, {root!r})
+    from vp8oclenc_amd import api
+    from vp8oclenc_amd.synth import SynthSequence
+    lib = api.load_library()
+    N, FRAMES = 12, 60
+    seq = SynthSequence(640, 352, seed=4)
+    ptrs = [tuple(api.to_device(p).ptr for p in seq.frame(t)) for t in range(4)]
+    keep = ptrs
+    drv = [api.NativeDriver(seq.W, seq.H, gop_size=1 << 30, check_ssim=0) for _ in range(N)]     # twelve videos, a stream each, no batches
+    for d in drv:
+        d.encode_video_device_no_frames(6, ptrs)
+    api.device_synchronize(0)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=d.encode_video_device_no_frames, args=(FRAMES, ptrs, k)) for k, d in enumerate(drv)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    api.device_synchronize(0)
+    el = time.perf_counter() - t0
+    print(json.dumps({{"fps": N * FRAMES / el, "hw_queues": int(lib.vp8hip_hw_queues())}}))
+    for d in drv:
+        d.close()
+""")
+
+
+def _run(tmp_path, queues):
+    script = tmp_path / "q.py"
+    script.write_text(CHILD.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["VP8HIP_QUIET"] = "1"
+    if queues is not None:
+        env["GPU_MAX_HW_QUEUES"] = str(queues)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_a_host_that_exports_nothing_gets_sixteen_queues(tmp_path):
+    unset, four, sixteen = _run(tmp_path, None), _run(tmp_path, 4), _run(tmp_path, 16)
+    assert (unset["hw_queues"], four["hw_queues"], sixteen["hw_queues"]) == (16, 4, 16)
+    # twelve independent videos on twelve streams: with 4 queues they serialise three deep
+    assert unset["fps"] > 0.85 * sixteen["fps"], (unset, sixteen)
+    if sixteen["fps"] > 1.15 * four["fps"]:       # (the setting matters for this load on this box: then the library's default must show it)
+        assert unset["fps"] > 1.08 * four["fps"], (unset, four, sixteen)
+    print("fps: nothing exported %.0f, GPU_MAX_HW_QUEUES=4 %.0f, =16 %.0f" % (unset["fps"], four["fps"], sixteen["fps"]))

@@ -286,6 +286,10 @@ def test_bench_launcher_starts_its_own_ranks():
     a = _bench()
     b = _bench("--spawn")
     assert a["config"]["launcher"] == "single process" and b["config"]["launcher"] == "self-spawned ranks"
+    assert a["rccl_ranks"] is None and b["rccl_ranks"] == 1 and len(b["per_rank"]) == 1     # the spawned rank formed the library's RCCL group
+    assert abs(b["per_rank"][0]["timed_region_s"] - b["timed_region_s"]) < 1e-3
+    for d in (a, b):
+        assert d["config"]["gpu_framework_in_process"] == "none" and d["config"]["hw_queues"] == 16, d["config"]
     for d in (a, b):
         g, per = d["config"]["gops_per_gpu"], d["config"]["chunks_per_batched_launch"]
         assert d["n_gpus"] == 1 and d["config"]["refs_per_frame"] >= 2.7 and d["config"]["frames_per_gpu"] == 20 * g
@@ -300,18 +304,20 @@ def test_bench_launcher_starts_its_own_ranks():
 
 
 def test_bench_under_torchrun_runs_its_child_legs():
-    """The driver's multi-GPU command, with one rank: `python -m torch.distributed.run ... bench.py --gpus N`.  The ranks inherit the
-    launcher's TORCHELASTIC_* variables, with which a process group CONNECTS to the launcher's store instead of making one -- the
-    child processes of the one- and two-video legs, which meet at MASTER_PORT + 1, once sat in that rendezvous until their time-out."""
+    """The driver's multi-GPU command, with one rank: `python -m torch.distributed.run ... bench.py --gpus N`.  Only the launcher is
+    PyTorch: the rank and the child process of its one- and two-video legs form the library's own RCCL groups (file rendezvous keyed by
+    the launcher's pid and port) and never import torch -- one HIP runtime, the one libvp8hip.so was built for, at every N."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29557", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, VP8_BENCH_CHILD_TIMEOUT="300"))
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, VP8_BENCH_CHILD_TIMEOUT="300", VP8_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert "few_stream_legs_error" not in d, d["few_stream_legs_error"]
     assert d["config5_literal"]["frames"] == 300 and d["ref_shard"]["value"] > 0 and d["single_stream"]["ms_per_frame"] > 0
+    assert d["config"]["gpu_framework_in_process"] == "none" and d["config"]["launcher"] == "torchrun (launcher only)"
+    assert d["rccl_ranks"] == 1 and len(d["per_rank"]) == 1 and d["config5_literal"]["gpu_framework_in_process"] == "none"
 
 
 def test_bench_last_only_config():
@@ -322,30 +328,41 @@ def test_bench_last_only_config():
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, {root!r})
-    import torch, torch.distributed as dist
-    from vp8oclenc_amd import gop_shard
+    import numpy as np
+    from vp8oclenc_amd import api, gop_shard
     from vp8oclenc_amd.synth import SynthSequence
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    grp = api.Group.from_env(0, "test-gather-%d" % os.getpid())          # RANK / WORLD_SIZE from the environment; id through a file
+    assert (grp.rank, grp.world, grp.count()) == (0, 1, 1)
     seq = SynthSequence(96, 64, seed=5)
     mine = gop_shard.encode_chunks_frames(lambda: gop_shard.NativeEncoder(seq.W, seq.H, device=0), seq, gop_shard.gop_chunks(6, 3))
     plain = gop_shard.gather_frames(mine, 6)
-    coll = gop_shard.gather_frames(mine, 6, dist, force_collective=True)     # all_gather of the lengths over RCCL
+    coll = gop_shard.gather_frames(mine, 6, grp)     # vp8hip_group_gather_bytes: ncclSend to self + ncclRecv from self, one group
     assert coll == plain and all(len(f) > 3 for f in coll)
-    dist.barrier()
-    dist.destroy_process_group()
+    grp.barrier()
+    assert abs(grp.max(2.5) - 2.5) < 1e-12
+    rec = grp.all_gather(np.arange(5, dtype=np.float64))
+    assert rec.shape == (1, 5) and np.array_equal(rec[0], np.arange(5))
+    assert grp.broadcast_bytes(b"0123456789abcdef", 16) == b"0123456789abcdef"
+    big = np.random.default_rng(1).integers(0, 256, 3 << 20, dtype=np.uint8)      # larger than the group's first staging buffer
+    got, counts = grp.gather_bytes(big)
+    assert counts.tolist() == [big.nbytes] and np.array_equal(got, big)
+    grp.close()
+    assert "torch" not in sys.modules
     print("rccl gather ok", sum(len(f) for f in coll))
 """)
 
 
 def test_gather_frames_over_rccl(tmp_path):
-    """The collective branch of gop_shard.gather_frames on the nccl (= RCCL) backend, one rank (a 1-GPU box); the two-rank
-    exchange itself is covered over gloo in tests/test_gop_shard.py."""
+    """The library's own process group (vp8hip_group_*: what bench.py --gpus N and a GOP-sharded transcoder use) on one rank: file
+    rendezvous, ncclCommInitRank, barrier / max / all_gather / broadcast, and gop_shard.gather_frames through vp8hip_group_gather_bytes
+    -- whose code path is the same at every world size (every rank, the root included, sends; the root receives from every rank,
+    itself included).  No PyTorch in the process.  The two-rank frame bookkeeping is covered on CPU in tests/test_gop_shard.py."""
     script = tmp_path / "w.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", VP8HIP_RENDEZVOUS_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("vp8hip-rdzv-")], "rank 0 removes the rendezvous file once the group stands"
 
 
 def test_two_contexts_on_two_devices_from_worker_threads():
@@ -396,6 +413,68 @@ def test_reference_split_exchanges_inside_the_library():
         assert drv.bytes_broadcast == frames * seq.W * seq.H * 3 // 2 and drv.bytes_gathered > 0
         assert abs(be.shard_max(1.25) - 1.25) < 1e-12
         be.close(); plain.close()
+
+
+def test_three_contexts_split_one_gop_by_reference_on_one_gpu_against_the_oracle():
+    """What a NON-ROOT rank of the by-reference split does, executed: three HipRefBackend contexts on device 0, a thread each, rank r
+    searching reference r; the vector / cost nets go owner -> vp8hip_export_search -> vp8hip_import_search on the two others (the
+    landing place of vp8hip_shard_share_search's broadcasts: csrc/api_shard.hip search_nets), rank 0 finishes and filters the frame
+    and its LAST goes vp8hip_export_last -> vp8hip_import_last on ranks 1 and 2 (receive_last_surface + adopt_last: the receiving
+    half of vp8hip_shard_share_last).  RCCL itself refuses two ranks on one GPU, so the transport here is device-buffer hand-over
+    between threads; everything behind the transport is the library's multi-rank code.  1080p, 14 frames with golden and altref
+    periods: every frame's digest (modes, vectors, coefficients, filtered reconstruction) equals the plain vp8hip_inter_transform
+    path AND the oracle loop -- and ranks 1 and 2, which never finish a frame, hold rank 0's LAST bit for bit at the end.
+    Reference: the three per-reference queues of inter_part.h:122-135, 201-266 and the hand-over of vp8enc.cpp:395-401."""
+    import threading
+    from vp8oclenc_amd import ref_shard
+    from vp8oclenc_amd.gop_shard import frame_digest
+    FRAMES, ALTREF = 14, 3
+    seq = SynthSequence(1920, 1080, seed=21)
+    W, H = seq.W, seq.H
+    frames = [seq.frame(t) for t in range(FRAMES)]
+    grp = ref_shard.ThreadGroup(3)
+    digests, lasts, errors, seen = [], [None] * 3, [], set()
+
+    def rank_main(r):
+        try:
+            be = ref_shard.HipRefBackend(W, H)
+            drv = ref_shard.RefShardDriver(be, grp.member(r), W, H, altref_range=ALTREF)
+            assert drv.collective and not drv.native and (drv.rank, drv.world) == (r, 3)
+            for t in range(FRAMES):
+                o = drv.encode_frame(*frames[t])
+                if r == 0:
+                    digests.append(frame_digest(None if o["key"] else o, be.download_last()))
+                    if not o["key"]:
+                        seen.add((o["use_golden"], o["use_altref"]))
+                else:
+                    assert o is None
+            lasts[r] = [p.copy() for p in be.download_last()]
+            if r == 0:
+                assert drv.bytes_broadcast == FRAMES * W * H * 3 // 2 and drv.bytes_gathered > 0
+            be.close()
+        except BaseException as e:      # noqa: BLE001 -- the other ranks must not wait for this one for ever
+            errors.append((r, repr(e)))
+            grp.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert (1, 1) in seen and (0, 0) in seen      # frames searched on all three ranks and frames with LAST only both occurred
+    for r in (1, 2):
+        for p_, q_ in zip(lasts[r], lasts[0]):
+            assert np.array_equal(p_, q_), f"rank {r} does not hold rank 0's LAST"
+    plain = api.Vp8Hip(W, H)
+    pdrv = InterPathDriver(plain, W, H, altref_range=ALTREF, check_ssim=False)
+    ora = Oracle(W, H, -1.0)
+    odrv = InterPathDriver(ora, W, H, altref_range=ALTREF, check_ssim=False)
+    for t in range(FRAMES):
+        b = pdrv.encode_frame(*frames[t])
+        assert frame_digest(b, plain.download_last()) == digests[t], f"frame {t}: the split differs from vp8hip_inter_transform"
+        o = odrv.encode_frame(*frames[t])
+        assert frame_digest(o, ora.download_last()) == digests[t], f"frame {t}: the split differs from the oracle loop"
+    plain.close()
+    ora.close()
 
 
 def test_contexts_driven_from_worker_threads_at_once():

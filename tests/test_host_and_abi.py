@@ -217,3 +217,39 @@ def test_integration_section_2_is_what_the_drop_in_script_does():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_integration_section2.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_the_library_sets_the_hardware_queue_count_when_it_is_loaded(tmp_path):
+    """The HIP runtime reads GPU_MAX_HW_QUEUES once, at the process's first HIP call; the reference creates the queues it needs itself
+    (init.h:1162-1165), and a drop-in must not depend on its host's environment for that: a constructor in libvp8hip.so sets 16
+    unless the host exported a value.  Checked from C (getenv is the C environment, not os.environ's snapshot): a program that
+    dlopens the library with nothing exported sees 16 afterwards, and a host's own value is left alone.  Also: the library can be
+    loaded where librccl is not resolvable (it is dlopened by the first vp8hip_shard_* / vp8hip_group_* call, not linked)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "q.c"
+    src.write_text("""
+        #include <dlfcn.h>
+        #include <stdio.h>
+        #include <stdlib.h>
+        int main(int argc, char **argv) {
+            const char *before = getenv("GPU_MAX_HW_QUEUES");
+            void *h = dlopen(argv[1], RTLD_NOW);
+            if (!h) { fprintf(stderr, "%s\\n", dlerror()); return 1; }
+            int (*q)(void) = (int (*)(void))dlsym(h, "vp8hip_hw_queues");
+            const char *after = getenv("GPU_MAX_HW_QUEUES");
+            printf("%s %s %d\\n", before ? before : "-", after ? after : "-", q());
+            return 0;
+        }""")
+    exe = tmp_path / "q"
+    subprocess.run(["gcc", str(src), "-o", str(exe), "-ldl"], check=True)
+    from vp8oclenc_amd import build
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([str(exe), build.LIB], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["-", "16", "16"], out
+    out = subprocess.run([str(exe), build.LIB], env=dict(env, GPU_MAX_HW_QUEUES="7"), capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["7", "7", "7"], out
+    needed = subprocess.run(["readelf", "-d", build.LIB], capture_output=True, text=True).stdout
+    assert "librccl" not in needed, "RCCL must be resolved lazily (dlopen), not linked"

@@ -81,3 +81,33 @@ def test_three_gloo_ranks_split_by_reference_reproduce_one_process(tmp_path):
                         "--master-port", "29523", str(script)], env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert np.array_equal(np.load(out), serial_digests())
+
+
+def test_three_thread_ranks_exchange_objects_and_reproduce_one_process():
+    """ref_shard.ThreadGroup: the ranks as threads of one process, the exchanges as objects changing hands (on the GPU box: device
+    buffers through vp8hip_export_* / vp8hip_import_*, tests/test_gpu_soak.py) -- here with the CPU oracle as the backend."""
+    import threading
+    grp = ref_shard.ThreadGroup(3)
+    got, errors = [], []
+
+    def rank_main(r):
+        try:
+            seq = SynthSequence(W, H, seed=7)
+            be = OracleRefBackend(seq.W, seq.H)
+            drv = ref_shard.RefShardDriver(be, grp.member(r), seq.W, seq.H, altref_range=3)
+            assert drv.collective and (drv.rank, drv.world) == (r, 3)
+            for t in range(FRAMES):
+                o = drv.encode_frame(*seq.frame(t))
+                if r == 0:
+                    got.append(frame_digest(None if o["key"] else o, be.download_last()))
+                else:
+                    assert o is None
+        except BaseException as e:      # noqa: BLE001
+            errors.append((r, repr(e)))
+            grp.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert np.array_equal(np.array(got, np.int64), serial_digests())

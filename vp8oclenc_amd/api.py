@@ -22,7 +22,7 @@ DBG_NET1, DBG_NET2, DBG_BDIFF, DBG_PYRAMID, DBG_MB_MASK, DBG_MB_NZ, DBG_THIRD_CO
 # every symbol include/vp8hip.h and include/vp8hip_host.h declare
 ABI_SYMBOLS = [
     "vp8hip_hw_queues", "vp8hip_profile_read_clock", "vp8hip_inter_search", "vp8hip_inter_finish", "vp8hip_export_search",
-    "vp8hip_import_search", "vp8hip_export_last", "vp8hip_batch_create", "vp8hip_batch_destroy", "vp8hip_batch_set_current_device",
+    "vp8hip_import_search", "vp8hip_export_last", "vp8hip_import_last", "vp8hip_group_rendezvous", "vp8hip_group_create", "vp8hip_group_destroy", "vp8hip_group_rank", "vp8hip_group_world", "vp8hip_group_count", "vp8hip_group_barrier", "vp8hip_group_max", "vp8hip_group_all_gather", "vp8hip_group_broadcast", "vp8hip_group_gather_bytes", "vp8hip_group_last_hip_error", "vp8hip_batch_create", "vp8hip_batch_destroy", "vp8hip_batch_set_current_device",
     "vp8hip_batch_auto_segments", "vp8hip_batch_inter_transform", "vp8hip_batch_loop_filter", "vp8drv_batch_create", "vp8drv_batch_destroy",
     "vp8drv_batch_encode_frame_device", "vp8hip_batch_encode_frame_begin", "vp8drv_batch_get_frame_begin", "vp8hip_profile_context_switches", "vp8hip_profile_read_search2_clock", "vp8hip_profile_search2_clock",
     "vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_current_device", "vp8hip_upload_last",
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3002  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 4003  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 SHARPNESS_ON_DEVICE = -2 ** 31   # VP8HIP_SHARPNESS_ON_DEVICE
@@ -216,6 +216,103 @@ def device_pci_bus_id(device: int = 0) -> str:
     if rc != 0:
         raise Vp8HipError("vp8hip_device_pci_bus_id failed")
     return buf.value.decode().lower()
+
+
+SHARD_ID_BYTES = 128     # VP8HIP_SHARD_ID_BYTES
+
+
+class Group:
+    """vp8hip_group_* (include/vp8hip.h): the process group of a GOP-sharded run -- one process per GPU, RCCL inside the library,
+    no GPU framework in the host.  Every method is collective and blocks.
+
+    Group.from_env(device): rank / world from RANK / WORLD_SIZE (torchrun's and bench.py's own launcher's variables), the id through a
+    file named by `key` (vp8hip_group_rendezvous)."""
+
+    def __init__(self, device: int, unique_id: bytes, rank: int, world: int, key: str | None = None):
+        self.lib = load_library()
+        L = self.lib
+        vp = C.c_void_p
+        L.vp8hip_group_create.argtypes = [C.POINTER(vp), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+        L.vp8hip_group_destroy.argtypes = [vp]
+        L.vp8hip_group_destroy.restype = None
+        for n in ("vp8hip_group_rank", "vp8hip_group_world", "vp8hip_group_count", "vp8hip_group_barrier", "vp8hip_group_last_hip_error"):
+            getattr(L, n).argtypes = [vp]
+        L.vp8hip_group_max.argtypes = [vp, C.POINTER(C.c_double)]
+        L.vp8hip_group_all_gather.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.vp8hip_group_broadcast.argtypes = [vp, C.c_int, C.c_void_p, C.c_size_t]
+        L.vp8hip_group_gather_bytes.argtypes = [vp, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        assert len(unique_id) == SHARD_ID_BYTES
+        h = vp()
+        rc = L.vp8hip_group_create(C.byref(h), device, unique_id, rank, world, key.encode() if key else None)
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_group_create(rank {rank} of {world}): {L.vp8hip_status_string(rc).decode()}")
+        self.h, self.rank, self.world, self.device = h, rank, world, device
+
+    @staticmethod
+    def rendezvous(key: str, rank: int, timeout_s: float = 120.0) -> bytes:
+        lib = load_library()
+        lib.vp8hip_group_rendezvous.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_void_p]
+        buf = (C.c_uint8 * SHARD_ID_BYTES)()
+        rc = lib.vp8hip_group_rendezvous(key.encode(), rank, float(timeout_s), buf)
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_group_rendezvous({key!r}, rank {rank}): {lib.vp8hip_status_string(rc).decode()}")
+        return bytes(buf)
+
+    @classmethod
+    def from_env(cls, device: int, key: str, timeout_s: float = 120.0) -> "Group":
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        return cls(device, cls.rendezvous(key, rank, timeout_s), rank, world, key)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_group_{what}: {self.lib.vp8hip_status_string(rc).decode()} (hip error {self.lib.vp8hip_group_last_hip_error(self.h)})")
+
+    def count(self) -> int:
+        """ncclCommCount: the ranks RCCL itself counts"""
+        return int(self.lib.vp8hip_group_count(self.h))
+
+    def barrier(self):
+        self._chk(self.lib.vp8hip_group_barrier(self.h), "barrier")
+
+    def max(self, value: float) -> float:
+        v = C.c_double(value)
+        self._chk(self.lib.vp8hip_group_max(self.h, C.byref(v)), "max")
+        return float(v.value)
+
+    def all_gather(self, record: np.ndarray) -> np.ndarray:
+        """a small fixed-size record (<= 4 KB) from every rank -> [world, ...] on every rank"""
+        a = np.ascontiguousarray(record)
+        out = np.empty((self.world,) + a.shape, a.dtype)
+        self._chk(self.lib.vp8hip_group_all_gather(self.h, a.ctypes.data, a.nbytes, out.ctypes.data), "all_gather")
+        return out
+
+    def broadcast_bytes(self, data: bytes | None, nbytes: int, root: int = 0) -> bytes:
+        buf = C.create_string_buffer(data if self.rank == root else b"", nbytes) if nbytes else None
+        if nbytes:
+            self._chk(self.lib.vp8hip_group_broadcast(self.h, root, buf, nbytes), "broadcast")
+        return buf.raw[:nbytes] if nbytes else b""
+
+    def gather_bytes(self, data, root: int = 0):
+        """every rank's bytes (any length) end to end in rank order on `root`: (buffer, counts) there, (None, counts) elsewhere.
+        `data`: bytes-like or a contiguous uint8 array."""
+        a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        counts = self.all_gather(np.array([a.nbytes], np.uint64)).reshape(-1).copy()
+        total = int(counts.sum())
+        dst = np.empty(max(total, 1), np.uint8) if self.rank == root else None
+        self._chk(self.lib.vp8hip_group_gather_bytes(self.h, root, a.ctypes.data if a.nbytes else None, a.nbytes,
+                                                     dst.ctypes.data if dst is not None else None, counts.ctypes.data), "gather_bytes")
+        return (dst[:total] if dst is not None else None), counts
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vp8hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def frame_check(h: int, frame: bytes) -> int:

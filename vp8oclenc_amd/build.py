@@ -8,8 +8,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvp8hip.so")
-SOURCES = ["vp8hip_api.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_lf4.hip", "kernels_entropy_stage.hip", "kernels_rc.hip", "kernels_intra.hip", "vp8_host.cpp", "vp8_driver.cpp", "vp8_bitstream.cpp"]
-HEADERS = ["vp8hip_dev.h", "kernels_rc_dev.h", "vp8_rfc6386_tables.inc", "vp8_mbhdr.h", "kernels_ent.hip", "kernels_hdr.hip"]   # the two .hip files are included by kernels_entropy_stage.hip
+SOURCES = ["api_context.hip", "api_inter.hip", "api_entropy.hip", "api_batch.hip", "api_shard.hip", "api_profile.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_lf4.hip", "kernels_entropy_stage.hip", "kernels_rc.hip", "kernels_intra.hip", "vp8_host.cpp", "vp8_driver.cpp", "vp8_bitstream.cpp"]
+HEADERS = ["vp8hip_ctx.h", "vp8hip_dev.h", "kernels_rc_dev.h", "vp8_rfc6386_tables.inc", "vp8_mbhdr.h", "kernels_ent.hip", "kernels_hdr.hip"]   # the two .hip files are included by kernels_entropy_stage.hip
 HEADERS = HEADERS + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h")]
 
 
@@ -54,9 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    # RCCL: the collectives of a frame split by reference run inside the library (vp8hip_shard_*), on the context's stream
-    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L", rocm_lib, "-lrccl"]
+    # (RCCL -- vp8hip_shard_*, vp8hip_group_* -- is not linked: api_shard.hip resolves it with dlopen when a host first asks for it)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

@@ -507,19 +507,21 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
 }
 
 uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size) {
-    uint64_t sum = 0;
+    // position-dependent: every word is folded into a running value that is rotated and multiplied before the next one, so words
+    // that trade places (a misplaced chunk of the parallel coder's output) or changes that cancel in a sum do not go unnoticed
+    uint64_t f = h * 0x9E3779B97F4A7C15ull + (uint64_t)size;
     size_t i = 0;
     for (; i + 8 <= size; i += 8) {
         uint64_t w;
         memcpy(&w, frame + i, 8);
-        sum += w;
+        f = (((f << 5) | (f >> 59)) ^ w) * 0x100000001B3ull;
     }
     if (i < size) {
         uint64_t w = 0;
         memcpy(&w, frame + i, size - i);
-        sum += w;
+        f = (((f << 5) | (f >> 59)) ^ w) * 0x100000001B3ull;
     }
-    return (h * 0x9E3779B97F4A7C15ull + (uint64_t)size) ^ sum;
+    return f;
 }
 
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
@@ -637,8 +639,15 @@ int vp8drv_encode_video_device(vp8drv *d, int nframes, const void *const (*frame
         const int rc = vp8drv_resolve(d);
         if (rc < 0) return rc;
         if (keys) *keys = -1;     // (not counted here: vp8drv_get_stats has key_frames and redone_as_key)
-        return VP8HIP_OK;
+        // The last frame's filter is still running, and a bounded device-side wait that expires INSIDE it shows only in a later
+        // verdict or here (the verdict workgroup samples the error word when the filter's launch starts): nobody comes after the last frame
+        return vp8hip_synchronize(d->hip);
     }
+    // Frame t + 1 is started before frame t's bytes are taken: a frame denser than the coder's scratch could not be coded again by
+    // then (vp8hip_encode_frame_end: VP8HIP_ERR_STATE), so the scratch is sized for the densest frame there can be -- a no-op if the
+    // caller has done it.  ~270 MB per context at 1080p, four times that at 4K; allocated behind a synchronisation, so callers that
+    // time this call reserve beforehand (vp8hip_reserve_frame_path_dense).
+    if (nframes > 0) DRV_CHK(vp8hip_reserve_frame_path_dense(d->hip));
     for (int t = 0; t < nframes; ++t) {
         const void *const *f = frames[(start + t) % nd];
         int rc = vp8drv_encode_frame_device(d, f[0], f[1], f[2], 0);          // frame t under way ...

@@ -103,6 +103,8 @@ def gather_frames(local: dict[int, bytes], total_frames: int, dist=None, dst: in
     they did not code.  (A padded frames x max-length byte matrix all_gathered to every rank, the first version, cost
     world * total_frames * max_len bytes per rank: key frames set max_len.)
     force_collective: take the collective path even with one rank, so that a 1-GPU box exercises the RCCL branch."""
+    if dist is not None and hasattr(dist, "gather_bytes"):      # the library's own process group (api.Group: RCCL, no torch)
+        return gather_frames_group(local, total_frames, dist, dst)
     collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
     if not collective:
         assert len(local) == total_frames
@@ -141,6 +143,36 @@ def gather_frames(local: dict[int, bytes], total_frames: int, dist=None, dst: in
             n = int(all_lens[r, t])
             out[t] = data[off:off + n]
             off += n
+    return out
+
+
+def gather_frames_group(local: dict[int, bytes], total_frames: int, group, dst: int = 0):
+    """gather_frames over vp8oclenc_amd.api.Group (vp8hip_group_gather_bytes: ncclSend / ncclRecv inside the library, the same code
+    path at every world size, one rank included).  Every rank sends ONE self-describing blob -- [count][(frame number, length) x
+    count] as little-endian uint64, then the frames' bytes in that order -- and `dst` takes the blobs apart."""
+    mine = sorted(local)
+    head = np.empty(1 + 2 * len(mine), np.uint64)
+    head[0] = len(mine)
+    head[1::2] = mine
+    head[2::2] = [len(local[t]) for t in mine]
+    blob = head.tobytes() + b"".join(local[t] for t in mine)
+    data, counts = group.gather_bytes(blob, root=dst)
+    if group.rank != dst:
+        return None
+    out: list = [None] * total_frames
+    at = 0
+    for r in range(group.world):
+        piece = data[at:at + int(counts[r])]
+        at += int(counts[r])
+        n = int(piece[:8].view(np.uint64)[0])
+        index = piece[8:8 + 16 * n].view(np.uint64).reshape(n, 2)
+        off = 8 + 16 * n
+        for t, ln in index:
+            assert out[int(t)] is None, "every frame must be encoded by exactly one rank"
+            out[int(t)] = piece[off:off + int(ln)].tobytes()
+            off += int(ln)
+        assert off == len(piece)
+    assert all(b is not None for b in out), "every frame must be encoded by exactly one rank"
     return out
 
 

@@ -13,6 +13,11 @@ This is the only data-path collective of the package; GOP-level sharding (gop_sh
 -- a 3 MB exchange per 0.5 ms frame is latency-bound -- so this path is for ONE live stream that must be coded faster
 than one GPU codes it.  The loop is InterPathDriver's (driver.py) without check_SSIM.
 
+Ranks that are THREADS of one process (ThreadGroup below: several contexts driven from one host process, on one device or on
+several) exchange device buffers: vp8hip_export_search / vp8hip_export_last on the owner, vp8hip_import_search / vp8hip_import_last
+on the others -- the import calls land the data where the receiving side of the RCCL exchanges lands it, by the same code
+(csrc/api_shard.hip: search_nets, receive_last_surface, adopt_last), so a three-context run on ONE GPU executes what a non-root rank does.
+
 A backend is an encoder context with the C ABI's method names.  The MI355X backend (HipRefBackend over vp8oclenc_amd.api.Vp8Hip)
 makes both exchanges INSIDE the library -- vp8hip_shard_share_search / vp8hip_shard_share_last: RCCL broadcasts on the context's
 stream, in place in the context's own buffers, no host synchronisation per frame -- and this file keeps only the frame-type state
@@ -41,6 +46,53 @@ def shard_unique_id() -> bytes:
     return bytes(buf)
 
 
+class ThreadGroup:
+    """The ranks of a by-reference split as threads of one process: object collectives over a barrier (nothing is copied -- the
+    objects are device buffers of this process).  member(r) is what RefShardDriver takes as `dist` on rank r's thread."""
+
+    object_collectives = True
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.bar = threading.Barrier(world)
+
+    class _Member:
+        object_collectives = True
+
+        def __init__(self, group, rank):
+            self.g, self.rank = group, rank
+
+        def is_initialized(self):
+            return True
+
+        def get_rank(self):
+            return self.rank
+
+        def get_world_size(self):
+            return self.g.world
+
+        def barrier(self):
+            self.g.bar.wait()
+
+        def all_gather_object(self, obj):
+            self.g.slots[self.rank] = obj
+            self.g.bar.wait()
+            out = list(self.g.slots)
+            self.g.bar.wait()          # (nobody overwrites a slot before everybody has read it)
+            return out
+
+        def broadcast_object(self, obj, src=0):
+            return self.all_gather_object(obj if self.rank == src else None)[src]
+
+    def member(self, rank: int):
+        return ThreadGroup._Member(self, rank)
+
+    def abort(self):
+        self.bar.abort()
+
+
 class HipRefBackend(api.Vp8Hip):
     """Vp8Hip + vp8hip_inter_search / vp8hip_inter_finish and the library's own exchanges (vp8hip_shard_*, include/vp8hip.h)."""
 
@@ -55,7 +107,45 @@ class HipRefBackend(api.Vp8Hip):
         self.lib.vp8hip_shard_max.argtypes = [vp, C.POINTER(C.c_double)]
         self.lib.vp8hip_shard_rank.argtypes = [vp]
         self.lib.vp8hip_shard_world.argtypes = [vp]
+        for n in ("vp8hip_export_search", "vp8hip_import_search"):
+            getattr(self.lib, n).argtypes = [vp, C.c_int, vp, vp]
+        for n in ("vp8hip_export_last", "vp8hip_import_last"):
+            getattr(self.lib, n).argtypes = [vp, vp, vp, vp]
         self.native_shard = False
+        self.device_ordinal = device
+        self._search_parcel = {}
+        self._last_parcel = None
+
+    # ---- the exchanges by hand: device buffers out of / into this context (what the RCCL calls below do in place) ----
+    def export_search(self, ref: int):
+        """reference `ref`'s vector and cost nets as two device buffers of this context's (reused frame after frame); complete on return"""
+        if ref not in self._search_parcel:
+            self._search_parcel[ref] = (api.DeviceBuffer(self.b8 * 4, self.device_ordinal), api.DeviceBuffer(self.b8 * 4, self.device_ordinal))
+        v, c = self._search_parcel[ref]
+        self._chk(self.lib.vp8hip_export_search(self.h, ref, v.ptr, c.ptr), "export_search")
+        self.synchronize()
+        return v, c
+
+    def import_search(self, ref: int, parcel):
+        v, c = parcel
+        self._chk(self.lib.vp8hip_import_search(self.h, ref, v.ptr, c.ptr), "import_search")
+        self.synchronize()       # (the owner reuses the buffers for its next frame)
+
+    def export_last(self):
+        """the filtered reconstruction (LAST) as three tight planes in device buffers of this context's; complete on return"""
+        if self._last_parcel is None:
+            n = self.W * self.H
+            self._last_parcel = tuple(api.DeviceBuffer(k, self.device_ordinal) for k in (n, n // 4, n // 4))
+        y, u, v = self._last_parcel
+        self._chk(self.lib.vp8hip_export_last(self.h, y.ptr, u.ptr, v.ptr), "export_last")
+        self.synchronize()
+        return y, u, v
+
+    def import_last(self, parcel):
+        """vp8hip_import_last: what a receiving rank of vp8hip_shard_share_last does with the planes"""
+        y, u, v = parcel
+        self._chk(self.lib.vp8hip_import_last(self.h, y.ptr, u.ptr, v.ptr), "import_last")
+        self.synchronize()
 
     def shard_init(self, unique_id: bytes, rank: int, world: int):
         assert len(unique_id) == SHARD_ID_BYTES
@@ -135,6 +225,13 @@ class RefShardDriver:
             self.be.shard_share_last(0)
             self.bytes_broadcast += self.W * self.H * 3 // 2
             return
+        if getattr(self.dist, "object_collectives", False):     # ranks are threads of this process: device buffers change hands
+            parcel = self.dist.broadcast_object(self.be.export_last() if self.rank == 0 else None, src=0)
+            self.bytes_broadcast += self.W * self.H * 3 // 2
+            if self.rank != 0 or self.loopback:
+                self.be.import_last(parcel)
+            self.dist.barrier()                                  # (rank 0 writes its parcel again only after everybody has taken it)
+            return
         if self.rank == 0:
             t = self.be.export_last()
         else:
@@ -152,6 +249,15 @@ class RefShardDriver:
         if self.native:
             self.be.shard_share_search(sum(1 << r for r in used))
             self.bytes_gathered += len(used) * 8 * self.be.b8
+            return
+        if getattr(self.dist, "object_collectives", False):
+            mine = {r: self.be.export_search(r) for r in used if self.owner(r) == self.rank}
+            allv = self.dist.all_gather_object(mine)
+            self.bytes_gathered += len(used) * 8 * self.be.b8
+            for r in used:
+                if self.owner(r) != self.rank or self.loopback:
+                    self.be.import_search(r, allv[self.owner(r)][r])
+            self.dist.barrier()
             return
         import torch
         mine = torch.zeros((3, 2, self.be.b8), dtype=torch.int32, device=self.be.dev)
