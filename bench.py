@@ -138,31 +138,31 @@ def spawn_ranks(args) -> int:
     return max(abs(rc) for rc in rcs)
 
 
+def golden_digest(name: str):
+    """tests/golden/full_length/<name>.json: per-frame digests of the CPU oracle loop over bench.py's own frames
+    (scripts/full_length_oracle.py --oracle; committed), or None"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "full_length", name + ".json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 class Leg:
     """G GOP chunks of one geometry on one GPU: frames in HBM, native drivers, pre-rolled to GOP steady state."""
 
     def __init__(self, api, W0, H0, G, refs, ssim_target, nd, device, seed, overlap_filter=0, batch=1, gop=None, conformant=0):
-        from vp8oclenc_amd.synth import SynthSequence
+        from vp8oclenc_amd.synth import bench_frames
         self.api, self.device = api, device
         self.overlap_filter, self.ssim_target, self.gop, self.conformant, self.seed0 = overlap_filter, ssim_target, gop, conformant, seed
-        seq = SynthSequence(W0, H0, seed=seed)
-        self.W, self.H = seq.W, seq.H
+        # a source below the coded size (1920x1080 in a 1920x1088 context) is handed over as it is: copy_with_padding
+        # (encIO.h:141-196) runs inside the launch that takes a frame in, i.e. inside every timed step (vp8hip_set_source_size);
+        # host_frames = the same frames padded on the host: what the CPU baseline codes
+        self.W, self.H, source, self.host_frames = bench_frames(W0, H0, seed, nd)
         self.mbs = (self.W // 16) * (self.H // 16)
         self.G, self.nd, self.refs = G, nd, refs
-        self.host_frames = [seq.frame(t) for t in range(nd)]
-        # a source below the coded size (1920x1080 in a 1920x1088 context) is handed over as it is: copy_with_padding
-        # (encIO.h:141-196) runs inside the launch that takes a frame in, i.e. inside every timed step (vp8hip_set_source_size)
-        src = {}
-        if (W0, H0) != (self.W, self.H) and W0 % 2 == 0 and H0 % 2 == 0 and self.W - W0 < 16 and self.H - H0 < 16:
-            import numpy as np
-            source = [(np.ascontiguousarray(y[:H0, :W0]), np.ascontiguousarray(u[:H0 // 2, :W0 // 2]), np.ascontiguousarray(v[:H0 // 2, :W0 // 2]))
-                      for y, u, v in self.host_frames]
-            pad = lambda p, h, w: np.pad(p, ((0, h - p.shape[0]), (0, w - p.shape[1])), mode="edge")
-            self.host_frames = [(pad(y, self.H, self.W), pad(u, self.H // 2, self.W // 2), pad(v, self.H // 2, self.W // 2)) for y, u, v in source]   # what the CPU baseline codes
-            src = dict(src_width=W0, src_height=H0)
-        else:
-            source = self.host_frames
+        src = dict(src_width=W0, src_height=H0) if source is not self.host_frames else {}
         self.source_size = (W0, H0) if src else (self.W, self.H)
         self.src_kw = src
         self.dev_frames = [tuple(api.to_device(p, device) for p in f) for f in source]     # (the library's own allocator: no second GPU runtime in the process)
@@ -319,6 +319,32 @@ class Leg:
                 p.free()
         self.dev_frames = []
 
+    def oracle_check(self):
+        """EVERY chunk's filtered reconstruction, as it stands now, against the CPU oracle loop: a chunk is a closed GOP that started
+        with its key frame at frame `phase` of the eight-frame cycle and has coded n frames since, and the committed table
+        tests/golden/full_length/chunks_<geometry>.json holds the oracle loop's reconstruction CRCs for every (phase, n) up to its
+        length.  None where no table applies (other seed than rank 0's, SSIM target, finite GOP, conformant stream)."""
+        import zlib
+        W0, H0 = self.source_size
+        name = f"chunks_{W0}x{H0}" + ("_last_only" if self.refs == "last" else "")
+        doc = golden_digest(name)
+        if doc is None or doc.get("seed") != self.seed0 or doc.get("distinct_frames") != self.nd or self.ssim_target != -1.0 or self.gop or self.conformant or not CHECK_SSIM or doc.get("refs", "all") != self.refs:
+            return None
+        checked, wrong, beyond = 0, [], 0
+        for k, d in enumerate(self.drv):
+            d.resolve()
+            n, phase = self.t[k] - self.t_key[k], self.t_key[k] % self.nd
+            if n > doc["frames"]:
+                beyond += 1
+                continue
+            got = [zlib.crc32(p.tobytes()) for p in d.hip.download_last()]
+            checked += 1
+            if got != doc["recon_crc32"][phase][n - 1]:
+                wrong.append(k)
+        return {"table": f"tests/golden/full_length/{name}.json", "chunks_checked": checked, "chunks_beyond_the_table": beyond, "differing_chunks": wrong,
+                "identical": not wrong, "what": "the filtered reconstruction every chunk stands on, CRC-32 of Y, U, V, against the CPU oracle loop run "
+                "over the same frames from the chunk's key frame (scripts/full_length_oracle.py --oracle); the run aborts on a mismatch"}
+
     def replay_chunk(self, k):
         """Chunk k coded AGAIN, from its key frame to where it stands now, on a fresh driver of its own -- no batch, no other chunk
         beside it, one frame at a time: the filtered reconstruction it ends with must be the chunk's, byte for byte (a closed GOP
@@ -349,12 +375,15 @@ def side_leg(api, W0, H0, G, refs, ssim_target, steps, warm, device, nd=4, seed=
     el, enq, nrefs = leg.run(steps)
     lf_ms, lf_n, ghz = leg.clock_read()
     frames = steps * G
+    oc = leg.oracle_check()
+    if oc and not oc["identical"] and not api.load_library().vp8hip_experiments_compiled_in():
+        raise SystemExit(f"bench.py: self-check of the {W0}x{H0} leg FAILED against the oracle digests: {oc}")
     out = {"workload": f"{W0}x{H0}, {'LAST+GOLDEN+ALTREF' if refs == 'all' else 'LAST only'}, SSIM target {ssim_target}, {G} GOP chunk(s) in flight"
                        + (f" in batches of {batch}" if G > 1 and batch > 1 else ""),
            "value": round(leg.mbs * frames / el, 1), "unit": "macroblocks/s", "ms_per_frame": round(el / frames * 1e3, 4),
            "fps": round(frames / el, 1), "frames": frames, "refs_per_frame": round(nrefs, 2), "macroblocks_per_frame": leg.mbs,
            "loop_filter_ms_by_its_own_clock": round(lf_ms / max(lf_n, 1), 4), "shader_clock_ghz": round(ghz, 3),
-           "waves_context_switched": leg.context_switches}
+           "waves_context_switched": leg.context_switches, "self_check_against_the_oracle": oc}
     if gop:
         out["gop_size"], out["key_frames"] = gop, leg.keys
     leg.close()
@@ -517,6 +546,19 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
         t5 = el5 + (time.perf_counter() - t0)
         if dist is not None:
             t5 = dist.max(t5)
+        # outside the time: THIS rank's 300 frames against the CPU oracle loop's (tests/golden/full_length/config5_rank<r>.json: CRC-32
+        # and length of every frame, made by scripts/full_length_oracle.py --oracle from the same synthetic frames)
+        import zlib
+        import numpy as np
+        doc = golden_digest(f"config5_rank{rank}") if (args.width, args.height, GOP5) == (1920, 1080, 300) and CHECK_SSIM else None
+        mine = [local_frames[rank * GOP5 + t] for t in range(GOP5)]
+        differing = -1 if doc is None else sum((zlib.crc32(b), len(b)) != (doc["frame_crc32"][t], doc["frame_len"][t]) for t, b in enumerate(mine))
+        verdicts = np.array([differing], np.int64) if dist is None else dist.all_gather(np.array([differing], np.int64)).reshape(-1)
+        oracle5 = {"ranks_checked": [r for r in range(world) if verdicts[r] >= 0], "ranks_without_a_committed_digest": [r for r in range(world) if verdicts[r] < 0],
+                   "frames_per_rank": GOP5, "differing_frames": int(sum(max(int(v), 0) for v in verdicts)), "identical": not any(int(v) > 0 for v in verdicts),
+                   "what": "every frame a rank delivered (CRC-32 + length) against the CPU oracle loop over the same frames, tests/golden/full_length/config5_rank<r>.json"}
+        if not oracle5["identical"] and not api.load_library().vp8hip_experiments_compiled_in():
+            raise SystemExit(f"bench.py: config5_literal FAILED its check against the oracle digests: {oracle5}")
         if rank == 0:
             assert gathered is not None and len(gathered) == GOP5 * world and all(gathered)
             out["config5_literal"] = {
@@ -524,7 +566,7 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
                             "finished VP8 frames gathered to rank 0 in frame order (vp8hip_group_gather_bytes: ncclSend / ncclRecv inside the library); the time includes the gather",
                 "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
                 "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
-                "encode_seconds_rank0": round(el5, 4), "n_gpus": world, "rccl_ranks": None if dist is None else int(dist.count()),
+                "encode_seconds_rank0": round(el5, 4), "self_check_against_the_oracle": oracle5, "n_gpus": world, "rccl_ranks": None if dist is None else int(dist.count()),
                 "gpu_framework_in_process": "torch" if "torch" in sys.modules else "none"}
         del gathered, local_frames
         # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
@@ -552,7 +594,7 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
                 # vp8hip_conformant_stream (NOT the reference's bytes: the format's predictor, so that the stream decodes to the
                 # encoder's own reconstruction): what the opt-in costs
                 ("1080p_conformant_stream", (1920, 1080, G, "all", -1.0, max(20, args.steps // 2), 5), dict(batch=B, conformant=1))):
-            oc[name] = side_leg(api, *leg_args, local, **kw)
+            oc[name] = side_leg(api, *leg_args, local, nd=nd, **kw)
             out["other_configs"] = dict(oc)      # (handed on after every geometry)
     return dict(out)
 
@@ -611,6 +653,34 @@ def main():
         sys.stdout.flush()
         os.close(json_fd)
         sys.exit(0)          # (through the ordinary teardown: every context of every leg has been destroyed by now)
+    # ---- side legs in fresh processes, BEFORE this process makes a stream: reported next to the headline value, never as it --------
+    # The legs that are ONE or TWO videos coded frame after frame, and the other geometries, run in child processes: the HIP runtime
+    # keeps every hardware queue a process ever used, and after 48 chunks in 8 batches a lone stream shares them badly (measured: the
+    # same two-chunk leg 3 800 frames/s in a fresh process, 2 100 behind the headline's leg).  And they run FIRST, while this process
+    # holds no queue: the part's scheduler keeps 24 queues resident PER DEVICE, not per process -- with the headline's eight batch
+    # streams alive in the parent a child's 48-chunk leg pushed the device past that and its loop filter's waves were context-switched
+    # (`waves_context_switched` 20-70 per leg in rounds 3 and 4, in a child of their own as well; 0 now).  The children of several
+    # ranks form their own RCCL groups.
+    child_out, child_rc = b"", 0
+    run_children = not args.no_side_legs and not args.only_bitstream
+    if run_children:
+        if dist is not None:
+            dist.barrier()
+        # the children are groups of their own; they meet through files named by this run's key + the child's name (no port, no store)
+        env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", VP8_BENCH_RDZV_KEY=rdzv_key)
+        if not env["VP8_BENCH_CHILD"]:
+            env.pop("VP8_BENCH_CHILD")
+        # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
+        for which in (["few"] + (["other"] if world == 1 else [])):
+            argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs", which]
+            try:
+                child = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,   # (a leg that dies says where, on stderr)
+                                       timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
+                child_out, child_rc = child_out + child.stdout, child_rc or child.returncode
+            except subprocess.TimeoutExpired as e:
+                child_out, child_rc = child_out + (e.stdout or b""), "timeout"
+        if dist is not None:
+            dist.barrier()
     G = max(1, args.gops_per_gpu)
     B = max(1, min(8, args.batch))   # VP8HIP_MAX_BATCH
     free_before = api.device_mem_info(local)[0]
@@ -660,6 +730,9 @@ def main():
     # (no batch, no other chunk in flight); the reconstruction it ends with must be the timed chunk's.  A run whose timed frames
     # are not the frames a single un-batched encoder produces prints no line.
     verify = leg.replay_chunk((7 * (rank + 1)) % G)
+    verify["against_the_oracle"] = leg.oracle_check()
+    if verify["against_the_oracle"] and not verify["against_the_oracle"]["identical"] and not experiment_build:
+        raise SystemExit(f"bench.py: self-check FAILED -- chunks of the timed region do not stand on the reconstruction the CPU oracle loop reaches: {verify['against_the_oracle']}")
     if not verify["identical"] and not experiment_build:      # (an experiment build leaves work out of launches: its line says INVALID)
         raise SystemExit(f"bench.py: self-check FAILED -- the timed region's chunk {verify['chunk']} does not end where the same frames coded alone end: {verify}")
     frames_per_gpu = args.steps * G
@@ -756,7 +829,8 @@ def main():
                                                         "value": round(mbs * frames_per_gpu / float(per_rank[r][0]), 1),
                                                         "refs_per_frame": round(float(per_rank[r][1]), 3)} for r in range(world)],
             "self_check": dict(verify, what="one chunk of the timed region coded again from its key frame on an un-batched driver of its own: "
-                                            "CRC-32 of the final filtered reconstruction (Y, U, V), key frames; the run aborts on a mismatch"),
+                                            "CRC-32 of the final filtered reconstruction (Y, U, V), key frames; and (against_the_oracle) EVERY chunk's "
+                                            "reconstruction against the committed digests of the CPU oracle loop; the run aborts on a mismatch"),
             "host_enqueue_ms_per_frame": round(enqueue_s / frames_per_gpu * 1e3, 4),
         }
     leg.profile([])
@@ -766,28 +840,7 @@ def main():
         # is 3 % of the rate -- 52.9 against 54.3 M MB/s at 40 and 54.8 at 120 on one box)
         out["with_bitstream"] = bitstream_leg(leg, max(40, args.steps))
     host_frames = leg.host_frames
-    if args.only_bitstream:
-        args.no_side_legs = True
-    if not args.no_side_legs:
-        # The legs that are ONE or TWO videos coded frame after frame run in a fresh process per rank: the HIP runtime keeps every
-        # hardware queue a process ever used, and after 48 chunks in 8 batches a lone stream shares them badly (measured: the same
-        # two-chunk leg 3 800 frames/s in a fresh process, 2 100 behind the headline's leg).  The children form their own RCCL group.
-        if dist is not None:
-            dist.barrier()
-        # the children are a group of their own; they meet through a file named by this run's key + "-legs" (no port, no store)
-        env = dict(os.environ, VP8_BENCH_CHILD="1" if (dist is not None) else "", VP8_BENCH_RDZV_KEY=rdzv_key)
-        if not env["VP8_BENCH_CHILD"]:
-            env.pop("VP8_BENCH_CHILD")
-        # (bounded: the children rendezvous among themselves, and a child that does not come up must not hold the headline line back)
-        child_out, child_rc = b"", 0
-        for which in (["few"] + (["other"] if world == 1 and not args.only_bitstream else [])):
-            argv = [a for a in sys.argv[1:] if a != "--spawn"] + ["--child-legs", which]
-            try:
-                child = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,   # (a leg that dies says where, on stderr)
-                                       timeout=float(os.environ.get("VP8_BENCH_CHILD_TIMEOUT", "420")))
-                child_out, child_rc = child_out + child.stdout, child_rc or child.returncode
-            except subprocess.TimeoutExpired as e:
-                child_out, child_rc = child_out + (e.stdout or b""), "timeout"
+    if run_children:
         if rank == 0:
             got = 0
             for line in child_out.decode(errors="replace").splitlines():      # one line per finished leg

@@ -109,3 +109,21 @@ def noise_frames(width: int, height: int, seed: int, amp: int = 120):
         V = np.clip(128 + rng.integers(-amp, amp + 1, size=(H // 2, W // 2)), 0, 255).astype(np.uint8)
         out.append((Y, U, V))
     return out
+
+
+def bench_frames(width: int, height: int, seed: int, nd: int = 8):
+    """The `nd` distinct synthetic frames bench.py's legs cycle through (frame t of a chunk that starts at phase p is frames[(p + t) % nd]),
+    as (W, H, source, padded): `source` = what is handed to the encoder (the source size when it is below the coded size: 1920x1080 in a
+    1920x1088 context -- copy_with_padding, encIO.h:141-196, then runs on the device), `padded` = the same frames padded on the host the
+    way copy_with_padding pads (what the CPU oracle and the CPU baseline code).  One definition, so that bench.py, the full-length oracle
+    runs (scripts/full_length_oracle.py) and the committed digests agree by construction."""
+    seq = SynthSequence(width, height, seed=seed)
+    W, H = seq.W, seq.H
+    frames = [seq.frame(t) for t in range(nd)]
+    if (width, height) != (W, H) and width % 2 == 0 and height % 2 == 0 and W - width < 16 and H - height < 16:
+        source = [(np.ascontiguousarray(y[:height, :width]), np.ascontiguousarray(u[:height // 2, :width // 2]), np.ascontiguousarray(v[:height // 2, :width // 2]))
+                  for y, u, v in frames]
+        pad = lambda p, h, w: np.pad(p, ((0, h - p.shape[0]), (0, w - p.shape[1])), mode="edge")
+        padded = [(pad(y, H, W), pad(u, H // 2, W // 2), pad(v, H // 2, W // 2)) for y, u, v in source]
+        return W, H, source, padded
+    return W, H, frames, frames
