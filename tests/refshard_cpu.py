@@ -2,14 +2,19 @@
 (oracle/vp8_oracle.c through oracle_lib.Stages) sequenced like include/vp8hip.h's vp8hip_inter_search /
 vp8hip_inter_finish, state in numpy, exchanges in CPU torch tensors.  Test infrastructure."""
 import numpy as np
-import torch
+
+# (torch is imported where a tensor is made, not with the module: pytest imports this file when it collects the suite, and the GPU
+# test process must not load PyTorch's bundled HIP runtime and RCCL beside the ones libvp8hip.so was built for)
 
 from oracle_lib import Oracle, oracle_intra
 from pipeline import pyramid
 
 
 class OracleRefBackend:
-    dev = torch.device("cpu")
+    @property
+    def dev(self):
+        import torch
+        return torch.device("cpu")
 
     def __init__(self, W, H):
         self.W, self.H = W, H
@@ -53,6 +58,7 @@ class OracleRefBackend:
             self.net[r], self.bd[r] = net[0], bd
 
     def export_search(self, ref):
+        import torch
         return torch.from_numpy(np.stack([self.net[ref].view(np.int32).reshape(-1), self.bd[ref]]).copy())
 
     def import_search(self, ref, t):
@@ -113,6 +119,7 @@ class OracleRefBackend:
         return self.refs[0]
 
     def export_last(self):
+        import torch
         return torch.from_numpy(np.concatenate([p.reshape(-1) for p in self.refs[0]]).copy())
 
     def import_last(self, t):

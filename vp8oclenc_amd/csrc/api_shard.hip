@@ -37,18 +37,26 @@ struct Rccl {
     bool ok = false;
 };
 
-// VP8HIP_RCCL_LIBRARY, then the process's own search path, then where the ROCm this library was built for keeps it
+// $VP8HIP_RCCL_LIBRARY; then the RCCL that belongs to the HIP runtime this process runs on (next to its libamdhip64: a process that
+// also holds another copy -- PyTorch bundles one, built for ITS runtime -- must not get that one by soname); then $ROCM_PATH/lib,
+// /opt/rocm/lib; then whatever the process's search path says
 const Rccl *rccl() {
     static const Rccl table = [] {
         Rccl r;
         void *h = nullptr;
-        std::string tried[6];
+        std::string tried[8];
         int n = 0;
         if (const char *e = getenv("VP8HIP_RCCL_LIBRARY")) tried[n++] = e;
-        tried[n++] = "librccl.so.1";
-        tried[n++] = "librccl.so";
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) tried[n++] = dir.substr(0, slash) + "/librccl.so.1";
+        }
         if (const char *e = getenv("ROCM_PATH")) tried[n++] = std::string(e) + "/lib/librccl.so.1";
         tried[n++] = "/opt/rocm/lib/librccl.so.1";
+        tried[n++] = "librccl.so.1";
+        tried[n++] = "librccl.so";
         for (int i = 0; i < n && !h; ++i) h = dlopen(tried[i].c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (!h) {
             fprintf(stderr, "vp8hip: librccl.so.1 not found (%s): the vp8hip_shard_* / vp8hip_group_* entry points need RCCL; set VP8HIP_RCCL_LIBRARY\n", dlerror());

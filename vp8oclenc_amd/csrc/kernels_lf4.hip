@@ -122,6 +122,112 @@ __device__ __forceinline__ void filter_line(int (&t)[20], const Limits &L, int i
     }
 }
 
+// ---- the same line in two parts ------------------------------------------------------------------------------------------
+// A lone wave issues an instruction every 5.3 cycles whether or not it depends on the one before (scripts/ubench/lone_wave.hip),
+// and an LDS round trip costs it 50-130 cycles of nothing: what a step can win is the waits.  Of a line's twenty samples the four in
+// front of the macroblock edge arrive LATE in both phases (P1: the columns P2 of the previous step has just written; P2: the rows
+// of the macroblock row above, behind the step's poll); the sixteen of the macroblock itself are there early.  And an inner edge
+// depends on the edge before it only through |p3 - p2| and |p2 - p1| (the edge at 4 also through p1, which the macroblock edge
+// moves): its hev, its filter value before the mask and six of its eight interior differences are functions of samples nobody
+// has touched.  line_pre computes all of that from t[4..19] while the late samples are in flight; line_post is the chain.
+// Same operations on the same values as filter_line (max3 regrouped: max is associative), so the results are bit for bit the same.
+struct BPre { int pre_max, a, hv; };            // an inner edge whose p1, p0 and q side are as loaded (the edges at 8 and 12); hv = max(|p1-p0|, |q1-q0|)
+struct LinePre {
+    int mb_dq10, mb_m2;                          // macroblock edge: |q1-q0|, max3(|q1-q0|, |q2-q1|, |q3-q2|)
+    int e4_dq10, e4_m2, e4_e0, e4_qp3;           // edge at 4: the same two, (|p0-q0| << 2) + b_delta, 3 (q0 - p0)
+    BPre e8, e12;
+};
+__device__ __forceinline__ BPre b_edge_pre(int p1, int p0, int q0, int q1, int q2, int q3, const Limits &L) {
+    const int d10 = ad(p1, p0), dq10 = ad(q1, q0);
+    const int m2 = max3i(dq10, ad(q2, q1), ad(q3, q2));
+    const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)p1, (uint32_t)q1, (uint32_t)((ad(p0, q0) << 2) + L.b_delta));
+    BPre r;
+    r.pre_max = max3i(d10, m2, edge);
+    r.hv = imax(d10, dq10);
+    int a = c128(p1 - q1);
+    a = r.hv > L.hev_thr ? a : 0;
+    r.a = iclamp(a + __mul24(q0 - p0, 3), -128, 123);
+    return r;
+}
+__device__ __forceinline__ void b_edge_post(EdgeRegs &e, const BPre &pre, int int_lim, int hev_thr) {
+    const bool mask = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), pre.pre_max) <= int_lim;
+    int a = mask ? pre.a : 0;
+    const int b = (a + 3) >> 3;
+    a = (a + 4) >> 3;
+    e.q0 -= a; e.p0 += b;
+    a = (a + 1) >> 1;
+    a = pre.hv > hev_thr ? 0 : a;
+    e.q1 -= a; e.p1 += a;
+}
+// the value exists HERE: the compiler may neither compute it later (it sinks what only a later block uses) nor move it across
+#define LF_KEEP(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ void line_pre(const int (&t)[20], const Limits &L, LinePre &pre) {
+    pre.mb_dq10 = ad(t[5], t[4]);
+    pre.mb_m2 = max3i(pre.mb_dq10, ad(t[6], t[5]), ad(t[7], t[6]));
+    pre.e4_dq10 = ad(t[9], t[8]);
+    pre.e4_m2 = max3i(pre.e4_dq10, ad(t[10], t[9]), ad(t[11], t[10]));
+    pre.e4_e0 = (ad(t[7], t[8]) << 2) + L.b_delta;
+    pre.e4_qp3 = __mul24(t[8] - t[7], 3);
+    pre.e8 = b_edge_pre(t[10], t[11], t[12], t[13], t[14], t[15], L);
+    pre.e12 = b_edge_pre(t[14], t[15], t[16], t[17], t[18], t[19], L);
+    LF_KEEP(pre.mb_dq10); LF_KEEP(pre.mb_m2); LF_KEEP(pre.e4_dq10); LF_KEEP(pre.e4_m2); LF_KEEP(pre.e4_e0); LF_KEEP(pre.e4_qp3);
+    LF_KEEP(pre.e8.pre_max); LF_KEEP(pre.e8.a); LF_KEEP(pre.e8.hv); LF_KEEP(pre.e12.pre_max); LF_KEEP(pre.e12.a); LF_KEEP(pre.e12.hv);
+}
+// t[0..3] have arrived.  Writes t[1..17] (unsaturated, like filter_line).
+__device__ __forceinline__ void line_post(int (&t)[20], const Limits &L, int il_mb, int il4, int il8, const LinePre &pre) {
+    EdgeRegs e;
+    e.p3 = t[0]; e.p2 = t[1]; e.p1 = t[2]; e.p0 = t[3];
+    e.q0 = t[4]; e.q1 = t[5]; e.q2 = t[6]; e.q3 = t[7];
+    {   // the macroblock edge (filter_mb_edge with its q-side differences taken from pre)
+        const int d10 = ad(e.p1, e.p0);
+        const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
+        const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)((ad(e.p0, e.q0) << 2) + L.mb_delta));
+        const bool mask = max3i(m1, pre.mb_m2, edge) <= il_mb;
+        const bool hev = imax(d10, pre.mb_dq10) > L.hev_thr;
+        int w = c128(e.p1 - e.q1);
+        w = c128(w + __mul24(e.q0 - e.p0, 3));
+        w = mask ? w : 0;
+        int a = imin(hev ? w : 0, 123);
+        const int b = (a + 3) >> 3;
+        a = (a + 4) >> 3;
+        e.q0 -= a; e.p0 += b;
+        w = hev ? 0 : w;
+        a = (w * 27 + 63) >> 7; e.q0 -= a; e.p0 += a;
+        a = (w * 18 + 63) >> 7; e.q1 -= a; e.p1 += a;
+        a = (w * 9 + 63) >> 7;  e.q2 -= a; e.p2 += a;
+    }
+    t[1] = e.p2; t[2] = e.p1; t[3] = e.p0;
+    t[4] = e.q0; t[5] = e.q1; t[6] = e.q2;
+    {   // the edge at 4: p3, p2, p1 are the macroblock edge's q0, q1, q2
+        e.p3 = e.q0; e.p2 = e.q1; e.p1 = e.q2; e.p0 = e.q3;
+        e.q0 = t[8]; e.q1 = t[9]; e.q2 = t[10]; e.q3 = t[11];
+        const int d10 = ad(e.p1, e.p0);
+        const int m1 = max3i(ad(e.p3, e.p2), ad(e.p2, e.p1), d10);
+        const int edge = (int)__builtin_amdgcn_sad_u16((uint32_t)e.p1, (uint32_t)e.q1, (uint32_t)pre.e4_e0);
+        const bool mask = max3i(m1, pre.e4_m2, edge) <= il4;
+        const bool hev = imax(d10, pre.e4_dq10) > L.hev_thr;
+        int a = c128(e.p1 - e.q1);
+        a = hev ? a : 0;
+        a = iclamp(a + pre.e4_qp3, -128, 123);
+        a = mask ? a : 0;
+        const int b = (a + 3) >> 3;
+        a = (a + 4) >> 3;
+        e.q0 -= a; e.p0 += b;
+        a = (a + 1) >> 1;
+        a = hev ? 0 : a;
+        e.q1 -= a; e.p1 += a;
+        t[6] = e.p1; t[7] = e.p0; t[8] = e.q0; t[9] = e.q1;
+    }
+    e.p3 = e.q0; e.p2 = e.q1; e.p1 = t[10]; e.p0 = t[11];
+    e.q0 = t[12]; e.q1 = t[13]; e.q2 = t[14]; e.q3 = t[15];
+    b_edge_post(e, pre.e8, il8, L.hev_thr);
+    t[10] = e.p1; t[11] = e.p0; t[12] = e.q0; t[13] = e.q1;
+    e.p3 = e.q0; e.p2 = e.q1; e.p1 = t[14]; e.p0 = t[15];
+    e.q0 = t[16]; e.q1 = t[17]; e.q2 = t[18]; e.q3 = t[19];
+    b_edge_post(e, pre.e12, il8, L.hev_thr);
+    t[14] = e.p1; t[15] = e.p0; t[16] = e.q0; t[17] = e.q1;
+}
+
 // biased sample -> biased saturated sample; its low byte is the pixel (BIAS = 256)
 __device__ __forceinline__ int satb(int v) { return iclamp(v, BIAS, BIAS + 255); }
 // four plane dwords (biased saturated samples) -> their four bytes
@@ -602,10 +708,17 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
 #ifdef LF_STAMPS
     unsigned long long st_p1 = 0, st_wait = 0, st_p2 = 0, st_spins = 0, st_t0, st_t1, tl0 = 0, tl64 = 0;
 #endif
-    // What P1 of a step reads of its own macroblock -- the parameter record and the sixteen fresh samples of the lane's pixel row --
-    // is requested half a step early, behind the poll that has just seen the porter's progress: the reads return during P2.
-    // (Only the four samples to the left, which P2 of this very step writes, are read when P1 starts.)
-    int4 n_pa = make_int4(0, 0, 0, 0), n_v1 = n_pa, n_v2 = n_pa, n_v3 = n_pa, n_v4 = n_pa;
+    // The step, arranged around its LDS round trips (a lone wave: 5.3 cycles per instruction of any kind, 50-130 cycles per round trip;
+    // LDS operations of one wave execute in program order -- scripts/ubench/lds_order.hip -- so a flag written right behind the data
+    // is seen behind them and no store is ever waited for):
+    //   P1    operands requested half a step earlier (the macroblock's own sixteen samples and its parameter record, behind the poll)
+    //         and at the end of the previous step (the four samples to the left, behind P2's stores): line_pre, line_post, stores,
+    //         flag 2S+1
+    //   poll  the three flags are read, then the macroblock's own sixteen rows for P2 (written by this wave: no wait needed);
+    //         line_pre of P2 runs while all of that is in flight; only then are the flags looked at
+    //   P2    the four rows above and the next step's P1 operands are requested; line_post, stores, the next step's left samples
+    //         requested, flag 2S+2
+    int4 n_pa = make_int4(0, 0, 0, 0), n_v0 = n_pa, n_v1 = n_pa, n_v2 = n_pa, n_v3 = n_pa, n_v4 = n_pa;
     int2 n_pb = make_int2(0, 0);
 // (Unconditional: an LDS read of a slot that holds nothing yet is harmless -- the values are used under `on` only -- and reads under a
 // predicate cost a register move per destination to merge the two paths.)
@@ -616,7 +729,10 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
         n_pa = ld128(pn); n_pb = ld64(pn + 16);                                               \
         n_v1 = ld128(sn); n_v2 = ld128(sn + 16); n_v3 = ld128(sn + 32); n_v4 = ld128(sn + 48); \
     }
+// the four samples to the left of step S_'s macroblock (the previous macroblock's last columns, which P2 has just written)
+#define P1_REQUEST_LEFT(S_) n_v0 = ld128(p1_base + (((((uint32_t)((S_) - r) & (RING - 1)) << mb_shift) - 16) & ringmask));
     P1_REQUEST(0)
+    P1_REQUEST_LEFT(0)
     const int up = imax(wave - 1, 0);
     for (int S = 0; S < steps; ++S) {
         STAMP(st_t0);
@@ -627,14 +743,18 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
         const uint32_t colB = slot << mb_shift, colA = (colB - 16) & ringmask;
         Limits L;
         int il_p1 = -1, il_in = -1, il_p2 = -1;
+        L.hev_thr = n_pa.w; L.mb_delta = n_pb.x; L.b_delta = n_pb.y;
         // ---- P1: vertical edges, lane = pixel row -------------------------------------------------
         if (on) {
             const uint32_t s = p1_base + colB;
-            const int4 v0 = ld128(p1_base + colA), v1 = n_v1, v2 = n_v2, v3 = n_v3, v4 = n_v4;
+            const int4 v1 = n_v1, v2 = n_v2, v3 = n_v3, v4 = n_v4;
             il_p1 = n_pa.x; il_in = n_pa.y; il_p2 = n_pa.z;
-            L.hev_thr = n_pa.w; L.mb_delta = n_pb.x; L.b_delta = n_pb.y;
-            int t[20] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
-            filter_line(t, L, il_p1, il_in, il_in | chroma_m1);
+            int t[20] = {0, 0, 0, 0, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y, v4.z, v4.w};
+            LinePre pre;
+            line_pre(t, L, pre);
+            const int4 v0 = n_v0;
+            t[0] = v0.x; t[1] = v0.y; t[2] = v0.z; t[3] = v0.w;
+            line_post(t, L, il_p1, il_in, il_in | chroma_m1, pre);
 #pragma unroll
             for (int k = 1; k < 18; ++k) t[k] = satb(t[k]);
             // macroblock 0 has nothing to its left (the slot belongs to a macroblock the porter may be bringing in); chroma
@@ -646,9 +766,9 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
             st128(sh_ + 32, make_int4(t[12], t[13], t[14], t[15]));
             st128(sh_ + 48, make_int4(t[16], t[17], t[18], t[19]));
         }
+        asm volatile("" ::: "memory");
+        flag[wave] = 2 * S + 1;   // (every lane, the same word: no exec mask to set up and restore.  Behind the stores: LDS executes a wave's operations in order)
         // ---- the one poll of the step ------------------------------------------------------------
-        // Its first reads are issued before this wave's own writes have landed (LDS operations of a wave complete in order): in the
-        // steady state the wave above and the porter are a hand-off ahead, and the poll costs the instructions, not a round trip.
         const int need_up = 2 * S + 1;                           // P1 of the rows above (their macroblock x+1)
         const int need_feed = imin(S + 2, mbw + 2 * wave + 1);   // the macroblocks of the next step's P1 (this wave's porter)
         const int need_top = imin(S + 1, mbw);                   // the rows above the band over this step's macroblock of row 0
@@ -656,8 +776,15 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
         if (wave > 0) f_up = flag[up];
         if (top_wave) f_top = flag[F_TOP];
         int f_feed = flag[F_FEED + wave];
-        lds_fence();
-        flag[wave] = 2 * S + 1;   // (every lane, the same word: no exec mask to set up and restore)
+        // P2's own sixteen rows (this wave's P1 has just written them: in order behind its stores), and everything of P2 that does
+        // not need the four rows above -- while the flags travel
+        const uint32_t s2 = p2_base + colB;
+        int t2[20];
+#pragma unroll
+        for (int k = 4; k < 20; ++k) t2[k] = ld32(s2 + k * LS);   // chroma lanes: rows 12-19 are don't-care
+        LinePre pre2;
+        line_pre(t2, L, pre2);
+        __builtin_amdgcn_sched_barrier(0);      // (the flags are looked at behind this work, not in front of it: they need the time)
         STAMP(st_t1);
 #ifdef LF_STAMPS
         st_p1 += st_t1 - st_t0; st_t0 = st_t1;
@@ -689,6 +816,10 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
 #ifdef LF_STAMPS
         if (wave == 0 && (S == 0 || S == 64)) { unsigned long long tt = __builtin_amdgcn_s_memrealtime(); if (S == 0) tl0 = tt; else tl64 = tt; }
 #endif
+        // the four rows above the macroblock (the row above has done P1 of its macroblock x + 1: what the poll has seen), then the
+        // next step's P1 operands
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t2[k] = ld32(s2 + k * LS);
         P1_REQUEST(S + 1)
         STAMP(st_t1);
 #ifdef LF_STAMPS
@@ -696,21 +827,18 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
 #endif
         // ---- P2: horizontal edges, lane = pixel column ---------------------------------------------
         if (on) {
-            const uint32_t s = p2_base + colB;
-            int t[20];
+            line_post(t2, L, il_p2, il_in, il_in | chroma_m1, pre2);
 #pragma unroll
-            for (int k = 0; k < 20; ++k) t[k] = ld32(s + k * LS);   // chroma lanes: rows 12-19 are don't-care
-            filter_line(t, L, il_p2, il_in, il_in | chroma_m1);
+            for (int k = 1; k < 18; ++k) t2[k] = satb(t2[k]);
 #pragma unroll
-            for (int k = 1; k < 18; ++k) t[k] = satb(t[k]);
-#pragma unroll
-            for (int k = 1; k < 12; ++k) st32(s + k * LS, t[k]);   // rows 1-3: the bottom of the row above (row 0 of the frame: rows nobody reads)
+            for (int k = 1; k < 12; ++k) st32(s2 + k * LS, t2[k]);   // rows 1-3: the bottom of the row above (row 0 of the frame: rows nobody reads)
             if (pl == 0) {
 #pragma unroll
-                for (int k = 12; k < 18; ++k) st32(s + k * LS, t[k]);
+                for (int k = 12; k < 18; ++k) st32(s2 + k * LS, t2[k]);
             }
         }
-        lds_fence();
+        asm volatile("" ::: "memory");
+        P1_REQUEST_LEFT(S + 1)    // (behind P2's stores, which wrote those columns)
         flag[wave] = 2 * S + 2;
         STAMP(st_t1);
 #ifdef LF_STAMPS
