@@ -139,6 +139,8 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * check_out (may be NULL; needs bytes_out): check_out[k][i] is folded with a checksum of every frame of member i as it is
  * delivered, in order -- vp8drv_frame_check(previous value, frame, size); start it at 0 -- so that a caller can hold the bytes of
  * a whole run against a second coding of the same frames without keeping them (bench.py's self-check).
+ * Every thread ends with its members' last verdicts taken (vp8drv_resolve) and their stream synchronised: a bounded device-side wait that
+ * expired anywhere in the run -- the last frame's loop filter included -- is THIS call's VP8HIP_ERR_TIMEOUT.
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
                                         const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out);

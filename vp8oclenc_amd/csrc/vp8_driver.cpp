@@ -553,8 +553,19 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                 if (rc[k] == VP8HIP_OK && keys_out && keys_out[k])   // (a failed call may not have filled key[])
                     for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
             };
+            // A bounded device-side wait that expires inside a frame's loop filter shows in the NEXT frame's verdict at the earliest (the
+            // verdict workgroup samples the error word when the filter's launch starts), and nobody comes after the last frame: the call
+            // ends with every member's last verdict taken and its stream synchronised, so that a time-out anywhere in the run is THIS
+            // call's return value (VP8HIP_ERR_TIMEOUT), not a later call's surprise.
+            auto finish = [&] {
+                for (int i = 0; i < b->n && rc[k] == VP8HIP_OK; ++i) {
+                    const int r = vp8drv_resolve(b->d[i]);
+                    rc[k] = r < 0 ? r : vp8hip_synchronize(b->d[i]->hip);
+                }
+            };
             if (!bytes_out) {
                 for (int t = 0; t < nframes && rc[k] == VP8HIP_OK; ++t) encode(t);
+                finish();
                 return;
             }
             // The frames as bytes: one set of launches for the batch's entropy stage, then every member's read-back -- with frame t + 1
@@ -575,6 +586,7 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                     if (check_out && check_out[k] && rc[k] == VP8HIP_OK) check_out[k][i] = vp8drv_frame_check(check_out[k][i], frame.data(), size);
                 }
             }
+            finish();
         });
     for (auto &t : th) t.join();
     for (int k = 0; k < nbatches; ++k)
