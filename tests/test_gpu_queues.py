@@ -18,7 +18,7 @@ CHILD = textwrap.dedent("""
     from vp8oclenc_amd import api
     from vp8oclenc_amd.synth import SynthSequence
     lib = api.load_library()
-    N, FRAMES = 12, 60
+    N, FRAMES = 12, 400
     seq = SynthSequence(640, 352, seed=4)
     ptrs = [tuple(api.to_device(p).ptr for p in seq.frame(t)) for t in range(4)]
     keep = ptrs
@@ -54,7 +54,7 @@ def test_a_host_that_exports_nothing_gets_sixteen_queues(tmp_path):
     unset, four, sixteen = _run(tmp_path, None), _run(tmp_path, 4), _run(tmp_path, 16)
     assert (unset["hw_queues"], four["hw_queues"], sixteen["hw_queues"]) == (16, 4, 16)
     # twelve independent videos on twelve streams: with 4 queues they serialise three deep
-    assert unset["fps"] > 0.85 * sixteen["fps"], (unset, sixteen)
-    if sixteen["fps"] > 1.15 * four["fps"]:       # (the setting matters for this load on this box: then the library's default must show it)
-        assert unset["fps"] > 1.08 * four["fps"], (unset, four, sixteen)
+    assert unset["fps"] > 0.8 * sixteen["fps"], (unset, sixteen)
+    if sixteen["fps"] > 1.2 * four["fps"]:        # (the setting matters for this load on this box: then the library's default must show it)
+        assert unset["fps"] > 1.05 * four["fps"], (unset, four, sixteen)
     print("fps: nothing exported %.0f, GPU_MAX_HW_QUEUES=4 %.0f, =16 %.0f" % (unset["fps"], four["fps"], sixteen["fps"]))
