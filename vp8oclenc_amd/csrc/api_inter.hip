@@ -59,9 +59,18 @@ void search_refs(vp8hip_ctx *c, const RefSet &which) {
     hipStream_t s = c->stream;
     const int net_width = c->mbw * 2;
     int src = 0;
-    for (int l = 4; l >= 0; --l) {
+    // one video coded frame after frame (filter on its own stream): nothing else fills the chip and every launch is a link of the
+    // frame's chain -- the four coarse levels are ONE launch there (k_search1_coarse), the finest follows
+    static const int fuse = [] { const char *v = getenv("VP8HIP_S1_COARSE"); return v && v[0] ? atoi(v) : 1; }();   // 0 = a launch per level, 1 = levels 4-1 fused (default), 2 = all five (no faster: the finest level is whole-chip work, profiles/README.md)
+    int first = 4;
+    if (c->lf_overlap && fuse) {
+        Timed t(c, fuse == 2 ? VP8HIP_K_SEARCH1_L0 : VP8HIP_K_SEARCH1_L1);
+        launch_search1_coarse(s, c->cur, which, c->nets, net_width, fuse == 2);
+        first = fuse == 2 ? -1 : 0;      // (level 0 reads the level-1 net: src index 0)
+    }
+    for (int l = first; l >= 0; --l) {
         Timed t(c, VP8HIP_K_SEARCH1_L4 + (4 - l));
-        // one video coded frame after frame (filter on its own stream): nothing else fills the chip, short waves pay
+        // (short waves on the coarse levels of a lone video when the fused launch is switched off: VP8HIP_S1_COARSE=0)
         launch_search1(s, c->cur, which, c->nets, l, src, net_width, c->lf_overlap && l > 0);
         src ^= 1;
     }

@@ -280,25 +280,14 @@ __device__ __forceinline__ void s1_subblock(const uint8_t *cp, int cstride, cons
     for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
 }
 
+// One 8x8 block of one level against one reference: the lanes of the block (M::LANES_PER_BLOCK of them: `sub` is the lane's number in
+// the block, `lane` its number in the wave) search the 25 candidates around the scaled parent vector `pv` (packed short2, 0 = none).
+// Returns the block's vector as the net holds it (packed short2, already multiplied by pixel_rate); valid in the lane with sub == 0.
+// `live` false: the lanes take part in the shuffles on harmless in-frame data.
 template <bool SPLIT>
-__device__ __forceinline__ void search1_body(const Search1Args &a) {
-    using M = S1Map<SPLIT>;
-    if ((int)blockIdx.y >= a.nrefs) return;
-    const int r = a.refmap[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
+__device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, int cx, int cy, uint32_t pv, bool live, int sub, int lane) {
     const int sb0 = sub / 5, j = sub - 5 * sb0;       // SPLIT: this lane's sub-block; otherwise sb0 = 0
-    const int b_raw = (xcd_band(blockIdx.x, gridDim.x) * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
-    const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
-    const int b = live ? b_raw : a.nblk - 1;
-    const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
-    const int cx = bx * 8, cy = by * 8;
-    // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
-    // coarser level's block grid are read but never written; reading them as 0 here is the same thing
-    // without the extra kernel.  vector / pixel_rate truncates toward zero (:495-500).
-    const int parent = (cy >> 4) * a.net_width + (cx >> 4);
-    const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
-    const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
+    // vector / pixel_rate truncates toward zero (:495-500)
     int v0x = (int16_t)(pv & 0xffffu), v0y = (int16_t)(pv >> 16);
     const int rmask = a.pixel_rate - 1;
     v0x = (v0x + ((v0x >> 31) & rmask)) >> a.rate_shift;
@@ -350,20 +339,126 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
         const uint32_t o = (uint32_t)__shfl((int)best, lane + off, 64);
         if (j + off < 5 && o < best) best = o;
     }
+    int bx, by;  // best position minus block position
+    if (best != 0xffffffffu) {
+        const int k = best & 0xff;
+        bx = v0x + (k % 5 - 2);
+        by = v0y + (k / 5 - 2);
+    } else {  // nothing accepted: "vector" still holds the scaled parent, :501,:551-556
+        bx = (int16_t)(v0x - cx);
+        by = (int16_t)(v0y - cy);
+    }
+    const uint32_t ox16 = (uint16_t)(int16_t)((int16_t)bx * (int16_t)a.pixel_rate);
+    const uint32_t oy16 = (uint16_t)(int16_t)((int16_t)by * (int16_t)a.pixel_rate);
+    return ox16 | (oy16 << 16);
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void search1_body(const Search1Args &a) {
+    using M = S1Map<SPLIT>;
+    if ((int)blockIdx.y >= a.nrefs) return;
+    const int r = a.refmap[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
+    const int b_raw = (xcd_band(blockIdx.x, gridDim.x) * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
+    const bool live = grp < M::BLOCKS_PER_WAVE && b_raw < a.nblk;
+    const int b = live ? b_raw : a.nblk - 1;
+    const int by = a.bw == 1 ? b : (int)__umulhi((uint32_t)b, a.bw_inv), bx = b - by * a.bw;   // b / bw: bw_inv = ceil(2^32 / bw), exact for b * bw < 2^32
+    const int cx = bx * 8, cy = by * 8;
+    // The reference zeroes the nets every frame (reset_vectors, :404-427) because parent cells beyond the
+    // coarser level's block grid are read but never written; reading them as 0 here is the same thing
+    // without the extra kernel.
+    const int parent = (cy >> 4) * a.net_width + (cx >> 4);
+    const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
+    const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
+    const uint32_t out = search1_block<SPLIT>(a, r, cx, cy, pv, live, sub, lane);
     if (sub == 0 && live) {
-        int bx, by;  // best position minus block position
-        if (best != 0xffffffffu) {
-            const int k = best & 0xff;
-            bx = v0x + (k % 5 - 2);
-            by = v0y + (k / 5 - 2);
-        } else {  // nothing accepted: "vector" still holds the scaled parent, :501,:551-556
-            bx = (int16_t)(v0x - cx);
-            by = (int16_t)(v0y - cy);
-        }
-        const uint32_t ox16 = (uint16_t)(int16_t)((int16_t)bx * (int16_t)a.pixel_rate);
-        const uint32_t oy16 = (uint16_t)(int16_t)((int16_t)by * (int16_t)a.pixel_rate);
         const int cell = (cy >> 3) * a.net_width + (cx >> 3);
-        reinterpret_cast<uint32_t *>(a.dst[r])[cell] = ox16 | (oy16 << 16);
+        reinterpret_cast<uint32_t *>(a.dst[r])[cell] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Levels 4, 3, 2 and 1 of one reference's search in ONE launch, for a single video coded frame after frame: there the five levels are
+// five links of the frame's dependency chain, each of the coarse four lasting as long as one wave of it plus a launch (4.5 + 4.8 + 5.0 +
+// 7.8 us at 1080p: profiles/r05_single_stream_timeline.txt), and nothing else fills the part.  A workgroup takes a tile of 4 x 4 level-1
+// blocks and computes the tile's ANCESTORS itself -- the one level-4 block, the one level-3 block and the 2 x 2 level-2 blocks whose
+// vectors the tile descends from (the parent of block (bx, by) is block (bx / 2, by / 2) of the level above) -- keeping their vectors in
+// LDS: 6 block searches on top of 16, no workgroup waits for another, and the chain has one link where it had four.  The same routine on
+// the same inputs (search1_block), so the level-1 net -- the only one the next launch reads -- is the one four launches leave.
+// ------------------------------------------------------------------------------------------------
+// FINEST: level 0 as well -- the 8 x 8 level-0 blocks under the tile, in the loop form (five lanes per block, twelve blocks per wave:
+// the tile's 64 blocks are one pass of the workgroup's six waves), their parents the tile's own level-1 vectors.  The whole hierarchical
+// search of a reference is then ONE link of the chain.
+struct CoarseArgs { Search1Args lv[5]; };   // lv[l] = level l
+constexpr int COARSE_WAVES = 6;             // 18 block slots of 20 lanes: the tile's 16 level-1 blocks in one pass
+template <bool FINEST>
+__global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse(CoarseArgs a) {
+    using M = S1Map<true>;
+    __shared__ uint32_t mv4, mv3, mv2[4], mv1[16];
+    const Search1Args &L1 = a.lv[1], &L2 = a.lv[2], &L3 = a.lv[3], &L4 = a.lv[4];
+    if ((int)blockIdx.y >= L1.nrefs) return;
+    const int r = L1.refmap[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
+    const int slot = grp < M::BLOCKS_PER_WAVE ? wave * M::BLOCKS_PER_WAVE + grp : 99;     // block slot of this lane in the workgroup, 0..17
+    const int tiles_x = (L1.bw + 3) / 4;
+    const int tile = xcd_band(blockIdx.x, gridDim.x);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    // ---- level 4: block (tx / 2, ty / 2) ----
+    {
+        const int bx = tx >> 1, by = ty >> 1;
+        const bool exists = bx < L4.bw && by * L4.bw + bx < L4.nblk;
+        if (wave == 0) {     // (whole waves only: the block's lanes shuffle among themselves)
+            const bool live = slot == 0 && exists;
+            const uint32_t out = search1_block<true>(L4, r, (live ? bx : 0) * 8, (live ? by : 0) * 8, 0u, live, sub, lane);
+            if (slot == 0 && sub == 0) mv4 = exists ? out : 0u;      // (a cell beyond the coarser grid reads as zero: reset_vectors, :404-427)
+        }
+    }
+    __syncthreads();
+    // ---- level 3: block (tx, ty) ----
+    {
+        const bool exists = tx < L3.bw && ty * L3.bw + tx < L3.nblk;
+        if (wave == 0) {
+            const bool live = slot == 0 && exists;
+            const uint32_t out = search1_block<true>(L3, r, (live ? tx : 0) * 8, (live ? ty : 0) * 8, mv4, live, sub, lane);
+            if (slot == 0 && sub == 0) mv3 = exists ? out : 0u;
+        }
+    }
+    __syncthreads();
+    // ---- level 2: blocks (2 tx + i, 2 ty + j) ----
+    if (wave < 2) {
+        const int i = slot & 1, j = (slot >> 1) & 1;
+        const int bx = 2 * tx + i, by = 2 * ty + j;
+        const bool exists = slot < 4 && bx < L2.bw && by * L2.bw + bx < L2.nblk;
+        const uint32_t out = search1_block<true>(L2, r, (exists ? bx : 0) * 8, (exists ? by : 0) * 8, mv3, exists, sub, lane);
+        if (slot < 4 && sub == 0) mv2[slot] = exists ? out : 0u;
+    }
+    __syncthreads();
+    // ---- level 1: the tile's 4 x 4 blocks; the only net that leaves the workgroup ----
+    {
+        const int i = slot & 3, j = (slot >> 2) & 3;
+        const int bx = 4 * tx + i, by = 4 * ty + j;
+        const bool live = slot < 16 && bx < L1.bw && by * L1.bw + bx < L1.nblk;
+        const uint32_t pv = mv2[(((j >> 1) & 1) << 1) | ((i >> 1) & 1)];
+        const uint32_t out = search1_block<true>(L1, r, (live ? bx : 0) * 8, (live ? by : 0) * 8, pv, live, sub, lane);
+        if (sub == 0 && live) reinterpret_cast<uint32_t *>(L1.dst[r])[by * L1.net_width + bx] = out;
+        if (FINEST && sub == 0 && slot < 16) mv1[slot] = live ? out : 0u;
+    }
+    if (!FINEST) return;
+    __syncthreads();
+    // ---- level 0: the 8 x 8 blocks under the tile ----
+    {
+        using M0 = S1Map<false>;
+        const Search1Args &L0 = a.lv[0];
+        const int grp0 = lane / M0::LANES_PER_BLOCK, sub0 = lane - M0::LANES_PER_BLOCK * grp0;
+        const int slot0 = grp0 < M0::BLOCKS_PER_WAVE ? wave * M0::BLOCKS_PER_WAVE + grp0 : 99;     // 0..71
+        const int i = slot0 & 7, j = (slot0 >> 3) & 7;
+        const int bx = 8 * tx + i, by = 8 * ty + j;
+        const bool live = slot0 < 64 && bx < L0.bw && by * L0.bw + bx < L0.nblk;
+        const uint32_t pv = mv1[((j >> 1) << 2) | (i >> 1)];
+        const uint32_t out = search1_block<false>(L0, r, (live ? bx : 0) * 8, (live ? by : 0) * 8, pv, live, sub0, lane);
+        if (sub0 == 0 && live) reinterpret_cast<uint32_t *>(L0.dst[r])[by * L0.net_width + bx] = out;
     }
 }
 
@@ -423,6 +518,19 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
         VP8_LAUNCH(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
     else
         VP8_LAUNCH(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+}
+
+// levels 4..1 (finest = false) or 4..0 in one launch (k_search1_coarse); the level-1 and level-0 nets land where launch_search1 leaves them
+void launch_search1_coarse(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int net_width, bool finest) {
+    CoarseArgs a;
+    for (int l = 0; l <= 4; ++l) a.lv[l] = search1_args(cur, refs, nets, l, l & 1, net_width);   // src of level l: 0 for 4, 2 and 0; 1 for 3 and 1
+    const Search1Args &L0 = a.lv[0], &L1 = a.lv[1];
+    if (L0.nblk <= 0 || L0.nrefs == 0 || search1_skip()) return;
+    // tiles of 4 x 4 level-1 blocks = 8 x 8 level-0 blocks; a frame of one macroblock row or column has level-0 blocks without a level-1 block above them
+    const int tiles_x = finest ? (L0.bw + 7) / 8 : (L1.bw + 3) / 4, tiles_y = finest ? (L0.h / 8 + 7) / 8 : (L1.h / 8 + 3) / 4;
+    if (tiles_x * tiles_y <= 0) return;
+    if (finest) VP8_LAUNCH(k_search1_coarse<true>, dim3(tiles_x * tiles_y, L0.nrefs), dim3(64 * COARSE_WAVES), 0, s, a);
+    else VP8_LAUNCH(k_search1_coarse<false>, dim3(tiles_x * tiles_y, L0.nrefs), dim3(64 * COARSE_WAVES), 0, s, a);
 }
 
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,

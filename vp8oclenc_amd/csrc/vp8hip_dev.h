@@ -154,6 +154,8 @@ void launch_loop_filter4_batch(hipStream_t s, const Frame *const *recon, const M
                                const LfCheck *chk = nullptr);
 void launch_auto_segments_batch(hipStream_t s, const Frame *const *cur, uint32_t *const *partial, uint32_t *const *stats, SegData *const *sd,
                                 int32_t *const *strength_out, const int *is_key, const int32_t (*refqi)[4], int qi_min, int n);
+// levels 4, 3, 2, 1 (and, finest, 0) in ONE launch (a single video: kernels_me.hip, k_search1_coarse); leaves the level-1 / level-0 nets where the per-level launches leave them
+void launch_search1_coarse(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int net_width, bool finest);
 void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, int level,
                     int src_idx, int net_width, bool latency = false);   // latency: the short-wave mapping whatever the size
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk = nullptr);
