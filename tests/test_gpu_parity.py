@@ -34,9 +34,13 @@ INTEGER_KEYS = ["MB_parts", "MB_reference_frame", "MB_vectors", "MB_coeffs", "MB
                 "prefilter_Y", "prefilter_U", "prefilter_V"]
 
 
-def _one_frame(W, H, frames, sd, flags, ssim_target=-1.0, saturate=False):
-    """LAST/GOLDEN/ALTREF = frames[0..2] (uploaded in the order that makes them so), current = frames[3]."""
+def _one_frame(W, H, frames, sd, flags, ssim_target=-1.0, saturate=False, one_video=False):
+    """LAST/GOLDEN/ALTREF = frames[0..2] (uploaded in the order that makes them so), current = frames[3].
+    one_video: the context in filter-overlap mode (vp8hip_filter_overlap): the loop filter on its own stream, GOLDEN / ALTREF searched
+    beside it, search levels 4-1 of a reference in ONE launch (k_search1_coarse)."""
     hip = api.Vp8Hip(W, H, ssim_target)
+    if one_video:
+        hip.filter_overlap(True)
     ora = Oracle(W, H, ssim_target)
     use_golden, use_altref = flags
     out = []
@@ -111,6 +115,25 @@ def test_single_frame_all_stages(W, H, seed, flags, ssim_target, kw):
     h, o = _one_frame(f[0][0].shape[1], f[0][0].shape[0], frames, sd, flags, ssim_target)
     keys = [k for k in o if k in h]
     _compare(h, o, keys, f"{W}x{H} seed {seed}")
+
+
+@pytest.mark.parametrize("W,H,seed,flags", [
+    (16, 16, 4, (1, 1)),          # a single macroblock: levels 2-4 have no block at all
+    (32, 16, 5, (1, 1)), (16, 48, 6, (1, 0)),      # one macroblock row / column
+    (64, 48, 1, (0, 0)), (80, 112, 2, (1, 1)),     # tiles of 4 x 4 level-1 blocks that hang over the level's grid on either side
+    (352, 288, 3, (1, 1)),
+    (1920, 1080, 8, (1, 1)),      # level 4 of 1088 rows: 8.5 blocks high, the half block is nobody's parent
+    (3840, 2160, 9, (1, 0)),
+    (4096, 16, 10, (1, 1)), (16, 2048, 11, (1, 1)),
+])
+def test_single_frame_all_stages_in_one_video_mode(W, H, seed, flags):
+    """The same stages with the context in filter-overlap mode: there the four coarse levels of a reference's search are ONE launch in which
+    every workgroup recomputes its tile's ancestors (k_search1_coarse, kernels_me.hip) -- the level-1 net (net1), the level-0 net (net2), the
+    quarter-pel costs and everything downstream must be what a launch per level leaves, i.e. the oracle's (GPU_kernels.cl:459-560)."""
+    f = _frames(W, H, seed)
+    frames = [f[2], f[0], f[1], f[3]]
+    h, o = _one_frame(f[0][0].shape[1], f[0][0].shape[0], frames, default_segments(), flags, -1.0, one_video=True)
+    _compare(h, o, [k for k in o if k in h], f"one video, {W}x{H} seed {seed}")
 
 
 def test_noise_frames_cost_wraparound():

@@ -842,6 +842,12 @@ class Vp8Hip:
     def loop_filter(self):
         self._chk(self.lib.vp8hip_loop_filter(self.h), "loop_filter")
 
+    def filter_overlap(self, on: bool = True):
+        """vp8hip_filter_overlap: one video coded frame after frame -- the loop filter on a stream of its own, the next frame's GOLDEN /
+        ALTREF searches beside it, the search's coarse levels as one launch (what vp8drv_config.overlap_filter turns on)"""
+        self.lib.vp8hip_filter_overlap.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.lib.vp8hip_filter_overlap(self.h, int(bool(on))), "filter_overlap")
+
     def loopfilter_strength(self):
         """get_loopfilter_strength (vp8enc.cpp:96-127) of the current frame, computed on the device."""
         red, sh = C.c_int32(), C.c_int32()
