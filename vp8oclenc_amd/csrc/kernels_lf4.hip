@@ -444,7 +444,15 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
     // accumulator the host reads with the profile (vp8hip_profile_read_clock).
     // hipEvents around a launch also count the time its packet waits for the queue when many streams share the part.
     unsigned long long *clk = reinterpret_cast<unsigned long long *>(a.err + 4);   // {start, sum of ticks, launches, sum of shader-clock cycles per tick x 1000, launches left out of that sum, launches whose last wave changed slots}
-    if (band == 0 && threadIdx.x == 0) __hip_atomic_store(clk, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the start is SUBTRACTED from the sum of ticks here and the end added by the frame's last wave: no wave has to read the start back.
+    // The word is meaningful when no launch is in flight, which is when the host reads it.)
+    if (band == 0 && threadIdx.x == 0) {
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(clk + 1, 0ull - t_start);
+#ifdef LF_STAMPS
+        __hip_atomic_store(clk, t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     const unsigned long long cyc0 = __builtin_amdgcn_s_memtime(), tick0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t hwid0 = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
     __syncthreads();
@@ -597,13 +605,14 @@ __device__ __forceinline__ void loop_filter4_body(const Args &a) {
             }
         }
         if (band + 1 == a.nbands && pi == (rows_real - 1) / 2 && lane == 0) {   // the frame's last rows: this wave is the last to finish real work
+            // (this is the tail of every frame's chain: no load to wait for, no 64-bit division -- fire-and-forget additions only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long t0 = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-            atomicAdd(clk + 1, t1 - t0);
+            atomicAdd(clk + 1, t1);
             atomicAdd(clk + 2, 1ull);
-            // the shader clock this wave saw while it ran: s_memtime cycles per 100 MHz tick (MI355X_MICROARCH.md, DVFS (6))
-            const unsigned long long ratio = (__builtin_amdgcn_s_memtime() - cyc0) * 1000ull / (t1 - tick0 + 1);
+            // the shader clock this wave saw while it ran: s_memtime cycles per 100 MHz tick (MI355X_MICROARCH.md, DVFS (6)), x 1000
+            const float cyc_f = (float)(__builtin_amdgcn_s_memtime() - cyc0), tick_f = (float)(t1 - tick0 + 1);
+            const unsigned long long ratio = (unsigned long long)(cyc_f * 1000.0f / tick_f);
             const uint32_t hwid1 = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
             // a wave that was context-switched (the hardware scheduler rotating an oversubscribed set of queues) comes back on
             // another slot, whose cycle counter is another one: such launches are counted, not averaged
