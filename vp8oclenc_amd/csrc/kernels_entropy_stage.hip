@@ -86,7 +86,19 @@ static_assert(sizeof(BatchOf<FirstArgs>) <= 4096 && sizeof(BatchOf<EmitArgs>) <=
 
 }  // namespace fe
 
-static fe::FirstArgs first_args(const FrameEntropy &e) {
+// lanes per macroblock of the header walks in a BATCH's launches (kernels_hdr.hip says why it differs from one video's): VP8HIP_HDR_BATCH_LPM = 1, 2, 4, 8, 16
+static int hdr_batch_lpm_shift() {
+    static const int sh = [] {
+        const char *v = getenv("VP8HIP_HDR_BATCH_LPM");
+        const int lpm = v && v[0] ? atoi(v) : 4;      // (same box, frames-out leg, M MB/s: 16 lanes 54.1-55.3, 8 56.3-56.8, 4 57.2-57.4, 2 55.6-57.7, 1 54.9-56.7)
+        int s = 0;
+        while ((1 << s) < lpm && s < 4) ++s;
+        return s;
+    }();
+    return sh;
+}
+
+static fe::FirstArgs first_args(const FrameEntropy &e, int lpm_shift = hdr::HDR_LPM_SHIFT_ONE_VIDEO) {
     const EntBuffers &c = *e.coef, &h = *e.hdr;
     const int mbs = e.mbw * e.mbh, nblocks = mbs * 25;
     fe::FirstArgs a;
@@ -97,7 +109,8 @@ static fe::FirstArgs first_args(const FrameEntropy &e) {
     a.cnt = c.offs; a.tile_sum = c.tile_sum;
     a.h = make_hdr_params(e.o, e.is_inter, e.modes, e.f, e.d_sd, e.strength, e.probs, e.denom0, h, e.mbw, e.mbh);
     a.hcnt = h.offs; a.hpartial = e.hdr_partial;
-    a.nb_hdr = (mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    a.h.lpm_shift = lpm_shift;
+    a.nb_hdr = (mbs + hdr::hdr_mb_per_wg(lpm_shift) - 1) / hdr::hdr_mb_per_wg(lpm_shift);
     a.nb_slots = (nblocks + 255) / 256;
     return a;
 }
@@ -121,7 +134,7 @@ static hdr::FrameItem hdr_frame_item(const FrameEntropy &e) {
     f.partial = e.hdr_partial; f.cnt = h.offs; f.bools = h.bools; f.sym_out = e.hdr_sym; f.plan = h.plan; f.info = e.hdr_info;
     return f;
 }
-static fe::EmitArgs emit_args(const FrameEntropy &e) {
+static fe::EmitArgs emit_args(const FrameEntropy &e, int lpm_shift = hdr::HDR_LPM_SHIFT_ONE_VIDEO) {
     const EntBuffers &c = *e.coef, &h = *e.hdr;
     const int mbs = e.mbw * e.mbh, nblocks = mbs * 25;
     fe::EmitArgs a;
@@ -138,7 +151,8 @@ static fe::EmitArgs emit_args(const FrameEntropy &e) {
     a.hplan = h.plan;
     a.hbools = h.bools;
     a.hacc = reinterpret_cast<unsigned long long *>(h.acc);
-    a.nb_hdr = (mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    a.h.lpm_shift = lpm_shift;
+    a.nb_hdr = (mbs + hdr::hdr_mb_per_wg(lpm_shift) - 1) / hdr::hdr_mb_per_wg(lpm_shift);
     a.nb_slots = (nblocks + 255) / 256;
     return a;
 }
@@ -169,7 +183,7 @@ void launch_fe_count_batch(hipStream_t s, const FrameEntropy *e, int n) {
     BatchOf<fe::MidArgs> m;
     a.n = c.n = m.n = n;
     for (int i = 0; i < n; ++i) {
-        a.item[i] = first_args(e[i]);
+        a.item[i] = first_args(e[i], hdr_batch_lpm_shift());
         c.item[i] = ent::CountItem{e[i].o.coeffs, e[i].o.nz, e[i].o.parts, e[i].flags, e[i].third, e[i].counts, e[i].mbw};
         m.item[i] = mid_args(e[i]);
     }
@@ -186,7 +200,7 @@ void launch_fe_emit_batch(hipStream_t s, const FrameEntropy *e, int n) {
     f.n = a.n = n;
     for (int i = 0; i < n; ++i) {
         f.item[i] = hdr_frame_item(e[i]);
-        a.item[i] = emit_args(e[i]);
+        a.item[i] = emit_args(e[i], hdr_batch_lpm_shift());
     }
     const unsigned skip = ent_skip_mask();
     if (!(skip & 8)) hipLaunchKernelGGL(hdr::k_hdr_frame_b, dim3(n), dim3(256), 0, s, f);

@@ -25,8 +25,14 @@ namespace hdr {
 
 using namespace vp8hdr;
 
-constexpr int HDR_MB_PER_WG = 16;            // macroblocks per workgroup of 256 threads (one per sixteen lanes)
-constexpr int HDR_LANES_PER_MB = 256 / HDR_MB_PER_WG;
+// Lanes per macroblock of the two walks (k_hdr_count, k_hdr_emit): every macroblock takes its own path through the header template, so
+// the lanes of a wavefront serialise.  ONE video wants the walk short: one macroblock per SIXTEEN lanes, a wavefront walks 4 paths
+// instead of 64 and the frame spreads over sixteen times as many wavefronts (104 us with one per lane, 47 us with one per four at
+// 1080p, alone on the part).  A BATCH of frames with the part full wants it cheap: what counts there is the issue slots a launch takes
+// from the other batches' kernels, and a wavefront that walks 64 paths issues their common instructions once -- a twelfth of the
+// wavefront instructions (profiles/README.md, round 5).
+constexpr int HDR_LPM_SHIFT_ONE_VIDEO = 4;
+__host__ __device__ constexpr int hdr_mb_per_wg(int lpm_shift) { return 256 >> lpm_shift; }
 constexpr int NSTAT = 2 * MV_PROBS * 2 + 8;   // mv num/den + {seg0..3, coded (nz != 0), ref last, ref golden, replaced}
 enum { ST_SEG = 76, ST_CODED = 80, ST_LAST = 81, ST_GF = 82, ST_REPLACED = 83 };
 
@@ -71,17 +77,15 @@ struct Params {
     const int32_t *strength;      // {reductor, sharpness, sharpness in force} of vp8hip_auto_segments / the check_SSIM verdict
     const uint32_t *probs, *denom0;
     uint32_t cap_bools, cap_chunks, cap_words;
+    int lpm_shift;                // lanes per macroblock of the two macroblock walks = 1 << lpm_shift (hdr_lanes_shift)
 };
 
 __device__ __forceinline__ void hdr_count_body(int vb, const Params &a, uint32_t *cnt, uint32_t *partial) {
     __shared__ uint32_t s_stat[NSTAT];
     for (int i = threadIdx.x; i < NSTAT; i += 256) s_stat[i] = 0;
     __syncthreads();
-    // Every macroblock takes its own path through the header template, so the lanes of a wavefront serialise; with one
-    // macroblock per SIXTEEN lanes a wavefront walks 4 paths instead of 64 and the frame spreads over sixteen times as
-    // many wavefronts (104 us with one per lane, 47 us with one per four lanes at 1080p).
-    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x / HDR_LANES_PER_MB);
-    if ((threadIdx.x % HDR_LANES_PER_MB) == 0 && mb < a.mbs) {
+    const int mb = vb * hdr_mb_per_wg(a.lpm_shift) + ((int)threadIdx.x >> a.lpm_shift);
+    if ((threadIdx.x & ((1u << a.lpm_shift) - 1u)) == 0 && mb < a.mbs) {
         CountSink s;
         s.stat = s_stat;
         mb_header(a.v, mb, a.key != 0, k_kf_bmode_probs, s);
@@ -320,8 +324,8 @@ __device__ __forceinline__ void hdr_emit_body(int vb, int nvb, const Params &a, 
     __shared__ uint8_t s_sym[64];
     if (threadIdx.x < 64) s_sym[threadIdx.x] = sym[threadIdx.x];
     __syncthreads();
-    const int mb = vb * HDR_MB_PER_WG + (threadIdx.x / HDR_LANES_PER_MB);
-    if ((threadIdx.x % HDR_LANES_PER_MB) != 0 || mb >= a.mbs || plan->overflow) return;
+    const int mb = vb * hdr_mb_per_wg(a.lpm_shift) + ((int)threadIdx.x >> a.lpm_shift);
+    if ((threadIdx.x & ((1u << a.lpm_shift) - 1u)) != 0 || mb >= a.mbs || plan->overflow) return;
     EmitSink s{bools + info[0] + offs[mb], s_sym};
     mb_header(a.v, mb, a.key != 0, k_kf_bmode_probs, s);
 }
@@ -362,7 +366,7 @@ void launch_hdr_encode(hipStream_t s, const MBOut &o, const int32_t *is_inter, c
                        const int32_t *strength, const uint32_t *probs, const uint32_t *denom0, const EntBuffers &eb, uint32_t *partial,
                        uint8_t *sym, uint32_t *info, int mbw, int mbh, bool code) {
     const hdr::Params a = make_hdr_params(o, is_inter, modes, f, d_sd, strength, probs, denom0, eb, mbw, mbh);
-    const int nwg = (a.mbs + hdr::HDR_MB_PER_WG - 1) / hdr::HDR_MB_PER_WG;
+    const int nwg = (a.mbs + hdr::hdr_mb_per_wg(a.lpm_shift) - 1) / hdr::hdr_mb_per_wg(a.lpm_shift);
     hipLaunchKernelGGL(hdr::k_hdr_count, dim3(nwg), dim3(256), 0, s, a, eb.offs, partial);
     hipLaunchKernelGGL(hdr::k_hdr_frame, dim3(1), dim3(256), 0, s, a, partial, eb.offs, eb.bools, sym, eb.plan, info);
     hipLaunchKernelGGL(hdr::k_hdr_emit, dim3(nwg), dim3(256), 0, s, a, eb.offs, sym, eb.plan, info, eb.bools,
@@ -390,6 +394,7 @@ static hdr::Params make_hdr_params_impl(const MBOut &o, const int32_t *is_inter,
     a.cap_bools = eb.cap_bools;
     a.cap_chunks = eb.cap_chunks;
     a.cap_words = eb.cap_words;
+    a.lpm_shift = hdr::HDR_LPM_SHIFT_ONE_VIDEO;
     return a;
 }
 
