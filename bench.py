@@ -839,6 +839,12 @@ def main():
         # (at least 40 frames per chunk: the leg starts from an idle part with its threads 200 us apart, and over 20 frames that start
         # is 3 % of the rate -- 52.9 against 54.3 M MB/s at 40 and 54.8 at 120 on one box)
         out["with_bitstream"] = bitstream_leg(leg, max(40, args.steps))
+        # ... and where the chunks stand after the leg, against the CPU oracle loop again (the frames' bytes are held against an un-batched
+        # driver inside the leg; the reconstructions they leave behind against the committed table)
+        oc = leg.oracle_check()
+        out["with_bitstream"]["self_check_against_the_oracle"] = oc
+        if oc and not oc["identical"] and not experiment_build:
+            raise SystemExit(f"bench.py: self-check FAILED -- after the frames-out leg chunks do not stand on the oracle loop's reconstruction: {oc}")
     host_frames = leg.host_frames
     if run_children:
         if rank == 0:

@@ -38,7 +38,7 @@ SEQUENCES = {"config3_4k": dict(W0=3840, H0=2160, seed=1, frames=300, gop=150, s
 for _r in range(8):
     SEQUENCES[f"config5_rank{_r}"] = dict(W0=1920, H0=1080, seed=1 + _r, frames=300, gop=1 << 30, start=0)
 SEQUENCES["selftest"] = dict(W0=180, H0=140, seed=5, frames=14, gop=9, start=0)      # (seconds: what the CPU test suite regenerates in full)
-TABLES = {"chunks_1920x1080": dict(W0=1920, H0=1080, seed=1, frames=96), "chunks_3840x2160": dict(W0=3840, H0=2160, seed=1, frames=40),
+TABLES = {"chunks_1920x1080": dict(W0=1920, H0=1080, seed=1, frames=176), "chunks_3840x2160": dict(W0=3840, H0=2160, seed=1, frames=40),
           "chunks_1280x720_last_only": dict(W0=1280, H0=720, seed=1, frames=48, refs="last")}
 
 
