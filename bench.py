@@ -611,6 +611,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VP8_BENCH_ALL_RANKS_ON_DEVICE"):     # test hook (tests/test_gpu_multirank_standin.py): several ranks on ONE GPU, over the stand-in transport
+        local = int(os.environ["VP8_BENCH_ALL_RANKS_ON_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # ONE GPU runtime per process and NO GPU framework in it, at every N: the synthetic frames live in memory the library allocates

@@ -253,3 +253,23 @@ def test_the_library_sets_the_hardware_queue_count_when_it_is_loaded(tmp_path):
     assert out == ["7", "7", "7"], out
     needed = subprocess.run(["readelf", "-d", build.LIB], capture_output=True, text=True).stdout
     assert "librccl" not in needed, "RCCL must be resolved lazily (dlopen), not linked"
+
+
+def test_the_stand_in_transport_exports_what_the_library_resolves(tmp_path):
+    """tests/standin_rccl/standin_rccl.cpp (the shared-memory stand-in for RCCL that lets tests/test_gpu_multirank_standin.py run several
+    ranks on one GPU) builds with g++ alone and exports every `nccl*` name csrc/api_shard.hip looks up with dlsym -- read from the
+    source's RCCL_SYM(...) list, so a twelfth entry point there cannot be forgotten here."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("needs g++ and the ROCm headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "vp8oclenc_amd", "csrc", "api_shard.hip")).read()
+    wanted = {"nccl" + m for m in re.findall(r"RCCL_SYM\((\w+)\);", src)}
+    assert len(wanted) >= 11, wanted
+    so = str(tmp_path / "standin_rccl.so")
+    subprocess.run(["g++", "-shared", "-fPIC", "-O2", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    os.path.join(root, "tests", "standin_rccl", "standin_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], check=True)
+    exported = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.splitlines() if l.strip()}
+    assert wanted <= exported, wanted - exported
