@@ -23,6 +23,8 @@ Prints ONE JSON line on rank 0 with, besides the contract's fields,
   cpu_baseline   the CPU oracle (oracle/vp8_oracle.c, OpenMP) on a bounded sample of the same workload, and the reference's own
                  kernels compiled for x86 on one core                                                   (N = 1 only)
   with_bitstream the same frames with finished VP8 frames delivered to host memory                     (N = 1 only)
+  from_host_memory  the rate WITH the host-device link in it: every source frame copied in from page-locked host memory inside the
+                 timed loop (vp8hip_batch_upload_current), without and with the finished frames delivered back   (N = 1 only)
 The legs that are ONE or TWO videos coded frame after frame, and the other geometries, run in a child process per rank (--child-legs;
 a process keeps every hardware queue it ever used; and a leg that dies -- destroying dozens of contexts has, rarely,
 ended a process inside the runtime -- takes only itself along: the child hands every finished leg over at once, the parent keeps
@@ -167,6 +169,7 @@ class Leg:
         self.src_kw = src
         self.dev_frames = [tuple(api.to_device(p, device) for p in f) for f in source]     # (the library's own allocator: no second GPU runtime in the process)
         self.ptrs = [tuple(p.data_ptr() for p in f) for f in self.dev_frames]
+        self.source, self.pinned, self.host_ptrs = source, [], None
         self.drv, self.t, self.batches = [], [], []
         self.frames = self.refsum = self.keys = 0
         if G == 0:
@@ -247,6 +250,15 @@ class Leg:
         for k in range(self.G):
             self.step_one(k)
 
+    def pin_host_frames(self):
+        """the nd source frames once more in page-locked HOST memory (the from_host_memory legs: every frame crosses the link on its way in)"""
+        if self.host_ptrs is None:
+            import numpy as np
+            # (a frame's planes end to end, as a Y4M reader or a decoder holds an I420 frame: one copy per frame)
+            self.pinned = [(self.api.HostBuffer(np.concatenate([np.ascontiguousarray(p).reshape(-1) for p in f]), self.device),) for f in self.source]
+            self.host_ptrs = [(b[0].data_ptr(), b[0].data_ptr() + f[0].size, b[0].data_ptr() + f[0].size + f[1].size) for b, f in zip(self.pinned, self.source)]
+        return self.host_ptrs
+
     def refs_searched(self):
         return sum(d.stats().refs_searched for d in self.drv)
 
@@ -276,8 +288,8 @@ class Leg:
         self.s2_clock = [sum(v) for v in zip(*[d.hip.profile_read_search2_clock() for d in self.drv])]
         return tot, n, ghz / max(n, 1)
 
-    def run(self, steps, barrier=None):
-        """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame)"""
+    def run(self, steps, barrier=None, host=False):
+        """time `steps` steps; returns (seconds, host enqueue seconds, refs per frame).  host: the frames come from host memory (batches only)"""
         sync = barrier or (lambda: self.api.device_synchronize(self.device))
         self.frames = self.refsum = self.keys = 0
         refs0 = self.refs_searched()
@@ -288,8 +300,8 @@ class Leg:
             # joins them): with check_SSIM in the loop a group's next frame waits for the verdict on its previous one, and a single
             # thread that serves the groups in turn couples them -- a late verdict holds up seven other streams (same box, M MB/s:
             # one thread 55.3-58.9, a thread per group 60.3-60.4, check_SSIM off 60.7-60.9).
-            keys = self.api.NativeBatch.encode_frames_device_all([nb for _, nb in self.batches], steps, self.ptrs,
-                                                                 [[self.t[k] for k in members] for members, _ in self.batches])
+            keys = self.api.NativeBatch.encode_frames_device_all([nb for _, nb in self.batches], steps, self.pin_host_frames() if host else self.ptrs,
+                                                                 [[self.t[k] for k in members] for members, _ in self.batches], host=host)
             for (members, _), kk in zip(self.batches, keys):
                 for i, k in enumerate(members):
                     self.t[k] += steps
@@ -314,10 +326,10 @@ class Leg:
         for d in self.drv:
             d.close()
         self.drv = []
-        for f in self.dev_frames:
+        for f in self.dev_frames + self.pinned:
             for p in f:
                 p.free()
-        self.dev_frames = []
+        self.dev_frames, self.pinned = [], []
 
     def oracle_check(self):
         """EVERY chunk's filtered reconstruction, as it stands now, against the CPU oracle loop: a chunk is a closed GOP that started
@@ -847,6 +859,31 @@ def main():
         out["with_bitstream"]["self_check_against_the_oracle"] = oc
         if oc and not oc["identical"] and not experiment_build:
             raise SystemExit(f"bench.py: self-check FAILED -- after the frames-out leg chunks do not stand on the oracle loop's reconstruction: {oc}")
+        if leg.batches and not os.environ.get("VP8_BENCH_PY_BITSTREAM"):
+            # the same two loops with the host-device link in them: every source frame copied in from page-locked host memory inside the
+            # timed loop (vp8hip_batch_upload_current: a copy stream per batch, two staging buffers per member), first without, then with
+            # the finished frames going back; the frames' bytes are held against an un-batched driver fed from DEVICE memory, the
+            # reconstructions against the oracle's table
+            hs = 40      # (with the legs before it the driver's command stays inside the oracle's table of 176 frames per chunk)
+            leg.pin_host_frames()
+            el_h, _, _ = leg.run(hs, host=True)
+            oc_in = leg.oracle_check()
+            both = bitstream_leg(leg, hs, host=True)
+            oc_both = leg.oracle_check()
+            src_bytes = leg.source_size[0] * leg.source_size[1] * 3 // 2
+            out["from_host_memory"] = {
+                "frames_in": {"value": round(leg.mbs * hs * leg.G / el_h, 1), "unit": "macroblocks/s", "fps": round(hs * leg.G / el_h, 1),
+                              "host_to_device_GBs": round(src_bytes * hs * leg.G / el_h / 1e9, 2), "self_check_against_the_oracle": oc_in},
+                "frames_in_and_out": {"value": both["value"], "unit": "macroblocks/s", "fps": both["fps"], "avg_frame_bytes": both["avg_frame_bytes"],
+                                      "host_to_device_GBs": round(src_bytes * both["fps"] / 1e9, 2), "self_check": both["self_check"],
+                                      "self_check_against_the_oracle": oc_both},
+                "source_bytes_per_frame": src_bytes, "frames": hs * leg.G,
+                "what": "the headline's chunks and native loop with every source frame copied in from page-locked host memory inside the timed region "
+                        "(vp8hip_batch_upload_current, the reference's clEnqueueWriteBuffer at vp8enc.cpp:386-388), and with the finished frames "
+                        "delivered to host memory as well: the whole-job rates WITH the host-device link in them.  Never `value`."}
+            for o in (oc_in, oc_both):
+                if o and not o["identical"] and not experiment_build:
+                    raise SystemExit(f"bench.py: self-check FAILED -- after a from_host_memory leg chunks do not stand on the oracle loop's reconstruction: {o}")
     host_frames = leg.host_frames
     if run_children:
         if rank == 0:
@@ -965,9 +1002,9 @@ def issue_roofline(W, H, nrefs, ms_frame, prof, held_clock_ghz=None):
     return out
 
 
-def bitstream_leg(leg, nb):
+def bitstream_leg(leg, nb, host=False):
     """the same chunks with finished VP8 frames delivered to host memory (vp8drv_get_frame: the whole entropy stage on the
-    device), one host thread per GOP chunk"""
+    device), one host thread per GOP chunk.  host: the source frames come from page-locked host memory as well (native loop only)"""
     import threading
     G = leg.G
     nbytes = [0] * G
@@ -1002,7 +1039,8 @@ def bitstream_leg(leg, nb):
     if leg.batches and not os.environ.get("VP8_BENCH_PY_BITSTREAM"):
         # the native loop: a host thread per batch, every frame coded and delivered (vp8drv_batches_encode_frames_device with bytes_out)
         t_before = list(leg.t)
-        _, nbo, chk = leg.api.NativeBatch.encode_frames_device_all([b for _, b in leg.batches], nb, leg.ptrs, [[leg.t[k] for k in m] for m, _ in leg.batches], frames_out="check")
+        _, nbo, chk = leg.api.NativeBatch.encode_frames_device_all([b for _, b in leg.batches], nb, leg.pin_host_frames() if host else leg.ptrs,
+                                                                   [[leg.t[k] for k in m] for m, _ in leg.batches], frames_out="check", host=host)
         for (members, _), row, crow in zip(leg.batches, nbo, chk):
             for i, k in enumerate(members):
                 leg.t[k] += nb

@@ -386,6 +386,16 @@ typedef struct vp8hip_batch vp8hip_batch;
 int vp8hip_batch_create(vp8hip_batch **out, vp8hip_ctx *const *ctxs, int n);
 void vp8hip_batch_destroy(vp8hip_batch *b);      /* the contexts stay, each back on its own stream; destroy a batch before its members */
 int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v);
+/* The same from HOST memory -- the reference's own hand-over (clEnqueueWriteBuffer of the frame it has read, vp8enc.cpp:386-388) for a
+ * batch: tight planes of the source size, copied on a stream of the batch's own into staging buffers (two per member, made on the first
+ * call) and packed from there.  With page-locked planes (vp8hip_host_alloc) the copies are asynchronous and run beside what the batch
+ * still has on the device (the previous frame's loop filter); pageable planes work and are copied before the call returns.  The
+ * planes must stay unchanged until the NEXT vp8hip_batch_upload_current of this batch has returned, or its contexts are synchronised. */
+int vp8hip_batch_upload_current(vp8hip_batch *b, const int *active, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v);
+/* The NEXT frame's planes started on their way early (y[i] NULL: nothing for member i): the following vp8hip_batch_upload_current, given the
+ * same planes, finds them in its staging buffers and copies nothing -- the copies had a whole frame's time instead of standing in front of
+ * the frame's first launch.  The planes stay unchanged until that vp8hip_batch_upload_current has returned. */
+int vp8hip_batch_prefetch_current(vp8hip_batch *b, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v);
 int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min);
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);
@@ -403,7 +413,7 @@ const char *vp8hip_status_string(int status);
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
  * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
  * vp8drv_frame_check folds position in (4: its values change). */
-#define VP8HIP_ABI_VERSION 4003
+#define VP8HIP_ABI_VERSION 4004
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with
@@ -425,6 +435,9 @@ int vp8hip_device_free(int device_ordinal, void *p);
 int vp8hip_device_upload(int device_ordinal, void *dst, const void *src, size_t bytes);
 int vp8hip_device_download(int device_ordinal, void *dst, const void *src, size_t bytes);
 int vp8hip_device_synchronize(int device_ordinal);
+/* page-locked host memory (hipHostMalloc): source planes handed to vp8hip_upload_* / vp8hip_batch_upload_current from it are copied asynchronously */
+int vp8hip_host_alloc(int device_ordinal, size_t bytes, void **out);
+int vp8hip_host_free(int device_ordinal, void *p);
 int vp8hip_device_mem_info(int device_ordinal, size_t *free_bytes, size_t *total_bytes);
 /* "dddd:bb:dd.f" of the device (for pinning the host threads to its NUMA node); len >= 16 */
 int vp8hip_device_pci_bus_id(int device_ordinal, char *out, int len);

@@ -116,6 +116,10 @@ int vp8drv_batch_create(vp8drv_batch **out, vp8drv *const *drv, int n);
 void vp8drv_batch_destroy(vp8drv_batch *b);      /* the drivers stay */
 int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL = all; 0 = this member sits the call out */,
                                      const void *const *y, const void *const *u, const void *const *v, const int *force_key, int *was_key);
+/* ... with the members' frames in host memory (vp8hip_batch_upload_current: tight planes of the source size, page-locked for the copies
+ * to be asynchronous, unchanged until the next call on this batch has returned) */
+int vp8drv_batch_encode_frame_host(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
+                                   const int *force_key, int *was_key);
 /* vp8drv_get_frame_begin for the members' frames in one set of launches (src/vp8enc.cpp:48-94 for up to four chunks at
  * once); then vp8drv_get_frame_end on every member */
 int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members);
@@ -144,6 +148,11 @@ int vp8drv_batches_encode_frame_device(vp8drv_batch *const *batches, int nbatche
  * Returns the first error of any batch, or VP8HIP_OK. */
 int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
                                         const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out);
+/* The same with the nd frames in HOST memory ({y, u, v} tight planes of the source size; page-locked -- vp8hip_host_alloc -- for the copies
+ * to overlap the device's work): every frame crosses the host-device link on its way in (vp8hip_batch_upload_current), and with bytes_out
+ * on its way out as well -- the whole-job rate WITH the link in it, the reference's own hand-over (vp8enc.cpp:386-388, 476-481). */
+int vp8drv_batches_encode_frames_host(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                      const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out);
 /* ONE video, `nframes` frames, frame after frame with the frames out -- the loop of scripts/native/y4m_to_ivf.cpp for frames that are
  * already in device memory: encode(t), take frame t - 1's bytes, enqueue frame t's entropy stage, take frame t's verdict; frame t
  * is frames[(start + t) % nd].  With overlap_filter the stage of a frame runs on a stream of its own beside its loop filter and the

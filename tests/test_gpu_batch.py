@@ -142,3 +142,67 @@ def test_a_batch_members_parameter_scan_is_there_when_somebody_asks_before_the_s
     lib.vp8hip_batch_destroy(hb)
     for m in members + alone:
         m.close()
+
+
+@pytest.mark.parametrize("W,H,src,pinned", [(320, 192, None, True), (336, 256, (330, 250), True), (640, 352, None, False)])
+def test_batches_fed_from_host_memory_give_the_frames_of_batches_fed_from_device_memory(W, H, src, pinned):
+    """vp8hip_batch_upload_current / vp8drv_batch_encode_frame_host / vp8drv_batches_encode_frames_host: the members' frames copied in
+    from HOST memory (page-locked: asynchronous copies on the batch's copy stream, two staging buffers per member, the pack behind
+    the copies and the copies behind the pack that last read their buffer; pageable: copied before the call returns) -- frame by frame
+    with members sitting a call out, and through the native loop with frames out: the same bytes, the same reconstructions, as the same
+    batches fed from device memory.  A source smaller than the coded size (copy_with_padding on the device, encIO.h:141-196) included.
+    Reference hand-over: vp8enc.cpp:386-388."""
+    nd, frames = 6, 9
+    sw, sh = src if src else (W, H)
+    seq = SynthSequence(sw if src else W, sh if src else H, seed=83)
+    planes = []
+    for t in range(nd):
+        y, u, v = seq.frame(t)
+        planes.append((np.ascontiguousarray(y[:sh, :sw]), np.ascontiguousarray(u[:sh // 2, :sw // 2]), np.ascontiguousarray(v[:sh // 2, :sw // 2])))
+    dev = [tuple(api.to_device(p) for p in f) for f in planes]
+    dptr = [tuple(p.data_ptr() for p in f) for f in dev]
+    if pinned and not src:       # a frame's planes end to end in ONE page-locked buffer (one copy per frame), or a buffer per plane (three)
+        host = [(api.HostBuffer(np.concatenate([p.reshape(-1) for p in f])),) for f in planes]
+        hptr = [(h[0].data_ptr(), h[0].data_ptr() + f[0].size, h[0].data_ptr() + f[0].size + f[1].size) for h, f in zip(host, planes)]
+    else:
+        host = [tuple(api.HostBuffer(p) for p in f) for f in planes] if pinned else None
+        hptr = [tuple(p.data_ptr() for p in f) for f in host] if pinned else [tuple(p.ctypes.data for p in f) for f in planes]
+    cfg = dict(gop_size=5, altref_range=2, num_partitions=2, device_params=1, check_ssim=1, qi_min=30, qi_max=100, ssim_target=0.9)
+    if src:
+        cfg.update(src_width=sw, src_height=sh)
+    starts = [[0, 2, 4], [1, 3, 5]]
+    a = [[api.NativeDriver(W, H, **cfg) for _ in row] for row in starts]
+    b = [[api.NativeDriver(W, H, **cfg) for _ in row] for row in starts]
+    na, nb = [api.NativeBatch(r) for r in a], [api.NativeBatch(r) for r in b]
+    pos = [list(r) for r in starts]
+    for t in range(4):            # frame by frame; in call 2 the middle member sits out
+        on = [True, t != 2, True]
+        for k in range(2):
+            ka = na[k].encode_frame_device([dptr[pos[k][i] % nd] for i in range(3)], on)
+            kb = nb[k].encode_frame_host([hptr[pos[k][i] % nd] for i in range(3)], on)
+            assert ka == kb, (t, k)
+            na[k].get_frames_begin(on)
+            nb[k].get_frames_begin(on)
+            for i in range(3):
+                if on[i]:
+                    assert a[k][i].get_frame_end() == b[k][i].get_frame_end(), (t, k, i)
+                    pos[k][i] += 1
+    ka, ba, ca = api.NativeBatch.encode_frames_device_all(na, frames, dptr, pos, frames_out="check")
+    kb, bb, cb = api.NativeBatch.encode_frames_device_all(nb, frames, hptr, pos, frames_out="check", host=True)
+    assert (ka, ba, ca) == (kb, bb, cb)          # key frames, bytes and the fold over every delivered frame's bytes, per member
+    kb2 = api.NativeBatch.encode_frames_device_all(nb, 3, hptr, [[p + frames for p in r] for r in pos], host=True)      # ... and without frames out
+    ka2 = api.NativeBatch.encode_frames_device_all(na, 3, dptr, [[p + frames for p in r] for r in pos])
+    assert ka2 == kb2
+    for k in range(2):
+        for i in range(3):
+            a[k][i].resolve(); b[k][i].resolve()
+            for p_, q_ in zip(a[k][i].hip.download_last(), b[k][i].hip.download_last()):
+                assert np.array_equal(p_, q_), (k, i)
+    for n_ in na + nb:
+        n_.close()
+    for row in a + b:
+        for d in row:
+            d.close()
+    for f in dev + (host or []):
+        for p in f:
+            p.free()

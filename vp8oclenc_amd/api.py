@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_frame_check", "vp8drv_encode_video_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_batches_encode_frames_host", "vp8drv_batch_encode_frame_host", "vp8hip_batch_upload_current", "vp8hip_batch_prefetch_current", "vp8hip_host_alloc", "vp8hip_host_free", "vp8drv_frame_check", "vp8drv_encode_video_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4003  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 4004  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 SHARPNESS_ON_DEVICE = -2 ** 31   # VP8HIP_SHARPNESS_ON_DEVICE
@@ -177,6 +177,36 @@ class DeviceBuffer:
     def free(self):
         if getattr(self, "ptr", None):
             self.lib.vp8hip_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostBuffer:
+    """Page-locked host memory (vp8hip_host_alloc): planes handed to vp8hip_batch_upload_current from it are copied asynchronously."""
+
+    def __init__(self, a: np.ndarray, device: int = 0):
+        a = np.ascontiguousarray(a)
+        self.lib, self.device, self.nbytes = load_library(), device, int(a.nbytes)
+        p = C.c_void_p()
+        self.lib.vp8hip_host_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        self.lib.vp8hip_host_free.argtypes = [C.c_int, C.c_void_p]
+        rc = self.lib.vp8hip_host_alloc(device, self.nbytes, C.byref(p))
+        if rc != 0:
+            raise Vp8HipError(f"vp8hip_host_alloc({self.nbytes}): {self.lib.vp8hip_status_string(rc).decode()}")
+        self.ptr = p.value
+        C.memmove(self.ptr, a.ctypes.data, self.nbytes)
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.vp8hip_host_free(self.device, self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -590,18 +620,24 @@ class NativeBatch:
         self._key = (C.c_int * n)()
         self._members = (C.c_int * n)()
 
-    def encode_frame_device(self, planes, members=None):
+    def encode_frame_device(self, planes, members=None, host=False):
         """planes[i] = (d_y, d_u, d_v) device pointers of member i's frame (None for a member that sits this call out, or
-        members[i] false); returns the list of "was a key frame" flags"""
+        members[i] false); returns the list of "was a key frame" flags.  host=True: the pointers are HOST addresses
+        (vp8drv_batch_encode_frame_host; the planes stay unchanged until the next call has returned)."""
         for i, p in enumerate(planes):
             on = p is not None and (members is None or members[i])
             self._members[i] = 1 if on else 0
             if on:
                 self._ptrs[0][i], self._ptrs[1][i], self._ptrs[2][i] = p
-        rc = self.lib.vp8drv_batch_encode_frame_device(self.h, self._members, self._ptrs[0], self._ptrs[1], self._ptrs[2], None, self._key)
+        fn = self.lib.vp8drv_batch_encode_frame_host if host else self.lib.vp8drv_batch_encode_frame_device
+        fn.argtypes = self.lib.vp8drv_batch_encode_frame_device.argtypes
+        rc = fn(self.h, self._members, self._ptrs[0], self._ptrs[1], self._ptrs[2], None, self._key)
         if rc < 0:
-            raise Vp8HipError(f"vp8drv_batch_encode_frame_device: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
+            raise Vp8HipError(f"vp8drv_batch_encode_frame_{'host' if host else 'device'}: {self.lib.vp8hip_status_string(rc).decode()} ({rc})")
         return [bool(k) for k in self._key]
+
+    def encode_frame_host(self, planes, members=None):
+        return self.encode_frame_device(planes, members, host=True)
 
     def ready(self) -> bool:
         """no member's check_SSIM verdict is still on its way: the next encode_frame_device would not wait (vp8drv_batch_ready)"""
@@ -624,9 +660,10 @@ class NativeBatch:
             self.h = None
 
     @staticmethod
-    def encode_frames_device_all(batches, nframes, frame_ptrs, starts, frames_out=False):
+    def encode_frames_device_all(batches, nframes, frame_ptrs, starts, frames_out=False, host=False):
         """nframes frames on every batch, one native host thread per batch (vp8drv_batches_encode_frames_device): frame t of member i of
-        batch k = frame_ptrs[(starts[k][i] + t) % len(frame_ptrs)], frame_ptrs = [(d_y, d_u, d_v)].  Returns key-frame counts [k][i]."""
+        batch k = frame_ptrs[(starts[k][i] + t) % len(frame_ptrs)], frame_ptrs = [(d_y, d_u, d_v)].  Returns key-frame counts [k][i].
+        host=True: the frames are in HOST memory (HostBuffer) and cross the link on their way in (vp8drv_batches_encode_frames_host)."""
         lib = batches[0].lib
         n, nd = len(batches), len(frame_ptrs)
         F = ((C.c_void_p * 3) * nd)(*[(C.c_void_p * 3)(*p) for p in frame_ptrs])
@@ -635,13 +672,14 @@ class NativeBatch:
         bo = [(C.c_uint64 * b.n)() for b in batches]
         co = [(C.c_uint64 * b.n)() for b in batches]       # vp8drv_frame_check folded over every delivered frame, per member
         IP, UP = C.POINTER(C.c_int), C.POINTER(C.c_uint64)
-        lib.vp8drv_batches_encode_frames_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP), C.POINTER(UP), C.POINTER(UP)]
-        rc = lib.vp8drv_batches_encode_frames_device((C.c_void_p * n)(*[b.h for b in batches]), n, int(nframes), C.cast(F, C.c_void_p), nd,
+        fn = lib.vp8drv_batches_encode_frames_host if host else lib.vp8drv_batches_encode_frames_device
+        fn.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(IP), C.POINTER(IP), C.POINTER(UP), C.POINTER(UP)]
+        rc = fn((C.c_void_p * n)(*[b.h for b in batches]), n, int(nframes), C.cast(F, C.c_void_p), nd,
                                                       (IP * n)(*[C.cast(a, IP) for a in st]), (IP * n)(*[C.cast(a, IP) for a in ko]),
                                                       (UP * n)(*[C.cast(a, UP) for a in bo]) if frames_out else None,
                                                       (UP * n)(*[C.cast(a, UP) for a in co]) if frames_out else None)
         if rc < 0:
-            raise Vp8HipError(f"vp8drv_batches_encode_frames_device: {lib.vp8hip_status_string(rc).decode()} ({rc})")
+            raise Vp8HipError(f"vp8drv_batches_encode_frames_{'host' if host else 'device'}: {lib.vp8hip_status_string(rc).decode()} ({rc})")
         if frames_out == "check":
             return [list(a) for a in ko], [list(a) for a in bo], [list(a) for a in co]
         if frames_out:

@@ -120,6 +120,14 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the
         hipStreamSynchronize(b->ent);
         hipStreamDestroy(b->ent);
     }
+    if (b->copy) {
+        hipStreamSynchronize(b->copy);
+        hipStreamDestroy(b->copy);
+        hipEventDestroy(b->ev_copied);
+        hipEventDestroy(b->ev_packed[0]);
+        hipEventDestroy(b->ev_packed[1]);
+        for (int i = 0; i < b->n; ++i) { hipFree(b->stage[i][0]); hipFree(b->stage[i][1]); }
+    }
     if (b->ev_ent_fork) hipEventDestroy(b->ev_ent_fork);
     if (b->ev_ent) hipEventDestroy(b->ev_ent);
     for (int i = 0; i < b->n; ++i) b->c[i]->frame_event = nullptr;
@@ -134,10 +142,78 @@ void vp8hip_batch_destroy(vp8hip_batch *b) {   // the contexts stay (destroy the
     delete b;
 }
 
-int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v) {
+// one frame's planes into a staging buffer: ONE copy when they lie end to end in the host's memory (an I420 frame as a file reader or a
+// decoder holds it), three otherwise
+static int stage_copy(vp8hip_batch *b, uint8_t *d, const void *y, const void *u, const void *v, size_t ny, size_t nc) {
+    vp8hip_ctx *c0 = b->c[0];
+    const uint8_t *py = static_cast<const uint8_t *>(y);
+    if (u == py + ny && v == py + ny + nc) {
+        HIPCHK(c0, hipMemcpyAsync(d, y, ny + 2 * nc, hipMemcpyHostToDevice, b->copy));
+        return VP8HIP_OK;
+    }
+    HIPCHK(c0, hipMemcpyAsync(d, y, ny, hipMemcpyHostToDevice, b->copy));
+    HIPCHK(c0, hipMemcpyAsync(d + ny, u, nc, hipMemcpyHostToDevice, b->copy));
+    HIPCHK(c0, hipMemcpyAsync(d + ny + nc, v, nc, hipMemcpyHostToDevice, b->copy));
+    return VP8HIP_OK;
+}
+
+// the copy stream, its events and the members' staging buffers (two each), made on first use and again when the source size has changed
+static int batch_stage_ready(vp8hip_batch *b) {
+    vp8hip_ctx *c0 = b->c[0];
+    const int sw = c0->src_w ? c0->src_w : c0->W, sh = c0->src_h ? c0->src_h : c0->H;
+    const size_t bytes = (size_t)sw * sh + 2 * (size_t)(sw / 2) * (sh / 2);
+    if (!b->copy) {
+        HIPCHK(c0, hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking));
+        HIPCHK(c0, hipEventCreateWithFlags(&b->ev_copied, hipEventDisableTiming));
+        HIPCHK(c0, hipEventCreateWithFlags(&b->ev_packed[0], hipEventDisableTiming));
+        HIPCHK(c0, hipEventCreateWithFlags(&b->ev_packed[1], hipEventDisableTiming));
+    }
+    if (b->stage_bytes == bytes) return VP8HIP_OK;
+    // (first call, or the source size has changed: nothing in flight reads the old buffers after this)
+    HIPCHK(c0, hipStreamSynchronize(b->copy));
+    HIPCHK(c0, hipStreamSynchronize(b->stream));
+    if (b->prep) HIPCHK(c0, hipStreamSynchronize(b->prep));
+    for (int i = 0; i < b->n; ++i)
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(b->stage[i][k]);
+            b->stage[i][k] = nullptr;
+            HIPCHK(c0, hipMalloc(&b->stage[i][k], bytes));
+        }
+    b->stage_bytes = bytes;
+    b->packed_valid[0] = b->packed_valid[1] = false;
+    b->pre_valid = false;
+    return VP8HIP_OK;
+}
+
+// the members' new frames, tight planes in device memory (host == false) or in host memory (copied into the batch's staging buffers first)
+static int batch_set_current(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v, bool host) {
     if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];
     USE_DEVICE_ONLY(c0);
+    const void *sy[MAX_BATCH], *su[MAX_BATCH], *sv[MAX_BATCH];
+    int slot = -1;
+    if (host) {
+        const int rc = batch_stage_ready(b);
+        if (rc) return rc;
+        const int sw = c0->src_w ? c0->src_w : c0->W, sh = c0->src_h ? c0->src_h : c0->H;
+        const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
+        slot = b->stage_idx ^= 1;
+        bool waited = false;
+        for (int i = 0; i < b->n; ++i) {
+            if (active && !active[i]) continue;
+            if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
+            uint8_t *d = b->stage[i][slot];
+            if (!(b->pre_valid && b->pre[i][0] == y[i] && b->pre[i][1] == u[i] && b->pre[i][2] == v[i])) {   // not prefetched: copied now
+                if (!waited && b->packed_valid[slot]) HIPCHK(c0, hipStreamWaitEvent(b->copy, b->ev_packed[slot], 0));   // the pack of two frames ago has read this buffer
+                waited = true;
+                { const int cr = stage_copy(b, d, y[i], u[i], v[i], ny, nc); if (cr) return cr; }
+            }
+            sy[i] = d; su[i] = d + ny; sv[i] = d + ny + nc;
+        }
+        b->pre_valid = false;
+        HIPCHK(c0, hipEventRecord(b->ev_copied, b->copy));
+        y = sy; u = su; v = sv;
+    }
     const Frame *f[MAX_BATCH];
     const void *py[MAX_BATCH], *pu[MAX_BATCH], *pv[MAX_BATCH];
     int n = 0;
@@ -165,10 +241,60 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
         b->prep_pending = true;
         ps = b->prep;
     }
-    Timed t(c0, VP8HIP_K_PACK);
-    launch_pack_batch(ps, f, py, pu, pv, n, c0->src_w, c0->src_h);
+    if (host) HIPCHK(c0, hipStreamWaitEvent(ps, b->ev_copied, 0));
+    {
+        Timed t(c0, VP8HIP_K_PACK);
+        launch_pack_batch(ps, f, py, pu, pv, n, c0->src_w, c0->src_h);
+    }
     HIPCHK(c0, hipGetLastError());
+    if (host) {
+        HIPCHK(c0, hipEventRecord(b->ev_packed[slot], ps));
+        b->packed_valid[slot] = true;
+    }
     return VP8HIP_OK;
+}
+
+int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const void *const *y, const void *const *u, const void *const *v) {
+    return batch_set_current(b, active, y, u, v, false);
+}
+
+// Planes in HOST memory (vp8enc.cpp:386-388, the reference's own hand-over: clEnqueueWriteBuffer from the frame it has read).  The
+// copies are asynchronous when the planes are page-locked (vp8hip_host_alloc) and then overlap the batch's previous frame still on the
+// device; the planes must stay as they are until the NEXT vp8hip_batch_upload_current of this batch has returned (it waits for these
+// copies first) or the batch's contexts have been synchronised.
+// The frame AFTER the one under way, started on its way early: the copies go into the buffers the next vp8hip_batch_upload_current
+// will pack from, and that call, given the same planes, finds them there.  A host that knows its next frame (a decoder's ring, a file
+// reader one frame ahead) calls this right after it has enqueued the current one: the copies then have a whole frame's time.
+int vp8hip_batch_prefetch_current(vp8hip_batch *b, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v) {
+    if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE_ONLY(c0);
+    const int rc = batch_stage_ready(b);
+    if (rc) return rc;
+    const int sw = c0->src_w ? c0->src_w : c0->W, sh = c0->src_h ? c0->src_h : c0->H;
+    const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
+    const int slot = b->stage_idx ^ 1;       // what the next upload will flip to
+    if (b->packed_valid[slot]) HIPCHK(c0, hipStreamWaitEvent(b->copy, b->ev_packed[slot], 0));
+    for (int i = 0; i < b->n; ++i) {
+        b->pre[i][0] = b->pre[i][1] = b->pre[i][2] = nullptr;
+        if (!y[i] || !u[i] || !v[i]) continue;
+        uint8_t *d = b->stage[i][slot];
+        { const int cr = stage_copy(b, d, y[i], u[i], v[i], ny, nc); if (cr) return cr; }
+        b->pre[i][0] = y[i]; b->pre[i][1] = u[i]; b->pre[i][2] = v[i];
+    }
+    HIPCHK(c0, hipEventRecord(b->ev_copied, b->copy));
+    b->pre_valid = true;
+    return VP8HIP_OK;
+}
+
+int vp8hip_batch_upload_current(vp8hip_batch *b, const int *active, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v) {
+    if (!b) return VP8HIP_ERR_ARG;
+    if (b->copy) {
+        (void)hipSetDevice(b->c[0]->device);
+        HIPCHK(b->c[0], hipEventSynchronize(b->ev_copied));     // the previous call's copies have left the host's planes
+    }
+    return batch_set_current(b, active, reinterpret_cast<const void *const *>(y), reinterpret_cast<const void *const *>(u),
+                             reinterpret_cast<const void *const *>(v), true);
 }
 
 // `active[i] == 0` leaves context i out of the stage (a chunk whose frame is a key frame goes through its own

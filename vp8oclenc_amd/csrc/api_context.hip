@@ -743,6 +743,20 @@ int vp8hip_device_synchronize(int device_ordinal) {
     DEVCHK(hipDeviceSynchronize());
     return VP8HIP_OK;
 }
+// page-locked host memory: what makes vp8hip_upload_* / vp8hip_batch_upload_current copies asynchronous (and what finished frames are written into)
+int vp8hip_host_alloc(int device_ordinal, size_t bytes, void **out) {
+    if (!out) return VP8HIP_ERR_ARG;
+    *out = nullptr;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return VP8HIP_OK;
+}
+int vp8hip_host_free(int device_ordinal, void *p) {
+    if (!p) return VP8HIP_OK;
+    DEVCHK(hipSetDevice(device_ordinal));
+    DEVCHK(hipHostFree(p));
+    return VP8HIP_OK;
+}
 int vp8hip_device_mem_info(int device_ordinal, size_t *free_bytes, size_t *total_bytes) {
     if (!free_bytes || !total_bytes) return VP8HIP_ERR_ARG;
     DEVCHK(hipSetDevice(device_ordinal));

@@ -394,8 +394,8 @@ void vp8drv_batch_destroy(vp8drv_batch *b) {
     delete b;
 }
 
-int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
-                                     const int *force_key, int *was_key) {
+static int batch_encode_frame(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
+                              const int *force_key, int *was_key, bool host) {
     if (!b || !y || !u || !v) return VP8HIP_ERR_ARG;
     int key[VP8HIP_MAX_BATCH], active[VP8HIP_MAX_BATCH], zero[VP8HIP_MAX_BATCH] = {};
     int pg[VP8HIP_MAX_BATCH], pa[VP8HIP_MAX_BATCH], ug[VP8HIP_MAX_BATCH], ua[VP8HIP_MAX_BATCH];
@@ -414,7 +414,9 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
         active[i] = !key[i];
         if (was_key) was_key[i] = key[i];
     }
-    DRV_CHK(vp8hip_batch_set_current_device(b->hb, members, y, u, v));          // vp8enc.cpp:386-388, all members in one launch
+    if (host) DRV_CHK(vp8hip_batch_upload_current(b->hb, members, reinterpret_cast<const uint8_t *const *>(y), reinterpret_cast<const uint8_t *const *>(u),
+                                                  reinterpret_cast<const uint8_t *const *>(v)));
+    else DRV_CHK(vp8hip_batch_set_current_device(b->hb, members, y, u, v));          // vp8enc.cpp:386-388, all members in one launch
     int n_inter = 0;
     for (int i = 0; i < b->n; ++i) {
         vp8drv *d = b->d[i];
@@ -459,6 +461,15 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const 
         d->last_altref = d->st.last_was_altref != 0;
     }
     return VP8HIP_OK;
+}
+
+int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
+                                     const int *force_key, int *was_key) {
+    return batch_encode_frame(b, members, y, u, v, force_key, was_key, false);
+}
+int vp8drv_batch_encode_frame_host(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
+                                   const int *force_key, int *was_key) {
+    return batch_encode_frame(b, members, y, u, v, force_key, was_key, true);
 }
 
 int vp8drv_resolve(vp8drv *d) {
@@ -524,8 +535,8 @@ uint64_t vp8drv_frame_check(uint64_t h, const uint8_t *frame, size_t size) {
     return f;
 }
 
-int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
-                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out) {
+static int batches_encode_frames(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                 const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out, bool host) {
     if (!batches || nbatches < 1 || nbatches > 64 || nframes < 0 || !frames || nd < 1 || !start || (check_out && !bytes_out)) return VP8HIP_ERR_ARG;
     for (int k = 0; k < nbatches; ++k)
         if (!batches[k] || batches[k]->n < 1 || !batches[k]->d[0] || !start[k]) return VP8HIP_ERR_ARG;
@@ -549,9 +560,17 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
                     const void *const *f = frames[(start[k][i] + t) % nd];
                     y[i] = f[0]; u[i] = f[1]; v[i] = f[2];
                 }
-                rc[k] = vp8drv_batch_encode_frame_device(b, nullptr, y, u, v, nullptr, key);
+                rc[k] = batch_encode_frame(b, nullptr, y, u, v, nullptr, key, host);
                 if (rc[k] == VP8HIP_OK && keys_out && keys_out[k])   // (a failed call may not have filled key[])
                     for (int i = 0; i < b->n; ++i) keys_out[k][i] += key[i];
+                if (host && rc[k] == VP8HIP_OK && t + 1 < nframes) {   // the next frame's planes on their way while this one is coded
+                    const uint8_t *py[VP8HIP_MAX_BATCH], *pu[VP8HIP_MAX_BATCH], *pv[VP8HIP_MAX_BATCH];
+                    for (int i = 0; i < b->n; ++i) {
+                        const void *const *f = frames[(start[k][i] + t + 1) % nd];
+                        py[i] = static_cast<const uint8_t *>(f[0]); pu[i] = static_cast<const uint8_t *>(f[1]); pv[i] = static_cast<const uint8_t *>(f[2]);
+                    }
+                    rc[k] = vp8hip_batch_prefetch_current(b->hb, py, pu, pv);
+                }
             };
             // A bounded device-side wait that expires inside a frame's loop filter shows in the NEXT frame's verdict at the earliest (the
             // verdict workgroup samples the error word when the filter's launch starts), and nobody comes after the last frame: the call
@@ -592,6 +611,15 @@ int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatch
     for (int k = 0; k < nbatches; ++k)
         if (rc[k] != VP8HIP_OK) return rc[k];
     return VP8HIP_OK;
+}
+
+int vp8drv_batches_encode_frames_device(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                        const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out) {
+    return batches_encode_frames(batches, nbatches, nframes, frames, nd, start, keys_out, bytes_out, check_out, false);
+}
+int vp8drv_batches_encode_frames_host(vp8drv_batch *const *batches, int nbatches, int nframes, const void *const (*frames)[3], int nd,
+                                      const int *const *start, int *const *keys_out, uint64_t *const *bytes_out, uint64_t *const *check_out) {
+    return batches_encode_frames(batches, nbatches, nframes, frames, nd, start, keys_out, bytes_out, check_out, true);
 }
 
 int vp8drv_get_frame(vp8drv *d, uint8_t *out, size_t capacity, size_t *size) {

@@ -164,6 +164,18 @@ struct vp8hip_batch {
     hipStream_t ent = nullptr;           // nullptr: the stage stays in the chain (VP8HIP_BATCH_ENT_STREAM=0)
     hipEvent_t ev_ent_fork = nullptr, ev_ent = nullptr;
     bool ent_fork_fresh = false;         // nothing was enqueued for a member since ev_ent_fork was recorded
+    // vp8hip_batch_upload_current: the members' new frames from HOST memory.  The copies run on a stream of their own (the copy engines,
+    // beside whatever the batch's stream still has: the previous frame's loop filter) into one of two staging buffers per member; the
+    // launch that packs them waits for the copies, the copies for the pack that last read their buffer.
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_packed[2] = {nullptr, nullptr};
+    bool packed_valid[2] = {false, false};
+    uint8_t *stage[vp8::MAX_BATCH][2] = {};
+    size_t stage_bytes = 0;
+    int stage_idx = 0;
+    // vp8hip_batch_prefetch_current: the NEXT frame's planes already on their way into the buffer the next upload will pack from
+    const void *pre[vp8::MAX_BATCH][3] = {};
+    bool pre_valid = false;
 };
 
 #define HIPCHK(c, call)                                  \
