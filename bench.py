@@ -864,8 +864,9 @@ def main():
             # timed loop (vp8hip_batch_upload_current: a copy stream per batch, two staging buffers per member), first without, then with
             # the finished frames going back; the frames' bytes are held against an un-batched driver fed from DEVICE memory, the
             # reconstructions against the oracle's table
-            hs = 40      # (with the legs before it the driver's command stays inside the oracle's table of 176 frames per chunk)
+            hs = 40      # (with the legs before it the driver's command stays inside the oracle's table of 176 frames per chunk: 166)
             leg.pin_host_frames()
+            leg.run(2, host=True)        # untimed: the batches make their copy streams and staging buffers on first use
             el_h, _, _ = leg.run(hs, host=True)
             oc_in = leg.oracle_check()
             both = bitstream_leg(leg, hs, host=True)
