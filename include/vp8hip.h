@@ -64,6 +64,11 @@ void vp8hip_destroy(vp8hip_ctx *ctx);
 
 /* clEnqueueWriteBuffer(current_frame_Y/U/V), vp8enc.cpp:386-388 */
 int vp8hip_upload_current(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* The NEXT frame's planes started on their way early, while the current frame is coded: tight planes of the source size (one copy when
+ * U follows Y and V follows U in memory), asynchronous when they are page-locked (vp8hip_host_alloc), into a staging buffer of the
+ * context's.  The vp8hip_upload_current that names the same three pointers then copies nothing: it packs from the staging buffer, behind
+ * the copy.  The planes stay unchanged until that vp8hip_upload_current has returned.  Touches nothing of the frame under way. */
+int vp8hip_prefetch_current(vp8hip_ctx *ctx, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 /* same, from planes already resident in this device's memory (tight stride); async on the ctx stream */
 int vp8hip_set_current_device(vp8hip_ctx *ctx, const void *d_y, const void *d_u, const void *d_v);
 
@@ -413,7 +418,7 @@ const char *vp8hip_status_string(int status);
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
  * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
  * vp8drv_frame_check folds position in (4: its values change). */
-#define VP8HIP_ABI_VERSION 4004
+#define VP8HIP_ABI_VERSION 4005
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

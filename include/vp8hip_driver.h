@@ -80,6 +80,9 @@ vp8hip_ctx *vp8drv_context(vp8drv *d);   /* for downloads, the entropy stage, pr
 int vp8drv_encode_frame_device(vp8drv *d, const void *d_y, const void *d_u, const void *d_v, int force_key);
 /* same for host planes (blocks for the upload).  With device_params == 0 the host mirror scans y. */
 int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v, int force_key);
+/* The frame AFTER the one just handed in, started on its way to the device (vp8hip_prefetch_current): a reader that is one frame ahead
+ * calls this right after vp8drv_encode_frame_host and hands the same pointers to the next vp8drv_encode_frame_host. */
+int vp8drv_prefetch_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 
 /* With check_ssim: waits for the verdict on the frame just coded and, if it sends the frame back (vp8enc.cpp:443-453), codes it
  * again as a key frame.  Returns 1 if the last frame ended as a key frame, 0 if as an inter frame, < 0 = vp8hip_status.  Implied by

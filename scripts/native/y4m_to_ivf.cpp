@@ -56,7 +56,18 @@ int main(int argc, char **argv) {
     uint8_t fh[32];
     fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, 0), out);     // frame count patched at the end (encIO.h:100-139)
     const size_t ysz = (size_t)W * H, csz = ysz / 4;
-    std::vector<uint8_t> frame(ysz + 2 * csz), bytes((size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20));
+    std::vector<uint8_t> bytes((size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20));
+    // two page-locked frame buffers: while frame t is coded, frame t + 1 is read and started on its way to the device
+    // (vp8drv_prefetch_frame_host), so the copy never stands in front of a frame's first launch
+    const size_t fsz = ysz + 2 * csz;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) CK(vp8hip_host_alloc(0, fsz, reinterpret_cast<void **>(&buf[k])));
+    auto read_frame = [&](uint8_t *dst) -> int {       // get_yuv420_frame, encIO.h:203-254: 1 = a frame, 0 = end of stream, -1 = broken
+        if (fread(dst, 1, fsz, in) != fsz) return 0;
+        uint8_t marker[6];
+        const size_t m = fread(marker, 1, 6, in);
+        return (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) ? -1 : 1;
+    };
     uint32_t n = 0, keys = 0;
     size_t total = 32;
     // One video: the loop filter of a frame runs beside the next frame's input side (vp8hip_filter_overlap), and its entropy stage
@@ -64,13 +75,18 @@ int main(int argc, char **argv) {
     // _end).  The scratch is sized for the densest frame there can be: no frame is ever coded twice.
     CK(vp8hip_reserve_frame_path_dense(vp8drv_context(drv)));
     bool pending = false;
+    int cur = 0;
+    int have = read_frame(buf[cur]);
+    if (have < 0) { fprintf(stderr, "broken stream!\n"); return 1; }
     for (;;) {
-        bool got = fread(frame.data(), 1, frame.size(), in) == frame.size();                 // get_yuv420_frame, encIO.h:203-254
+        const bool got = have > 0;
         if (got) {
-            uint8_t marker[6];
-            const size_t m = fread(marker, 1, 6, in);
-            if (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) { fprintf(stderr, "broken stream!\n"); return 1; }
-            CK(vp8drv_encode_frame_host(drv, frame.data(), frame.data() + ysz, frame.data() + ysz + csz, 0));
+            uint8_t *f = buf[cur];
+            CK(vp8drv_encode_frame_host(drv, f, f + ysz, f + ysz + csz, 0));
+            cur ^= 1;
+            have = read_frame(buf[cur]);               // the next frame, read while this one is coded ...
+            if (have < 0) { fprintf(stderr, "broken stream!\n"); return 1; }
+            if (have > 0) CK(vp8drv_prefetch_frame_host(drv, buf[cur], buf[cur] + ysz, buf[cur] + ysz + csz));      // ... and started on its way
         }
         if (pending) {      // the previous frame's bytes
             size_t size = 0;
@@ -99,6 +115,7 @@ int main(int argc, char **argv) {
     vp8drv_stats st;
     vp8drv_get_stats(drv, &st);
     vp8drv_destroy(drv);
+    for (int k = 0; k < 2; ++k) vp8hip_host_free(0, buf[k]);
     printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes; %d hardware queues\n", argv[2], n, W, H, Wc, Hc, keys,
            st.scene_changes, st.redone_as_key, total, vp8hip_hw_queues());
     return 0;

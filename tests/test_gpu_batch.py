@@ -206,3 +206,49 @@ def test_batches_fed_from_host_memory_give_the_frames_of_batches_fed_from_device
     for f in dev + (host or []):
         for p in f:
             p.free()
+
+
+@pytest.mark.parametrize("W,H,src", [(320, 192, None), (336, 256, (330, 250)), (1920, 1088, (1920, 1080))])
+def test_one_video_with_the_next_frame_prefetched_from_host_memory(W, H, src):
+    """vp8hip_prefetch_current / vp8drv_prefetch_frame_host: while frame t is coded, frame t + 1's planes (page-locked host memory, a frame's
+    planes end to end or apart) are copied into a staging buffer of the context's; the vp8drv_encode_frame_host that names the same
+    pointers packs from there.  One video with the filter on its own stream, frames out: the same bytes as the video fed from device
+    memory -- with a frame that was NOT prefetched and a prefetch that is never used (other pointers follow) in between."""
+    sw, sh = src if src else (W, H)
+    seq = SynthSequence(sw, sh, seed=29)
+    nd, frames = 5, 11
+    planes = []
+    for t in range(nd):
+        y, u, v = seq.frame(t)
+        planes.append((np.ascontiguousarray(y[:sh, :sw]), np.ascontiguousarray(u[:sh // 2, :sw // 2]), np.ascontiguousarray(v[:sh // 2, :sw // 2])))
+    dev = [tuple(api.to_device(p) for p in f) for f in planes]
+    dptr = [tuple(p.data_ptr() for p in f) for f in dev]
+    host, hptr = [], []
+    for t, f in enumerate(planes):
+        if t % 2 == 0:           # end to end (one copy) ...
+            h = api.HostBuffer(np.concatenate([p.reshape(-1) for p in f]))
+            host.append((h,))
+            hptr.append((h.data_ptr(), h.data_ptr() + f[0].size, h.data_ptr() + f[0].size + f[1].size))
+        else:                    # ... or a buffer per plane (three)
+            hs = tuple(api.HostBuffer(p) for p in f)
+            host.append(hs)
+            hptr.append(tuple(h.data_ptr() for h in hs))
+    cfg = dict(gop_size=6, altref_range=2, num_partitions=2, device_params=1, check_ssim=1, overlap_filter=1)
+    if src:
+        cfg.update(src_width=sw, src_height=sh)
+    a, b = api.NativeDriver(W, H, **cfg), api.NativeDriver(W, H, **cfg)
+    for t in range(frames):
+        ka = a.encode_frame_device(*dptr[t % nd])
+        kb = b.encode_frame_host_ptr(*hptr[t % nd])
+        if t == 3:
+            b.prefetch_frame_host_ptr(*hptr[(t + 2) % nd])      # never used: frame t + 1 arrives with other pointers
+        elif t != 6:                                            # (frame 7 arrives without a prefetch)
+            b.prefetch_frame_host_ptr(*hptr[(t + 1) % nd])
+        assert ka == kb, t
+        assert a.get_frame() == b.get_frame(), t
+    for p_, q_ in zip(a.hip.download_last(), b.hip.download_last()):
+        assert np.array_equal(p_, q_)
+    a.close(); b.close()
+    for f in dev + host:
+        for p in f:
+            p.free()

@@ -432,6 +432,15 @@ void vp8hip_destroy(vp8hip_ctx *c) {
             hipEventDestroy(c->ev_ent);
         }
     }
+    if (c->h2d_stream) {
+        hipStreamSynchronize(c->h2d_stream);
+        hipStreamDestroy(c->h2d_stream);
+        hipEventDestroy(c->ev_h2d);
+        hipEventDestroy(c->ev_stage_read[0]);
+        hipEventDestroy(c->ev_stage_read[1]);
+        hipFree(c->h2d_stage[0]);
+        hipFree(c->h2d_stage[1]);
+    }
     if (c->stream) hipStreamSynchronize(c->stream);
     shard_release(c);
     event_pool_put(c->device, c->ev, c->ev_made);
@@ -493,9 +502,68 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     delete c;
 }
 
+// The next frame's planes started on their way while the current frame is coded (vp8hip_ctx.h): tight planes of the source size, one
+// copy when they lie end to end (an I420 frame as a file reader holds it), on a stream of their own into the staging buffer the pack
+// of two frames ago has finished with.  Touches nothing of the frame under way.
+int vp8hip_prefetch_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    USE_DEVICE_ONLY(c);
+    if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    const int sw = c->src_w ? c->src_w : c->W, sh = c->src_h ? c->src_h : c->H;
+    const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
+    if (!c->h2d_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage_read[0], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage_read[1], hipEventDisableTiming));
+    }
+    if (c->h2d_stage_bytes != ny + 2 * nc) {     // first use, or the source size has changed: whatever still reads the old buffers ends first
+        HIPCHK(c, hipStreamSynchronize(c->h2d_stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->lf_stream) HIPCHK(c, hipStreamSynchronize(c->lf_stream));
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(c->h2d_stage[k]);
+            c->h2d_stage[k] = nullptr;
+            HIPCHK(c, hipMalloc(&c->h2d_stage[k], ny + 2 * nc));
+        }
+        c->h2d_stage_bytes = ny + 2 * nc;
+        c->stage_read_valid[0] = c->stage_read_valid[1] = false;
+    }
+    const int slot = c->h2d_idx ^ 1;
+    if (c->stage_read_valid[slot]) HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ev_stage_read[slot], 0));
+    uint8_t *d = c->h2d_stage[slot];
+    if (u == y + ny && v == u + nc) {
+        HIPCHK(c, hipMemcpyAsync(d, y, ny + 2 * nc, hipMemcpyHostToDevice, c->h2d_stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(d, y, ny, hipMemcpyHostToDevice, c->h2d_stream));
+        HIPCHK(c, hipMemcpyAsync(d + ny, u, nc, hipMemcpyHostToDevice, c->h2d_stream));
+        HIPCHK(c, hipMemcpyAsync(d + ny + nc, v, nc, hipMemcpyHostToDevice, c->h2d_stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_h2d, c->h2d_stream));
+    c->h2d_pre[0] = y; c->h2d_pre[1] = u; c->h2d_pre[2] = v;
+    c->h2d_pre_valid = true;
+    return VP8HIP_OK;
+}
+
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
     USE_DEVICE(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
+    if (c->h2d_pre_valid && c->h2d_pre[0] == y && c->h2d_pre[1] == u && c->h2d_pre[2] == v) {
+        // prefetched: the planes are in (or on their way into) the staging buffer; the pack waits for the copy, nothing is copied here
+        c->h2d_pre_valid = false;
+        const int slot = c->h2d_idx ^= 1;
+        const int sw = c->src_w ? c->src_w : c->W, sh = c->src_h ? c->src_h : c->H;
+        const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
+        next_current(c);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
+        const uint8_t *d = c->h2d_stage[slot];
+        const int rc = set_frame_planes(c, c->cur, d, d + ny, d + ny + nc, hipMemcpyDeviceToDevice, c->src_w, c->src_h);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_stage_read[slot], c->stream));
+        c->stage_read_valid[slot] = true;
+        HIPCHK(c, hipEventSynchronize(c->ev_h2d));      // the host's planes are the host's again when this returns (done long ago, normally)
+        return VP8HIP_OK;
+    }
+    c->h2d_pre_valid = false;
     next_current(c);
     int rc = set_frame_planes(c, c->cur, y, u, v, hipMemcpyHostToDevice, c->src_w, c->src_h);
     if (rc) return rc;

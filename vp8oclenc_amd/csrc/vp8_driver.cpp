@@ -355,6 +355,11 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
     return frame_body(d, y, d->gop.current_is_key || force_key);
 }
 
+int vp8drv_prefetch_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (!d || !y || !u || !v) return VP8HIP_ERR_ARG;
+    return vp8hip_prefetch_current(d->hip, y, u, v);
+}
+
 // ---- several GOP chunks one frame at a time, every stage one launch for all of them (vp8hip_batch_*) -----------------------
 struct vp8drv_batch {
     int n = 0;

@@ -116,6 +116,16 @@ struct vp8hip_ctx {
     // vp8hip_filter_overlap: the entropy stage of a frame on a THIRD stream, beside its loop filter and beside the next frame's side
     // work -- a caller may start the next frame between vp8hip_encode_frame_begin and _end (the chain waits for the stage before
     // anything overwrites what it reads)
+    // vp8hip_prefetch_current: the NEXT frame's planes (host memory) on their way into one of two staging buffers on a stream of their own,
+    // while the current frame is coded; the vp8hip_upload_current that names the same planes packs from there and copies nothing
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_stage_read[2] = {nullptr, nullptr};
+    bool stage_read_valid[2] = {false, false};
+    uint8_t *h2d_stage[2] = {nullptr, nullptr};
+    size_t h2d_stage_bytes = 0;
+    int h2d_idx = 0;
+    const void *h2d_pre[3] = {nullptr, nullptr, nullptr};
+    bool h2d_pre_valid = false;
     hipStream_t ent_stream = nullptr;
     hipEvent_t ev_ent = nullptr;
     bool ent_pending = false;           // the chain has not yet been told to wait for ev_ent
