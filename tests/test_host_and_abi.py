@@ -209,6 +209,18 @@ def test_status_strings_and_bad_arguments():
     assert lib.vp8hip_create(C.byref(h), 100, 64, -1.0, 0) == -1          # not a multiple of 16
     assert lib.vp8hip_inter_transform(None, 0, 0, 0, 0) == -1
     assert lib.vp8hip_loop_filter(None) == -1
+    # the host-memory entry points refuse what they cannot use before they touch a device
+    for fn in (lib.vp8hip_prefetch_current, lib.vp8hip_upload_current):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert fn(None, None, None, None) == -1
+    lib.vp8hip_batch_upload_current.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.vp8hip_batch_upload_current(None, None, None, None, None) == -1
+    lib.vp8hip_batch_prefetch_current.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.vp8hip_batch_prefetch_current(None, None, None, None) == -1
+    lib.vp8drv_prefetch_frame_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.vp8drv_prefetch_frame_host(None, None, None, None) == -1
+    lib.vp8hip_host_alloc.argtypes = [C.c_int, C.c_size_t, C.c_void_p]
+    assert lib.vp8hip_host_alloc(0, 16, None) == -1
 
 
 def test_integration_section_2_is_what_the_drop_in_script_does():
