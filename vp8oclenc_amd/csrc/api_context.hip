@@ -432,7 +432,8 @@ void vp8hip_destroy(vp8hip_ctx *c) {
             hipEventDestroy(c->ev_ent);
         }
     }
-    if (c->h2d_stream) {
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->h2d_stream) {      // (behind the context's stream: its last pack may have read a staging buffer)
         hipStreamSynchronize(c->h2d_stream);
         hipStreamDestroy(c->h2d_stream);
         hipEventDestroy(c->ev_h2d);
@@ -441,7 +442,6 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         hipFree(c->h2d_stage[0]);
         hipFree(c->h2d_stage[1]);
     }
-    if (c->stream) hipStreamSynchronize(c->stream);
     shard_release(c);
     event_pool_put(c->device, c->ev, c->ev_made);
     hipFree(c->pixel_pool);
