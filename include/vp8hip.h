@@ -418,7 +418,7 @@ const char *vp8hip_status_string(int status);
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
  * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
  * vp8drv_frame_check folds position in (4: its values change). */
-#define VP8HIP_ABI_VERSION 4005
+#define VP8HIP_ABI_VERSION 4006
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

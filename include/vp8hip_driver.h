@@ -123,6 +123,9 @@ int vp8drv_batch_encode_frame_device(vp8drv_batch *b, const int *members /* NULL
  * to be asynchronous, unchanged until the next call on this batch has returned) */
 int vp8drv_batch_encode_frame_host(vp8drv_batch *b, const int *members, const void *const *y, const void *const *u, const void *const *v,
                                    const int *force_key, int *was_key);
+/* the members' NEXT frames started on their way (vp8hip_batch_prefetch_current; y[i] NULL: nothing for member i): hand the same pointers
+ * to the next vp8drv_batch_encode_frame_host */
+int vp8drv_batch_prefetch_frame_host(vp8drv_batch *b, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v);
 /* vp8drv_get_frame_begin for the members' frames in one set of launches (src/vp8enc.cpp:48-94 for up to four chunks at
  * once); then vp8drv_get_frame_end on every member */
 int vp8drv_batch_get_frame_begin(vp8drv_batch *b, const int *members);

@@ -1,0 +1,175 @@
+// y4m_to_ivf_gops.cpp -- one YUV4MPEG2 file to one IVF file with its closed GOPs coded SIDE BY SIDE: the file-to-file form of what
+// bench.py's headline measures, as a complete C++ user of the C ABI.
+//   y4m_to_ivf_gops <in.y4m> <out.ivf> [-g gop] [-partitions P] [-qmin q] [-qmax q] [-SSIM-target t] [-altref-range n]
+//                   [-no-check-ssim] [-conformant] [-chunks N (48)] [-batch B (6)]
+// A key frame resets every reference (intra_part.h:1091-1098, inter_part.h:35-50), so the frames [k g, (k + 1) g) of a run with
+// `-g g` are a unit of their own: N such chunks are in flight at once, B of them advance together as one batch (every stage ONE
+// launch for the batch: vp8drv_batch_*), a host thread per batch; the frames come from host memory (the whole file is read into
+// page-locked memory; a frame's planes lie end to end there, one copy per frame, the next frame's copy started while the current
+// one is coded: vp8hip_batch_upload_current / _prefetch_current), the finished frames are written in order at the end.
+// The file is, byte for byte, what `y4m_to_ivf -no-scene-detect -g g` (one video, frame after frame: the reference's loop) writes --
+// as long as no frame is sent back by check_SSIM to be a key frame (the reference then restarts its GOP counter, vp8enc.cpp:443-453,
+// intra_part.h:1091, and the serial run's later key frames move; with the default -SSIM-target -1 none is) and no scene detection
+// is asked for (a cut moves the key frames the same way).  tests/test_gpu_file_roundtrip.py holds the two programs against each other.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "vp8hip_bitstream.h"
+#include "vp8hip_driver.h"
+#include "vp8hip_host.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #x, rc_, vp8hip_status_string(rc_)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: see the head of y4m_to_ivf_gops.cpp\n"); return 2; }
+    vp8drv_config cfg;
+    vp8drv_default_config(&cfg);
+    int in_flight = 48, batch = 6;
+    for (int i = 3; i < argc; ++i) {
+        auto val = [&]() { return i + 1 < argc ? argv[++i] : "0"; };
+        if (!strcmp(argv[i], "-g")) cfg.gop_size = atoi(val());
+        else if (!strcmp(argv[i], "-partitions")) cfg.num_partitions = atoi(val());
+        else if (!strcmp(argv[i], "-qmin")) cfg.qi_min = atoi(val());
+        else if (!strcmp(argv[i], "-qmax")) cfg.qi_max = atoi(val());
+        else if (!strcmp(argv[i], "-SSIM-target")) cfg.ssim_target = (float)atof(val());
+        else if (!strcmp(argv[i], "-altref-range")) cfg.altref_range = atoi(val());
+        else if (!strcmp(argv[i], "-no-check-ssim")) cfg.check_ssim = 0;
+        else if (!strcmp(argv[i], "-conformant")) cfg.conformant_stream = 1;
+        else if (!strcmp(argv[i], "-chunks")) in_flight = atoi(val());
+        else if (!strcmp(argv[i], "-batch")) batch = atoi(val());
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    if (cfg.gop_size < 1 || batch < 1 || batch > VP8HIP_MAX_BATCH || in_flight < 1) { fprintf(stderr, "bad -g / -batch / -chunks\n"); return 2; }
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) { perror(argv[1]); return 1; }
+    uint8_t head[256];
+    const size_t got = fread(head, 1, sizeof head, in);
+    int32_t W = 0, H = 0, fps = 0;
+    size_t first = 0;
+    if (vp8host_y4m_parse_header(head, got, &W, &H, &fps, &first) != 0 || (W & 1) || (H & 1)) {
+        fprintf(stderr, "%s: not a YUV4MPEG2 stream the reference accepts\n", argv[1]);
+        return 1;
+    }
+    fseek(in, 0, SEEK_END);
+    const size_t file_size = (size_t)ftell(in);
+    const size_t ysz = (size_t)W * H, csz = ysz / 4, fsz = ysz + 2 * csz, rec = fsz + 6;      // a frame and the marker behind it (get_yuv420_frame, encIO.h:203-254)
+    const int nframes = (int)((file_size - first + 6) / rec);
+    if (nframes < 1) { fprintf(stderr, "%s: no frame\n", argv[1]); return 1; }
+    // the whole input in page-locked memory: frame t's planes at data + t * rec, end to end
+    uint8_t *data = nullptr;
+    CK(vp8hip_host_alloc(0, (size_t)nframes * rec, reinterpret_cast<void **>(&data)));
+    fseek(in, (long)first, SEEK_SET);
+    const size_t have = fread(data, 1, (size_t)nframes * rec, in);
+    fclose(in);
+    if (have + 6 < (size_t)nframes * rec) { fprintf(stderr, "short read\n"); return 1; }
+    for (int t = 0; t + 1 < nframes; ++t)
+        if (!vp8host_y4m_frame_marker_ok(data + (size_t)t * rec + fsz)) { fprintf(stderr, "broken stream!\n"); return 1; }
+
+    const double t_read = now();
+    const int Wc = (W + 15) / 16 * 16, Hc = (H + 15) / 16 * 16;      // video.wrk_*, init.h:375-392
+    if (Wc != W || Hc != H) { cfg.src_width = W; cfg.src_height = H; }
+    const int g = cfg.gop_size, nchunks = (nframes + g - 1) / g;
+    if (in_flight > nchunks) in_flight = nchunks;
+    const int nbatches = (in_flight + batch - 1) / batch;
+    // a driver per chunk in flight, formed into batches as they are made (every batch then sits on a hardware queue of its own,
+    // INTEGRATION.md section 6); driver j codes chunks j, j + in_flight, j + 2 in_flight ...: after g frames its own GOP counter is
+    // at a key frame again
+    std::vector<vp8drv *> drv((size_t)in_flight, nullptr);
+    std::vector<vp8drv_batch *> bat((size_t)nbatches, nullptr);
+    for (int j = 0; j < in_flight; ++j) {
+        CK(vp8drv_create(&drv[j], Wc, Hc, 0, &cfg));
+        CK(vp8hip_reserve_frame_path_dense(vp8drv_context(drv[j])));      // frame t + 1 is started before frame t's bytes are taken: no frame is ever coded twice
+        if ((j + 1) % batch == 0 || j == in_flight - 1) {
+            const int k = j / batch, j0 = k * batch;
+            CK(vp8drv_batch_create(&bat[k], &drv[j0], j - j0 + 1));
+        }
+    }
+    const double t_made = now();
+    std::vector<std::vector<uint8_t>> out_frames((size_t)nframes);
+    std::vector<int> rc((size_t)nbatches, VP8HIP_OK), keys((size_t)nbatches, 0);
+    const size_t cap = (size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nbatches; ++k)
+        th.emplace_back([&, k] {
+            if (k) std::this_thread::sleep_for(std::chrono::microseconds(200 * k));      // batches that start together stay in lockstep (vp8hip_driver.h)
+            const int j0 = k * batch, n = (k == nbatches - 1 ? in_flight - j0 : batch);
+            std::vector<uint8_t> buf(cap);
+            const void *y[VP8HIP_MAX_BATCH], *u[VP8HIP_MAX_BATCH], *v[VP8HIP_MAX_BATCH];
+            const uint8_t *py[VP8HIP_MAX_BATCH], *pu[VP8HIP_MAX_BATCH], *pv[VP8HIP_MAX_BATCH];
+            int on[VP8HIP_MAX_BATCH], on_next[VP8HIP_MAX_BATCH], force[VP8HIP_MAX_BATCH], was_key[VP8HIP_MAX_BATCH];
+            for (int round = 0; rc[k] == VP8HIP_OK && (size_t)round * in_flight + j0 < (size_t)nchunks; ++round) {
+                // member i codes chunk c_i = round * in_flight + j0 + i: frames c_i g + t, t < g
+                auto frame_of = [&](int i, int t) { const long c = (long)round * in_flight + j0 + i; return c < nchunks && c * g + t < nframes ? (int)(c * g + t) : -1; };
+                auto planes = [&](int t, int *members) {
+                    int any = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const int f = frame_of(i, t);
+                        members[i] = f >= 0;
+                        any |= members[i];
+                        const uint8_t *p = f >= 0 ? data + (size_t)f * rec : nullptr;
+                        y[i] = py[i] = p; u[i] = pu[i] = p ? p + ysz : nullptr; v[i] = pv[i] = p ? p + ysz + csz : nullptr;
+                    }
+                    return any;
+                };
+                // the loop of vp8drv_batches_encode_frames_host with the bytes kept: frame t + 1 enqueued before frame t's bytes are waited for
+                planes(0, on);
+                for (int i = 0; i < n; ++i) force[i] = 1;
+                rc[k] = vp8drv_batch_encode_frame_host(bat[k], on, y, u, v, force, was_key);
+                if (rc[k] == VP8HIP_OK && g > 1 && planes(1, on_next)) rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);      // frame 1 on its way
+                for (int t = 0; t < g && rc[k] == VP8HIP_OK; ++t) {
+                    int cur_on[VP8HIP_MAX_BATCH];
+                    if (!planes(t, cur_on)) break;
+                    rc[k] = vp8drv_batch_get_frame_begin(bat[k], cur_on);        // frame t's type is final here (its verdict is in)
+                    if (rc[k] != VP8HIP_OK) break;
+                    for (int i = 0; i < n; ++i)
+                        if (cur_on[i]) keys[k] += vp8drv_resolve(drv[j0 + i]) == 1;
+                    if (t + 1 < g && planes(t + 1, on_next)) {
+                        for (int i = 0; i < n; ++i) force[i] = 0;
+                        rc[k] = vp8drv_batch_encode_frame_host(bat[k], on_next, y, u, v, force, was_key);
+                        if (rc[k] == VP8HIP_OK && t + 2 < g && planes(t + 2, on)) rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);   // ... and the one after it
+                        if (rc[k] != VP8HIP_OK) break;
+                    }
+                    for (int i = 0; i < n && rc[k] == VP8HIP_OK; ++i) {
+                        if (!cur_on[i]) continue;
+                        size_t size = 0;
+                        rc[k] = vp8drv_get_frame_end(drv[j0 + i], buf.data(), buf.size(), &size);
+                        if (rc[k] == VP8HIP_OK) out_frames[(size_t)frame_of(i, t)].assign(buf.begin(), buf.begin() + (long)size);
+                    }
+                }
+            }
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < nbatches; ++k) CK(rc[k]);
+    const double t_coded = now();
+
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) { perror(argv[2]); return 1; }
+    uint8_t fh[32];
+    // the reference's file says one frame more than it holds (encIO.h:124-134, vp8enc.cpp:487-489; REFERENCE_DEFECTS.md #8) -- reproduced
+    fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, (uint32_t)nframes + 1), out);
+    size_t total = 32;
+    int nkeys = 0;
+    for (int t = 0; t < nframes; ++t) {
+        uint8_t ph[12];
+        fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)out_frames[(size_t)t].size(), (uint32_t)t), out);
+        fwrite(out_frames[(size_t)t].data(), 1, out_frames[(size_t)t].size(), out);
+        total += 12 + out_frames[(size_t)t].size();
+    }
+    fclose(out);
+    const double t_written = now();
+    for (int k = 0; k < nbatches; ++k) { nkeys += keys[k]; vp8drv_batch_destroy(bat[k]); }
+    for (auto d : drv) vp8drv_destroy(d);
+    vp8hip_host_free(0, data);
+    printf("%s: %d frames %dx%d (coded %dx%d) in %d closed GOPs of %d, %d in flight in %d batches, %d key frames, %zu bytes; %d hardware queues\n", argv[2], nframes, W, H, Wc,
+           Hc, nchunks, g, in_flight, nbatches, nkeys, total, vp8hip_hw_queues());
+    printf("  seconds: input into page-locked memory %.3f, %d contexts and their scratch %.3f, coding %.3f (%.0f frames/s, %.2f M macroblocks/s, every frame over the host-device link "
+           "both ways), writing %.3f, tearing down %.3f\n", t_read - t_start, in_flight, t_made - t_read, t_coded - t_made, nframes / (t_coded - t_made),
+           (double)nframes * (Wc / 16) * (Hc / 16) / (t_coded - t_made) / 1e6, t_written - t_coded, now() - t_written);
+    return 0;
+}

@@ -125,3 +125,38 @@ def test_native_y4m_to_ivf_program(tmp_path):
         assert drv.get_frame() == packets[t], t
     assert drv.stats().scene_changes == 1
     drv.close()
+
+
+@pytest.mark.parametrize("W,H,frames,gop,chunks,batch,partitions", [(360, 200, 50, 7, 5, 3, 2), (320, 192, 23, 5, 48, 6, 1), (640, 352, 36, 12, 2, 1, 4)])
+def test_native_gop_parallel_program_writes_the_serial_programs_file(tmp_path, W, H, frames, gop, chunks, batch, partitions):
+    """scripts/native/y4m_to_ivf_gops.cpp: one Y4M file with its closed GOPs coded SIDE BY SIDE -- `chunks` of them in flight in batches of
+    `batch`, a host thread per batch, the frames from page-locked host memory with the next frame's copy under way while the current one
+    is coded, drivers reused round after round, members sitting out where the file ends -- writes, byte for byte, the file the one-video
+    program (scripts/native/y4m_to_ivf.cpp: the reference's loop, frame after frame) writes with the same -g.  SURVEY 8(e): a key frame
+    resets every reference (intra_part.h:1091-1098), the host concatenates the frames in order."""
+    import shutil
+    from vp8oclenc_amd import y4m
+    from vp8oclenc_amd.synth import SynthSequence
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exes = {}
+    for name in ("y4m_to_ivf", "y4m_to_ivf_gops"):
+        exes[name] = str(tmp_path / name)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", name + ".cpp"), "-o", exes[name],
+                        "-L", os.path.join(ROOT, "vp8oclenc_amd"), "-lvp8hip", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "vp8oclenc_amd")], check=True, timeout=300)
+    seq = SynthSequence(W + 16, H + 16, seed=17)
+    src = []
+    for t in range(frames):
+        y, u, v = seq.frame(t)
+        src.append((np.ascontiguousarray(y[:H, :W]), np.ascontiguousarray(u[:H // 2, :W // 2]), np.ascontiguousarray(v[:H // 2, :W // 2])))
+    y4m.write_y4m(str(tmp_path / "in.y4m"), src, framerate=25)
+    common = ["-g", str(gop), "-partitions", str(partitions)]
+    a = subprocess.run([exes["y4m_to_ivf"], str(tmp_path / "in.y4m"), str(tmp_path / "serial.ivf"), "-no-scene-detect"] + common, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([exes["y4m_to_ivf_gops"], str(tmp_path / "in.y4m"), str(tmp_path / "gops.ivf"), "-chunks", str(chunks), "-batch", str(batch)] + common,
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout + b.stderr
+    nchunks = (frames + gop - 1) // gop
+    assert f"{frames} frames {W}x{H}" in b.stdout and f"in {nchunks} closed GOPs of {gop}" in b.stdout and f"{nchunks} key frames" in b.stdout, b.stdout
+    one, many = open(tmp_path / "serial.ivf", "rb").read(), open(tmp_path / "gops.ivf", "rb").read()
+    assert len(one) == len(many) and one == many, f"{len(one)} vs {len(many)} bytes, first difference at {next((i for i, (p, q) in enumerate(zip(one, many)) if p != q), None)}"

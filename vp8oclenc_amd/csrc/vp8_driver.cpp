@@ -477,6 +477,11 @@ int vp8drv_batch_encode_frame_host(vp8drv_batch *b, const int *members, const vo
     return batch_encode_frame(b, members, y, u, v, force_key, was_key, true);
 }
 
+int vp8drv_batch_prefetch_frame_host(vp8drv_batch *b, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v) {
+    if (!b) return VP8HIP_ERR_ARG;
+    return vp8hip_batch_prefetch_current(b->hb, y, u, v);
+}
+
 int vp8drv_resolve(vp8drv *d) {
     if (!d) return VP8HIP_ERR_ARG;
     const int rc = resolve(d);
