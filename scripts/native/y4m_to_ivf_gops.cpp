@@ -4,9 +4,10 @@
 //                   [-no-check-ssim] [-conformant] [-chunks N (48)] [-batch B (6)]
 // A key frame resets every reference (intra_part.h:1091-1098, inter_part.h:35-50), so the frames [k g, (k + 1) g) of a run with
 // `-g g` are a unit of their own: N such chunks are in flight at once, B of them advance together as one batch (every stage ONE
-// launch for the batch: vp8drv_batch_*), a host thread per batch; the frames come from host memory (the whole file is read into
-// page-locked memory; a frame's planes lie end to end there, one copy per frame, the next frame's copy started while the current
-// one is coded: vp8hip_batch_upload_current / _prefetch_current), the finished frames are written in order at the end.
+// launch for the batch: vp8drv_batch_*), a host thread per batch; the input is streamed (two page-locked frame buffers per chunk in
+// flight: the batch's thread reads frame t + 2 of its members while frame t + 1, already on its way to the device, is coded; a frame's
+// planes lie end to end, one copy per frame: vp8hip_batch_upload_current / _prefetch_current), the finished frames are written in order
+// at the end.
 // The file is, byte for byte, what `y4m_to_ivf -no-scene-detect -g g` (one video, frame after frame: the reference's loop) writes --
 // as long as no frame is sent back by check_SSIM to be a key frame (the reference then restarts its GOP counter, vp8enc.cpp:443-453,
 // intra_part.h:1091, and the serial run's later key frames move; with the default -SSIM-target -1 none is) and no scene detection
@@ -14,6 +15,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -61,16 +64,12 @@ int main(int argc, char **argv) {
     const size_t ysz = (size_t)W * H, csz = ysz / 4, fsz = ysz + 2 * csz, rec = fsz + 6;      // a frame and the marker behind it (get_yuv420_frame, encIO.h:203-254)
     const int nframes = (int)((file_size - first + 6) / rec);
     if (nframes < 1) { fprintf(stderr, "%s: no frame\n", argv[1]); return 1; }
-    // the whole input in page-locked memory: frame t's planes at data + t * rec, end to end
-    uint8_t *data = nullptr;
-    CK(vp8hip_host_alloc(0, (size_t)nframes * rec, reinterpret_cast<void **>(&data)));
-    fseek(in, (long)first, SEEK_SET);
-    const size_t have = fread(data, 1, (size_t)nframes * rec, in);
     fclose(in);
-    if (have + 6 < (size_t)nframes * rec) { fprintf(stderr, "short read\n"); return 1; }
-    for (int t = 0; t + 1 < nframes; ++t)
-        if (!vp8host_y4m_frame_marker_ok(data + (size_t)t * rec + fsz)) { fprintf(stderr, "broken stream!\n"); return 1; }
-
+    // The input is STREAMED: every chunk in flight has two page-locked frame buffers, and the thread of its batch reads frame t + 2
+    // of its members into the one while frame t + 1 (in the other, already on its way to the device) is coded -- the file is read by
+    // as many threads as there are batches, beside the device's work, and no more of it is in memory than the chunks need
+    const int fd = open(argv[1], O_RDONLY);
+    if (fd < 0) { perror(argv[1]); return 1; }
     const double t_read = now();
     const int Wc = (W + 15) / 16 * 16, Hc = (H + 15) / 16 * 16;      // video.wrk_*, init.h:375-392
     if (Wc != W || Hc != H) { cfg.src_width = W; cfg.src_height = H; }
@@ -90,6 +89,8 @@ int main(int argc, char **argv) {
             CK(vp8drv_batch_create(&bat[k], &drv[j0], j - j0 + 1));
         }
     }
+    uint8_t *pinned = nullptr;
+    CK(vp8hip_host_alloc(0, (size_t)in_flight * 2 * rec, reinterpret_cast<void **>(&pinned)));
     const double t_made = now();
     std::vector<std::vector<uint8_t>> out_frames((size_t)nframes);
     std::vector<int> rc((size_t)nbatches, VP8HIP_OK), keys((size_t)nbatches, 0);
@@ -106,22 +107,35 @@ int main(int argc, char **argv) {
             for (int round = 0; rc[k] == VP8HIP_OK && (size_t)round * in_flight + j0 < (size_t)nchunks; ++round) {
                 // member i codes chunk c_i = round * in_flight + j0 + i: frames c_i g + t, t < g
                 auto frame_of = [&](int i, int t) { const long c = (long)round * in_flight + j0 + i; return c < nchunks && c * g + t < nframes ? (int)(c * g + t) : -1; };
+                auto slot = [&](int i, int t) { return pinned + ((size_t)(j0 + i) * 2 + (size_t)(t & 1)) * rec; };
+                auto load = [&](int t) {      // frame t of every member's chunk from the file into the member's buffer t & 1 (get_yuv420_frame, encIO.h:203-254)
+                    for (int i = 0; i < n; ++i) {
+                        const int f = frame_of(i, t);
+                        if (f < 0) continue;
+                        const size_t want = f + 1 < nframes ? rec : fsz;          // ... with the next frame's marker, if there is one
+                        if (pread(fd, slot(i, t), want, (off_t)(first + (size_t)f * rec)) != (ssize_t)want) return VP8HIP_ERR_ARG;
+                        if (want == rec && !vp8host_y4m_frame_marker_ok(slot(i, t) + fsz)) return VP8HIP_ERR_FORMAT;
+                    }
+                    return VP8HIP_OK;
+                };
                 auto planes = [&](int t, int *members) {
                     int any = 0;
                     for (int i = 0; i < n; ++i) {
                         const int f = frame_of(i, t);
                         members[i] = f >= 0;
                         any |= members[i];
-                        const uint8_t *p = f >= 0 ? data + (size_t)f * rec : nullptr;
+                        const uint8_t *p = f >= 0 ? slot(i, t) : nullptr;
                         y[i] = py[i] = p; u[i] = pu[i] = p ? p + ysz : nullptr; v[i] = pv[i] = p ? p + ysz + csz : nullptr;
                     }
                     return any;
                 };
                 // the loop of vp8drv_batches_encode_frames_host with the bytes kept: frame t + 1 enqueued before frame t's bytes are waited for
+                if ((rc[k] = load(0)) != VP8HIP_OK) break;
                 planes(0, on);
                 for (int i = 0; i < n; ++i) force[i] = 1;
                 rc[k] = vp8drv_batch_encode_frame_host(bat[k], on, y, u, v, force, was_key);
-                if (rc[k] == VP8HIP_OK && g > 1 && planes(1, on_next)) rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);      // frame 1 on its way
+                if (rc[k] == VP8HIP_OK && g > 1 && planes(1, on_next) && (rc[k] = load(1)) == VP8HIP_OK)
+                    rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);      // frame 1 read and on its way
                 for (int t = 0; t < g && rc[k] == VP8HIP_OK; ++t) {
                     int cur_on[VP8HIP_MAX_BATCH];
                     if (!planes(t, cur_on)) break;
@@ -132,7 +146,9 @@ int main(int argc, char **argv) {
                     if (t + 1 < g && planes(t + 1, on_next)) {
                         for (int i = 0; i < n; ++i) force[i] = 0;
                         rc[k] = vp8drv_batch_encode_frame_host(bat[k], on_next, y, u, v, force, was_key);
-                        if (rc[k] == VP8HIP_OK && t + 2 < g && planes(t + 2, on)) rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);   // ... and the one after it
+                        // ... and the one after it read (into the buffer frame t came from: its upload has returned) and started on its way
+                        if (rc[k] == VP8HIP_OK && t + 2 < g && planes(t + 2, on) && (rc[k] = load(t + 2)) == VP8HIP_OK)
+                            rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);
                         if (rc[k] != VP8HIP_OK) break;
                     }
                     for (int i = 0; i < n && rc[k] == VP8HIP_OK; ++i) {
@@ -163,13 +179,15 @@ int main(int argc, char **argv) {
     }
     fclose(out);
     const double t_written = now();
-    for (int k = 0; k < nbatches; ++k) { nkeys += keys[k]; vp8drv_batch_destroy(bat[k]); }
+    for (int k = 0; k < nbatches; ++k) vp8drv_batch_destroy(bat[k]);
     for (auto d : drv) vp8drv_destroy(d);
-    vp8hip_host_free(0, data);
+    for (int k = 0; k < nbatches; ++k) nkeys += keys[k];
+    vp8hip_host_free(0, pinned);
+    close(fd);
     printf("%s: %d frames %dx%d (coded %dx%d) in %d closed GOPs of %d, %d in flight in %d batches, %d key frames, %zu bytes; %d hardware queues\n", argv[2], nframes, W, H, Wc,
            Hc, nchunks, g, in_flight, nbatches, nkeys, total, vp8hip_hw_queues());
-    printf("  seconds: input into page-locked memory %.3f, %d contexts and their scratch %.3f, coding %.3f (%.0f frames/s, %.2f M macroblocks/s, every frame over the host-device link "
-           "both ways), writing %.3f, tearing down %.3f\n", t_read - t_start, in_flight, t_made - t_read, t_coded - t_made, nframes / (t_coded - t_made),
+    printf("  seconds: opening %.3f, %d contexts, their scratch and frame buffers %.3f, reading + coding %.3f (%.0f frames/s, %.2f M macroblocks/s, every frame from the file and over the "
+           "host-device link both ways), writing %.3f, tearing down %.3f\n", t_read - t_start, in_flight, t_made - t_read, t_coded - t_made, nframes / (t_coded - t_made),
            (double)nframes * (Wc / 16) * (Hc / 16) / (t_coded - t_made) / 1e6, t_written - t_coded, now() - t_written);
     return 0;
 }
