@@ -351,59 +351,47 @@ int vp8hip_create(vp8hip_ctx **out, int width, int height, float ssim_target, in
     // [0..3] sums, [4] reductor, [5] sharpness, [6] sharpness in force, [8..] partials; two blocks, like the segment data they
     // belong to: a frame's parameters are produced while the previous frame's are still being read
     const size_t stats_words = 8 + rc_partial_words();
-    CR(hipMalloc(&c->d_stats2[0], 2 * stats_words * sizeof(uint32_t)));
-    CR(hipMemsetAsync(c->d_stats2[0], 0, 2 * stats_words * sizeof(uint32_t), c->stream));   // (holds a completion counter that is zero at rest)
+    // every fixed device buffer of the context out of ONE allocation, zeroed by one memset (DeviceArena, vp8hip_ctx.h)
+    DeviceArena &A = c->arena;
+    A.want(&c->d_stats2[0], 2 * stats_words * sizeof(uint32_t));      // (holds a completion counter that is zero at rest)
+    for (int r = 0; r < 3; ++r) {
+        A.want(&c->nets.net[r][0], (size_t)c->b8 * 4);
+        A.want(&c->nets.net[r][1], (size_t)c->b8 * 4);
+        A.want(&c->nets.bdiff[r], (size_t)c->b8 * 4);
+    }
+    A.want(&c->out.parts, (size_t)c->mbs * 4);
+    A.want(&c->out.ref, (size_t)c->mbs * 4);
+    A.want(&c->out.seg, (size_t)c->mbs * 4);
+    A.want(&c->out.nz, (size_t)c->mbs * 4);
+    A.want(&c->out.mask, (size_t)c->mbs * 4);
+    A.want(&c->out.ssim, (size_t)c->mbs * 4);
+    A.want(&c->out.vec, (size_t)c->mbs * 16);
+    A.want(&c->out.coeffs, (size_t)c->mbs * 800);
+    A.want(&c->out.flags, 64);
+    A.want(&c->d_sd2[0], 2 * sizeof(SegData));
+    A.want(&c->d_progress, (size_t)c->mbh * 4 + 8192);   // band counters (+ diagnostic stamps at +4096, error word)
+    A.want(&c->d_lf_handoff, loop_filter4_handoff_bytes(c->mbw, c->mbh));
+    A.want(&c->scratch, (size_t)width * height);
+    A.want(&c->ent_flags, (size_t)c->mbs * 25);
+    A.want(&c->ent_third, (size_t)c->mbs * 25);
+    A.want(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * c->mbh * 4);   // four partial histograms per macroblock row
+    A.want(&c->ent_probs, sizeof(uint32_t) * ENT_NCTX);
+    A.want(&c->ent_denom0, sizeof(uint32_t) * ENT_NCTX);
+    A.want(&c->intra_modes, (size_t)c->mbs * 64);
+    A.want(&c->intra_is_inter, (size_t)c->mbs * 4);
+    A.want(&c->intra_prog, (size_t)c->mbh * 4);
+    A.want(&c->intra_stats, 32);
+    CR(A.commit());
+    CR(hipMemsetAsync(A.base, 0, A.bytes, c->stream));
     c->d_stats2[1] = c->d_stats2[0] + stats_words;
     c->d_stats = c->d_stats2[0];
-    CR(hipHostMalloc(&c->h_verdict, 16 * sizeof(int32_t), hipHostMallocCoherent));   // fine-grained: the device's stores arrive while its kernel runs
-    memset(c->h_verdict, 0, 16 * sizeof(int32_t));
-    for (int r = 0; r < 3; ++r) {
-        CR(hipMalloc(&c->nets.net[r][0], (size_t)c->b8 * 4));
-        CR(hipMalloc(&c->nets.net[r][1], (size_t)c->b8 * 4));
-        CR(hipMalloc(&c->nets.bdiff[r], (size_t)c->b8 * 4));
-    }
-    CR(hipMalloc(&c->out.parts, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.ref, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.seg, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.nz, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.mask, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.ssim, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->out.vec, (size_t)c->mbs * 16));
-    CR(hipMalloc(&c->out.coeffs, (size_t)c->mbs * 800));
-    CR(hipMalloc(&c->out.flags, 64));
-    CR(hipMemsetAsync(c->out.flags, 0, 64, c->stream));
-    CR(hipMalloc(&c->d_sd2[0], 2 * sizeof(SegData)));
     c->d_sd2[1] = c->d_sd2[0] + 1;
     c->d_sd = c->d_sd2[0];
-    CR(hipHostMalloc(&c->h_sd_ring, 16 * sizeof(SegData)));
-    CR(hipMalloc(&c->d_progress, (size_t)c->mbh * 4 + 8192));   // band counters (+ diagnostic stamps at +4096, error word)
-    CR(hipMemsetAsync(c->d_progress, 0, (size_t)c->mbh * 4 + 8192, c->stream));
-    CR(hipMalloc(&c->d_lf_handoff, loop_filter4_handoff_bytes(c->mbw, c->mbh)));
-    CR(hipMemsetAsync(c->d_lf_handoff, 0, loop_filter4_handoff_bytes(c->mbw, c->mbh), c->stream));
     CR(hipMemsetAsync(c->d_progress + S2_CLOCK_WORD, 0xff, 8, c->stream));   // k_search2's launch clock: "earliest start" is ~0 at rest
-    CR(hipMalloc(&c->scratch, (size_t)width * height));
-    CR(hipMalloc(&c->ent_flags, (size_t)c->mbs * 25));
-    CR(hipMalloc(&c->ent_third, (size_t)c->mbs * 25));
-    CR(hipMemsetAsync(c->ent_third, 0, (size_t)c->mbs * 25, c->stream));
-    CR(hipMalloc(&c->ent_counts, sizeof(uint32_t) * ENT_NCTX * 2 * c->mbh * 4));   // four partial histograms per macroblock row
-    CR(hipMalloc(&c->ent_probs, sizeof(uint32_t) * ENT_NCTX));
-    CR(hipMalloc(&c->ent_denom0, sizeof(uint32_t) * ENT_NCTX));
-    CR(hipMalloc(&c->intra_modes, (size_t)c->mbs * 64));
-    CR(hipMalloc(&c->intra_is_inter, (size_t)c->mbs * 4));
-    CR(hipMalloc(&c->intra_prog, (size_t)c->mbh * 4));
-    CR(hipMalloc(&c->intra_stats, 32));
-    CR(hipMemsetAsync(c->intra_prog, 0, (size_t)c->mbh * 4, c->stream));
-    CR(hipMemsetAsync(c->intra_modes, 0, (size_t)c->mbs * 64, c->stream));
-    CR(hipMemsetAsync(c->intra_is_inter, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.parts, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.ref, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.seg, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.nz, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.mask, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.ssim, 0, (size_t)c->mbs * 4, c->stream));
-    CR(hipMemsetAsync(c->out.vec, 0, (size_t)c->mbs * 16, c->stream));
-    CR(hipMemsetAsync(c->out.coeffs, 0, (size_t)c->mbs * 800, c->stream));
-    CR(hipMemsetAsync(c->d_sd2[0], 0, 2 * sizeof(SegData), c->stream));
+    // one page-locked block: the verdict words (fine-grained: the device's stores arrive while its kernel runs), then the segment-data ring
+    CR(hipHostMalloc(&c->h_verdict, 256 + 16 * sizeof(SegData), hipHostMallocCoherent));
+    memset(c->h_verdict, 0, 16 * sizeof(int32_t));
+    c->h_sd_ring = reinterpret_cast<SegData *>(reinterpret_cast<uint8_t *>(c->h_verdict) + 256);
     c->recon = 0;
     CR(hipStreamSynchronize(c->stream));
 #undef CR
@@ -445,59 +433,12 @@ void vp8hip_destroy(vp8hip_ctx *c) {
     shard_release(c);
     event_pool_put(c->device, c->ev, c->ev_made);
     hipFree(c->pixel_pool);
-    for (int r = 0; r < 3; ++r) {
-        hipFree(c->nets.net[r][0]);
-        hipFree(c->nets.net[r][1]);
-        hipFree(c->nets.bdiff[r]);
-    }
-    hipFree(c->out.parts);
-    hipFree(c->out.ref);
-    hipFree(c->out.seg);
-    hipFree(c->out.nz);
-    hipFree(c->out.mask);
-    hipFree(c->out.ssim);
-    hipFree(c->out.vec);
-    hipFree(c->out.coeffs);
-    hipFree(c->out.flags);
-    hipFree(c->d_sd2[0]);
-    if (c->h_sd_ring) hipHostFree(c->h_sd_ring);
+    c->arena.release();
+    c->ent_arena.release();
+    c->hdr_arena.release();
     if (c->h_frame) hipHostFree(c->h_frame);
     hipFree(c->d_frame);
-    hipFree(c->d_progress);
-    hipFree(c->d_lf_handoff);
-    hipFree(c->d_stats2[0]);
     if (c->h_verdict) hipHostFree(c->h_verdict);
-    hipFree(c->scratch);
-    hipFree(c->ent_flags);
-    hipFree(c->ent_third);
-    hipFree(c->ent_counts);
-    hipFree(c->ent_probs);
-    hipFree(c->ent_denom0);
-    hipFree(c->ent.offs);
-    hipFree(c->ent.tile_sum);
-    hipFree(c->ent.bools);
-    hipFree(c->ent.maps);
-    hipFree(c->ent.start);
-    hipFree(c->ent.acc);
-    hipFree(c->ent.bytes);
-    hipFree(c->ent.sizes);
-    hipFree(c->ent.plan);
-    hipFree(c->intra_modes);
-    hipFree(c->intra_is_inter);
-    hipFree(c->intra_prog);
-    hipFree(c->intra_stats);
-    hipFree(c->hdr.offs);
-    hipFree(c->hdr.tile_sum);
-    hipFree(c->hdr.bools);
-    hipFree(c->hdr.maps);
-    hipFree(c->hdr.start);
-    hipFree(c->hdr.acc);
-    hipFree(c->hdr.bytes);
-    hipFree(c->hdr.sizes);
-    hipFree(c->hdr.plan);
-    hipFree(c->hdr_partial);
-    hipFree(c->hdr_info);
-    hipFree(c->hdr_sym);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }

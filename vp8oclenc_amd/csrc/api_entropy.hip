@@ -10,8 +10,7 @@ namespace vp8 {
 // inter path never pays for it): 64 bools per 4x4 block on average (of at most 304)
 void ent_free(vp8hip_ctx *c) {
     EntBuffers &e = c->ent;
-    hipFree(e.offs); hipFree(e.tile_sum); hipFree(e.bools); hipFree(e.maps); hipFree(e.start); hipFree(e.acc); hipFree(e.bytes);
-    hipFree(e.sizes); hipFree(e.plan);
+    c->ent_arena.release();
     e = EntBuffers{};
     if (c->h_frame) hipHostFree(c->h_frame);   // sized from the scratch: reallocated with it
     hipFree(c->d_frame);
@@ -27,15 +26,19 @@ int ent_alloc(vp8hip_ctx *c) {
     e.cap_bools = (uint32_t)(nslots * (size_t)c->ent_bools_per_block);
     e.cap_chunks = e.cap_bools / 256 + 2 * ENT_MAX_PARTITIONS;
     e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 8 * ENT_MAX_PARTITIONS);
-    HIPCHK(c, hipMalloc(&e.offs, (nslots + 1) * 4));
-    HIPCHK(c, hipMalloc(&e.tile_sum, (nslots / 256 + 8) * 4));   // the frame path sums per 256 slots
-    HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
-    HIPCHK(c, hipMalloc(&e.maps, ent_maps_entries(e.cap_chunks) * 4));
-    HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
-    HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
-    HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
-    HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
-    HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
+    DeviceArena &A = c->ent_arena;        // one allocation (DeviceArena, vp8hip_ctx.h); e.plan, set last, says that it succeeded
+    EntPlan *plan = nullptr;
+    A.want(&e.offs, (nslots + 1) * 4);
+    A.want(&e.tile_sum, (nslots / 256 + 8) * 4);   // the frame path sums per 256 slots
+    A.want(&e.bools, (size_t)e.cap_bools * 2 + 1024);
+    A.want(&e.maps, ent_maps_entries(e.cap_chunks) * 4);
+    A.want(&e.start, (size_t)e.cap_chunks * 8);
+    A.want(&e.acc, (size_t)e.cap_words * 8);
+    A.want(&e.bytes, (size_t)e.cap_words * 4);
+    A.want(&e.sizes, ENT_MAX_PARTITIONS * 4);
+    A.want(&plan, sizeof(EntPlan));
+    HIPCHK(c, A.commit());
+    e.plan = plan;
     return VP8HIP_OK;
 }
 
@@ -58,20 +61,24 @@ int hdr_alloc(vp8hip_ctx *c) {
     e.cap_bools = (uint32_t)(n * 128 + 16384);   // a macroblock header is at most ~125 bools, the frame header < 10 k
     e.cap_chunks = e.cap_bools / 256 + 4;
     e.cap_words = (uint32_t)(((size_t)e.cap_bools * 7 + 31) / 32 + 16);
-    HIPCHK(c, hipMalloc(&e.offs, (n + 1) * 4));
-    HIPCHK(c, hipMalloc(&e.tile_sum, (n / 1024 + 8) * 4));
-    HIPCHK(c, hipMalloc(&e.bools, (size_t)e.cap_bools * 2 + 1024));
-    HIPCHK(c, hipMalloc(&e.maps, ent_maps_entries(e.cap_chunks) * 4));
-    HIPCHK(c, hipMalloc(&e.start, (size_t)e.cap_chunks * 8));
-    HIPCHK(c, hipMalloc(&e.acc, (size_t)e.cap_words * 8));
-    HIPCHK(c, hipMalloc(&e.bytes, (size_t)e.cap_words * 4));
-    HIPCHK(c, hipMalloc(&e.sizes, ENT_MAX_PARTITIONS * 4));
-    HIPCHK(c, hipMalloc(&e.plan, sizeof(EntPlan)));
-    HIPCHK(c, hipMalloc(&c->hdr_partial, HDR_STAT_WORDS * 4));   // the census of k_hdr_count: zero at rest (k_hdr_frame clears it)
+    DeviceArena &A = c->hdr_arena;        // one allocation; e.bools -- what hdr_alloc looks at -- is set when it has succeeded
+    uint16_t *bools = nullptr;
+    A.want(&e.offs, (n + 1) * 4);
+    A.want(&e.tile_sum, (n / 1024 + 8) * 4);
+    A.want(&bools, (size_t)e.cap_bools * 2 + 1024);
+    A.want(&e.maps, ent_maps_entries(e.cap_chunks) * 4);
+    A.want(&e.start, (size_t)e.cap_chunks * 8);
+    A.want(&e.acc, (size_t)e.cap_words * 8);
+    A.want(&e.bytes, (size_t)e.cap_words * 4);
+    A.want(&e.sizes, ENT_MAX_PARTITIONS * 4);
+    A.want(&e.plan, sizeof(EntPlan));
+    A.want(&c->hdr_partial, HDR_STAT_WORDS * 4);   // the census of k_hdr_count: zero at rest (k_hdr_frame clears it)
+    A.want(&c->hdr_info, 16);
+    A.want(&c->hdr_sym, 64);
+    HIPCHK(c, A.commit());
     HIPCHK(c, hipMemsetAsync(c->hdr_partial, 0, HDR_STAT_WORDS * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // once per context: the stage may run on another stream than this one (a batch's, the third)
-    HIPCHK(c, hipMalloc(&c->hdr_info, 16));
-    HIPCHK(c, hipMalloc(&c->hdr_sym, 64));
+    e.bools = bools;
     return VP8HIP_OK;
 }
 

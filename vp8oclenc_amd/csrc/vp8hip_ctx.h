@@ -40,6 +40,30 @@ struct FrameSurf {
 }  // namespace vp8
 
 struct vp8hip_batch;
+// Device buffers that are made and freed together come out of ONE allocation: a context has forty of them, and forty hipMalloc + forty
+// hipFree -- each a trip through the driver, the frees synchronising -- were 11 ms to make a context and 15 ms to destroy it (48 chunks:
+// 1.2 s).  Every buffer starts 256-byte aligned and has a page of slack behind it.
+struct DeviceArena {
+    uint8_t *base = nullptr;
+    size_t bytes = 0;
+    struct Want { void **p; size_t bytes; };
+    std::vector<Want> wants;
+    template <class T> void want(T **p, size_t n) { wants.push_back(Want{reinterpret_cast<void **>(p), n}); }
+    static size_t room(size_t n) { return ((n + 255) & ~(size_t)255) + 4096; }
+    hipError_t commit() {      // one hipMalloc; the pointers handed to want() are set
+        size_t total = 0;
+        for (const Want &w : wants) total += room(w.bytes);
+        bytes = total ? total : 256;
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), bytes);
+        if (e != hipSuccess) { base = nullptr; wants.clear(); return e; }
+        size_t at = 0;
+        for (const Want &w : wants) { *w.p = base + at; at += room(w.bytes); }
+        wants.clear();
+        return hipSuccess;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; bytes = 0; }
+};
+
 struct vp8hip_ctx {
     int W = 0, H = 0, mbw = 0, mbh = 0, mbs = 0, b8 = 0;
     float ssim_target = -1.0f;
@@ -91,6 +115,8 @@ struct vp8hip_ctx {
     uint8_t *ent_flags = nullptr, *ent_third = nullptr;
     uint32_t *ent_counts = nullptr, *ent_probs = nullptr, *ent_denom0 = nullptr;
     int ent_counted_partitions = 0; // partitions of the vp8hip_count_probs whose block contexts are current (0 = stale)
+    DeviceArena arena;                   // every fixed device buffer of the context but the pixel planes (vp8hip_create)
+    DeviceArena ent_arena, hdr_arena;    // the boolean coder's scratch for the coefficient partitions / the first partition
     vp8::EntBuffers ent{};               // boolean coder scratch, allocated on first vp8hip_encode_coefficients
     // vp8hip_filter_overlap: the context has a second stream and the loop filter and whatever does not depend on it run side
     // by side (the entropy stage of the same frame, the next frame's pack / parameter scan / GOLDEN + ALTREF searches).  The
