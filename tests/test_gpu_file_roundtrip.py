@@ -160,3 +160,39 @@ def test_native_gop_parallel_program_writes_the_serial_programs_file(tmp_path, W
     assert f"{frames} frames {W}x{H}" in b.stdout and f"in {nchunks} closed GOPs of {gop}" in b.stdout and f"{nchunks} key frames" in b.stdout, b.stdout
     one, many = open(tmp_path / "serial.ivf", "rb").read(), open(tmp_path / "gops.ivf", "rb").read()
     assert len(one) == len(many) and one == many, f"{len(one)} vs {len(many)} bytes, first difference at {next((i for i, (p, q) in enumerate(zip(one, many)) if p != q), None)}"
+
+
+def test_native_gop_parallel_program_with_frames_sent_back_still_writes_a_stream_that_decodes(tmp_path):
+    """y4m_to_ivf_gops with an SSIM target: check_SSIM replaces macroblocks and sends frames back to be key frames INSIDE chunks (the
+    serial run's key frames would move then, so the file is not compared with the serial program's) -- every chunk still starts with its
+    key frame, drivers are reused round after round, and the conformant stream decodes (tests' RFC 6386 decoder) to pictures that look
+    like the source, frame by frame."""
+    import shutil
+    import decode_ivf
+    import vp8_decode
+    from vp8oclenc_amd import y4m
+    from vp8oclenc_amd.synth import SynthSequence
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "y4m_to_ivf_gops")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf_gops.cpp"), "-o", exe,
+                    "-L", os.path.join(ROOT, "vp8oclenc_amd"), "-lvp8hip", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "vp8oclenc_amd")], check=True, timeout=300)
+    W, H, frames, gop = 320, 192, 40, 8
+    seq = SynthSequence(W, H, seed=23)
+    src = [seq.frame(t) for t in range(frames)]
+    y4m.write_y4m(str(tmp_path / "in.y4m"), src, framerate=30)
+    r = subprocess.run([exe, str(tmp_path / "in.y4m"), str(tmp_path / "out.ivf"), "-g", str(gop), "-partitions", "2", "-chunks", "3", "-batch", "3", "-conformant",
+                        "-SSIM-target", "0.93", "-qmin", "40", "-qmax", "110"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    Wf, Hf, rate, scale, packets = decode_ivf.read_ivf(str(tmp_path / "out.ivf"))
+    assert (Wf, Hf, len(packets)) == (W, H, frames)
+    dec = vp8_decode.Decoder()
+    keys = 0
+    for t, fr in enumerate(packets):
+        f, (Y, U, V) = dec.decode(fr)
+        keys += int(f.key)
+        if t % gop == 0:
+            assert f.key, t                       # every chunk starts with its key frame
+        assert decode_ivf.psnr(Y[:H, :W], src[t][0]) > 24.0, t
+    assert keys >= frames // gop
+    assert f"{keys} key frames" in r.stdout, (keys, r.stdout)
