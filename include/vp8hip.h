@@ -404,6 +404,10 @@ int vp8hip_batch_prefetch_current(vp8hip_batch *b, const uint8_t *const *y, cons
 int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is_key_frame, const int32_t (*refqi)[4], int qi_min);
 int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *prev_is_golden, const int *prev_is_altref,
                                  const int *use_golden, const int *use_altref);
+/* vp8hip_intra_transform + vp8hip_prepare_filter_mask for the members whose frame is a KEY frame (active[i] != 0), the intra wavefronts
+ * of all of them in one launch; vp8hip_batch_loop_filter for the same members follows.  (The members' segment data: vp8hip_batch_auto_segments
+ * with is_key_frame set, or vp8hip_set_segments per member.) */
+int vp8hip_batch_intra_transform(vp8hip_batch *b, const int *active);
 int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active);
 /* vp8hip_check_ssim_async for the active members (one launch; the verdicts ride in the following vp8hip_batch_loop_filter);
  * vp8hip_check_ssim_result per member afterwards */
@@ -418,7 +422,7 @@ const char *vp8hip_status_string(int status);
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
  * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
  * vp8drv_frame_check folds position in (4: its values change). */
-#define VP8HIP_ABI_VERSION 4006
+#define VP8HIP_ABI_VERSION 4007
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

@@ -493,6 +493,54 @@ int vp8hip_batch_loop_filter(vp8hip_batch *b, const int *active) {
     return VP8HIP_OK;
 }
 
+// intra_transform (intra_part.h:1089-1109) for the members whose frame is a key frame, in ONE launch (the members' wavefronts side by side:
+// a batch whose chunks all start a GOP used to run them one after the other), then every member's filter mask
+// (prepare_filter_mask, loop_filter.h:25-55).  vp8hip_batch_loop_filter for the same members follows.
+int vp8hip_batch_intra_transform(vp8hip_batch *b, const int *active) {
+    if (!b) return VP8HIP_ERR_ARG;
+    vp8hip_ctx *c0 = b->c[0];
+    USE_DEVICE(c0);
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        if (b->c[i]->cur_count == 0) return VP8HIP_ERR_STATE;
+    }
+    CheckItem it[MAX_BATCH];
+    vp8hip_ctx *m[MAX_BATCH];
+    int n = 0;
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        vp8hip_ctx *c = b->c[i];
+        const int rc = claim_recon(c);
+        if (rc) return rc;
+        c->ent_counted_partitions = 0;
+        drop_overflowed_frame(c);
+        ++c->out_gen;
+        CheckItem &k = it[n];
+        k.cur = &c->cur;
+        k.recon = &c->frames[c->recon].f;
+        k.o = &c->out;
+        k.sd = c->d_sd;
+        k.modes = c->intra_modes;
+        k.is_inter = c->intra_is_inter;
+        k.prog = c->intra_prog;
+        k.err = c->d_progress + LF_ERR_WORD;
+        k.gen = ++c->intra_gen;
+        m[n++] = c;
+    }
+    if (!n) return VP8HIP_OK;
+    {
+        Timed t(c0, VP8HIP_K_INTRA);
+        launch_intra_key_batch(b->stream, it, n, c0->mbw, c0->mbh);
+    }
+    {
+        Timed t(c0, VP8HIP_K_FILTER_MASK);
+        for (int i = 0; i < n; ++i) launch_filter_mask(b->stream, m[i]->out, m[i]->d_sd, m[i]->mbs);
+    }
+    for (int i = 0; i < n; ++i) m[i]->recon_ready = true;
+    HIPCHK(c0, hipGetLastError());
+    return VP8HIP_OK;
+}
+
 int vp8hip_batch_check_ssim_async(vp8hip_batch *b, const int *active, const int32_t (*refqi)[4], int qi_min) {
     if (!b || !refqi) return VP8HIP_ERR_ARG;
     vp8hip_ctx *c0 = b->c[0];

@@ -656,7 +656,7 @@ constexpr int K4_WAVES = 5;
         if (*abort_flag) return;                                                                        \
     }
 
-__global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) {
+__device__ __forceinline__ void intra_key4_body(const IntraArgs &a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x, mbw = a.mbw;
     const int BW = mbw * 16 + 16;                      // bytes per pixel row: x = -4 .. W + 11 at byte x + 4
@@ -916,6 +916,12 @@ __device__ __forceinline__ SsimStats ssim_stats_body(const float *ssim, const in
     }
     return r;
 }
+
+__global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4(IntraArgs a) { intra_key4_body(a); }
+// the key frames of several members of a batch in one launch (blockIdx.z = member): a key frame is a wavefront of mb_h workgroups a
+// millisecond and a half long, and a batch whose members all start a GOP -- every chunk of a file does, together -- ran six of them
+// one after the other on its stream
+__global__ __launch_bounds__(64 * K4_WAVES) void k_intra_key4_b(BatchOf<IntraArgs> b) { intra_key4_body(b.item[blockIdx.z]); }
 __global__ __launch_bounds__(256) void k_ssim_stats(const float *ssim, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {
     const SsimStats r = ssim_stats_body(ssim, is_inter, mbs);
     if (threadIdx.x == 0) {
@@ -964,6 +970,17 @@ void launch_intra(hipStream_t s, const Frame &cur, const Frame &recon, const MBO
     } else {
         hipLaunchKernelGGL(k_intra, dim3(mbh), dim3(64), 0, s, a);
     }
+}
+
+void launch_intra_key_batch(hipStream_t s, const CheckItem *items, int n, int mbw, int mbh) {
+    BatchOf<IntraArgs> b;
+    b.n = n;
+    for (int i = 0; i < n; ++i) {
+        const CheckItem &c = items[i];
+        b.item[i] = intra_args(*c.cur, *c.recon, *c.o, c.sd, c.modes, c.is_inter, c.prog, c.gen, c.err, 0.0f, 1, mbw, mbh, 0, 0);
+    }
+    const size_t shmem = 5 * (size_t)(mbw * 16 + 16) + 3856;
+    hipLaunchKernelGGL(k_intra_key4_b, dim3(mbh, 1, n), dim3(64 * K4_WAVES), shmem, s, b);
 }
 
 void launch_ssim_stats(hipStream_t s, const MBOut &o, const int32_t *is_inter, int mbs, const int32_t *err, int32_t *out) {

@@ -422,11 +422,43 @@ static int batch_encode_frame(vp8drv_batch *b, const int *members, const void *c
     if (host) DRV_CHK(vp8hip_batch_upload_current(b->hb, members, reinterpret_cast<const uint8_t *const *>(y), reinterpret_cast<const uint8_t *const *>(u),
                                                   reinterpret_cast<const uint8_t *const *>(v)));
     else DRV_CHK(vp8hip_batch_set_current_device(b->hb, members, y, u, v));          // vp8enc.cpp:386-388, all members in one launch
-    int n_inter = 0;
+    int n_inter = 0, n_key = 0;
+    for (int i = 0; i < b->n; ++i) n_key += key[i];
+    static const bool batch_keys = [] { const char *e = getenv("VP8DRV_BATCH_KEYS"); return !(e && e[0] == '0'); }();   // =0: one after the other, as before (A/B runs)
+    if (!batch_keys) n_key = n_key ? 1 : 0;
+    if (n_key > 1) {
+        // Several members start a GOP in this call (every chunk of a file coded GOPs side by side does, together): their key frames --
+        // each a raster-order wavefront a millisecond and a half long -- in ONE launch instead of one after the other on the shared
+        // stream, with the segment data, filter masks and loop filters of key_frame() batched the same way
+        int32_t kq[VP8HIP_MAX_BATCH][4];
+        int ones[VP8HIP_MAX_BATCH];
+        for (int i = 0; i < b->n; ++i) {
+            ones[i] = 1;
+            for (int k = 0; k < 4; ++k) kq[i][k] = b->d[i]->altrefqi[k];
+        }
+        DRV_CHK(vp8hip_batch_auto_segments(b->hb, key, ones, kq, b->d[0]->qi_min));   // prepare_segments_data(), vp8enc.cpp:379-383
+        DRV_CHK(vp8hip_batch_intra_transform(b->hb, key));                            // intra_transform() + prepare_filter_mask
+        DRV_CHK(vp8hip_batch_loop_filter(b->hb, key));
+        for (int i = 0; i < b->n; ++i) {
+            if (!key[i]) continue;
+            vp8drv *d = b->d[i];
+            d->scene.last_key_detect = d->gop.frame_number;       // intra_part.h:1093
+            vp8host_gop_key_coded(&d->gop);
+            vp8host_gop_frame_done(&d->gop);
+            d->st.key_frames++;
+            d->st.frame_number = d->gop.frame_number;
+            d->have_frame = true;
+            d->last_key = d->last_altref = true;
+            d->checked = false;
+            d->replaced = 0;
+            d->sharpness = VP8HIP_SHARPNESS_ON_DEVICE;
+        }
+    }
     for (int i = 0; i < b->n; ++i) {
         vp8drv *d = b->d[i];
         if (members && !members[i]) continue;
-        if (key[i]) {   // a key frame is a raster-order wavefront of its own: the member's ordinary path, on the shared stream
+        if (key[i]) {   // a single key frame: the member's ordinary path, on the shared stream
+            if (n_key > 1) continue;
             const int rc = key_frame(d, nullptr);
             if (rc < 0) return rc;
             continue;

@@ -282,6 +282,7 @@ struct LfCheck {
     uint32_t seq;
 };
 void launch_check_fallback(hipStream_t s, const CheckItem *items, int n, float target, int mbw, int mbh, int modes_of_kept);
+void launch_intra_key_batch(hipStream_t s, const CheckItem *items, int n, int mbw, int mbh);   // the key frames of n members of a batch, one launch
 
 // ---- device helpers ---------------------------------------------------------------------------
 #if defined(__HIPCC__)
