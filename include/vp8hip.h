@@ -394,7 +394,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
 /* The same from HOST memory -- the reference's own hand-over (clEnqueueWriteBuffer of the frame it has read, vp8enc.cpp:386-388) for a
  * batch: tight planes of the source size, copied on a stream of the batch's own into staging buffers (two per member, made on the first
  * call) and packed from there.  With page-locked planes (vp8hip_host_alloc) the copies are asynchronous and run beside what the batch
- * still has on the device (the previous frame's loop filter); pageable planes work and are copied before the call returns.  The
+ * still has on the device (the previous frame's loop filter); pageable planes work as well (the runtime stages them).  Either way the
  * planes must stay unchanged until the NEXT vp8hip_batch_upload_current of this batch has returned, or its contexts are synchronised. */
 int vp8hip_batch_upload_current(vp8hip_batch *b, const int *active, const uint8_t *const *y, const uint8_t *const *u, const uint8_t *const *v);
 /* The NEXT frame's planes started on their way early (y[i] NULL: nothing for member i): the following vp8hip_batch_upload_current, given the
@@ -444,7 +444,8 @@ int vp8hip_device_free(int device_ordinal, void *p);
 int vp8hip_device_upload(int device_ordinal, void *dst, const void *src, size_t bytes);
 int vp8hip_device_download(int device_ordinal, void *dst, const void *src, size_t bytes);
 int vp8hip_device_synchronize(int device_ordinal);
-/* page-locked host memory (hipHostMalloc): source planes handed to vp8hip_upload_* / vp8hip_batch_upload_current from it are copied asynchronously */
+/* page-locked host memory (hipHostMalloc): source planes handed to vp8hip_prefetch_current / vp8hip_batch_upload_current / _prefetch_current from it
+ * are copied asynchronously (vp8hip_upload_current itself returns when its copy is done, whatever the memory) */
 int vp8hip_host_alloc(int device_ordinal, size_t bytes, void **out);
 int vp8hip_host_free(int device_ordinal, void *p);
 int vp8hip_device_mem_info(int device_ordinal, size_t *free_bytes, size_t *total_bytes);

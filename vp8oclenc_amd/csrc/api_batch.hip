@@ -260,7 +260,7 @@ int vp8hip_batch_set_current_device(vp8hip_batch *b, const int *active, const vo
 
 // Planes in HOST memory (vp8enc.cpp:386-388, the reference's own hand-over: clEnqueueWriteBuffer from the frame it has read).  The
 // copies are asynchronous when the planes are page-locked (vp8hip_host_alloc) and then overlap the batch's previous frame still on the
-// device; the planes must stay as they are until the NEXT vp8hip_batch_upload_current of this batch has returned (it waits for these
+// device; page-locked or not, the planes must stay as they are until the NEXT vp8hip_batch_upload_current of this batch has returned (it waits for these
 // copies first) or the batch's contexts have been synchronised.
 // The frame AFTER the one under way, started on its way early: the copies go into the buffers the next vp8hip_batch_upload_current
 // will pack from, and that call, given the same planes, finds them there.  A host that knows its next frame (a decoder's ring, a file
