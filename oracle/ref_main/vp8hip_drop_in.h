@@ -21,7 +21,21 @@
 #include "vp8hip.h"
 #include "vp8hip_host.h"
 
+#include <time.h>
+
 static vp8hip_ctx *hip_ctx = NULL;
+// the frame loop by the host's clock -- from the end of init_all() to the start of finalize(), i.e. main()'s while loop with its reads and
+// writes (vp8enc.cpp:351-488) -- printed on stderr by hip_finalize(): what bench.py's drop_in leg reports next to the process's wall time
+static struct timespec hip_loop_t0;
+static double hip_seconds_in[8];      // time inside the library's calls, by call site (VP8HIP_DROP_IN_TIMELINE=1)
+static const char *const hip_site_name[8] = {"upload_current", "set_segments", "inter_transform", "download/check_ssim", "filter_mask", "loop_filter", "entropy_encode", "intra_transform"};
+static int hip_timeline = 0;
+static inline double hip_now() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+struct hip_site_timer {
+    int site; double t0;
+    hip_site_timer(int s) : site(s), t0(hip_timeline ? hip_now() : 0.0) {}
+    ~hip_site_timer() { if (hip_timeline) hip_seconds_in[site] += hip_now() - t0; }
+};
 
 #define HIP_CK(call)                                                                                                   \
     do {                                                                                                               \
@@ -47,12 +61,24 @@ static int hip_init()
         printf("no usable MI355X: %s\n", vp8hip_status_string(rc));     // where the reference says "no GPU device found" (init.h:146-150)
         return -1;
     }
+    hip_timeline = getenv("VP8HIP_DROP_IN_TIMELINE") != NULL;
+    clock_gettime(CLOCK_MONOTONIC, &hip_loop_t0);
     return 1;
 }
 
 // finalize(), vp8enc.cpp:505-681: ~170 clRelease* calls
 static void hip_finalize()
 {
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double loop_s = (double)(t1.tv_sec - hip_loop_t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - hip_loop_t0.tv_nsec);
+    fprintf(stderr, "vp8hip_drop_in: frame loop %d frames %.6f s\n", (int)frames.frame_number, loop_s);
+    if (hip_timeline) {
+        double in_calls = 0.0;
+        for (int i = 0; i < 8; ++i) in_calls += hip_seconds_in[i];
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "vp8hip_drop_in: in %-20s %.6f s\n", hip_site_name[i], hip_seconds_in[i]);
+        fprintf(stderr, "vp8hip_drop_in: in the reference's own host code (reader, padding, scans, frame types, writer) %.6f s\n", loop_s - in_calls);
+    }
     vp8hip_destroy(hip_ctx);
     free(frames.MB);
     free(frames.reconstructed_Y);
@@ -61,23 +87,25 @@ static void hip_finalize()
 }
 
 // prepare_segments_data()'s tail, vp8enc.cpp:222-227: clEnqueueWriteBuffer(segments_data_gpu / _cpu)
-static void hip_set_segments() { HIP_CK(vp8hip_set_segments(hip_ctx, (const int32_t *)frames.segments_data)); }
+static void hip_set_segments() { hip_site_timer t_(1); HIP_CK(vp8hip_set_segments(hip_ctx, (const int32_t *)frames.segments_data)); }
 
 // main(), vp8enc.cpp:386-406: three clEnqueueWriteBuffer(current_frame_Y/U/V); the re-upload of the filtered reconstruction
 // (:389-404) has no counterpart -- it never leaves the device
-static void hip_upload_current() { HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V)); }
+static void hip_upload_current() { hip_site_timer t_(0); HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V)); }
 
 // inter_part.h:1-384: prepare_GPU_buffers() + inter_transform(), ~82 kernel launches on three queues
 static void inter_transform()
 {
     const int use_golden = !frames.prev_is_golden_frame;                                                                        // :103
     const int use_altref = (!frames.prev_is_altref_frame) && (frames.altref_frame_number != frames.golden_frame_number);        // :104
+    hip_site_timer t_(2);
     HIP_CK(vp8hip_inter_transform(hip_ctx, frames.prev_is_golden_frame, frames.prev_is_altref_frame, use_golden, use_altref));
 }
 
 // main(), vp8enc.cpp:421-434 and inter_part.h:263-265: nine clEnqueueReadBuffer
 static void hip_download_results()
 {
+    hip_site_timer t_(3);
 #ifdef VP8HIP_KEEP_HOST_STAGES
     vp8hip_results r;
     r.MB_parts = frames.MB_parts;
@@ -99,6 +127,7 @@ static void hip_check_ssim(float *min1, float *min2)
 {
     int32_t replaced = 0;
     float new_ssim = 0.0f, mn = 2.0f;
+    hip_site_timer t_(3);
     HIP_CK(vp8hip_check_ssim(hip_ctx, &replaced, &new_ssim, &mn));
     frames.replaced = replaced;
     frames.new_SSIM = new_ssim;
@@ -110,6 +139,7 @@ static void hip_check_ssim(float *min1, float *min2)
 // reconstruction to the device)
 static void hip_intra_transform()
 {
+    hip_site_timer t_(7);
     HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V));   // key frames were host-only
     HIP_CK(vp8hip_intra_transform(hip_ctx));
 }
@@ -117,6 +147,7 @@ static void hip_intra_transform()
 // intra_transform()'s uploads, intra_part.h:1112-1126: the host-coded key frame goes to the device
 static void hip_upload_intra_results()
 {
+    hip_site_timer t_(7);
     HIP_CK(vp8hip_upload_mb_data(hip_ctx, (const int16_t *)frames.MB, frames.MB_parts, frames.MB_segment_id));
     HIP_CK(vp8hip_upload_recon(hip_ctx, frames.reconstructed_Y, frames.reconstructed_U, frames.reconstructed_V));
 }
@@ -137,6 +168,7 @@ static void hip_upload_host_results()
 // loop_filter.h:1-55: prepare_filter_mask on either device + the read-back of the non-zero counts + skip_prob (:37-44)
 static void prepare_filter_mask_and_non_zero_coeffs()
 {
+    hip_site_timer t_(4);
     HIP_CK(vp8hip_prepare_filter_mask(hip_ctx, frames.MB_non_zero_coeffs));
     frames.skip_prob = vp8host_skip_prob(frames.MB_non_zero_coeffs, video.mb_count);
 }
@@ -145,6 +177,7 @@ static void prepare_filter_mask_and_non_zero_coeffs()
 static void do_loop_filter()
 {
     if (video.GOP_size < 2) return;     // :59, :142
+    hip_site_timer t_(5);
     HIP_CK(vp8hip_loop_filter(hip_ctx));
 }
 
@@ -156,6 +189,7 @@ extern void encode_header(cl_uchar *const partition);   // entropy_host.cpp:709
 // entropy_encode()'s body, vp8enc.cpp:50-91
 static void hip_entropy_encode()
 {
+    hip_site_timer t_(6);
 #ifdef VP8HIP_KEEP_HOST_STAGES
     // count_probs + num_div_denom on the CPU device and their two read-backs (:58-68)
     HIP_CK(vp8hip_count_probs(hip_ctx, (int)video.number_of_partitions, (uint32_t *)frames.new_probs, (uint32_t *)frames.new_probs_denom));

@@ -11,7 +11,7 @@ synthetic frames, and writes inputs + every stage output.  It also runs the CPU 
 what differs (report.json) -- that is the pin of the restatement and of oracle/ref_shim.cl.
 
     gpurun -- 'python3 scripts/gen_golden_gfx950.py --out gpurun_out/golden_gfx950'
-    cp gpurun_out/golden_gfx950/*.npz tests/golden/gfx950/ ; cp .../report.json tests/golden/gfx950/
+    cp gpurun_out/golden_gfx950/*.npz tests/golden/gfx950/ ; cp .../report*.json tests/golden/gfx950/
 """
 import argparse
 import json
@@ -43,6 +43,12 @@ CASES = [
 ]
 
 
+# The metric's geometries (BASELINE configs[1]-[3]): too large to commit as arrays, so the fixture is the CRC-32 of every stage output of
+# the reference's kernels (+ MB_SSIM itself, the one float output, for the 1e-4 comparison).  1920x1080 is the only configuration with padded
+# rows (wrk 1088) and a half block row at pyramid level 4 (src/inter_part.h:110, src/init.h:383-386).  tests/large_cases.py regenerates the inputs.
+from large_cases import LARGE_CASES, crc_of_outputs, large_case_frames  # noqa: E402
+
+
 def case_frames(W, H, seed, kind, kw):
     if kind == "noise":
         nf = noise_frames(W, H, seed)
@@ -72,6 +78,7 @@ def compare(a: dict, b: dict) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "golden_gfx950"))
+    ap.add_argument("--only-large", action="store_true", help="only the L* fixtures of the metric's geometries (report_large.json)")
     args = ap.parse_args()
     cl = ref_cl_stages()
     if cl is None:
@@ -81,7 +88,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     report = {"device": cl.device_name, "CL_DEVICE_IMAGE_SUPPORT": cl.image_support, "opencl_runtime": "AMD (libamdocl64), clCreateProgramWithBinary on the code objects of oracle/build_ref.sh",
               "cases": {}, "entropy": {}}
-    for name, W, H, seed, kind, target, ug, ua, kw in CASES:
+    for name, W, H, seed, kind, target, ug, ua, kw in ([] if args.only_large else CASES):
         t0 = time.time()
         f = case_frames(W, H, seed, kind, kw)
         cur, refs = f[3], [f[2], f[0], f[1]]
@@ -109,6 +116,32 @@ def main():
         rep["seconds"] = round(time.time() - t0, 1)
         report["cases"][name] = rep
         print(name, rep, flush=True)
+
+    large = {"device": cl.device_name, "CL_DEVICE_IMAGE_SUPPORT": cl.image_support, "cases": {}}
+    for name, W, H, seed, target, ug, ua, kw in LARGE_CASES:
+        t0 = time.time()
+        cur, refs = large_case_frames(W, H, seed, kw)
+        sd = default_segments()
+        r = run_inter_frame(cl, cur, refs, sd, ug, ua, target)
+        t_cl = time.time() - t0
+        o = run_inter_frame(ora, cur, refs, sd, ug, ua, target)
+        rep = {"restatement_vs_gfx950": compare(o, r), "seconds_reference_kernels": round(t_cl, 1)}
+        if x86 is not None and W * H <= 1920 * 1088:
+            rep["x86_shim_build_vs_gfx950"] = compare(run_inter_frame(x86, cur, refs, sd, ug, ua, target), r)
+        crcs = crc_of_outputs(r)
+        ins = {f"in_{nm}_{pn}": pl for nm, fr in (("cur", cur), ("ref0", refs[0]), ("ref1", refs[1]), ("ref2", refs[2])) for pn, pl in zip("YUV", fr)}
+        meta = dict(W=W, H=H, wrk_W=int(cur[0].shape[1]), wrk_H=int(cur[0].shape[0]), seed=seed, ssim_target=target, use_golden=ug, use_altref=ua,
+                    synth_kwargs=repr(kw), device=cl.device_name, crc32=crcs, crc32_inputs=crc_of_outputs(ins),
+                    segments_histogram=np.bincount(r["MB_segment_id"], minlength=4).tolist(),
+                    reference_histogram=np.bincount(r["MB_reference_frame"], minlength=4).tolist())
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), segments=sd, meta=np.array(json.dumps(meta)), MB_SSIM=r["MB_SSIM"])
+        rep["seconds"] = round(time.time() - t0, 1)
+        large["cases"][name] = rep
+        print(name, rep, flush=True)
+    with open(os.path.join(args.out, "report_large.json"), "w") as fjs:
+        json.dump(large, fjs, indent=1)
+    if args.only_large:
+        return
 
     # coefficient entropy stage (src/CPU_kernels.cl:347-778) on the same device
     ent = [("e_synthetic_6x4_p1", synthetic(6, 4, 11), 6, 4, 1),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "vp8hip_bitstream.h"
@@ -76,6 +77,7 @@ int main(int argc, char **argv) {
     CK(vp8hip_reserve_frame_path_dense(vp8drv_context(drv)));
     bool pending = false;
     int cur = 0;
+    const auto t_loop = std::chrono::steady_clock::now();      // (the frame loop by the host's clock: what scripts/drop_in_bench.py quotes as fps_loop)
     int have = read_frame(buf[cur]);
     if (have < 0) { fprintf(stderr, "broken stream!\n"); return 1; }
     for (;;) {
@@ -105,6 +107,7 @@ int main(int argc, char **argv) {
         keys += key;
         pending = true;
     }
+    const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
     fseek(out, 0, SEEK_SET);
     // the reference's file says one frame more than it holds: write_output_header counts from a frame number that main() has
     // already advanced past the last frame (encIO.h:124-134, vp8enc.cpp:487-489; REFERENCE_DEFECTS.md #8) -- reproduced, the bar
@@ -118,5 +121,6 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 2; ++k) vp8hip_host_free(0, buf[k]);
     printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes; %d hardware queues\n", argv[2], n, W, H, Wc, Hc, keys,
            st.scene_changes, st.redone_as_key, total, vp8hip_hw_queues());
+    printf("%.6f s of reading + coding + writing (%.1f frames/s)\n", loop_s, n / (loop_s > 0 ? loop_s : 1));
     return 0;
 }

@@ -452,3 +452,31 @@ def test_golden_vectors(path):
         if not np.array_equal(h[f"last_pyr{l}"], z[f"ref0_pyr_{l}"]):
             bad.append((f"last_pyr{l}",))
     assert not bad, f"{_os.path.basename(path)}: HIP differs from the reference kernels' outputs: {bad}"
+
+
+# ---- the metric's geometries against the reference's kernels: CRC fixtures (tests/large_cases.py, tests/golden/gfx950/L*.npz) ----
+from large_cases import FIXTURES as _LARGE, LARGE_BY_NAME as _LARGE_BY_NAME, diff_against_fixture as _diff_fixture, \
+    large_case_frames as _large_frames, load_fixture as _load_fixture
+
+
+@pytest.mark.parametrize("path", _LARGE, ids=[_os.path.basename(p)[:-4] for p in _LARGE])
+@pytest.mark.parametrize("one_video", [False, True], ids=["plain", "one_video"])
+def test_reference_kernel_fixtures_at_the_metrics_geometry(path, one_video):
+    """1280x720 / 1920x1080 (wrk 1088) / 3840x2160 through libvp8hip.so against the CRC-32 of every stage output of the REFERENCE'S OWN
+    kernels run on an MI355X; MB_SSIM at 1e-4.  Block 24 is compared where it exists (16x16 macroblocks)."""
+    meta, seg, ssim = _load_fixture(path)
+    name, W, H, seed, target, ug, ua, kw = _LARGE_BY_NAME[_os.path.basename(path)[:-4]]
+    cur, refs = _large_frames(W, H, seed, kw)
+    h, _ = _one_frame(cur[0].shape[1], cur[0].shape[0], [refs[0], refs[1], refs[2], cur], seg, (ug, ua), target, one_video=one_video)
+    out = {k: h[k] for k in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_segment_id", "prefilter_Y", "prefilter_U", "prefilter_V",
+                             "MB_non_zero_coeffs", "mb_mask", "recon_Y", "recon_U", "recon_V", "MB_SSIM", "MB_coeffs")}
+    rename = {}
+    for r in range(3):
+        if r == 0 or (ug, ua)[r - 1]:
+            out[f"net1_r{r}"], out[f"bdiff_r{r}"], out[f"net2_r{r}"] = h[f"net1_r{r}"], h[f"bdiff_r{r}"], h[f"net2_r{r}"]
+            rename[f"net2_r{r}"] = f"net_r{r}_l0"
+    for l in range(5):
+        out[f"cur_pyr{l}"], out[f"last_pyr{l}"] = h[f"cur_pyr{l}"], h[f"last_pyr{l}"]
+        rename[f"cur_pyr{l}"], rename[f"last_pyr{l}"] = f"cur_pyr_{l}", f"ref0_pyr_{l}"
+    bad = _diff_fixture(out, meta, ssim, rename=rename, skip=("MB_coeffs",))
+    assert not bad, f"{name}: HIP differs from the reference kernels' outputs on gfx950: {bad}"

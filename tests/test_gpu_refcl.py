@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from entropy_cases import run_stage, synthetic
+from large_cases import FIXTURES, LARGE_CASES, diff_against_fixture, large_case_frames, load_fixture
 from oracle_lib import Oracle, ref_cl_stages
 from pipeline import default_segments, run_inter_frame
 from vp8oclenc_amd.synth import SynthSequence, noise_frames
@@ -76,15 +77,10 @@ def test_restatement_matches_reference_kernels_on_this_gpu(W, H, seed, kind, tar
     assert not bad, f"restatement differs from the reference kernels run on {cl_stages.device_name}: {bad}"
 
 
-@pytest.mark.parametrize("W,H,seed,kind,target,ug,ua,kw", CASES[:4])
-def test_hip_path_matches_reference_kernels_on_this_gpu(W, H, seed, kind, target, ug, ua, kw, cl_stages):
-    """The same frame through the C ABI of libvp8hip.so and through the reference's kernels, both on this GPU."""
+def _hip_against(r, cur, refs, sd, ug, ua, target):
+    """what of the same frame through the C ABI of libvp8hip.so differs from the stage outputs `r`"""
     from test_gpu_parity import _one_frame
-    f = _frames(W, H, seed, kind, kw)
-    cur, refs = f[3], [f[2], f[0], f[1]]
-    sd = default_segments()
-    r = run_inter_frame(cl_stages, cur, refs, sd, ug, ua, target)
-    h, _ = _one_frame(W, H, [refs[0], refs[1], refs[2], cur], sd, (ug, ua), target)
+    h, _ = _one_frame(cur[0].shape[1], cur[0].shape[0], [refs[0], refs[1], refs[2], cur], sd, (ug, ua), target)
     bad = []
     for k in ("MB_parts", "MB_reference_frame", "MB_vectors", "MB_segment_id", "prefilter_Y", "prefilter_U", "prefilter_V",
               "MB_non_zero_coeffs", "mb_mask", "recon_Y", "recon_U", "recon_V"):
@@ -103,7 +99,43 @@ def test_hip_path_matches_reference_kernels_on_this_gpu(W, H, seed, kind, target
             for hk, rk in ((f"net1_r{ref}", f"net1_r{ref}"), (f"bdiff_r{ref}", f"bdiff_r{ref}"), (f"net2_r{ref}", f"net_r{ref}_l0")):
                 if not np.array_equal(h[hk], r[rk]):
                     bad.append((hk, int((h[hk] != r[rk]).sum())))
+    for l in range(5):
+        for hk, rk in ((f"cur_pyr{l}", "cur_pyr"), (f"last_pyr{l}", "ref0_pyr")):
+            if not np.array_equal(h[hk], r[rk][l]):
+                bad.append((hk, int((h[hk] != r[rk][l]).sum())))
+    return bad
+
+
+@pytest.mark.parametrize("W,H,seed,kind,target,ug,ua,kw", CASES[:4])
+def test_hip_path_matches_reference_kernels_on_this_gpu(W, H, seed, kind, target, ug, ua, kw, cl_stages):
+    """The same frame through the C ABI of libvp8hip.so and through the reference's kernels, both on this GPU."""
+    f = _frames(W, H, seed, kind, kw)
+    cur, refs = f[3], [f[2], f[0], f[1]]
+    sd = default_segments()
+    r = run_inter_frame(cl_stages, cur, refs, sd, ug, ua, target)
+    bad = _hip_against(r, cur, refs, sd, ug, ua, target)
     assert not bad, f"HIP differs from the reference kernels run on {cl_stages.device_name}: {bad}"
+
+
+@pytest.mark.parametrize("case", LARGE_CASES, ids=[c[0] for c in LARGE_CASES])
+def test_reference_kernels_restatement_and_hip_agree_at_the_metrics_geometry(case, cl_stages, oracle_stages):
+    """BASELINE configs[1]-[3]: 1280x720, 1920x1080 (wrk 1088: padded rows, half a block row at level 4) and 3840x2160, three references,
+    one per size with the four-pass SSIM ladder -- the reference's own kernels on this GPU, the CPU restatement and libvp8hip.so on the
+    same frame; the committed CRC fixture of the case (tests/golden/gfx950/L*.npz) must be what the reference's kernels give here."""
+    name, W, H, seed, target, ug, ua, kw = case
+    cur, refs = large_case_frames(W, H, seed, kw)
+    sd = default_segments()
+    r = run_inter_frame(cl_stages, cur, refs, sd, ug, ua, target)
+    bad = _diff(run_inter_frame(oracle_stages, cur, refs, sd, ug, ua, target), r)
+    assert not bad, f"{name}: restatement differs from the reference kernels run on {cl_stages.device_name}: {bad}"
+    bad = _hip_against(r, cur, refs, sd, ug, ua, target)
+    assert not bad, f"{name}: HIP differs from the reference kernels run on {cl_stages.device_name}: {bad}"
+    fx = [p for p in FIXTURES if p.endswith(name + ".npz")]
+    assert fx, f"{name}: no committed fixture (scripts/gen_golden_gfx950.py --only-large)"
+    meta, seg, ssim = load_fixture(fx[0])
+    assert np.array_equal(seg, sd)
+    bad = diff_against_fixture(r, meta, ssim)
+    assert not bad, f"{name}: the reference kernels give other outputs here than the committed fixture holds: {bad}"
 
 
 @pytest.mark.parametrize("mbw,mbh,seed,P,kw", [(8, 5, 31, 2, {}), (11, 9, 32, 8, dict(density=0.5, big=0.1))])

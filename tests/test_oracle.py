@@ -12,6 +12,7 @@ import os
 import numpy as np
 import pytest
 
+from large_cases import FIXTURES as LARGE_FIXTURES, LARGE_BY_NAME, crc_of_outputs, diff_against_fixture, large_case_frames, load_fixture
 from oracle_lib import Oracle
 from pipeline import default_segments, load_meta, run_inter_frame
 from vp8oclenc_amd.synth import SynthSequence, noise_frames
@@ -78,6 +79,36 @@ def test_gfx950_report_says_what_the_fixtures_pin():
             assert ssim is None or ssim["max_abs_diff"] < 1e-6, (name, who, ssim)
     for name, e in rep["entropy"].items():
         assert e["restatement_vs_gfx950"] == [], name
+
+
+@pytest.mark.parametrize("path", LARGE_FIXTURES, ids=[os.path.basename(p)[:-4] for p in LARGE_FIXTURES])
+def test_restatement_matches_reference_kernels_run_on_gfx950_at_the_metrics_geometry(path, oracle_stages):
+    """BASELINE configs[1]-[3] (1280x720, 1920x1080 -> wrk 1088, 3840x2160; one per size with -SSIM-target 0.93): CRC-32 of every stage
+    output of the reference's own kernels run on an MI355X (scripts/gen_golden_gfx950.py --only-large), MB_SSIM at 1e-4."""
+    meta, seg, ssim = load_fixture(path)
+    assert "gfx950" in meta["device"]
+    name, W, H, seed, target, ug, ua, kw = LARGE_BY_NAME[os.path.basename(path)[:-4]]
+    assert (W, H, seed, target, ug, ua, repr(kw)) == (meta["W"], meta["H"], meta["seed"], meta["ssim_target"], meta["use_golden"], meta["use_altref"], meta["synth_kwargs"])
+    cur, refs = large_case_frames(W, H, seed, kw)
+    ins = {f"in_{nm}_{pn}": pl for nm, fr in (("cur", cur), ("ref0", refs[0]), ("ref1", refs[1]), ("ref2", refs[2])) for pn, pl in zip("YUV", fr)}
+    assert crc_of_outputs(ins) == meta["crc32_inputs"], "this numpy renders other synthetic frames than the box the fixture was made on"
+    out = run_inter_frame(oracle_stages, cur, refs, seg, ug, ua, target)
+    bad = diff_against_fixture(out, meta, ssim)
+    assert not bad, f"{name}: restatement differs from the reference kernels run on gfx950: {bad}"
+
+
+def test_large_fixtures_present_and_their_report_is_clean():
+    import json
+    assert len(LARGE_FIXTURES) == len(LARGE_BY_NAME) >= 5
+    with open(os.path.join(os.path.dirname(__file__), "golden", "gfx950", "report_large.json")) as f:
+        rep = json.load(f)
+    assert "gfx950" in rep["device"] and set(rep["cases"]) == set(LARGE_BY_NAME)
+    for name, c in rep["cases"].items():
+        for who in ("restatement_vs_gfx950", "x86_shim_build_vs_gfx950"):
+            d = dict(c.get(who, {}))
+            ssim = d.pop("MB_SSIM", None)
+            assert not d, (name, who, d)
+            assert ssim is None or ssim["max_abs_diff"] < 1e-6, (name, who, ssim)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
