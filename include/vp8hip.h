@@ -293,7 +293,10 @@ int vp8hip_last_hip_error(const vp8hip_ctx *ctx);
  * context-switches running waves.  Returns the value in force as far as the library can tell: what the environment said when the
  * runtime initialised.  If the runtime was ALREADY initialised when the library was loaded (a host that made HIP calls first) the
  * constructor changes nothing, says so on stderr once (VP8HIP_QUIET=1 silences it) and this returns what the environment held then
- * (4 if nothing).  vp8hip_inter_transform prints one line when more contexts launch on streams of their own than there are queues. */
+ * (4 if nothing).  vp8hip_inter_transform prints one line when more contexts launch on streams of their own than there are queues.
+ * SIDE EFFECTS of that constructor, stated: (1) setenv() in the host process -- safe when the library is loaded at program start or
+ * before the host has made threads; a host that dlopen()s it while other threads may call getenv() exports GPU_MAX_HW_QUEUES itself or
+ * sets VP8HIP_NO_ENV=1, with which the library touches nothing; (2) the variable is inherited by the host's child processes. */
 int vp8hip_hw_queues(void);
 
 /* ---- one frame's reference searches on different devices (reference: the three searches of a frame run
@@ -343,19 +346,29 @@ int vp8hip_shard_max(vp8hip_ctx *ctx, double *value);
  * the slowest rank's time, the finished frames in the hands of the one writer (the reference's single output file, encIO.h:1-30,
  * vp8enc.cpp:476-481) -- is here, over RCCL on a stream of the group's own, so that a host needs no GPU framework of its own for it:
  *   vp8hip_group_rendezvous   the 128 id bytes from rank 0 to the other ranks of ONE node through a file
- *                             ($VP8HIP_RENDEZVOUS_DIR or /tmp)/vp8hip-rdzv-<uid>-<key>: rank 0 makes the id (vp8hip_shard_unique_id) and
- *                             writes the file atomically, the others poll for it up to timeout_s (VP8HIP_ERR_TIMEOUT).  `key` names the
- *                             run: the same string on every rank, different for runs alive on the node at the same time.  A host with a
- *                             store of its own (MPI, TCP) hands the id over itself and skips this call;
- *   vp8hip_group_create       every rank, the same id (ncclCommInitRank: collective); key (may be NULL): rank 0 removes the rendezvous file;
+ *                             <dir>/vp8hip-rdzv-<uid>-<key>, <dir> = $VP8HIP_RENDEZVOUS_DIR (taken as named), else $XDG_RUNTIME_DIR, else
+ *                             /tmp/vp8hip-<uid> -- the last two only if they belong to this user and are closed to everybody else
+ *                             (0700; VP8HIP_ERR_STATE otherwise): rank 0 removes a leftover of the same name, makes the id
+ *                             (vp8hip_shard_unique_id) and writes the file atomically (O_EXCL | O_NOFOLLOW, rename); the others poll for
+ *                             it up to timeout_s (VP8HIP_ERR_TIMEOUT) and accept only a regular file of this user no older than timeout_s
+ *                             before their own start.  `key` names the run: the same string on every rank, different for runs alive on
+ *                             the node at the same time.  A host with a store of its own (MPI, TCP) hands the id over itself and skips
+ *                             this call;
+ *   vp8hip_group_create       every rank, the same id (ncclCommInitRank: collective); key (may be NULL): rank 0 removes the rendezvous file.
+ *                             Waits for the other ranks at most $VP8HIP_GROUP_TIMEOUT_S seconds (default 300, 0 = for ever), then
+ *                             VP8HIP_ERR_TIMEOUT: a rank that died or read a wrong id must not hang the others for good (a process that
+ *                             gets this error should exit; the abandoned init cannot be taken back);
  *   vp8hip_group_count        the ranks RCCL counts in the communicator (ncclCommCount);
  *   vp8hip_group_barrier / _max (maximum of one double: a wall time) / _all_gather (<= 4 KB per rank, in rank order, on every rank) /
  *   _broadcast (host memory of rank root to every rank);
  *   vp8hip_group_gather_bytes every rank's `bytes` of host memory (counts[] = every rank's size, from _all_gather, the same on all
  *                             ranks) end to end in rank order into dst on root.  One code path at every world size: every rank, root
  *                             included, sends (ncclSend), root receives from every rank, itself included (ncclRecv).
- * All calls are collective (every rank, same order) and block.  RCCL is loaded (dlopen) by the first call that needs it:
- * $VP8HIP_RCCL_LIBRARY, librccl.so.1 on the process's search path, $ROCM_PATH/lib, /opt/rocm/lib. */
+ * All calls are collective (every rank, same order) and block.  RCCL is loaded (dlopen) by the first call that needs it: the librccl.so.1
+ * beside the HIP runtime the process runs on, $ROCM_PATH/lib, /opt/rocm/lib, the process's search path.
+ * TEST HOOK, not configuration: $VP8HIP_RCCL_LIBRARY, if set, names the file that is dlopen'ed INSTEAD (tests/standin_rccl: several ranks
+ * on one GPU over shared memory, which RCCL refuses).  It makes the library load and run an arbitrary shared object with the
+ * process's rights: never set it in a production environment, and a set-uid / privileged host should clear it before the first call. */
 typedef struct vp8hip_group vp8hip_group;
 int vp8hip_group_rendezvous(const char *key, int rank, double timeout_s, uint8_t id[VP8HIP_SHARD_ID_BYTES]);
 int vp8hip_group_create(vp8hip_group **out, int device_ordinal, const uint8_t id[VP8HIP_SHARD_ID_BYTES], int rank, int world, const char *key);

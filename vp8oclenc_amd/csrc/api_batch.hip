@@ -192,6 +192,13 @@ static int batch_set_current(vp8hip_batch *b, const int *active, const void *con
     USE_DEVICE_ONLY(c0);
     const void *sy[MAX_BATCH], *su[MAX_BATCH], *sv[MAX_BATCH];
     int slot = -1;
+    // every member's pointers are looked at BEFORE anything changes: an error return must leave the staging slots, the prefetch record and
+    // the members' current frames as they were (a retry that flipped stage_idx once more would pack an older frame from the other slot)
+    for (int i = 0; i < b->n; ++i) {
+        if (active && !active[i]) continue;
+        if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
+        if (b->c[i]->src_w != c0->src_w || b->c[i]->src_h != c0->src_h) return VP8HIP_ERR_ARG;   // one launch, one source size
+    }
     if (host) {
         const int rc = batch_stage_ready(b);
         if (rc) return rc;
@@ -201,12 +208,18 @@ static int batch_set_current(vp8hip_batch *b, const int *active, const void *con
         bool waited = false;
         for (int i = 0; i < b->n; ++i) {
             if (active && !active[i]) continue;
-            if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
             uint8_t *d = b->stage[i][slot];
             if (!(b->pre_valid && b->pre[i][0] == y[i] && b->pre[i][1] == u[i] && b->pre[i][2] == v[i])) {   // not prefetched: copied now
                 if (!waited && b->packed_valid[slot]) HIPCHK(c0, hipStreamWaitEvent(b->copy, b->ev_packed[slot], 0));   // the pack of two frames ago has read this buffer
                 waited = true;
-                { const int cr = stage_copy(b, d, y[i], u[i], v[i], ny, nc); if (cr) return cr; }
+                {
+                    const int cr = stage_copy(b, d, y[i], u[i], v[i], ny, nc);
+                    if (cr) {       // a failed copy: nothing of this call counts -- not the flip, not the prefetch
+                        b->stage_idx ^= 1;
+                        b->pre_valid = false;
+                        return cr;
+                    }
+                }
             }
             sy[i] = d; su[i] = d + ny; sv[i] = d + ny + nc;
         }
@@ -219,8 +232,6 @@ static int batch_set_current(vp8hip_batch *b, const int *active, const void *con
     int n = 0;
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
-        if (!y[i] || !u[i] || !v[i]) return VP8HIP_ERR_ARG;
-        if (b->c[i]->src_w != c0->src_w || b->c[i]->src_h != c0->src_h) return VP8HIP_ERR_ARG;   // one launch, one source size
         flush_scan(b->c[i]);      // (a parameter scan of the frame that is being replaced, asked for and never used: on that frame, now)
         next_current(b->c[i]);
         f[n] = &b->c[i]->cur;

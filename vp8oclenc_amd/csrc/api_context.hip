@@ -1,5 +1,6 @@
 // api_context.hip -- the context: HBM surfaces, per-frame parameters, stream ordering, downloads, device memory for hosts that have none.
 // Replaces init_all()'s GPU half (init.h:133-312, 430-582, 595-1166), the uploads of vp8enc.cpp:386-401 and the read-backs of inter_part.h:263-265.
+#include <dirent.h>
 #include <unistd.h>
 
 #include "vp8hip_ctx.h"
@@ -139,22 +140,31 @@ static bool g_runtime_was_up = false;
 
 // Has this process initialised the GPU runtime already?  Its first act is to open the compute driver's device node.
 static bool kfd_is_open() {
-    char link[64], target[128];
-    for (int fd = 0; fd < 1024; ++fd) {
-        snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+    DIR *dir = opendir("/proc/self/fd");      // every descriptor the process holds, however many (not a fixed range of numbers)
+    if (!dir) return false;
+    bool found = false;
+    char link[300], target[128];
+    while (const dirent *e = readdir(dir)) {
+        if (e->d_name[0] < '0' || e->d_name[0] > '9') continue;
+        snprintf(link, sizeof(link), "/proc/self/fd/%s", e->d_name);
         const ssize_t n = readlink(link, target, sizeof(target) - 1);
         if (n <= 0) continue;
         target[n] = 0;
-        if (!strcmp(target, "/dev/kfd")) return true;
+        if (!strcmp(target, "/dev/kfd")) { found = true; break; }
     }
-    return false;
+    closedir(dir);
+    return found;
 }
 
 // (priority 101: ahead of this library's other load-time work -- the registration of its code objects with the runtime)
 __attribute__((constructor(101))) static void vp8hip_loaded() {
     g_runtime_was_up = kfd_is_open();
     const char *q = getenv("GPU_MAX_HW_QUEUES");
-    if (!q && !g_runtime_was_up) {
+    // A SIDE EFFECT ON THE HOST PROCESS, documented in include/vp8hip.h (vp8hip_hw_queues): setenv from a library's constructor.  It is safe
+    // where the library is loaded as libraries usually are -- at program start or from a host's main thread before it has made threads; a
+    // host that dlopen()s the library while other threads may be calling getenv() exports GPU_MAX_HW_QUEUES itself, or sets VP8HIP_NO_ENV=1
+    // (the library then touches nothing and reports the value in force).  The variable is inherited by the host's children, like any other.
+    if (!q && !g_runtime_was_up && !getenv("VP8HIP_NO_ENV")) {
         setenv("GPU_MAX_HW_QUEUES", "16", 0);
         q = getenv("GPU_MAX_HW_QUEUES");
     }
@@ -488,12 +498,14 @@ int vp8hip_prefetch_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, c
 int vp8hip_upload_current(vp8hip_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
     USE_DEVICE(c);
     if (!c || !y || !u || !v) return VP8HIP_ERR_ARG;
-    if (c->h2d_pre_valid && c->h2d_pre[0] == y && c->h2d_pre[1] == u && c->h2d_pre[2] == v) {
+    const int sw = c->src_w ? c->src_w : c->W, sh = c->src_h ? c->src_h : c->H;
+    const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
+    // a prefetch counts only for the source size it was made for: the staging buffers hold ny + 2 nc bytes of THAT size and the pack would read
+    // them with this one's offsets (vp8hip_set_source_size also drops a pending prefetch; this is the second lock on the same door)
+    if (c->h2d_pre_valid && c->h2d_stage_bytes == ny + 2 * nc && c->h2d_pre[0] == y && c->h2d_pre[1] == u && c->h2d_pre[2] == v) {
         // prefetched: the planes are in (or on their way into) the staging buffer; the pack waits for the copy, nothing is copied here
         c->h2d_pre_valid = false;
         const int slot = c->h2d_idx ^= 1;
-        const int sw = c->src_w ? c->src_w : c->W, sh = c->src_h ? c->src_h : c->H;
-        const size_t ny = (size_t)sw * sh, nc = (size_t)(sw / 2) * (sh / 2);
         next_current(c);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));
         const uint8_t *d = c->h2d_stage[slot];
@@ -522,11 +534,16 @@ int vp8hip_set_current_device(vp8hip_ctx *c, const void *y, const void *u, const
 
 int vp8hip_set_source_size(vp8hip_ctx *c, int src_width, int src_height) {
     if (!c) return VP8HIP_ERR_ARG;
-    if (src_width == 0 && src_height == 0) { c->src_w = c->src_h = 0; return VP8HIP_OK; }
+    if (src_width == 0 && src_height == 0) {
+        if (c->src_w || c->src_h) c->h2d_pre_valid = false;
+        c->src_w = c->src_h = 0;
+        return VP8HIP_OK;
+    }
     if (src_width <= 0 || src_height <= 0 || (src_width & 1) || (src_height & 1) || src_width > c->W || src_height > c->H ||
         c->W - src_width >= 16 || c->H - src_height >= 16)
         return VP8HIP_ERR_ARG;
     const bool same = src_width == c->W && src_height == c->H;
+    if ((same ? 0 : src_width) != c->src_w || (same ? 0 : src_height) != c->src_h) c->h2d_pre_valid = false;     // planes prefetched at the old size are not this size's frame
     c->src_w = same ? 0 : src_width;
     c->src_h = same ? 0 : src_height;
     return VP8HIP_OK;

@@ -12,7 +12,12 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include <rccl/rccl.h>
 
@@ -279,9 +284,27 @@ int group_reserve(vp8hip_group *g, size_t bytes) {
     return VP8HIP_OK;
 }
 
+// Where the id file of a run lives: $VP8HIP_RENDEZVOUS_DIR (the caller's responsibility), else $XDG_RUNTIME_DIR, else /tmp/vp8hip-<uid> --
+// in every case a directory that must belong to this user and be closed to everybody else (0700): on a shared node nobody else can then
+// plant a file or a symbolic link where the ranks will read or rank 0 will write.  Empty string = no such directory can be had.
+std::string rendezvous_dir() {
+    const uid_t me = getuid();
+    auto private_dir = [&](const std::string &d) {
+        struct stat st;
+        return lstat(d.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == me && (st.st_mode & 077) == 0;
+    };
+    if (const char *e = getenv("VP8HIP_RENDEZVOUS_DIR"))
+        if (e[0]) return e;          // (a test's tmp_path, a job's scratch: named explicitly, taken as it is)
+    if (const char *e = getenv("XDG_RUNTIME_DIR"))
+        if (e[0] && private_dir(e)) return e;
+    const std::string d = "/tmp/vp8hip-" + std::to_string((unsigned)me);
+    if (mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) return "";
+    return private_dir(d) ? d : "";     // (somebody else's directory, a link, or one open to others: refused)
+}
+
 std::string rendezvous_path(const char *key) {
-    const char *dir = getenv("VP8HIP_RENDEZVOUS_DIR");
-    std::string p = dir && dir[0] ? dir : "/tmp";
+    std::string p = rendezvous_dir();
+    if (p.empty()) return p;
     p += "/vp8hip-rdzv-";
     p += std::to_string((unsigned)getuid());
     p += "-";
@@ -293,18 +316,23 @@ std::string rendezvous_path(const char *key) {
 
 extern "C" {
 
-// The 128 bytes of vp8hip_shard_unique_id from rank 0 to the other ranks of ONE node through a file: rank 0 makes the id and writes
-// <dir>/vp8hip-rdzv-<uid>-<key> atomically (write + rename), the others poll for it (timeout_s).  `key` names the run: every rank of
-// a run passes the same string, and no two runs alive on the node at once may share it (bench.py: launcher pid + MASTER_PORT).
-// dir = $VP8HIP_RENDEZVOUS_DIR or /tmp.  Rank 0 removes the file in vp8hip_group_create once every rank has joined.
+// The 128 bytes of vp8hip_shard_unique_id from rank 0 to the other ranks of ONE node through a file: rank 0 removes whatever a crashed run
+// of the same key left behind, makes the id and writes <dir>/vp8hip-rdzv-<uid>-<key> atomically (a new file opened O_EXCL | O_NOFOLLOW,
+// then rename), the others poll for it (timeout_s) and take only a regular file of THIS user that is not older than timeout_s before their
+// own start (the ranks of a run start within that of each other; anything older is a leftover).  `key` names the run: every rank of a run
+// passes the same string, and no two runs alive on the node at once may share it (bench.py: launcher pid + MASTER_PORT).  The directory:
+// rendezvous_dir() above -- private to the user.  Rank 0 removes the file in vp8hip_group_create once every rank has joined.
 int vp8hip_group_rendezvous(const char *key, int rank, double timeout_s, uint8_t id[VP8HIP_SHARD_ID_BYTES]) {
     if (!key || !key[0] || rank < 0 || !id) return VP8HIP_ERR_ARG;
     const std::string path = rendezvous_path(key);
+    if (path.empty()) return VP8HIP_ERR_STATE;
     if (rank == 0) {
         const int rc = vp8hip_shard_unique_id(id);
         if (rc) return rc;
+        unlink(path.c_str());                                    // a stale id of an earlier run with this key must never be read
         const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
         if (fd < 0) return VP8HIP_ERR_STATE;
         const bool ok = write(fd, id, VP8HIP_SHARD_ID_BYTES) == VP8HIP_SHARD_ID_BYTES;
         close(fd);
@@ -314,12 +342,18 @@ int vp8hip_group_rendezvous(const char *key, int rank, double timeout_s, uint8_t
         }
         return VP8HIP_OK;
     }
-    timespec t0;
+    timespec t0, wall0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    clock_gettime(CLOCK_REALTIME, &wall0);
+    const double oldest = (double)wall0.tv_sec + 1e-9 * (double)wall0.tv_nsec - (timeout_s > 1.0 ? timeout_s : 1.0);
+    const uid_t me = getuid();
     for (;;) {
-        const int fd = open(path.c_str(), O_RDONLY);
+        const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
         if (fd >= 0) {
-            const ssize_t n = read(fd, id, VP8HIP_SHARD_ID_BYTES);
+            struct stat st;
+            const bool mine = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == me &&
+                              (double)st.st_mtim.tv_sec + 1e-9 * (double)st.st_mtim.tv_nsec >= oldest;
+            const ssize_t n = mine ? read(fd, id, VP8HIP_SHARD_ID_BYTES) : -1;
             close(fd);
             if (n == VP8HIP_SHARD_ID_BYTES) return VP8HIP_OK;
         }
@@ -346,14 +380,36 @@ int vp8hip_group_create(vp8hip_group **out, int device_ordinal, const uint8_t id
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     bool ok = hipSetDevice(device_ordinal) == hipSuccess && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&g->h_pin, GROUP_PIN_BYTES) == hipSuccess;
-    if (ok && r->CommInitRank(&g->comm, world, u, rank) != ncclSuccess) {    // collective: returns when every rank has joined
-        g->comm = nullptr;
-        ok = false;
+    bool timed_out = false;
+    if (ok) {
+        // ncclCommInitRank is a collective that returns when EVERY rank has joined -- and never, if one of them died or read a wrong id.
+        // It runs on a thread of its own and this call waits for it $VP8HIP_GROUP_TIMEOUT_S seconds (default 300; 0 = for ever): past that
+        // the call fails with VP8HIP_ERR_TIMEOUT and the host can end the run (the thread and the half-made communicator are abandoned --
+        // RCCL offers no way to take a blocking init back; a process that gets this error is expected to exit).
+        struct Init { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+        std::shared_ptr<Init> st = std::make_shared<Init>();
+        std::thread([st, r, u, world, rank, device_ordinal] {
+            ncclComm_t c = nullptr;
+            ncclResult_t res = hipSetDevice(device_ordinal) == hipSuccess ? r->CommInitRank(&c, world, u, rank) : ncclUnhandledCudaError;
+            std::lock_guard<std::mutex> l(st->m);
+            st->res = res;
+            st->comm = c;
+            st->done = true;
+            st->cv.notify_all();
+        }).detach();
+        const char *e = getenv("VP8HIP_GROUP_TIMEOUT_S");
+        const double limit = e && e[0] ? atof(e) : 300.0;
+        std::unique_lock<std::mutex> l(st->m);
+        if (limit > 0) timed_out = !st->cv.wait_for(l, std::chrono::duration<double>(limit), [&] { return st->done; });
+        else st->cv.wait(l, [&] { return st->done; });
+        if (timed_out || st->res != ncclSuccess) ok = false;
+        else g->comm = st->comm;
     }
     if (!g->id_file.empty()) unlink(g->id_file.c_str());                     // (every rank has read it by then -- or never will)
     if (!ok) {
+        if (timed_out) fprintf(stderr, "vp8hip_group_create: rank %d of %d waited for the other ranks in ncclCommInitRank and gave up (VP8HIP_GROUP_TIMEOUT_S)\n", rank, world);
         vp8hip_group_destroy(g);
-        return VP8HIP_ERR_HIP;
+        return timed_out ? VP8HIP_ERR_TIMEOUT : VP8HIP_ERR_HIP;
     }
     *out = g;
     return VP8HIP_OK;
