@@ -77,6 +77,7 @@ def measure(W=1920, H=1080, nframes=300, repeats=3, opts=(), programs=None, time
         return {"skipped": "oracle/_ref/vp8oclenc_hip* absent: oracle/ref_main/build.sh builds them where the reference checkout exists"}
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="vp8_drop_in_", dir=base)
+    bindir = tempfile.mkdtemp(prefix="vp8_drop_in_bin_")        # (/dev/shm is mounted noexec on the GPU boxes: the comparator is built elsewhere)
     try:
         src = os.path.join(tmp, "in.y4m")
         size = write_source(src, W, H, nframes)
@@ -85,7 +86,7 @@ def measure(W=1920, H=1080, nframes=300, repeats=3, opts=(), programs=None, time
         out = {"workload": f"{W}x{H} YUV420, {nframes} frames, the reference's defaults" + (" " + " ".join(opts) if opts else "") + " (-g 150, LAST+GOLDEN+ALTREF, check_SSIM, "
                            "loop filter, one partition), .y4m -> .ivf on tmpfs, a fresh process per run",
                "source_bytes": size, "tmpfs": base is not None, "repeats": repeats, "programs": {}}
-        mine = build_y4m_to_ivf(tmp)
+        mine = build_y4m_to_ivf(bindir)
         ref_sha = None
         if mine:
             runs = []
@@ -125,6 +126,7 @@ def measure(W=1920, H=1080, nframes=300, repeats=3, opts=(), programs=None, time
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+        shutil.rmtree(bindir, ignore_errors=True)
 
 
 if __name__ == "__main__":
