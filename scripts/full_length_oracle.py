@@ -39,22 +39,30 @@ for _r in range(8):
     SEQUENCES[f"config5_rank{_r}"] = dict(W0=1920, H0=1080, seed=1 + _r, frames=300, gop=1 << 30, start=0)
 SEQUENCES["selftest"] = dict(W0=180, H0=140, seed=5, frames=14, gop=9, start=0)      # (seconds: what the CPU test suite regenerates in full)
 TABLES = {"chunks_1920x1080": dict(W0=1920, H0=1080, seed=1, frames=176), "chunks_3840x2160": dict(W0=3840, H0=2160, seed=1, frames=40),
-          "chunks_1280x720_last_only": dict(W0=1280, H0=720, seed=1, frames=48, refs="last")}
+          "chunks_1280x720_last_only": dict(W0=1280, H0=720, seed=1, frames=48, refs="last"),
+          # bench.py's other legs (round 6): the four-pass SSIM ladder, the conformant stream (vp8hip_conformant_stream / vp8o_set_conformant_stream:
+          # the format's predictor), and ONE video longer than the chunk table (single_stream: phase 0 only).  A finite GOP needs no table of its
+          # own: a chunk n frames past a key frame it coded itself stands where a chunk that STARTED with that key frame stands (closed GOPs).
+          "chunks_1920x1080_ssim93": dict(W0=1920, H0=1080, seed=1, frames=96, ssim_target=0.93),
+          "chunks_1920x1080_conformant": dict(W0=1920, H0=1080, seed=1, frames=96, conformant=1),
+          "chunks_1920x1080_phase0_long": dict(W0=1920, H0=1080, seed=1, frames=280, phases=[0])}
 
 
 def crc_planes(planes):
     return [zlib.crc32(np.ascontiguousarray(p).tobytes()) for p in planes]
 
 
-def oracle_run(W0, H0, seed, frames, gop, start, refs="all", want_bytes=True, log=None):
+def oracle_run(W0, H0, seed, frames, gop, start, refs="all", want_bytes=True, log=None, ssim_target=-1.0, conformant=0):
     """the reference's loop on the CPU oracle: per frame (key?, crc32 of the frame's bytes, length, [crc32 of Y, U, V of the filtered reconstruction])"""
     from bitstream_cases import expected_frame
     from oracle_lib import Oracle
     from vp8oclenc_amd.driver import InterPathDriver
     from vp8oclenc_amd.synth import bench_frames
     W, H, _, padded = bench_frames(W0, H0, seed, ND)
-    ora = Oracle(W, H, -1.0)
-    do = InterPathDriver(ora, W, H, gop_size=gop, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, check_ssim=True, ref_mask=3 if refs == "all" else 0)
+    Oracle.lib().vp8o_set_conformant_stream(int(conformant))      # (a global of the oracle library: set for every run)
+    ora = Oracle(W, H, ssim_target)
+    do = InterPathDriver(ora, W, H, gop_size=gop, altref_range=ALTREF_RANGE, qi_min=0, qi_max=48, ssim_target=ssim_target, check_ssim=True,
+                         ref_mask=3 if refs == "all" else 0)
     rows, t0 = [], time.perf_counter()
     for t in range(frames):
         out = do.encode_frame(*padded[(start + t) % ND])
@@ -67,6 +75,7 @@ def oracle_run(W0, H0, seed, frames, gop, start, refs="all", want_bytes=True, lo
         if log and (t % 25 == 24 or t == frames - 1):
             log(f"    frame {t + 1}/{frames}  {time.perf_counter() - t0:.0f} s")
     ora.close()
+    Oracle.lib().vp8o_set_conformant_stream(0)
     return W, H, rows
 
 
@@ -88,10 +97,15 @@ def do_oracle(names):
             log(f"{name}: {c}")
             table = []
             for phase in range(ND):
-                W, H, rows = oracle_run(c["W0"], c["H0"], c["seed"], c["frames"], 1 << 30, phase, refs=c.get("refs", "all"), want_bytes=False)
+                if phase not in c.get("phases", range(ND)):
+                    table.append([])         # (a phase the table does not hold: nothing is looked up there)
+                    continue
+                W, H, rows = oracle_run(c["W0"], c["H0"], c["seed"], c["frames"], 1 << 30, phase, refs=c.get("refs", "all"), want_bytes=False,
+                                        ssim_target=c.get("ssim_target", -1.0), conformant=c.get("conformant", 0))
                 table.append([r[3] for r in rows])
                 log(f"    phase {phase} done")
             doc = dict(kind="table", name=name, source=[c["W0"], c["H0"]], coded=[W, H], seed=c["seed"], frames=c["frames"], refs=c.get("refs", "all"),
+                       ssim_target=c.get("ssim_target", -1.0), conformant=c.get("conformant", 0), phases=list(c.get("phases", range(ND))),
                        altref_range=ALTREF_RANGE, distinct_frames=ND,
                        what="recon_crc32[phase][n - 1] = CRC-32 of (Y, U, V) of the filtered reconstruction after n frames of a chunk whose key frame is frame `phase` of the cycle",
                        recon_crc32=table)
@@ -161,7 +175,8 @@ def do_verify(names):
             bad += len(wrong_b) + len(wrong_r)
         else:
             n, tot, wrong = doc["frames"], 0, 0
-            for phase in range(ND):
+            cfg = dict(cfg, ssim_target=doc.get("ssim_target", -1.0), conformant_stream=doc.get("conformant", 0))
+            for phase in doc.get("phases", range(ND)):
                 d = api.NativeDriver(W, H, gop_size=1 << 30, ref_mask=3 if doc["refs"] == "all" else 0, **cfg)
                 for t in range(n):
                     d.encode_frame_device(*ptrs[(phase + t) % ND])
@@ -169,7 +184,7 @@ def do_verify(names):
                     tot += 1
                     wrong += crc_planes(d.hip.download_last()) != doc["recon_crc32"][phase][t]
                 d.close()
-            log(f"{name}: {ND} start phases x {n} frames: {tot - wrong}/{tot} filtered reconstructions identical to the oracle loop")
+            log(f"{name}: {len(doc.get('phases', range(ND)))} start phases x {n} frames: {tot - wrong}/{tot} filtered reconstructions identical to the oracle loop")
             bad += wrong
         for f in dev:
             for p in f:

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 BIN = os.path.join(ROOT, "oracle", "_ref", "vp8oclenc_hip")
 BIN_HOST = os.path.join(ROOT, "oracle", "_ref", "vp8oclenc_hip_host")
+BIN_FAST = os.path.join(ROOT, "oracle", "_ref", "vp8oclenc_hip_fast")     # -DVP8HIP_FAST: asynchronous entry points, device-side scans, a reader thread
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="no reference checkout here (the GPU box uses the prebuilt binaries)")
@@ -23,15 +24,20 @@ def test_the_references_main_builds_against_the_library():
     api.load_library()      # (builds libvp8hip.so if stale)
     r = subprocess.run(["sh", os.path.join(ROOT, "oracle", "ref_main", "build.sh"), REF], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    for exe in (BIN, BIN_HOST):
+    for exe in (BIN, BIN_HOST, BIN_FAST):
         assert os.path.exists(exe)
         dyn = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
         assert "libvp8hip.so" in dyn and "OpenCL" not in dyn, dyn       # the library instead of the OpenCL loader, not beside it
         und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
         calls = sorted({l.split()[-1] for l in und.splitlines() if " vp8hip_" in l or " vp8host_" in l})
         assert not [l for l in und.splitlines() if " cl" in l and l.split()[-1].startswith("cl")], und    # no OpenCL entry point is referenced
-        assert {"vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_set_segments", "vp8hip_inter_transform",
-                "vp8hip_prepare_filter_mask", "vp8hip_loop_filter"} <= set(calls), calls
+        assert {"vp8hip_create", "vp8hip_destroy", "vp8hip_upload_current", "vp8hip_inter_transform", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter"} <= set(calls), calls
+        assert ("vp8hip_set_segments" in calls) == (exe != BIN_FAST), calls
+    fast = subprocess.run(["nm", "-D", "--undefined-only", BIN_FAST], capture_output=True, text=True).stdout
+    for sym in ("vp8hip_prefetch_current", "vp8hip_auto_segments", "vp8hip_chroma_change", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result",
+                "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_set_source_size", "vp8hip_host_alloc"):
+        assert sym in fast, sym
+    assert " vp8hip_check_ssim\n" not in fast and " vp8hip_encode_frame\n" not in fast      # the blocking forms are gone from the fast build
     host_only = subprocess.run(["nm", "-D", "--undefined-only", BIN_HOST], capture_output=True, text=True).stdout
     assert "vp8hip_download_results" in host_only and "vp8hip_upload_mb_data" in host_only and "vp8hip_encode_coefficients" in host_only
 
@@ -56,6 +62,8 @@ def _y4m(path, W, H, frames, cut=None, seed=3):
     (320, 192, 10, None, ["-g", "6", "-partitions", "4", "-qmin", "40", "-qmax", "110", "-SSIM-target", "92", "-altref-range", "3"]),   # replaced macroblocks
     (176, 144, 8, 4, ["-qmin", "50", "-qmax", "110", "-SSIM-target", "90"]),              # a frame sent back to be a key frame
     (1920, 1080, 4, None, ["-partitions", "8"]),
+    (1920, 1080, 40, 23, ["-g", "16"]),                                                   # the metric's geometry: key frames at GOP boundaries, a cut, golden and altref periods
+    (352, 288, 30, None, ["-g", "1"]),                                                    # every frame a key frame
 ])
 def test_the_references_main_writes_the_products_file(tmp_path, W, H, frames, cut, opts):
     if not (os.path.exists(BIN) and os.path.exists(BIN_HOST)):
@@ -71,7 +79,10 @@ def test_the_references_main_writes_the_products_file(tmp_path, W, H, frames, cu
     env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     outs = {}
     for name, cmd in (("device", [BIN, "-i", src, "-o", str(tmp_path / "ref_device.ivf")] + opts),
-                      ("host", [BIN_HOST, "-i", src, "-o", str(tmp_path / "ref_host.ivf")] + opts)):
+                      ("host", [BIN_HOST, "-i", src, "-o", str(tmp_path / "ref_host.ivf")] + opts),
+                      ("fast", [BIN_FAST, "-i", src, "-o", str(tmp_path / "ref_fast.ivf")] + opts)):
+        if name == "fast" and not os.path.exists(BIN_FAST):
+            continue
         if name == "host" and W > 1000:
             continue          # (the reference's host intra path takes a tenth of a second per 1080p key frame: not the point here)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
