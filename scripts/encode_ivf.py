@@ -42,10 +42,9 @@ def main():
     a = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     dist = None
-    if world > 1:
-        import torch, torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if world > 1:      # the library's own process group (vp8hip_group_*: RCCL inside libvp8hip.so, the id through a file): no GPU framework in the host
+        from vp8oclenc_amd import api
+        dist = api.Group.from_env(local, f"encode_ivf-{os.getppid()}-{os.environ.get('MASTER_PORT', '0')}")
     if a.y4m:
         from vp8oclenc_amd.y4m import Y4mFile
         seq = Y4mFile(a.y4m)
@@ -66,7 +65,7 @@ def main():
         el = time.perf_counter() - t0
         print(f"{a.out}: {frames} frames {seq.W}x{seq.H}, {n} bytes, {world} GPU(s), {frames / el:.1f} frames/s including the host-side frame source")
     if dist is not None:
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":

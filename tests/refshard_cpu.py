@@ -1,21 +1,14 @@
 """CPU backend of vp8oclenc_amd.ref_shard.RefShardDriver for the gloo tests: the restatement's per-stage functions
 (oracle/vp8_oracle.c through oracle_lib.Stages) sequenced like include/vp8hip.h's vp8hip_inter_search /
-vp8hip_inter_finish, state in numpy, exchanges in CPU torch tensors.  Test infrastructure."""
+vp8hip_inter_finish, state in numpy, exchanges as numpy parcels over object collectives (ref_shard.ThreadGroup; tests/torch_transport.py
+over gloo).  Test infrastructure."""
 import numpy as np
-
-# (torch is imported where a tensor is made, not with the module: pytest imports this file when it collects the suite, and the GPU
-# test process must not load PyTorch's bundled HIP runtime and RCCL beside the ones libvp8hip.so was built for)
 
 from oracle_lib import Oracle, oracle_intra
 from pipeline import pyramid
 
 
 class OracleRefBackend:
-    @property
-    def dev(self):
-        import torch
-        return torch.device("cpu")
-
     def __init__(self, W, H):
         self.W, self.H = W, H
         self.mbs = (W // 16) * (H // 16)
@@ -58,11 +51,10 @@ class OracleRefBackend:
             self.net[r], self.bd[r] = net[0], bd
 
     def export_search(self, ref):
-        import torch
-        return torch.from_numpy(np.stack([self.net[ref].view(np.int32).reshape(-1), self.bd[ref]]).copy())
+        return np.stack([self.net[ref].view(np.int32).reshape(-1), self.bd[ref]]).copy()
 
     def import_search(self, ref, t):
-        a = t.numpy()
+        a = np.asarray(t)
         self.net[ref] = np.ascontiguousarray(a[0]).view(np.int16).reshape(-1, 2).copy()
         self.bd[ref] = np.ascontiguousarray(a[1]).copy()
 
@@ -119,11 +111,10 @@ class OracleRefBackend:
         return self.refs[0]
 
     def export_last(self):
-        import torch
-        return torch.from_numpy(np.concatenate([p.reshape(-1) for p in self.refs[0]]).copy())
+        return np.concatenate([p.reshape(-1) for p in self.refs[0]]).copy()
 
     def import_last(self, t):
-        a = t.numpy()
+        a = np.asarray(t)
         n = self.W * self.H
         self.refs[0] = (a[:n].reshape(self.H, self.W).copy(), a[n:n + n // 4].reshape(self.H // 2, self.W // 2).copy(),
                         a[n + n // 4:].reshape(self.H // 2, self.W // 2).copy())

@@ -39,7 +39,8 @@ WORKER = textwrap.dedent("""
                                    gop_shard.chunks_of_rank({FRAMES}, {GOP}, rank, world), seq.W, seq.H)
     dist.barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    allv = gop_shard.gather_digests(mine, {FRAMES}, dist)
+    from torch_transport import TorchObjectGroup
+    allv = gop_shard.gather_digests(mine, {FRAMES}, TorchObjectGroup(dist))
     if rank == 0:
         np.save({out!r}, allv)
     dist.destroy_process_group()
@@ -93,7 +94,8 @@ WORKER_IVF = textwrap.dedent("""
     rank, world = dist.get_rank(), dist.get_world_size()
     seq = SynthSequence({W}, {H}, seed=5)
     mine = gop_shard.encode_chunks_frames(lambda: OracleEncoder(seq.W, seq.H), seq, gop_shard.chunks_of_rank({FRAMES}, {GOP}, rank, world))
-    frames = gop_shard.gather_frames(mine, {FRAMES}, dist)
+    from torch_transport import TorchObjectGroup
+    frames = gop_shard.gather_frames(mine, {FRAMES}, TorchObjectGroup(dist))
     if rank == 0:
         gop_shard.write_ivf({out!r}, frames, seq.W, seq.H)
     dist.destroy_process_group()

@@ -172,3 +172,28 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path, standin):
     assert c5["frames"] == 600 and c5["n_gpus"] == 2 and c5["rccl_ranks"] == 2
     assert c5["self_check_against_the_oracle"]["ranks_checked"] == [0, 1] and c5["self_check_against_the_oracle"]["identical"]
     assert d["ref_shard"]["ranks"] == 2 and d["ref_shard"]["value"] > 0
+
+
+def test_bench_with_eight_ranks_on_one_gpu_codes_configs4_per_rank(tmp_path, standin):
+    """BASELINE configs[4] as the driver's 8-GPU run shards it -- 2400 frames of 1080p, one closed GOP of 300 frames per rank, seed 1 + rank --
+    with all EIGHT ranks on device 0 over the stand-in transport: `bench.py --gpus 8` whole (launcher, the ranks' group of eight, barriers,
+    max over ranks, the children's own group, the gather of 2400 finished frames on rank 0), every rank's 300 frames held against ITS
+    committed oracle digest (tests/golden/full_length/config5_rank{0..7}.json).  What is left untested is eight PHYSICAL GPUs and RCCL
+    itself; the rates mean nothing."""
+    env = dict(os.environ, VP8HIP_RCCL_LIBRARY=standin, VP8HIP_RENDEZVOUS_DIR=str(tmp_path), VP8_BENCH_ALL_RANKS_ON_DEVICE="0",
+               VP8_BENCH_CHILD_TIMEOUT="1200", VP8_BENCH_REFSHARD_FRAMES="8", VP8_BENCH_RDZV_TIMEOUT="600", VP8HIP_QUIET="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0",
+                        "--gops-per-gpu", "4", "--batch", "4"], env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    if os.environ.get("VP8_TEST_KEEP_BENCH_LINE"):
+        open(os.environ["VP8_TEST_KEEP_BENCH_LINE"] + ".8ranks", "w").write(lines[0] + "\n" + r.stderr[-6000:])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and [p["rank"] for p in d["per_rank"]] == list(range(8))
+    assert "few_stream_legs_error" not in d, d.get("few_stream_legs_error")
+    c5 = d["config5_literal"]
+    assert c5["frames"] == 2400 and c5["n_gpus"] == 8 and c5["rccl_ranks"] == 8 and c5["key_frames"] == 8
+    oc = c5["self_check_against_the_oracle"]
+    assert oc["ranks_checked"] == list(range(8)) and oc["frames_per_rank"] == 300 and oc["differing_frames"] == 0 and oc["identical"] is True
+    assert d["ref_shard"]["ranks"] == 3 and d["ref_shard"]["value"] > 0

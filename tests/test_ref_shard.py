@@ -58,7 +58,8 @@ WORKER = textwrap.dedent("""
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     seq = SynthSequence({W}, {H}, seed=7)
     be = OracleRefBackend(seq.W, seq.H)
-    drv = ref_shard.RefShardDriver(be, dist, seq.W, seq.H, altref_range=3)
+    from torch_transport import TorchObjectGroup
+    drv = ref_shard.RefShardDriver(be, TorchObjectGroup(dist), seq.W, seq.H, altref_range=3)
     got = []
     for t in range({FRAMES}):
         o = drv.encode_frame(*seq.frame(t))

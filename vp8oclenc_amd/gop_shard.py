@@ -2,8 +2,9 @@
 
 A key frame resets every reference (intra_part.h:1091-1098, inter_part.h:35-50), so GOPs are independent
 units: rank r encodes chunks r, r+world, ... with the ordinary single-GPU pipeline and the outputs are
-concatenated in frame order.  No collective sits on the data path; torch.distributed (RCCL on the GPUs,
-gloo in the CPU tests) carries only the barrier, the max-over-ranks time and the gathering of results.
+concatenated in frame order.  No collective sits on the data path; the process group -- vp8oclenc_amd.api.Group, i.e. vp8hip_group_*:
+RCCL inside libvp8hip.so -- carries only the barrier, the max-over-ranks time and the gathering of results.  (The multi-process CPU
+tests hand in an adapter of the same shape over gloo, tests/torch_transport.py: there is no second transport in this package.)
 """
 from __future__ import annotations
 
@@ -50,18 +51,15 @@ def encode_chunks(make_backend, sequence, chunks, width, height, **driver_kw) ->
     return digests
 
 
-def gather_digests(local: dict[int, int], total_frames: int, dist=None) -> np.ndarray:
-    """All ranks' digests in frame order (all_gather of a dense int64 vector; -1 = not mine)."""
+def gather_digests(local: dict[int, int], total_frames: int, group=None) -> np.ndarray:
+    """All ranks' digests in frame order (-1 = not mine): one all_gather of a dense int64 vector over `group` (anything with
+    all_gather_object: ref_shard.ThreadGroup members, the tests' gloo adapter), or this process's alone"""
     vec = np.full(total_frames, -1, np.int64)
     for t, d in local.items():
         vec[t] = d
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if group is None or group.get_world_size() == 1:
         return vec
-    import torch
-    mine = torch.from_numpy(vec)
-    bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(bufs, mine)
-    allv = torch.stack(bufs).numpy()
+    allv = np.stack([np.asarray(v, np.int64) for v in group.all_gather_object(vec)])
     assert ((allv >= 0).sum(axis=0) == 1).all(), "every frame must be encoded by exactly one rank"
     return allv.max(axis=0)
 
@@ -95,55 +93,13 @@ def encode_chunks_frames(make_encoder, sequence, chunks) -> dict[int, bytes]:
     return frames
 
 
-def gather_frames(local: dict[int, bytes], total_frames: int, dist=None, dst: int = 0, force_collective: bool = False):
-    """The sequence's frames in frame order on rank `dst` (None on the other ranks).
-
-    Each rank sends only the frames it owns: one small all_gather of the per-frame lengths (-1 = not mine), then every
-    rank's frames, concatenated, go to `dst` point to point -- `dst` holds the sequence once, the others hold nothing
-    they did not code.  (A padded frames x max-length byte matrix all_gathered to every rank, the first version, cost
-    world * total_frames * max_len bytes per rank: key frames set max_len.)
-    force_collective: take the collective path even with one rank, so that a 1-GPU box exercises the RCCL branch."""
-    if dist is not None and hasattr(dist, "gather_bytes"):      # the library's own process group (api.Group: RCCL, no torch)
-        return gather_frames_group(local, total_frames, dist, dst)
-    collective = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
-    if not collective:
+def gather_frames(local: dict[int, bytes], total_frames: int, group=None, dst: int = 0):
+    """The sequence's frames in frame order on rank `dst` (None on the other ranks).  group: vp8oclenc_amd.api.Group (or anything with its
+    rank / world / gather_bytes); None = one process, which owns every frame."""
+    if group is None:
         assert len(local) == total_frames
         return [local[t] for t in range(total_frames)]
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    lens = torch.full((total_frames,), -1, dtype=torch.int64)
-    for t, b in local.items():
-        lens[t] = len(b)
-    lens = lens.to(dev)
-    all_lens = [torch.empty_like(lens) for _ in range(world)]
-    dist.all_gather(all_lens, lens)
-    all_lens = torch.stack(all_lens).cpu()
-    assert ((all_lens >= 0).sum(dim=0) == 1).all(), "every frame must be encoded by exactly one rank"
-    mine = sorted(local)
-    blob = b"".join(local[t] for t in mine)
-    if rank != dst:
-        if blob:
-            dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst=dst)
-        return None
-    out: list = [None] * total_frames
-    for r in range(world):
-        owned = [t for t in range(total_frames) if all_lens[r, t] >= 0]
-        total = int(sum(int(all_lens[r, t]) for t in owned))
-        if r == rank:
-            data = blob
-        elif total:
-            buf = torch.empty(total, dtype=torch.uint8, device=dev)
-            dist.recv(buf, src=r)
-            data = buf.cpu().numpy().tobytes()
-        else:
-            data = b""
-        off = 0
-        for t in owned:
-            n = int(all_lens[r, t])
-            out[t] = data[off:off + n]
-            off += n
-    return out
+    return gather_frames_group(local, total_frames, group, dst)
 
 
 def gather_frames_group(local: dict[int, bytes], total_frames: int, group, dst: int = 0):

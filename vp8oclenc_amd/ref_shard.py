@@ -21,10 +21,11 @@ on the others -- the import calls land the data where the receiving side of the 
 A backend is an encoder context with the C ABI's method names.  The MI355X backend (HipRefBackend over vp8oclenc_amd.api.Vp8Hip)
 makes both exchanges INSIDE the library -- vp8hip_shard_share_search / vp8hip_shard_share_last: RCCL broadcasts on the context's
 stream, in place in the context's own buffers, no host synchronisation per frame -- and this file keeps only the frame-type state
-machine.  A backend without those calls (the CPU oracle, tests/refshard_cpu.py) gets the same exchanges made here over a
-torch.distributed group (gloo), through four methods in torch tensors on the backend's device:
-    export_search(ref) -> int32 [2, b8]   (vectors, costs)      import_search(ref, tensor)
-    export_last()      -> uint8 [W*H*3/2] (Y, U, V tight)       import_last(tensor)
+machine.  A backend without those calls (the CPU oracle, tests/refshard_cpu.py; several contexts as threads of one process) gets the
+same exchanges made here over OBJECT collectives (ThreadGroup below; the multi-process CPU tests hand in an adapter of the same shape
+over gloo, tests/torch_transport.py -- this package holds no second transport), through four methods of the backend:
+    export_search(ref) -> (vectors, costs) of reference ref          import_search(ref, parcel)
+    export_last()      -> the filtered reconstruction (Y, U, V)      import_last(parcel)
 """
 from __future__ import annotations
 
@@ -232,15 +233,7 @@ class RefShardDriver:
                 self.be.import_last(parcel)
             self.dist.barrier()                                  # (rank 0 writes its parcel again only after everybody has taken it)
             return
-        if self.rank == 0:
-            t = self.be.export_last()
-        else:
-            import torch
-            t = torch.empty(self.W * self.H * 3 // 2, dtype=torch.uint8, device=self.be.dev)
-        self.dist.broadcast(t, src=0)
-        self.bytes_broadcast += t.numel()
-        if self.rank != 0 or self.loopback:
-            self.be.import_last(t)
+        raise TypeError("RefShardDriver: `dist` must offer object collectives (ref_shard.ThreadGroup.member(r), tests/torch_transport.py) or the backend its own exchanges (native_shard)")
 
     def _share_search(self, used):
         """every used reference's vectors and costs from its owner to every rank (one all_gather)"""
@@ -259,17 +252,7 @@ class RefShardDriver:
                     self.be.import_search(r, allv[self.owner(r)][r])
             self.dist.barrier()
             return
-        import torch
-        mine = torch.zeros((3, 2, self.be.b8), dtype=torch.int32, device=self.be.dev)
-        for r in used:
-            if self.owner(r) == self.rank:
-                mine[r] = self.be.export_search(r)
-        allv = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(allv, mine)
-        self.bytes_gathered += self.world * mine.numel() * 4
-        for r in used:
-            if self.owner(r) != self.rank or self.loopback:
-                self.be.import_search(r, allv[self.owner(r)][r])
+        raise TypeError("RefShardDriver: `dist` must offer object collectives or the backend its own exchanges (native_shard)")
 
     def encode_frame(self, y: np.ndarray, u: np.ndarray, v: np.ndarray):
         g = self.gop.next()
