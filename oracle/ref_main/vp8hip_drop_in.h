@@ -32,6 +32,7 @@
 #include "vp8hip_host.h"
 
 #include <time.h>
+#include <unistd.h>
 #ifdef VP8HIP_FAST
 #include <condition_variable>
 #include <mutex>
@@ -59,7 +60,9 @@ struct hip_site_timer {
         if (rc_ != VP8HIP_OK) {   /* the reference parks cl_int errors in device.state_gpu (inter_part.h:380) and goes on */ \
             device.state_gpu = rc_;                                                                                    \
             printf("%s -> %d (%s)\n", #call, rc_, vp8hip_status_string(rc_));                                          \
-            exit(3);                                                                                                   \
+            fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, vp8hip_status_string(rc_));                                 \
+            fflush(NULL);                                                                                              \
+            _exit(3);       /* (no static destructors: the fast build's reader thread may be in the middle of a read) */ \
         }                                                                                                              \
     } while (0)
 

@@ -392,13 +392,11 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
 // search of a reference is then ONE link of the chain.
 struct CoarseArgs { Search1Args lv[5]; };   // lv[l] = level l
 constexpr int COARSE_WAVES = 6;             // 18 block slots of 20 lanes: the tile's 16 level-1 blocks in one pass
+// the tile's work: L0..L4 = the five levels' arguments (L0 read only with FINEST), r = the reference's slot in them
 template <bool FINEST>
-__global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse(CoarseArgs a) {
+__device__ __forceinline__ void coarse_tile(const Search1Args &L0, const Search1Args &L1, const Search1Args &L2, const Search1Args &L3, const Search1Args &L4, int r) {
     using M = S1Map<true>;
     __shared__ uint32_t mv4, mv3, mv2[4], mv1[16];
-    const Search1Args &L1 = a.lv[1], &L2 = a.lv[2], &L3 = a.lv[3], &L4 = a.lv[4];
-    if ((int)blockIdx.y >= L1.nrefs) return;
-    const int r = L1.refmap[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
     const int slot = grp < M::BLOCKS_PER_WAVE ? wave * M::BLOCKS_PER_WAVE + grp : 99;     // block slot of this lane in the workgroup, 0..17
@@ -450,7 +448,6 @@ __global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse(CoarseArgs
     // ---- level 0: the 8 x 8 blocks under the tile ----
     {
         using M0 = S1Map<false>;
-        const Search1Args &L0 = a.lv[0];
         const int grp0 = lane / M0::LANES_PER_BLOCK, sub0 = lane - M0::LANES_PER_BLOCK * grp0;
         const int slot0 = grp0 < M0::BLOCKS_PER_WAVE ? wave * M0::BLOCKS_PER_WAVE + grp0 : 99;     // 0..71
         const int i = slot0 & 7, j = (slot0 >> 3) & 7;
@@ -460,6 +457,49 @@ __global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse(CoarseArgs
         const uint32_t out = search1_block<false>(L0, r, (live ? bx : 0) * 8, (live ? by : 0) * 8, pv, live, sub0, lane);
         if (sub0 == 0 && live) reinterpret_cast<uint32_t *>(L0.dst[r])[by * L0.net_width + bx] = out;
     }
+}
+
+template <bool FINEST>
+__global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse(CoarseArgs a) {
+    if ((int)blockIdx.y >= a.lv[1].nrefs) return;
+    coarse_tile<FINEST>(a.lv[0], a.lv[1], a.lv[2], a.lv[3], a.lv[4], a.lv[1].refmap[blockIdx.y]);
+}
+
+// The same for the members of a BATCH (blockIdx.z = member): ONE launch where the batched path had four (levels 4-1) or five.  Eight members'
+// Search1Args of four or five levels do not fit the 4 KiB kernel-argument segment, so what all members share -- the levels' geometry: the
+// members are contexts of one size, their surfaces and nets are laid out alike -- travels once and a member brings its addresses only.
+struct CoarseGeom { int w, h, cur_stride, ref_stride; };
+struct CoarseMember {
+    const uint8_t *cur[5];          // pixel (0, 0) of level l of the current frame
+    const uint8_t *ref[3][5];       // ... of reference r
+    int16_t *dst1[3], *dst0[3];     // the level-1 and level-0 nets of reference r (where launch_search1_batch leaves them)
+    int refmap[3], nrefs;
+};
+struct CoarseBatchArgs { CoarseGeom g[5]; int net_width, n; CoarseMember m[MAX_BATCH]; };
+static_assert(sizeof(CoarseBatchArgs) <= 4096, "a batch's argument block travels in the 4 KiB kernel-argument segment");
+__device__ __forceinline__ Search1Args coarse_level(const CoarseBatchArgs &a, const CoarseMember &m, int l, int r) {
+    Search1Args s;
+    const CoarseGeom &g = a.g[l];
+    s.cur = Plane{const_cast<uint8_t *>(m.cur[l]), g.cur_stride, g.w, g.h};
+    s.ref[0] = Plane{const_cast<uint8_t *>(m.ref[r][l]), g.ref_stride, g.w, g.h};
+    s.dst[0] = l == 1 ? m.dst1[r] : m.dst0[r];        // (only levels 1 and 0 leave the workgroup)
+    s.net_width = a.net_width;
+    s.w = g.w;
+    s.h = g.h;
+    s.pixel_rate = 1 << l;
+    s.rate_shift = l;
+    s.bw = g.w / 8;
+    s.nblk = (g.w / 8) * (g.h / 8);
+    return s;
+}
+template <bool FINEST>
+__global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse_b(CoarseBatchArgs a) {
+    const CoarseMember &m = a.m[blockIdx.z];
+    if ((int)blockIdx.y >= m.nrefs) return;
+    const int r = m.refmap[blockIdx.y];
+    const Search1Args L0 = coarse_level(a, m, 0, r), L1 = coarse_level(a, m, 1, r), L2 = coarse_level(a, m, 2, r), L3 = coarse_level(a, m, 3, r),
+                      L4 = coarse_level(a, m, 4, r);
+    coarse_tile<FINEST>(L0, L1, L2, L3, L4, 0);       // (slot 0 of the locals holds reference r)
 }
 
 template <bool SPLIT>
@@ -531,6 +571,44 @@ void launch_search1_coarse(hipStream_t s, const Frame &cur, const RefSet &refs, 
     if (tiles_x * tiles_y <= 0) return;
     if (finest) VP8_LAUNCH(k_search1_coarse<true>, dim3(tiles_x * tiles_y, L0.nrefs), dim3(64 * COARSE_WAVES), 0, s, a);
     else VP8_LAUNCH(k_search1_coarse<false>, dim3(tiles_x * tiles_y, L0.nrefs), dim3(64 * COARSE_WAVES), 0, s, a);
+}
+
+// levels 4..1 (finest = false) or 4..0 of every member of a batch in ONE launch; false = the members' surfaces are not laid out alike
+// (never so for contexts of one size: the caller then launches level by level)
+bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n, bool finest) {
+    CoarseBatchArgs a;
+    a.net_width = net_width;
+    a.n = n;
+    int maxrefs = 0;
+    for (int l = 0; l <= 4; ++l) {
+        const Plane &c = cur[0]->Y[l];
+        a.g[l] = CoarseGeom{c.w, c.h, c.stride, refs[0].ref[0].Y[l].stride};
+    }
+    for (int i = 0; i < n; ++i) {
+        CoarseMember &m = a.m[i];
+        int k = 0;
+        for (int r = 0; r < 3; ++r) {
+            for (int l = 0; l <= 4; ++l) {
+                const Plane &rp = refs[i].ref[r].Y[l], &cp = cur[i]->Y[l];
+                if (rp.stride != a.g[l].ref_stride || cp.stride != a.g[l].cur_stride || cp.w != a.g[l].w || cp.h != a.g[l].h || rp.w != cp.w || rp.h != cp.h) return false;
+                m.ref[r][l] = rp.p;
+                if (r == 0) m.cur[l] = cp.p;
+            }
+            m.dst1[r] = nets[i]->net[r][0];       // launch_search1_batch's ping-pong: level 4 reads net 0 ... level 1 writes net 0, level 0 writes net 1
+            m.dst0[r] = nets[i]->net[r][1];
+            if (refs[i].use[r]) m.refmap[k++] = r;
+        }
+        m.nrefs = k;
+        for (int j = k; j < 3; ++j) m.refmap[j] = 0;
+        maxrefs = k > maxrefs ? k : maxrefs;
+    }
+    const int bw0 = a.g[0].w / 8, bh0 = a.g[0].h / 8, bw1 = a.g[1].w / 8, bh1 = a.g[1].h / 8;
+    if (bw0 * bh0 <= 0 || maxrefs == 0 || search1_skip()) return true;
+    const int tiles_x = finest ? (bw0 + 7) / 8 : (bw1 + 3) / 4, tiles_y = finest ? (bh0 + 7) / 8 : (bh1 + 3) / 4;
+    if (tiles_x * tiles_y <= 0) return !finest ? true : false;
+    if (finest) VP8_LAUNCH(k_search1_coarse_b<true>, dim3(tiles_x * tiles_y, maxrefs, n), dim3(64 * COARSE_WAVES), 0, s, a);
+    else VP8_LAUNCH(k_search1_coarse_b<false>, dim3(tiles_x * tiles_y, maxrefs, n), dim3(64 * COARSE_WAVES), 0, s, a);
+    return true;
 }
 
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
