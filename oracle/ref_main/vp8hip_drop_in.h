@@ -40,7 +40,7 @@
 #endif
 
 static vp8hip_ctx *hip_ctx = NULL;
-static bool hip_redo_as_key = false;       // (fast build) intra_transform() is being called for a frame check_SSIM sent back
+static bool hip_cur_on_device = false;     // (fast build) this iteration's frame has been handed to the device (once: an upload also rotates the previous frame scene_change compares with)
 // the frame loop by the host's clock -- from the end of init_all() to the start of finalize(), i.e. main()'s while loop with its reads and
 // writes (vp8enc.cpp:351-488) -- printed on stderr by hip_finalize(): what bench.py's drop_in leg reports next to the process's wall time
 static struct timespec hip_loop_t0;
@@ -71,6 +71,7 @@ struct hip_site_timer {
 // The reader: get_yuv420_frame()'s fread (encIO.h:204-254) on a thread of its own, one to two frames ahead, into a ring of page-locked
 // buffers (vp8hip_host_alloc: the copies to the device are then asynchronous).  The frames keep their SOURCE size: copy_with_padding
 // (encIO.h:141-202) runs on the device (vp8hip_set_source_size), with the reference's own quirks (REFERENCE_DEFECTS.md).
+static void hip_upload_current();
 enum { HIP_RING = 4 };
 static uint8_t *hip_ring[HIP_RING];
 static int hip_ring_state[HIP_RING];       // what get_yuv420_frame would have returned for the frame in this slot: 1, 0 (end of stream), -1 (broken)
@@ -157,6 +158,7 @@ static int hip_get_frame()
     frames.current_Y = frames.tmp_Y;      // source size; the device pads
     frames.current_U = frames.tmp_U;
     frames.current_V = frames.tmp_V;
+    hip_cur_on_device = false;
     return 1;
 }
 
@@ -181,6 +183,7 @@ static void hip_prefetch_next()
 static void hip_prepare_segments(const int update_filter, const int shrpnss)
 {
     (void)update_filter; (void)shrpnss;
+    hip_upload_current();       // key frames reach this call before anything of theirs is on the device (vp8enc.cpp:379-383): the scan needs the frame
     hip_site_timer t_(1);
     const cl_int *refqi = frames.current_is_altref_frame ? video.altrefqi : video.lastqi;     // :149-151
     HIP_CK(vp8hip_auto_segments(hip_ctx, frames.current_is_key_frame, (const int32_t *)refqi, (int)video.qi_min));
@@ -250,6 +253,10 @@ static void hip_set_segments() { hip_site_timer t_(1); HIP_CK(vp8hip_set_segment
 static void hip_upload_current()
 {
     hip_site_timer t_(0);
+#ifdef VP8HIP_FAST
+    if (hip_cur_on_device) return;
+    hip_cur_on_device = true;
+#endif
     HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V));
 #ifdef VP8HIP_FAST
     hip_prefetch_next();
@@ -315,10 +322,10 @@ static void hip_check_ssim(float *min1, float *min2)
 static void hip_intra_transform()
 {
     hip_site_timer t_(7);
-    if (!hip_redo_as_key)      // (a frame sent back by check_SSIM is on the device already)
-        HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V));   // key frames were host-only
 #ifdef VP8HIP_FAST
-    hip_prefetch_next();
+    hip_upload_current();       // (a no-op by now: prepare_segments_data() stands in front of every intra_transform())
+#else
+    HIP_CK(vp8hip_upload_current(hip_ctx, frames.current_Y, frames.current_U, frames.current_V));   // key frames were host-only
 #endif
     HIP_CK(vp8hip_intra_transform(hip_ctx));
 }
@@ -429,9 +436,7 @@ static void hip_entropy_encode()
             else ++encStat.scene_changes_by_replaced;
             frames.current_is_key_frame = 1;        // redo as intra: the current frame is still on the device
             hip_prepare_segments(0, 0);
-            hip_redo_as_key = true;
             intra_transform();
-            hip_redo_as_key = false;
             if (video.print_info) printf("\nkey frame FORCED by bad inter-result: replaced(%d) and SSIM(%f)!\n", frames.replaced, frames.new_SSIM);
             HIP_CK(vp8hip_prepare_filter_mask(hip_ctx, NULL));
             if (video.GOP_size >= 2) HIP_CK(vp8hip_loop_filter(hip_ctx));
