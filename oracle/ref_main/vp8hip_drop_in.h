@@ -113,8 +113,10 @@ static void hip_reader_main()
     }
 }
 
+static cl_uchar *hip_own_current[3];       // init_all()'s allocations behind frames.current_* (init.h:419-421): finalize() frees them
 static int hip_fast_init()
 {
+    hip_own_current[0] = frames.current_Y; hip_own_current[1] = frames.current_U; hip_own_current[2] = frames.current_V;
     HIP_CK(vp8hip_filter_overlap(hip_ctx, 1));      // one video: the loop filter beside the next frame's input side, the entropy stage beside both
     if (video.wrk_width != video.src_width || video.wrk_height != video.src_height)
         HIP_CK(vp8hip_set_source_size(hip_ctx, video.src_width, video.src_height));
@@ -133,6 +135,7 @@ static void hip_fast_shutdown()
     }
     hip_ring_cv.notify_all();
     if (hip_reader.joinable()) hip_reader.join();
+    frames.current_Y = hip_own_current[0]; frames.current_U = hip_own_current[1]; frames.current_V = hip_own_current[2];
     for (int k = 0; k < HIP_RING; ++k) vp8hip_host_free((int)device.gpu_preferred_platform_number, hip_ring[k]);
 }
 
