@@ -86,6 +86,12 @@ int vp8hip_loopfilter_strength(vp8hip_ctx *ctx, int32_t *reductor, int32_t *shar
  * frame and the previous current frame (the context keeps both; 0,0 while there is only one).  The decision
  * logic with its hold-over stays on the host: vp8host_scene_change(), include/vp8hip_host.h. */
 int vp8hip_chroma_change(vp8hip_ctx *ctx, int32_t *Udiff, int32_t *Vdiff);
+/* ... in two halves: _async enqueues the scan behind the current frame's pack and returns; _result waits for the two sums only (they
+ * arrive in page-locked memory; not for the stream) and returns what vp8hip_chroma_change returns.  A second _async before a _result
+ * replaces the first; _result without a pending _async: VP8HIP_ERR_STATE.  For a host that hands the next frame over early (while the
+ * previous frame's loop filter runs) and wants scene_change()'s verdict without a round trip in its critical path. */
+int vp8hip_chroma_change_async(vp8hip_ctx *ctx);
+int vp8hip_chroma_change_result(vp8hip_ctx *ctx, int32_t *Udiff, int32_t *Vdiff);
 
 /* get_loopfilter_strength() + prepare_segments_data() (vp8enc.cpp:96-127, 129-221) evaluated on the device for the
  * current frame: the segment data of the following vp8hip_inter_transform / vp8hip_loop_filter are produced without
@@ -435,7 +441,7 @@ const char *vp8hip_status_string(int status);
  * built against an older header checks it once after loading the library.  3001: the shard, device-memory and frame-check entry points;
  * 3002: vp8drv_encode_video_device; 3003: vp8hip_import_last, vp8hip_group_*, the load-time hardware-queue setting;
  * vp8drv_frame_check folds position in (4: its values change). */
-#define VP8HIP_ABI_VERSION 4007
+#define VP8HIP_ABI_VERSION 4008
 int vp8hip_abi_version(void);
 /* 1 if this build of the library honours the timing-experiment switches that leave work out of a launch or a wait
  * (VP8HIP_EXPERIMENT_SKIP, VP8HIP_EXPERIMENT_SKIP_ENT, VP8HIP_EXPERIMENT_NOWAIT, VP8DRV_EXPERIMENT_READY_FIRST; built with

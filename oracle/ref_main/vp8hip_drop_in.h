@@ -72,7 +72,8 @@ struct hip_site_timer {
 // buffers (vp8hip_host_alloc: the copies to the device are then asynchronous).  The frames keep their SOURCE size: copy_with_padding
 // (encIO.h:141-202) runs on the device (vp8hip_set_source_size), with the reference's own quirks (REFERENCE_DEFECTS.md).
 static void hip_upload_current();
-enum { HIP_RING = 4 };
+static void hip_prefetch_next();
+enum { HIP_RING = 6 };      // the frame being coded, the one handed over early, the one on its way (prefetch), the one being read, and slack
 static uint8_t *hip_ring[HIP_RING];
 static int hip_ring_state[HIP_RING];       // what get_yuv420_frame would have returned for the frame in this slot: 1, 0 (end of stream), -1 (broken)
 static size_t hip_ring_head = 0, hip_ring_tail = 0, hip_ring_freed = 0;      // filled by the reader / handed to main() / given back by main()
@@ -82,6 +83,8 @@ static std::thread hip_reader;
 static bool hip_reader_stop = false;
 static int hip_cur_slot = -1;
 static size_t hip_prefetched_seq = (size_t)-1;      // the frame (by its number in the stream) that has been started on its way
+static int hip_early_slot = -1;            // the NEXT frame, already handed to the device (hip_early_next) while this one's loop filter runs
+static bool hip_chroma_async = false;      // ... with scene_change()'s scan under way (vp8hip_chroma_change_async)
 static bool hip_frame_pending = false;     // a frame is between vp8hip_encode_frame_begin and _end
 static bool hip_have_lagged = false;       // frames.encoded_frame holds the PREVIOUS iteration's frame, not yet written
 
@@ -148,12 +151,20 @@ static int hip_get_frame()
         hip_cur_slot = -1;
         hip_ring_cv.notify_all();
     }
-    hip_ring_cv.wait(l, [] { return hip_ring_tail < hip_ring_head; });
-    const size_t slot = hip_ring_tail % HIP_RING;
-    const int state = hip_ring_state[slot];
-    if (state == -1) printf("broken stream!\n");
-    if (state != 1) return state;
-    ++hip_ring_tail;
+    size_t slot;
+    if (hip_early_slot >= 0) {      // taken out of the ring (and handed to the device) by hip_early_next() already
+        slot = (size_t)hip_early_slot;
+        hip_early_slot = -1;
+    } else {
+        hip_ring_cv.wait(l, [] { return hip_ring_tail < hip_ring_head; });
+        slot = hip_ring_tail % HIP_RING;
+        const int state = hip_ring_state[slot];
+        if (state == -1) printf("broken stream!\n");
+        if (state != 1) return state;
+        ++hip_ring_tail;
+        hip_cur_on_device = false;
+        hip_chroma_async = false;
+    }
     hip_cur_slot = (int)slot;
     frames.tmp_Y = hip_ring[slot];
     frames.tmp_U = frames.tmp_Y + video.src_frame_size_luma;
@@ -161,8 +172,30 @@ static int hip_get_frame()
     frames.current_Y = frames.tmp_Y;      // source size; the device pads
     frames.current_U = frames.tmp_U;
     frames.current_V = frames.tmp_V;
-    hip_cur_on_device = false;
     return 1;
+}
+
+// The NEXT frame, if the reader has it, handed to the device NOW -- at the end of an iteration, while this frame's loop filter has most of
+// its time in front of it: its upload (a pack from the staging buffer the prefetch filled), the following frame started on its way, and
+// scene_change()'s scan enqueued (vp8hip_chroma_change_async).  The next iteration then finds frame and answer on the device, and its side
+// work (parameter scan, pyramid, GOLDEN / ALTREF searches) is enqueued early enough to run beside the filter instead of behind it.
+static void hip_early_next()
+{
+    size_t slot;
+    {
+        std::lock_guard<std::mutex> l(hip_ring_m);
+        if (hip_early_slot >= 0 || !(hip_ring_tail < hip_ring_head) || hip_ring_state[hip_ring_tail % HIP_RING] != 1) return;
+        slot = hip_ring_tail % HIP_RING;
+        ++hip_ring_tail;
+    }
+    hip_early_slot = (int)slot;
+    uint8_t *y = hip_ring[slot];
+    hip_site_timer t_(0);
+    HIP_CK(vp8hip_upload_current(hip_ctx, y, y + video.src_frame_size_luma, y + video.src_frame_size_luma + video.src_frame_size_chroma));
+    hip_cur_on_device = true;
+    hip_prefetch_next();
+    HIP_CK(vp8hip_chroma_change_async(hip_ctx));
+    hip_chroma_async = true;
 }
 
 // the frame after the current one, if the reader has it: started on its way to the device now (vp8hip_prefetch_current); the upload that
@@ -197,7 +230,11 @@ static void hip_chroma_diffs(int *Udiff, int *Vdiff)
 {
     int32_t u = 0, v = 0;
     hip_site_timer t_(3);
-    HIP_CK(vp8hip_chroma_change(hip_ctx, &u, &v));
+    if (hip_chroma_async) {
+        hip_chroma_async = false;
+        HIP_CK(vp8hip_chroma_change_result(hip_ctx, &u, &v));
+    } else
+        HIP_CK(vp8hip_chroma_change(hip_ctx, &u, &v));
     *Udiff = u;
     *Vdiff = v;
 }
@@ -459,6 +496,8 @@ static void hip_entropy_encode()
     hp.use_intra_info = !frames.current_is_key_frame && replaced > 0;     // (with nothing replaced the fallback did not even initialise them: the same bits)
     HIP_CK(vp8hip_encode_frame_begin(hip_ctx, (int)video.number_of_partitions, &hp));
     hip_frame_pending = true;
+    // (d) ... and the next frame, early
+    if (!getenv("VP8HIP_DROP_IN_NO_EARLY")) hip_early_next();
 #else
     // ... and, on the device, everything up to the finished frame: gather_frame() (encIO.h:1-30) has nothing left to do
     vp8hip_header_params hp;

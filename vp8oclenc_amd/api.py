@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "vp8hip_set_last_device", "vp8hip_set_segments", "vp8hip_inter_transform", "vp8hip_download_results",
     "vp8hip_upload_mb_data", "vp8hip_upload_recon", "vp8hip_prepare_filter_mask", "vp8hip_loop_filter",
     "vp8hip_download_last", "vp8hip_synchronize", "vp8hip_stream", "vp8hip_last_hip_error", "vp8hip_status_string",
-    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_auto_segments", "vp8hip_get_segments",
+    "vp8hip_profile_enable", "vp8hip_profile_read", "vp8hip_debug_download", "vp8hip_count_probs", "vp8hip_encode_coefficients", "vp8hip_loopfilter_strength", "vp8hip_chroma_change", "vp8hip_chroma_change_async", "vp8hip_chroma_change_result", "vp8hip_auto_segments", "vp8hip_get_segments",
     "vp8hip_intra_transform", "vp8hip_check_ssim", "vp8hip_download_intra", "vp8hip_conformant_stream", "vp8hip_set_source_size", "vp8hip_abi_version", "vp8hip_experiments_compiled_in", "vp8hip_batch_prep_mode", "vp8hip_device_count", "vp8hip_device_alloc", "vp8hip_device_free", "vp8hip_device_upload", "vp8hip_device_download", "vp8hip_device_synchronize", "vp8hip_device_mem_info", "vp8hip_device_pci_bus_id", "vp8hip_runtime_version", "vp8hip_shard_unique_id", "vp8hip_shard_init", "vp8hip_shard_rank", "vp8hip_shard_world", "vp8hip_shard_share_search", "vp8hip_shard_share_last", "vp8hip_shard_max", "vp8hip_encode_header", "vp8hip_encode_frame",
     "vp8hip_encode_frame_begin", "vp8hip_encode_frame_end", "vp8hip_filter_overlap",
     "vp8host_quantizer_ladders", "vp8host_loopfilter_strength", "vp8host_prepare_segments_data", "vp8host_skip_prob",
@@ -45,7 +45,7 @@ class Vp8HipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4007  # VP8HIP_ABI_VERSION, include/vp8hip.h
+ABI_VERSION = 4008  # VP8HIP_ABI_VERSION, include/vp8hip.h
 ERR_OVERFLOW = -7   # VP8HIP_ERR_OVERFLOW, include/vp8hip.h
 ERR_FORMAT = -8     # VP8HIP_ERR_FORMAT
 SHARPNESS_ON_DEVICE = -2 ** 31   # VP8HIP_SHARPNESS_ON_DEVICE

@@ -440,6 +440,7 @@ void vp8hip_destroy(vp8hip_ctx *c) {
         hipFree(c->h2d_stage[0]);
         hipFree(c->h2d_stage[1]);
     }
+    if (c->ev_chroma) hipEventDestroy(c->ev_chroma);
     shard_release(c);
     event_pool_put(c->device, c->ev, c->ev_made);
     hipFree(c->pixel_pool);
@@ -586,6 +587,39 @@ int vp8hip_chroma_change(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
     const int nc = (c->W / 2) * (c->H / 2);
     *Udiff = (int32_t)st[0] / nc;      // vp8enc.cpp:277, 284
     *Vdiff = (int32_t)st[1] / nc;
+    return VP8HIP_OK;
+}
+
+// The same scan without the host waiting for it: enqueued behind the current frame's pack, its two sums written to page-locked memory by
+// the folding kernel itself; vp8hip_chroma_change_result waits for THEM only (an event behind the fold), not for the stream.  A host that
+// hands the next frame over early (while the previous frame's loop filter still runs) has the answer by the time scene_change() asks.
+int vp8hip_chroma_change_async(vp8hip_ctx *c) {
+    USE_DEVICE(c);
+    if (!c) return VP8HIP_ERR_ARG;
+    if (c->cur_count == 0) return VP8HIP_ERR_STATE;
+    c->chroma_pending = true;
+    c->chroma_none = c->cur_count < 2;
+    if (c->chroma_none) return VP8HIP_OK;
+    if (!c->ev_chroma) HIPCHK(c, hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
+    uint32_t *words = reinterpret_cast<uint32_t *>(c->h_verdict) + 32;      // (the verdict block's second half: coherent page-locked memory)
+    launch_chroma_sad(c->stream, c->cur, c->cur_prev, c->d_stats + 8, words - 2);   // (the fold writes words 2 and 3 of what it is given)
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_chroma, c->stream));
+    return VP8HIP_OK;
+}
+
+int vp8hip_chroma_change_result(vp8hip_ctx *c, int32_t *Udiff, int32_t *Vdiff) {
+    if (!c || !Udiff || !Vdiff) return VP8HIP_ERR_ARG;
+    if (!c->chroma_pending) return VP8HIP_ERR_STATE;
+    c->chroma_pending = false;
+    *Udiff = *Vdiff = 0;
+    if (c->chroma_none) return VP8HIP_OK;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipEventSynchronize(c->ev_chroma));
+    const volatile uint32_t *words = reinterpret_cast<const volatile uint32_t *>(c->h_verdict) + 32;
+    const int nc = (c->W / 2) * (c->H / 2);
+    *Udiff = (int32_t)words[0] / nc;      // vp8enc.cpp:277, 284
+    *Vdiff = (int32_t)words[1] / nc;
     return VP8HIP_OK;
 }
 

@@ -146,6 +146,8 @@ struct vp8hip_ctx {
     // while the current frame is coded; the vp8hip_upload_current that names the same planes packs from there and copies nothing
     hipStream_t h2d_stream = nullptr;
     hipEvent_t ev_h2d = nullptr, ev_stage_read[2] = {nullptr, nullptr};
+    hipEvent_t ev_chroma = nullptr;    // behind the fold of vp8hip_chroma_change_async
+    bool chroma_pending = false, chroma_none = false;
     bool stage_read_valid[2] = {false, false};
     uint8_t *h2d_stage[2] = {nullptr, nullptr};
     size_t h2d_stage_bytes = 0;
