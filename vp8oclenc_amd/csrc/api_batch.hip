@@ -428,21 +428,21 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         launch_pyramid_batch(s, pyr, npyr, pyr_border);
     }
     const int net_width = c0->mbw * 2;
-    // The five levels of the hierarchical search as ONE or TWO launches (k_search1_coarse_b: a workgroup takes a tile of 4 x 4 level-1
-    // blocks and computes the tile's ancestors itself; nothing waits between workgroups) instead of five: with the part full a launch costs its
-    // place in the batch's queue, not its work.  VP8HIP_BATCH_S1_COARSE: 0 = a launch per level, 1 = levels 4-1 in one + level 0, 2 = all five in one.
-    static const int coarse_mode = [] { const char *v = getenv("VP8HIP_BATCH_S1_COARSE"); return v && v[0] ? atoi(v) : 1; }();
-    bool fused = false;
+    // Fewer launches for the five levels of the hierarchical search?  Measured (profiles/README.md, round 6): NO.  k_search1_coarse_b (a workgroup
+    // takes a tile of 4 x 4 level-1 blocks and computes the tile's ancestors itself) is bit-exact and 9 % (levels 4-1 in one launch) to 15 %
+    // (all five) SLOWER than a launch per level with 48 chunks in flight: the fused workgroup holds six waves through four barrier-separated
+    // phases of which the first three occupy one or two, and its level 1 runs in the short-wave form.  VP8HIP_BATCH_S1_COARSE: 0 = a launch per
+    // level (default), 1 = levels 4-1 in one + level 0, 2 = all five in one, 3 = levels 4-2 in one (two-wave workgroups) + levels 1 and 0.
+    static const int coarse_mode = [] { const char *v = getenv("VP8HIP_BATCH_S1_COARSE"); return v && v[0] ? atoi(v) : 0; }();
+    int first_level = 4, src = 0;
     if (coarse_mode > 0 && c0->mbw >= 2 && c0->mbh >= 2) {
-        Timed t(c0, VP8HIP_K_SEARCH1_L1);
-        fused = launch_search1_coarse_batch(s, cur, refs, nets, net_width, n, coarse_mode == 2);
+        Timed t(c0, VP8HIP_K_SEARCH1_L2);
+        if (launch_search1_coarse_batch(s, cur, refs, nets, net_width, n, coarse_mode == 2, coarse_mode == 3)) {
+            first_level = coarse_mode == 2 ? -1 : (coarse_mode == 3 ? 1 : 0);
+            src = first_level == 1 ? 1 : 0;      // level 1 reads net 1 (level 2's), level 0 reads net 0 (level 1's)
+        }
     }
-    if (fused && coarse_mode != 2) {
-        Timed t(c0, VP8HIP_K_SEARCH1_L4 + 4);
-        launch_search1_batch(s, cur, refs, nets, 0, 0, net_width, n);      // level 0 reads net 0 (level 1's), writes net 1
-    }
-    int src = 0;
-    for (int l = 4; l >= 0 && !fused; --l) {
+    for (int l = first_level; l >= 0; --l) {
         Timed t(c0, VP8HIP_K_SEARCH1_L4 + (4 - l));
         launch_search1_batch(s, cur, refs, nets, l, src, net_width, n);
         src ^= 1;

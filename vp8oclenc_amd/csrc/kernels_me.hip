@@ -393,7 +393,8 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
 struct CoarseArgs { Search1Args lv[5]; };   // lv[l] = level l
 constexpr int COARSE_WAVES = 6;             // 18 block slots of 20 lanes: the tile's 16 level-1 blocks in one pass
 // the tile's work: L0..L4 = the five levels' arguments (L0 read only with FINEST), r = the reference's slot in them
-template <bool FINEST>
+// TOP_ONLY: levels 4, 3 and 2 only (two waves are enough); the level-2 net leaves the workgroup and levels 1 and 0 are launches of their own
+template <bool FINEST, bool TOP_ONLY = false>
 __device__ __forceinline__ void coarse_tile(const Search1Args &L0, const Search1Args &L1, const Search1Args &L2, const Search1Args &L3, const Search1Args &L4, int r) {
     using M = S1Map<true>;
     __shared__ uint32_t mv4, mv3, mv2[4], mv1[16];
@@ -431,7 +432,9 @@ __device__ __forceinline__ void coarse_tile(const Search1Args &L0, const Search1
         const bool exists = slot < 4 && bx < L2.bw && by * L2.bw + bx < L2.nblk;
         const uint32_t out = search1_block<true>(L2, r, (exists ? bx : 0) * 8, (exists ? by : 0) * 8, mv3, exists, sub, lane);
         if (slot < 4 && sub == 0) mv2[slot] = exists ? out : 0u;
+        if (TOP_ONLY && slot < 4 && sub == 0 && exists) reinterpret_cast<uint32_t *>(L2.dst[r])[by * L2.net_width + bx] = out;
     }
+    if (TOP_ONLY) return;
     __syncthreads();
     // ---- level 1: the tile's 4 x 4 blocks; the only net that leaves the workgroup ----
     {
@@ -491,6 +494,13 @@ __device__ __forceinline__ Search1Args coarse_level(const CoarseBatchArgs &a, co
     s.bw = g.w / 8;
     s.nblk = (g.w / 8) * (g.h / 8);
     return s;
+}
+__global__ __launch_bounds__(128) void k_search1_top_b(CoarseBatchArgs a) {
+    const CoarseMember &m = a.m[blockIdx.z];
+    if ((int)blockIdx.y >= m.nrefs) return;
+    const int r = m.refmap[blockIdx.y];
+    const Search1Args L2 = coarse_level(a, m, 2, r), L3 = coarse_level(a, m, 3, r), L4 = coarse_level(a, m, 4, r);
+    coarse_tile<false, true>(L2, L2, L2, L3, L4, 0);
 }
 template <bool FINEST>
 __global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse_b(CoarseBatchArgs a) {
@@ -575,7 +585,7 @@ void launch_search1_coarse(hipStream_t s, const Frame &cur, const RefSet &refs, 
 
 // levels 4..1 (finest = false) or 4..0 of every member of a batch in ONE launch; false = the members' surfaces are not laid out alike
 // (never so for contexts of one size: the caller then launches level by level)
-bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n, bool finest) {
+bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n, bool finest, bool top_only) {
     CoarseBatchArgs a;
     a.net_width = net_width;
     a.n = n;
@@ -606,6 +616,10 @@ bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const R
     if (bw0 * bh0 <= 0 || maxrefs == 0 || search1_skip()) return true;
     const int tiles_x = finest ? (bw0 + 7) / 8 : (bw1 + 3) / 4, tiles_y = finest ? (bh0 + 7) / 8 : (bh1 + 3) / 4;
     if (tiles_x * tiles_y <= 0) return !finest ? true : false;
+    if (top_only) {     // tiles of 2 x 2 level-2 blocks = one level-3 block (the tile grid is the same: 4 x 4 level-1 blocks)
+        VP8_LAUNCH(k_search1_top_b, dim3(tiles_x * tiles_y, maxrefs, n), dim3(128), 0, s, a);
+        return true;
+    }
     if (finest) VP8_LAUNCH(k_search1_coarse_b<true>, dim3(tiles_x * tiles_y, maxrefs, n), dim3(64 * COARSE_WAVES), 0, s, a);
     else VP8_LAUNCH(k_search1_coarse_b<false>, dim3(tiles_x * tiles_y, maxrefs, n), dim3(64 * COARSE_WAVES), 0, s, a);
     return true;

@@ -137,7 +137,7 @@ void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uin
 struct ScanRequest { uint32_t *partial, *stats; SegData *sd; int32_t *strength_out; int is_key; int32_t refqi[4]; int qi_min; };
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n,
                        int sw = 0, int sh = 0);
-bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n, bool finest);
+bool launch_search1_coarse_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int net_width, int n, bool finest, bool top_only = false);
 void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int level, int src_idx,
                           int net_width, int n);
 // scan[i] (may be nullptr, as may scan): member i's new frame gets its loop-filter strength scan + segment data in this launch.
