@@ -499,8 +499,8 @@ __global__ __launch_bounds__(128) void k_search1_top_b(CoarseBatchArgs a) {
     const CoarseMember &m = a.m[blockIdx.z];
     if ((int)blockIdx.y >= m.nrefs) return;
     const int r = m.refmap[blockIdx.y];
-    const Search1Args L2 = coarse_level(a, m, 2, r), L3 = coarse_level(a, m, 3, r), L4 = coarse_level(a, m, 4, r);
-    coarse_tile<false, true>(L2, L2, L2, L3, L4, 0);
+    const Search1Args L1 = coarse_level(a, m, 1, r), L2 = coarse_level(a, m, 2, r), L3 = coarse_level(a, m, 3, r), L4 = coarse_level(a, m, 4, r);
+    coarse_tile<false, true>(L1, L1, L2, L3, L4, 0);      // (level 1 gives the tile grid; its blocks are not searched here)
 }
 template <bool FINEST>
 __global__ __launch_bounds__(64 * COARSE_WAVES) void k_search1_coarse_b(CoarseBatchArgs a) {
