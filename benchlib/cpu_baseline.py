@@ -4,6 +4,25 @@ from __future__ import annotations
 import os
 import time
 
+def cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max or v1 cfs quota), or None: a box that SHOWS 256 hardware threads may
+    grant 16 -- threads beyond the quota only take turns"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(args, api, host_frames, W, H, mbs):
     """Times oracle/vp8_oracle.c (the checker; OpenMP over blocks/MBs) on the host cores: kind 'port'."""
     # all host cores this process may run on (libgomp reads the variable when liboracle.so is loaded)
@@ -50,7 +69,7 @@ def cpu_baseline(args, api, host_frames, W, H, mbs):
             break
     out = {"value": round(mbs * n / el, 1), "unit": "macroblocks/s", "cores": threads, "kind": "port",
            "value_per_core": round(mbs * n / el / max(threads, 1), 1), "threads_tried": {str(k): v for k, v in sorted(tried.items())},
-           "host_hardware_threads": all_threads,
+           "host_hardware_threads": all_threads, "cpu_quota_of_this_container": cpu_quota(),
            "sample": f"{n} inter frames {W}x{H}, 3 references, oracle/vp8_oracle.c with OpenMP on {threads} threads, "
                      f"{el:.1f} s"}
     # the same restatement on ONE thread (what a core does when it does not wait for 255 others at every kernel's barrier)
@@ -74,7 +93,12 @@ def cpu_baseline(args, api, host_frames, W, H, mbs):
     if args.cpu_seconds >= 5:
         try:
             out["one_chunk"] = {k: out[k] for k in ("value", "unit", "cores", "value_per_core", "threads_tried", "sample")}
-            par = chunk_parallel(args, host_frames, W, H, mbs, sorted(os.sched_getaffinity(0)))
+            cpus = sorted(os.sched_getaffinity(0))
+            quota = cpu_quota()
+            if quota and quota < len(cpus):        # the cores this container really gets (the first ones of its list: distinct cores where
+                cpus = cpus[:max(1, int(quota + 0.5))]      # the siblings are numbered behind all first threads, as on this part)
+            par = chunk_parallel(args, host_frames, W, H, mbs, cpus)
+            par["cores_granted"] = quota if quota else len(cpus)
             out["chunk_parallel"] = par
             if par.get("value", 0) > out["value"]:
                 out.update(value=par["value"], cores=par["cores"], chunks=par["chunks"], value_per_core=par["value_per_core"], sample=par["sample"])
