@@ -46,7 +46,7 @@ def build_y4m_to_ivf(tmp: str) -> str | None:
     if shutil.which("g++") is None:
         return None
     exe, lib = os.path.join(tmp, "y4m_to_ivf"), os.path.join(ROOT, "vp8oclenc_amd")
-    r = subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
                         "-L", lib, "-lvp8hip", "-Wl,-rpath," + lib], capture_output=True, text=True, timeout=300)
     return exe if r.returncode == 0 else None
 

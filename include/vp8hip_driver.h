@@ -83,6 +83,12 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
 /* The frame AFTER the one just handed in, started on its way to the device (vp8hip_prefetch_current): a reader that is one frame ahead
  * calls this right after vp8drv_encode_frame_host and hands the same pointers to the next vp8drv_encode_frame_host. */
 int vp8drv_prefetch_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* ... and handed over altogether -- made the context's current frame (a pack from the prefetch's staging buffer), with cfg.scene_detect its
+ * chroma scan started (vp8hip_chroma_change_async) -- while the frame just coded is still in its loop filter: a reader that is a frame ahead
+ * calls this after vp8drv_get_frame_begin (or vp8drv_resolve) of the frame just coded and hands the same pointers to the next
+ * vp8drv_encode_frame_host, which then uploads nothing and waits for no scan: the new frame's side work is enqueued a hundred microseconds
+ * earlier, early enough to run beside the previous frame's loop filter (scripts/native/y4m_to_ivf.cpp).  Takes the open verdict first. */
+int vp8drv_stage_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 
 /* With check_ssim: waits for the verdict on the frame just coded and, if it sends the frame back (vp8enc.cpp:443-453), codes it
  * again as a key frame.  Returns 1 if the last frame ended as a key frame, 0 if as an inter frame, < 0 = vp8hip_status.  Implied by

@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "vp8hip_bitstream.h"
@@ -58,17 +61,55 @@ int main(int argc, char **argv) {
     fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, 0), out);     // frame count patched at the end (encIO.h:100-139)
     const size_t ysz = (size_t)W * H, csz = ysz / 4;
     std::vector<uint8_t> bytes((size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20));
-    // two page-locked frame buffers: while frame t is coded, frame t + 1 is read and started on its way to the device
-    // (vp8drv_prefetch_frame_host), so the copy never stands in front of a frame's first launch
+    // A reader thread keeps a ring of page-locked frame buffers filled ahead of the coder (get_yuv420_frame's fread, encIO.h:204-254, off the
+    // frame loop's thread: 3 MB per 1080p frame is 0.4 ms of the loop's 0.5), the frame after the one under way is started on its way to the
+    // device (vp8drv_prefetch_frame_host) and, once the frame just coded has its verdict and its entropy stage enqueued, handed over
+    // altogether (vp8drv_stage_frame_host: the pack, scene_change()'s scan) while that frame's loop filter still has most of its time to run.
     const size_t fsz = ysz + 2 * csz;
-    uint8_t *buf[2] = {nullptr, nullptr};
-    for (int k = 0; k < 2; ++k) CK(vp8hip_host_alloc(0, fsz, reinterpret_cast<void **>(&buf[k])));
-    auto read_frame = [&](uint8_t *dst) -> int {       // get_yuv420_frame, encIO.h:203-254: 1 = a frame, 0 = end of stream, -1 = broken
-        if (fread(dst, 1, fsz, in) != fsz) return 0;
-        uint8_t marker[6];
-        const size_t m = fread(marker, 1, 6, in);
-        return (m > 0 && !vp8host_y4m_frame_marker_ok(marker)) ? -1 : 1;
+    enum { RING = 6 };
+    uint8_t *buf[RING];
+    int state[RING];                 // get_yuv420_frame's verdict on the frame in this slot: 1 = a frame, 0 = end of stream, -1 = broken
+    for (int k = 0; k < RING; ++k) CK(vp8hip_host_alloc(0, fsz, reinterpret_cast<void **>(&buf[k])));
+    std::mutex m;
+    std::condition_variable cv;
+    size_t rd_head = 0, rd_tail = 0, rd_freed = 0;      // filled by the reader / taken by the loop / given back by the loop
+    bool stop = false;
+    std::thread reader([&] {
+        for (;;) {
+            size_t slot;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || rd_head - rd_freed < RING; });
+                if (stop) return;
+                slot = rd_head % RING;
+            }
+            int st = 1;
+            if (fread(buf[slot], 1, fsz, in) != fsz) st = 0;
+            else {
+                uint8_t marker[6];
+                const size_t n = fread(marker, 1, 6, in);
+                if (n > 0 && !vp8host_y4m_frame_marker_ok(marker)) st = -1;
+            }
+            {
+                std::lock_guard<std::mutex> l(m);
+                state[slot] = st;
+                ++rd_head;
+            }
+            cv.notify_all();
+            if (st != 1) return;
+        }
+    });
+    auto stop_reader = [&] {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        if (reader.joinable()) reader.join();
     };
+    auto peek = [&](bool wait) -> int {          // the state of the next frame in the ring: 1 / 0 / -1, or 2 = not read yet (wait == false)
+        std::unique_lock<std::mutex> l(m);
+        if (wait) cv.wait(l, [&] { return rd_tail < rd_head; });
+        return rd_tail < rd_head ? state[rd_tail % RING] : 2;
+    };
+    auto planes = [&](size_t seq, const uint8_t *p[3]) { p[0] = buf[seq % RING]; p[1] = p[0] + ysz; p[2] = p[1] + csz; };
     uint32_t n = 0, keys = 0;
     size_t total = 32;
     // One video: the loop filter of a frame runs beside the next frame's input side (vp8hip_filter_overlap), and its entropy stage
@@ -76,19 +117,30 @@ int main(int argc, char **argv) {
     // _end).  The scratch is sized for the densest frame there can be: no frame is ever coded twice.
     CK(vp8hip_reserve_frame_path_dense(vp8drv_context(drv)));
     bool pending = false;
-    int cur = 0;
+    size_t prefetched = (size_t)-1;
+    auto prefetch_next = [&]() -> int {           // the frame at the ring's rd_tail started on its way, once
+        if (peek(false) != 1 || prefetched == rd_tail) return 0;
+        const uint8_t *p[3];
+        planes(rd_tail, p);
+        prefetched = rd_tail;
+        return vp8drv_prefetch_frame_host(drv, p[0], p[1], p[2]);
+    };
     const auto t_loop = std::chrono::steady_clock::now();      // (the frame loop by the host's clock: what scripts/drop_in_bench.py quotes as fps_loop)
-    int have = read_frame(buf[cur]);
-    if (have < 0) { fprintf(stderr, "broken stream!\n"); return 1; }
     for (;;) {
+        const int have = peek(true);
+        if (have < 0) { fprintf(stderr, "broken stream!\n"); stop_reader(); return 1; }
         const bool got = have > 0;
         if (got) {
-            uint8_t *f = buf[cur];
-            CK(vp8drv_encode_frame_host(drv, f, f + ysz, f + ysz + csz, 0));
-            cur ^= 1;
-            have = read_frame(buf[cur]);               // the next frame, read while this one is coded ...
-            if (have < 0) { fprintf(stderr, "broken stream!\n"); return 1; }
-            if (have > 0) CK(vp8drv_prefetch_frame_host(drv, buf[cur], buf[cur] + ysz, buf[cur] + ysz + csz));      // ... and started on its way
+            const uint8_t *p[3];
+            planes(rd_tail, p);
+            {   // the previous frame's buffer goes back to the reader; this one is taken
+                std::lock_guard<std::mutex> l(m);
+                if (rd_tail > rd_freed) rd_freed = rd_tail;
+                ++rd_tail;
+            }
+            cv.notify_all();
+            CK(vp8drv_encode_frame_host(drv, p[0], p[1], p[2], 0));      // (uploads nothing if the frame was handed over early)
+            CK(prefetch_next());
         }
         if (pending) {      // the previous frame's bytes
             size_t size = 0;
@@ -106,7 +158,13 @@ int main(int argc, char **argv) {
         CK(key);
         keys += key;
         pending = true;
+        if (peek(false) == 1) {     // the next frame, early: current on the device, its scene scan under way, the one after it on its way
+            const uint8_t *p[3];
+            planes(rd_tail, p);
+            CK(vp8drv_stage_frame_host(drv, p[0], p[1], p[2]));
+        }
     }
+    stop_reader();
     const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
     fseek(out, 0, SEEK_SET);
     // the reference's file says one frame more than it holds: write_output_header counts from a frame number that main() has
@@ -118,7 +176,7 @@ int main(int argc, char **argv) {
     vp8drv_stats st;
     vp8drv_get_stats(drv, &st);
     vp8drv_destroy(drv);
-    for (int k = 0; k < 2; ++k) vp8hip_host_free(0, buf[k]);
+    for (int k = 0; k < RING; ++k) vp8hip_host_free(0, buf[k]);
     printf("%s: %u frames %dx%d (coded %dx%d), %u key (%d by scene change, %d recoded), %zu bytes; %d hardware queues\n", argv[2], n, W, H, Wc, Hc, keys,
            st.scene_changes, st.redone_as_key, total, vp8hip_hw_queues());
     printf("%.6f s of reading + coding + writing (%.1f frames/s)\n", loop_s, n / (loop_s > 0 ? loop_s : 1));

@@ -100,7 +100,7 @@ def test_native_y4m_to_ivf_program(tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "y4m_to_ivf")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
                     "-L", os.path.join(ROOT, "vp8oclenc_amd"), "-lvp8hip", "-Wl,-rpath," + os.path.join(ROOT, "vp8oclenc_amd")], check=True, timeout=300)
     W, H = 360, 200
     a, b = SynthSequence(W + 16, H + 16, seed=3), SynthSequence(W + 16, H + 16, seed=90)

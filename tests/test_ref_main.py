@@ -72,7 +72,7 @@ def test_the_references_main_writes_the_products_file(tmp_path, W, H, frames, cu
         pytest.skip("no g++")
     exe = str(tmp_path / "y4m_to_ivf")
     lib = os.path.join(ROOT, "vp8oclenc_amd")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "native", "y4m_to_ivf.cpp"), "-o", exe,
                     "-L", lib, "-lvp8hip", "-Wl,-rpath," + lib], check=True, timeout=300)
     src = str(tmp_path / "in.y4m")
     _y4m(src, W, H, frames, cut)

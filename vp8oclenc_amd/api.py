@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vp8host_gop_init", "vp8host_gop_next", "vp8host_gop_key_coded", "vp8host_gop_inter_flags",
     "vp8host_gop_frame_done", "vp8host_scene_change", "vp8host_y4m_parse_header", "vp8host_y4m_frame_marker_ok",
     "vp8drv_default_config", "vp8drv_create", "vp8drv_destroy", "vp8drv_context", "vp8drv_encode_frame_device",
-    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_batches_encode_frames_host", "vp8drv_batch_encode_frame_host", "vp8hip_batch_upload_current", "vp8hip_batch_intra_transform", "vp8hip_batch_prefetch_current", "vp8hip_prefetch_current", "vp8drv_prefetch_frame_host", "vp8drv_batch_prefetch_frame_host", "vp8hip_host_alloc", "vp8hip_host_free", "vp8drv_frame_check", "vp8drv_encode_video_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
+    "vp8drv_encode_frame_host", "vp8drv_get_stats", "vp8hip_reserve_frame_path", "vp8hip_reserve_frame_path_dense", "vp8drv_resolve", "vp8drv_ready", "vp8drv_batch_ready", "vp8drv_batches_encode_frame_device", "vp8drv_batches_encode_frames_device", "vp8drv_batches_encode_frames_host", "vp8drv_batch_encode_frame_host", "vp8hip_batch_upload_current", "vp8hip_batch_intra_transform", "vp8hip_batch_prefetch_current", "vp8hip_prefetch_current", "vp8drv_prefetch_frame_host", "vp8drv_stage_frame_host", "vp8drv_batch_prefetch_frame_host", "vp8hip_host_alloc", "vp8hip_host_free", "vp8drv_frame_check", "vp8drv_encode_video_device", "vp8hip_check_ssim_ready", "vp8hip_check_ssim_async", "vp8hip_check_ssim_result", "vp8hip_batch_check_ssim_async", "vp8drv_get_frame", "vp8drv_get_frame_begin", "vp8drv_get_frame_end",
     "vp8bs_default_probs", "vp8bs_encode_header", "vp8bs_gather_frame", "vp8bs_ivf_file_header", "vp8bs_ivf_frame_header",
 ]
 

@@ -27,6 +27,8 @@ struct vp8drv {
     int sharpness = VP8HIP_SHARPNESS_ON_DEVICE;   // video.loop_filter_sharpness in force, or: still on the device (vp8hip_get_segments).  May be NEGATIVE (vp8hip.h)
     int replaced = 0;
     bool verdict_pending = false;    // check_SSIM's verdict on the frame just coded is still on its way (resolve())
+    const uint8_t *staged = nullptr; // vp8drv_stage_frame_host: these planes are the context's current frame already (and, with scene_detect, their scan is under way)
+    bool staged_scan = false;
     // read-back buffers of vp8drv_get_frame
     std::vector<int32_t> seg, nz, ref, parts, is_inter, modes;
     std::vector<int16_t> vectors;
@@ -175,9 +177,12 @@ int resolve(vp8drv *d) {
 
 // the loop body once the current frame is on the device; host_y: the caller's luma plane or nullptr
 int frame_body(vp8drv *d, const uint8_t *host_y, bool key) {
+    const bool scan_under_way = d->staged_scan;
+    d->staged_scan = false;
     if (!key && d->cfg.scene_detect) {     // vp8enc.cpp:408-416: only frames that would be inter frames are looked at
         int32_t Udiff = 0, Vdiff = 0;
-        DRV_CHK(vp8hip_chroma_change(d->hip, &Udiff, &Vdiff));
+        if (scan_under_way) DRV_CHK(vp8hip_chroma_change_result(d->hip, &Udiff, &Vdiff));     // (started when the frame was handed over early)
+        else DRV_CHK(vp8hip_chroma_change(d->hip, &Udiff, &Vdiff));
         if (vp8host_scene_change(&d->scene, Udiff, Vdiff, d->gop.frame_number)) {
             d->st.scene_changes++;
             key = true;
@@ -351,8 +356,32 @@ int vp8drv_encode_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, cons
     if (!d || !y || !u || !v) return VP8HIP_ERR_ARG;
     { const int rc = resolve(d); if (rc < 0) return rc; }
     vp8host_gop_next(&d->gop);
-    DRV_CHK(vp8hip_upload_current(d->hip, y, u, v));
+    const bool staged = d->staged == y;
+    d->staged = nullptr;
+    if (!staged) {
+        d->staged_scan = false;
+        DRV_CHK(vp8hip_upload_current(d->hip, y, u, v));
+    }
     return frame_body(d, y, d->gop.current_is_key || force_key);
+}
+
+// The NEXT frame handed to the device early -- while the frame just coded is in its loop filter -- so that the next
+// vp8drv_encode_frame_host, given the same planes, finds the frame there and (with cfg.scene_detect) scene_change()'s two sums on their
+// way or back: its side work (parameter scan, pyramid, GOLDEN / ALTREF searches) is then enqueued early enough to run beside the filter.
+// Takes the open verdict first (the frame it belongs to must not lose its place as the context's current frame before a "redo as key
+// frame").  Call it after vp8drv_get_frame_begin / vp8drv_resolve of the frame just coded; the planes stay unchanged until the
+// vp8drv_encode_frame_host that names them has returned.
+int vp8drv_stage_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (!d || !y || !u || !v) return VP8HIP_ERR_ARG;
+    { const int rc = resolve(d); if (rc < 0) return rc; }
+    DRV_CHK(vp8hip_upload_current(d->hip, y, u, v));
+    d->staged = y;
+    d->staged_scan = false;
+    if (d->cfg.scene_detect) {
+        DRV_CHK(vp8hip_chroma_change_async(d->hip));
+        d->staged_scan = true;
+    }
+    return VP8HIP_OK;
 }
 
 int vp8drv_prefetch_frame_host(vp8drv *d, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
