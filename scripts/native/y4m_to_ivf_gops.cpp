@@ -6,18 +6,22 @@
 // `-g g` are a unit of their own: N such chunks are in flight at once, B of them advance together as one batch (every stage ONE
 // launch for the batch: vp8drv_batch_*), a host thread per batch; the input is streamed (two page-locked frame buffers per chunk in
 // flight: the batch's thread reads frame t + 2 of its members while frame t + 1, already on its way to the device, is coded; a frame's
-// planes lie end to end, one copy per frame: vp8hip_batch_upload_current / _prefetch_current), the finished frames are written in order
-// at the end.
+// planes lie end to end, one copy per frame: vp8hip_batch_upload_current / _prefetch_current), a writer thread writes every finished frame as soon as all
+// frames before it are written (a frame's bytes are held only until then).  An error in one batch stops the others; a frame that
+// check_SSIM sends back is reported (the file is then not the serial program's: see below).
 // The file is, byte for byte, what `y4m_to_ivf -no-scene-detect -g g` (one video, frame after frame: the reference's loop) writes --
 // as long as no frame is sent back by check_SSIM to be a key frame (the reference then restarts its GOP counter, vp8enc.cpp:443-453,
 // intra_part.h:1091, and the serial run's later key frames move; with the default -SSIM-target -1 none is) and no scene detection
 // is asked for (a cut moves the key frames the same way).  tests/test_gpu_file_roundtrip.py holds the two programs against each other.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <fcntl.h>
 #include <unistd.h>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -92,7 +96,36 @@ int main(int argc, char **argv) {
     uint8_t *pinned = nullptr;
     CK(vp8hip_host_alloc(0, (size_t)in_flight * 2 * rec, reinterpret_cast<void **>(&pinned)));
     const double t_made = now();
+    if (cfg.ssim_target > 0.0f)
+        fprintf(stderr, "y4m_to_ivf_gops: -SSIM-target %.2f: a frame that check_SSIM sends back to be a key frame restarts the serial program's GOP counter "
+                        "(vp8enc.cpp:443-453); if that happens this file is a valid stream but NOT byte for byte `y4m_to_ivf -g %d`'s (reported below)\n", cfg.ssim_target, g);
+    FILE *out = fopen(argv[2], "wb");
+    if (!out) { perror(argv[2]); return 1; }
+    uint8_t fh[32];
+    // the reference's file says one frame more than it holds (encIO.h:124-134, vp8enc.cpp:487-489; REFERENCE_DEFECTS.md #8) -- reproduced
+    fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, (uint32_t)nframes + 1), out);
     std::vector<std::vector<uint8_t>> out_frames((size_t)nframes);
+    std::vector<char> ready((size_t)nframes, 0);
+    std::mutex wm;
+    std::condition_variable wcv;
+    std::atomic<bool> failed{false};
+    std::atomic<int> resent{0};
+    size_t total = 32;
+    std::thread writer([&] {      // frames leave in order as soon as every frame before them has left
+        for (int t = 0; t < nframes; ++t) {
+            std::vector<uint8_t> f;
+            {
+                std::unique_lock<std::mutex> l(wm);
+                wcv.wait(l, [&] { return ready[(size_t)t] || failed.load(); });
+                if (!ready[(size_t)t]) return;
+                f.swap(out_frames[(size_t)t]);
+            }
+            uint8_t ph[12];
+            fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)f.size(), (uint32_t)t), out);
+            fwrite(f.data(), 1, f.size(), out);
+            total += 12 + f.size();
+        }
+    });
     std::vector<int> rc((size_t)nbatches, VP8HIP_OK), keys((size_t)nbatches, 0);
     const size_t cap = (size_t)(Wc / 16) * (Hc / 16) * 1900 + (1 << 20);
     std::vector<std::thread> th;
@@ -104,7 +137,7 @@ int main(int argc, char **argv) {
             const void *y[VP8HIP_MAX_BATCH], *u[VP8HIP_MAX_BATCH], *v[VP8HIP_MAX_BATCH];
             const uint8_t *py[VP8HIP_MAX_BATCH], *pu[VP8HIP_MAX_BATCH], *pv[VP8HIP_MAX_BATCH];
             int on[VP8HIP_MAX_BATCH], on_next[VP8HIP_MAX_BATCH], force[VP8HIP_MAX_BATCH], was_key[VP8HIP_MAX_BATCH];
-            for (int round = 0; rc[k] == VP8HIP_OK && (size_t)round * in_flight + j0 < (size_t)nchunks; ++round) {
+            for (int round = 0; rc[k] == VP8HIP_OK && !failed.load() && (size_t)round * in_flight + j0 < (size_t)nchunks; ++round) {
                 // member i codes chunk c_i = round * in_flight + j0 + i: frames c_i g + t, t < g
                 auto frame_of = [&](int i, int t) { const long c = (long)round * in_flight + j0 + i; return c < nchunks && c * g + t < nframes ? (int)(c * g + t) : -1; };
                 auto slot = [&](int i, int t) { return pinned + ((size_t)(j0 + i) * 2 + (size_t)(t & 1)) * rec; };
@@ -136,13 +169,17 @@ int main(int argc, char **argv) {
                 rc[k] = vp8drv_batch_encode_frame_host(bat[k], on, y, u, v, force, was_key);
                 if (rc[k] == VP8HIP_OK && g > 1 && planes(1, on_next) && (rc[k] = load(1)) == VP8HIP_OK)
                     rc[k] = vp8drv_batch_prefetch_frame_host(bat[k], py, pu, pv);      // frame 1 read and on its way
-                for (int t = 0; t < g && rc[k] == VP8HIP_OK; ++t) {
+                for (int t = 0; t < g && rc[k] == VP8HIP_OK && !failed.load(); ++t) {
                     int cur_on[VP8HIP_MAX_BATCH];
                     if (!planes(t, cur_on)) break;
                     rc[k] = vp8drv_batch_get_frame_begin(bat[k], cur_on);        // frame t's type is final here (its verdict is in)
                     if (rc[k] != VP8HIP_OK) break;
                     for (int i = 0; i < n; ++i)
-                        if (cur_on[i]) keys[k] += vp8drv_resolve(drv[j0 + i]) == 1;
+                        if (cur_on[i]) {
+                            const int key = vp8drv_resolve(drv[j0 + i]) == 1;
+                            keys[k] += key;
+                            if (key && t > 0) ++resent;      // a frame inside a chunk ended as a key frame: check_SSIM sent it back
+                        }
                     if (t + 1 < g && planes(t + 1, on_next)) {
                         for (int i = 0; i < n; ++i) force[i] = 0;
                         rc[k] = vp8drv_batch_encode_frame_host(bat[k], on_next, y, u, v, force, was_key);
@@ -155,35 +192,42 @@ int main(int argc, char **argv) {
                         if (!cur_on[i]) continue;
                         size_t size = 0;
                         rc[k] = vp8drv_get_frame_end(drv[j0 + i], buf.data(), buf.size(), &size);
-                        if (rc[k] == VP8HIP_OK) out_frames[(size_t)frame_of(i, t)].assign(buf.begin(), buf.begin() + (long)size);
+                        if (rc[k] == VP8HIP_OK) {
+                            const size_t f = (size_t)frame_of(i, t);
+                            std::lock_guard<std::mutex> l(wm);
+                            out_frames[f].assign(buf.begin(), buf.begin() + (long)size);
+                            ready[f] = 1;
+                        }
                     }
+                    wcv.notify_all();
                 }
+            }
+            if (rc[k] != VP8HIP_OK) {      // one batch failed: the others stop at their next frame, the writer at the first frame that never comes
+                failed = true;
+                wcv.notify_all();
             }
         });
     for (auto &t : th) t.join();
-    for (int k = 0; k < nbatches; ++k) CK(rc[k]);
     const double t_coded = now();
-
-    FILE *out = fopen(argv[2], "wb");
-    if (!out) { perror(argv[2]); return 1; }
-    uint8_t fh[32];
-    // the reference's file says one frame more than it holds (encIO.h:124-134, vp8enc.cpp:487-489; REFERENCE_DEFECTS.md #8) -- reproduced
-    fwrite(fh, 1, vp8bs_ivf_file_header(fh, W, H, (uint32_t)(fps ? fps : 30), 1, (uint32_t)nframes + 1), out);
-    size_t total = 32;
-    int nkeys = 0;
-    for (int t = 0; t < nframes; ++t) {
-        uint8_t ph[12];
-        fwrite(ph, 1, vp8bs_ivf_frame_header(ph, (uint32_t)out_frames[(size_t)t].size(), (uint32_t)t), out);
-        fwrite(out_frames[(size_t)t].data(), 1, out_frames[(size_t)t].size(), out);
-        total += 12 + out_frames[(size_t)t].size();
-    }
+    { std::lock_guard<std::mutex> l(wm); }
+    wcv.notify_all();
+    writer.join();
     fclose(out);
     const double t_written = now();
+    int nkeys = 0, first_error = VP8HIP_OK;
+    // one way out, with or without an error: batches, drivers, the page-locked block and the file descriptor are given back
     for (int k = 0; k < nbatches; ++k) vp8drv_batch_destroy(bat[k]);
     for (auto d : drv) vp8drv_destroy(d);
-    for (int k = 0; k < nbatches; ++k) nkeys += keys[k];
+    for (int k = 0; k < nbatches; ++k) { nkeys += keys[k]; if (rc[k] != VP8HIP_OK && first_error == VP8HIP_OK) first_error = rc[k]; }
     vp8hip_host_free(0, pinned);
     close(fd);
+    if (first_error != VP8HIP_OK) {
+        fprintf(stderr, "y4m_to_ivf_gops: a batch failed: %d (%s); %s is incomplete\n", first_error, vp8hip_status_string(first_error), argv[2]);
+        return 1;
+    }
+    if (resent.load())
+        fprintf(stderr, "y4m_to_ivf_gops: check_SSIM sent %d frame(s) back to be key frames: the serial program restarts its GOP counter there, so this file is a "
+                        "valid stream but NOT byte for byte `y4m_to_ivf -g %d`'s\n", resent.load(), g);
     printf("%s: %d frames %dx%d (coded %dx%d) in %d closed GOPs of %d, %d in flight in %d batches, %d key frames, %zu bytes; %d hardware queues\n", argv[2], nframes, W, H, Wc,
            Hc, nchunks, g, in_flight, nbatches, nkeys, total, vp8hip_hw_queues());
     printf("  seconds: opening %.3f, %d contexts, their scratch and frame buffers %.3f, reading + coding %.3f (%.0f frames/s, %.2f M macroblocks/s, every frame from the file and over the "

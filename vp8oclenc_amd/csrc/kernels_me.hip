@@ -280,12 +280,53 @@ __device__ __forceinline__ void s1_subblock(const uint8_t *cp, int cstride, cons
     for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
 }
 
+// The same with the current block's share of the metric taken from LDS (pre16: the 16 ints weight_pre_column x 4 of this sub-block, made once
+// per wave by s1_make_pre below): the five dy lanes of a block -- and every reference -- need the same 16 dot4, 8 permutes and 4 biases per
+// sub-block; as instructions of the wave they cost what they cost one lane.
+__device__ __forceinline__ void s1_subblock_pre(const int *pre16, const uint8_t *rp, int rstride, int acc[5]) {
+    uint32_t q0[4], q1[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const uint2 q = ld_u64(rp + (ptrdiff_t)y * rstride);
+        q0[y] = q.x ^ 0x80808080u; q1[y] = q.y ^ 0x80808080u;
+    }
+    uint32_t col[8];
+    transpose4x4(q0, col);
+    transpose4x4(q1, col + 4);
+    int pre[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int4 v = *reinterpret_cast<const int4 *>(pre16 + 4 * k);
+        pre[4 * k] = v.x; pre[4 * k + 1] = v.y; pre[4 * k + 2] = v.z; pre[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] += weight_cols_pre(pre, col + i);
+}
+// ... made by the wave for its twelve blocks: lane = (block slot, sub-block), 48 of the 64 lanes; 16 ints each into pre_lds[slot][sub-block][16]
+constexpr int S1_PRE_INTS = 12 * 4 * 16;
+__device__ __forceinline__ void s1_make_pre(const Plane &cur, int cx, int cy, int sb, bool on, int *dst16) {
+    const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;      // the order of the cost loop: (0,0), (0,+4 rows), (+4 cols,0), (+4,+4)
+    const uint8_t *cp = cur.p + (ptrdiff_t)(cy + sy) * cur.stride + cx + sx;
+    uint32_t c[4], cc[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) c[y] = *reinterpret_cast<const uint32_t *>(cp + (ptrdiff_t)y * cur.stride) ^ 0x80808080u;
+    transpose4x4(c, cc);
+    int pre[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) weight_pre_column(cc[k], pre + 4 * k);
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<int4 *>(dst16 + 4 * k) = make_int4(pre[4 * k], pre[4 * k + 1], pre[4 * k + 2], pre[4 * k + 3]);
+    }
+}
+
 // One 8x8 block of one level against one reference: the lanes of the block (M::LANES_PER_BLOCK of them: `sub` is the lane's number in
 // the block, `lane` its number in the wave) search the 25 candidates around the scaled parent vector `pv` (packed short2, 0 = none).
 // Returns the block's vector as the net holds it (packed short2, already multiplied by pixel_rate); valid in the lane with sub == 0.
 // `live` false: the lanes take part in the shuffles on harmless in-frame data.
-template <bool SPLIT>
-__device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, int cx, int cy, uint32_t pv, bool live, int sub, int lane) {
+template <bool SPLIT, bool PRE_LDS = false>
+__device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, int cx, int cy, uint32_t pv, bool live, int sub, int lane,
+                                                  const int *pre_lds = nullptr /* PRE_LDS (loop form): this block's [sub-block][16] from s1_make_pre */) {
     const int sb0 = sub / 5, j = sub - 5 * sb0;       // SPLIT: this lane's sub-block; otherwise sb0 = 0
     // vector / pixel_rate truncates toward zero (:495-500)
     int v0x = (int16_t)(pv & 0xffffu), v0y = (int16_t)(pv >> 16);
@@ -314,10 +355,18 @@ __device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, i
         }
     } else {
         // one sub-block at a time (loop NOT unrolled: the register footprint decides how many waves a SIMD holds)
+        if (PRE_LDS) {
 #pragma unroll 1
-        for (int sb = 0; sb < 4; ++sb) {
-            const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
-            s1_subblock(cp + (ptrdiff_t)sy * a.cur.stride + sx, a.cur.stride, rp + (ptrdiff_t)sy * a.ref[r].stride + sx, a.ref[r].stride, acc);
+            for (int sb = 0; sb < 4; ++sb) {
+                const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
+                s1_subblock_pre(pre_lds + 16 * sb, rp + (ptrdiff_t)sy * a.ref[r].stride + sx, a.ref[r].stride, acc);
+            }
+        } else {
+#pragma unroll 1
+            for (int sb = 0; sb < 4; ++sb) {
+                const int sx = (sb >> 1) * 4, sy = (sb & 1) * 4;
+                s1_subblock(cp + (ptrdiff_t)sy * a.cur.stride + sx, a.cur.stride, rp + (ptrdiff_t)sy * a.ref[r].stride + sx, a.ref[r].stride, acc);
+            }
         }
     }
     const int pen_scale = a.pixel_rate < 4 ? 32 : 0;
@@ -353,7 +402,8 @@ __device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, i
     return ox16 | (oy16 << 16);
 }
 
-template <bool SPLIT>
+// PRE_LDS (loop form): the current blocks' share of the metric made once per wave into LDS (s1_make_pre) instead of by every lane of a block
+template <bool SPLIT, bool PRE_LDS = false>
 __device__ __forceinline__ void search1_body(const Search1Args &a) {
     using M = S1Map<SPLIT>;
     if ((int)blockIdx.y >= a.nrefs) return;
@@ -371,7 +421,20 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
     const int parent = (cy >> 4) * a.net_width + (cx >> 4);
     const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
     const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
-    const uint32_t out = search1_block<SPLIT>(a, r, cx, cy, pv, live, sub, lane);
+    const int *pre_lds = nullptr;
+    if (!SPLIT && PRE_LDS) {
+        // the current blocks' share of the metric, once per wave into LDS: lane = (block slot, sub-block).  The stages hand over inside the wave
+        // (LDS executes a wave's operations in order): no barrier, the compiler is kept from moving the reads up
+        __shared__ __attribute__((aligned(16))) int s_pre[4][S1_PRE_INTS];
+        const int slot = lane >> 2, sb = lane & 3;
+        const int tb_raw = (xcd_band(blockIdx.x, gridDim.x) * 4 + wave) * M::BLOCKS_PER_WAVE + slot;
+        const int tb = tb_raw < a.nblk ? tb_raw : a.nblk - 1;
+        const int tby = a.bw == 1 ? tb : (int)__umulhi((uint32_t)tb, a.bw_inv), tbx = tb - tby * a.bw;
+        s1_make_pre(a.cur, tbx * 8, tby * 8, sb, slot < M::BLOCKS_PER_WAVE, &s_pre[wave][(slot < M::BLOCKS_PER_WAVE ? slot : 0) * 64 + sb * 16]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pre_lds = &s_pre[wave][(grp < M::BLOCKS_PER_WAVE ? grp : 0) * 64];
+    }
+    const uint32_t out = search1_block<SPLIT, !SPLIT && PRE_LDS>(a, r, cx, cy, pv, live, sub, lane, pre_lds);
     if (sub == 0 && live) {
         const int cell = (cy >> 3) * a.net_width + (cx >> 3);
         reinterpret_cast<uint32_t *>(a.dst[r])[cell] = out;
@@ -517,6 +580,13 @@ __global__ __launch_bounds__(256) void k_search1(Search1Args a) { search1_body<S
 static_assert(sizeof(BatchOf<Search1Args>) <= 4096 && sizeof(PyrArgs) <= 4096 && sizeof(BatchOf<PackItem>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_search1_pl(Search1Args a) { search1_body<false, true>(a); }
+__global__ __launch_bounds__(256) void k_search1_pl_b(BatchOf<Search1Args> b) { search1_body<false, true>(b.item[blockIdx.z]); }
+// VP8HIP_S1_PRE_LDS=0: the loop form as it was (every lane makes the current block's share itself); same-box A/B runs
+static bool search1_pre_lds() {
+    static const bool on = [] { const char *v = getenv("VP8HIP_S1_PRE_LDS"); return !(v && v[0] == '0'); }();
+    return on;
+}
 
 static Search1Args search1_args(const Frame &cur, const RefSet &refs, const NetSet &nets, int level, int src_idx, int net_width) {
     Search1Args a;
@@ -566,6 +636,8 @@ void launch_search1(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     if (a.nblk <= 0 || n == 0 || search1_skip()) return;
     if (search1_split((size_t)a.nblk * n, latency))
         VP8_LAUNCH(k_search1<true>, dim3((a.nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
+    else if (search1_pre_lds())
+        VP8_LAUNCH(k_search1_pl, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
     else
         VP8_LAUNCH(k_search1<false>, dim3((a.nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, n), dim3(256), 0, s, a);
 }
@@ -639,6 +711,8 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
     if (nblk <= 0 || maxrefs == 0 || search1_skip()) return;
     if (search1_split((size_t)nblk * totrefs, false))
         VP8_LAUNCH(k_search1_b<true>, dim3((nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
+    else if (search1_pre_lds())
+        VP8_LAUNCH(k_search1_pl_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
     else
         VP8_LAUNCH(k_search1_b<false>, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
 }
