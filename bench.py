@@ -51,7 +51,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))     # (oracle_lib: the cpu_baseline leg only)
 
-from benchlib.common import pin_to_gpu_numa_node  # noqa: E402
+from benchlib.common import ALTREF_RANGE, pin_to_gpu_numa_node  # noqa: E402,F401
+# (the measurement scripts under scripts/ -- trace_single.py, stress_*.py ... -- reach the legs through `import bench`)
+from benchlib.leg import Leg, side_leg  # noqa: E402,F401
+from benchlib.legs_bitstream import bitstream_leg  # noqa: E402,F401
 
 
 def parse():

@@ -38,8 +38,8 @@ SEQUENCES = {"config3_4k": dict(W0=3840, H0=2160, seed=1, frames=300, gop=150, s
 for _r in range(8):
     SEQUENCES[f"config5_rank{_r}"] = dict(W0=1920, H0=1080, seed=1 + _r, frames=300, gop=1 << 30, start=0)
 SEQUENCES["selftest"] = dict(W0=180, H0=140, seed=5, frames=14, gop=9, start=0)      # (seconds: what the CPU test suite regenerates in full)
-TABLES = {"chunks_1920x1080": dict(W0=1920, H0=1080, seed=1, frames=176), "chunks_3840x2160": dict(W0=3840, H0=2160, seed=1, frames=40),
-          "chunks_1280x720_last_only": dict(W0=1280, H0=720, seed=1, frames=48, refs="last"),
+TABLES = {"chunks_1920x1080": dict(W0=1920, H0=1080, seed=1, frames=176), "chunks_3840x2160": dict(W0=3840, H0=2160, seed=1, frames=64),
+          "chunks_1280x720_last_only": dict(W0=1280, H0=720, seed=1, frames=96, refs="last"),
           # bench.py's other legs (round 6): the four-pass SSIM ladder, the conformant stream (vp8hip_conformant_stream / vp8o_set_conformant_stream:
           # the format's predictor), and ONE video longer than the chunk table (single_stream: phase 0 only).  A finite GOP needs no table of its
           # own: a chunk n frames past a key frame it coded itself stands where a chunk that STARTED with that key frame stands (closed GOPs).
