@@ -126,6 +126,12 @@ __device__ __forceinline__ v16i mfma_round(v4i a, v4i b) {
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
 
+// SPREAD: the cost phase's 26 x 4 (candidate, 4x4 block) tasks of a block spread over ALL 32 lanes of its half-wave and, for what is left, over
+// one wave of the workgroup.  With lane = candidate, 6 of a block's 32 lanes idle through four rounds of the metric (the wave issues them all the
+// same); here the idle lanes take the FOURTH 4x4 block of candidates 0..17 during the first three rounds, and the fourth 4x4 block of candidates
+// 18..25 of all eight blocks -- 64 tasks -- is one round of wave 0 alone: 3.25 rounds per wave on average instead of 4.  The costs meet in LDS
+// (in the H array's dead bytes), two workgroup barriers around wave 0's extra round.  Same integer sums in another order: the same result.
+template <bool SPREAD>
 __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_idx) {
     if (ref_idx >= a.nrefs) return;
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
@@ -234,6 +240,39 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     int qx = (int16_t)(cx * 4 + v0x + dx), qy = (int16_t)(cy * 4 + v0y + dy);
     if (k == 25) { qx = cx * 4; qy = cy * 4; }
     const bool valid = live && k < 26 && qx >= 0 && qx <= a.w * 4 - 32 && qy >= 0 && qy <= a.h * 4 - 32;
+    int diff = 0;
+    if (SPREAD) {
+        int *q3 = &s_pre[g][64];          // [candidate]: the cost of its fourth 4x4 block, made by another lane (the H array's bytes behind the pre table)
+        const bool helper = lane >= 26;
+        const int hb = (lane - 26) * 3;
+        // one task: the metric of 4x4 block sb = (m * 2 + n) of candidate `cand` of block slot `slot`
+        auto task = [&](int slot, int cand, int poff /* dwords: 8 n + m */, int preoff /* ints: 16 sb */) {
+            const uint32_t *src = (cand < 25 ? &s_V[slot][cand * V_STRIDE] : &s_cz[slot][16]) + poff;
+            int pre[16];
+            uint32_t pp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int4 v = *reinterpret_cast<const int4 *>(&s_pre[slot][preoff + 4 * j]);
+                pre[4 * j] = v.x; pre[4 * j + 1] = v.y; pre[4 * j + 2] = v.z; pre[4 * j + 3] = v.w;
+                pp[j] = src[2 * j];
+            }
+            return weight_cols_pre(pre, pp);
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {       // rounds 0..2: a candidate's own lane its 4x4 blocks 0..2, the idle lanes block 3 of candidates 0..17
+            const int cand = helper ? hb + j : k;
+            const int c = task(g, cand, helper ? 8 * 1 + 1 : 8 * (j & 1) + (j >> 1), helper ? 48 : 16 * j);
+            if (helper) q3[cand] = c;
+            else diff += c;
+        }
+        __syncthreads();                    // every wave's V / pre / zero-MV arrays (and the idle lanes' costs) are in LDS
+        if ((threadIdx.x >> 6) == 0) {      // wave 0: block 3 of candidates 18..25 of all eight block slots
+            const int slot = wl >> 3, cand = 18 + (wl & 7);
+            s_pre[slot][64 + cand] = task(slot, cand, 8 * 1 + 1, 48);
+        }
+        __syncthreads();
+        if (k < 26) diff += q3[k];
+    } else {
     uint32_t P[8][2];
     {
         // candidates 0..24: their prediction from the producer; lane 25 (zero MV: whole-pel, both passes are the identity)
@@ -245,7 +284,6 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
             P[2 * c4][0] = v.x; P[2 * c4][1] = v.y; P[2 * c4 + 1][0] = v.z; P[2 * c4 + 1][1] = v.w;
         }
     }
-    int diff = 0;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -260,6 +298,7 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
             }
             diff += weight_cols_pre(pre, pp);
         }
+    }
     if (k < 25) diff += (iabs(dx) + iabs(dy)) * 32;  // :1176-1178
     uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)k : 0xffffffffu;
     key = halfwave_min_upper(key);
@@ -278,15 +317,17 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
 }
 
+template <bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_search2(S2Args a) {   // (a register budget of 128 also makes the MFMAs write VGPRs: no v_accvgpr_read per result)
     launch_clock_begin(a.clk);
-    search2_body(a, xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
+    search2_body<SPREAD>(a, xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(a.clk);
 }
 static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
+template <bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
     launch_clock_begin(b.item[0].clk);
-    search2_body(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
+    search2_body<SPREAD>(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
 // The same launch carrying the loop-filter strength scans of its members' NEW frames (kernels_rc_dev.h): the workgroups behind the
@@ -297,6 +338,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
 // spread through the launch's 12 000 per member.
 struct S2Scans { rc::ScanCore item[MAX_BATCH]; uint32_t mask; int nbx, wgs; };
 static_assert(sizeof(BatchOf<S2Args>) + sizeof(S2Scans) <= 4096, "the kernel-argument segment");
+template <bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scans sc) {
     if ((int)blockIdx.x >= sc.nbx) {
         const int wg = (int)blockIdx.x - sc.nbx;
@@ -304,7 +346,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scan
         return;
     }
     launch_clock_begin(b.item[0].clk);
-    search2_body(b.item[blockIdx.z], xcd_band(blockIdx.x, sc.nbx), blockIdx.y);
+    search2_body<SPREAD>(b.item[blockIdx.z], xcd_band(blockIdx.x, sc.nbx), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
@@ -316,7 +358,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_p(BatchOf<S2Args> b, int nbx
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int item = w / (nbx * maxrefs), rem = w - item * (nbx * maxrefs);
         const int ref_idx = rem / nbx, wg_x = rem - ref_idx * nbx;
-        search2_body(b.item[item], wg_x, ref_idx);
+        search2_body<false>(b.item[item], wg_x, ref_idx);
         lds_fence();   // the next round reuses this workgroup's LDS: every read of this round has returned
     }
 }
@@ -344,6 +386,11 @@ static S2Args search2_args(const Frame &cur, const RefSet &refs, const NetSet &n
     a.nblk = a.w * a.h / 64;
     return a;
 }
+// VP8HIP_S2_SPREAD=0: lane = candidate through all four rounds, as it was (same-box A/B runs)
+static bool search2_spread() {
+    static const bool on = [] { const char *v = getenv("VP8HIP_S2_SPREAD"); return !(v && v[0] == '0'); }();
+    return on;
+}
 static bool search2_skip() {
     static const bool skip = experiment_skip("s2");
     return skip;   // timing experiment only
@@ -352,7 +399,8 @@ static bool search2_skip() {
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk) {
     const S2Args a = search2_args(cur, refs, nets, clk);
     if (a.nrefs == 0 || search2_skip()) return;
-    VP8_LAUNCH(k_search2, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
+    if (search2_spread()) VP8_LAUNCH(k_search2<true>, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
+    else VP8_LAUNCH(k_search2<false>, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
 }
 
 bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n, unsigned long long *clk,
@@ -382,12 +430,14 @@ bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
                                   rc::SegArgs{y.w * y.h, (y.h - 1) * (y.w - 1), q.is_key, q.refqi[0], q.refqi[1], q.refqi[2], q.refqi[3], q.qi_min}};
     }
     if (!sc.mask) {
-        VP8_LAUNCH(k_search2_b, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+        if (search2_spread()) VP8_LAUNCH(k_search2_b<true>, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+        else VP8_LAUNCH(k_search2_b<false>, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
         return false;
     }
     sc.nbx = nbx;
     sc.wgs = (b.item[0].h + rc::ROWS_PER_BLOCK - 1) / rc::ROWS_PER_BLOCK;
-    VP8_LAUNCH(k_search2_bs, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    if (search2_spread()) VP8_LAUNCH(k_search2_bs<true>, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    else VP8_LAUNCH(k_search2_bs<false>, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
     return true;
 }
 
