@@ -58,7 +58,7 @@ def main():
     for (name, grid), vals in acc.items():
         v = sum(vals) / len(vals)
         if "k_search1" in name:
-            variant = "k_search1<split>" if "<true>" in name or "ILb1E" in name else "k_search1<loop>"
+            variant = "k_search1<split>" if "<true>" in name or "ILb1E" in name else ("k_search1_pl" if "k_search1_pl" in name else "k_search1<loop>")
             bpw = 12 if variant.endswith("<split>") else 48
             for lvl in range(5):
                 nblk = ((W >> lvl) // 8) * ((H >> lvl) // 8)

@@ -18,7 +18,8 @@ find gpurun_out/${TAG}_kt1 -name "*kernel_trace.csv" -size +20M -delete
 CMD1="python3 bench.py --gops-per-gpu 1 --steps 40 --warmup 10 --no-side-legs --cpu-seconds 0"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${TAG}_pmc_fetch -o fetch --output-format csv -- $CMD1 > gpurun_out/${TAG}_pmc_fetch.json 2>/dev/null
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${TAG}_pmc_write -o write --output-format csv -- $CMD1 > gpurun_out/${TAG}_pmc_write.json 2>/dev/null
-for d in fetch write; do find gpurun_out/${TAG}_pmc_$d -name "*.csv" -size +20M -delete; done
+rocprofv3 --pmc SQ_INSTS_VALU -d gpurun_out/${TAG}_pmc_valu -o valu --output-format csv -- $CMD1 > gpurun_out/${TAG}_pmc_valu.json 2>/dev/null
+for d in fetch write valu; do find gpurun_out/${TAG}_pmc_$d -name "*.csv" -size +20M -delete; done
 # fewer launches per batch step?  the fused forms of the hierarchical search against a launch per level, alternating on this box
 for m in 0 1 0 3 0 2 0; do
   VP8HIP_BATCH_S1_COARSE=$m python3 bench.py --steps 20 --warmup 5 --no-side-legs --cpu-seconds 0 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('VP8HIP_BATCH_S1_COARSE=$m', d['value'], 'M MB/s; chunks against the oracle:', d['self_check']['against_the_oracle']['chunks_checked'], d['self_check']['against_the_oracle']['identical'])"
