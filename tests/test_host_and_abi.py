@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = []
-    for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h"):
+    for h in ("vp8hip.h", "vp8hip_multi.h", "vp8hip_taps.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         names += re.findall(r"\b(vp8(?:hip|host|drv|bs)_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))

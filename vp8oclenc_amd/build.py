@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvp8hip.so")
 SOURCES = ["api_context.hip", "api_inter.hip", "api_entropy.hip", "api_batch.hip", "api_shard.hip", "api_profile.hip", "kernels_me.hip", "kernels_s2.hip", "kernels_mb.hip", "kernels_lf3.hip", "kernels_lf4.hip", "kernels_entropy_stage.hip", "kernels_rc.hip", "kernels_intra.hip", "vp8_host.cpp", "vp8_driver.cpp", "vp8_bitstream.cpp"]
 HEADERS = ["vp8hip_ctx.h", "vp8hip_dev.h", "kernels_rc_dev.h", "vp8_rfc6386_tables.inc", "vp8_mbhdr.h", "kernels_ent.hip", "kernels_hdr.hip"]   # the two .hip files are included by kernels_entropy_stage.hip
-HEADERS = HEADERS + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h")]
+HEADERS = HEADERS + [os.path.join("..", "..", "include", h) for h in ("vp8hip.h", "vp8hip_multi.h", "vp8hip_taps.h", "vp8hip_host.h", "vp8hip_driver.h", "vp8hip_bitstream.h")]
 
 
 def _hipcc() -> str:
