@@ -403,11 +403,13 @@ __device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, i
 }
 
 // PRE_LDS (loop form): the current blocks' share of the metric made once per wave into LDS (s1_make_pre) instead of by every lane of a block
-template <bool SPLIT, bool PRE_LDS = false>
+// REF_LOOP: a workgroup searches its blocks in EVERY enabled reference, one after the other (grid y = 1), instead of a workgroup per reference:
+// the block arithmetic and the current blocks' share of the metric are made once for the two or three of them (batches; one video keeps a
+// workgroup per reference: there a launch is as long as one wave)
+template <bool SPLIT, bool PRE_LDS = false, bool REF_LOOP = false>
 __device__ __forceinline__ void search1_body(const Search1Args &a) {
     using M = S1Map<SPLIT>;
-    if ((int)blockIdx.y >= a.nrefs) return;
-    const int r = a.refmap[blockIdx.y];
+    if (!REF_LOOP && (int)blockIdx.y >= a.nrefs) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / M::LANES_PER_BLOCK, sub = lane - M::LANES_PER_BLOCK * grp;
     const int b_raw = (xcd_band(blockIdx.x, gridDim.x) * 4 + wave) * M::BLOCKS_PER_WAVE + grp;
@@ -420,7 +422,6 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
     // without the extra kernel.
     const int parent = (cy >> 4) * a.net_width + (cx >> 4);
     const bool parent_written = (cx >> 4) < a.pbw && (cy >> 4) < a.pbh;
-    const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
     const int *pre_lds = nullptr;
     if (!SPLIT && PRE_LDS) {
         // the current blocks' share of the metric, once per wave into LDS: lane = (block slot, sub-block).  The stages hand over inside the wave
@@ -434,10 +435,16 @@ __device__ __forceinline__ void search1_body(const Search1Args &a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pre_lds = &s_pre[wave][(grp < M::BLOCKS_PER_WAVE ? grp : 0) * 64];
     }
-    const uint32_t out = search1_block<SPLIT, !SPLIT && PRE_LDS>(a, r, cx, cy, pv, live, sub, lane, pre_lds);
-    if (sub == 0 && live) {
-        const int cell = (cy >> 3) * a.net_width + (cx >> 3);
-        reinterpret_cast<uint32_t *>(a.dst[r])[cell] = out;
+    const int nr = REF_LOOP ? a.nrefs : 1;
+#pragma unroll 1
+    for (int ri = 0; ri < nr; ++ri) {
+        const int r = a.refmap[REF_LOOP ? ri : (int)blockIdx.y];
+        const uint32_t pv = parent_written ? reinterpret_cast<const uint32_t *>(a.src[r])[parent] : 0u;
+        const uint32_t out = search1_block<SPLIT, !SPLIT && PRE_LDS>(a, r, cx, cy, pv, live, sub, lane, pre_lds);
+        if (sub == 0 && live) {
+            const int cell = (cy >> 3) * a.net_width + (cx >> 3);
+            reinterpret_cast<uint32_t *>(a.dst[r])[cell] = out;
+        }
     }
 }
 
@@ -582,6 +589,13 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { search1_body<SPLIT>(b.item[blockIdx.z]); }
 __global__ __launch_bounds__(256) void k_search1_pl(Search1Args a) { search1_body<false, true>(a); }
 __global__ __launch_bounds__(256) void k_search1_pl_b(BatchOf<Search1Args> b) { search1_body<false, true>(b.item[blockIdx.z]); }
+__global__ __launch_bounds__(256) void k_search1_plr_b(BatchOf<Search1Args> b) { search1_body<false, true, true>(b.item[blockIdx.z]); }
+__global__ __launch_bounds__(256, 8) void k_search1_plr8_b(BatchOf<Search1Args> b) { search1_body<false, true, true>(b.item[blockIdx.z]); }
+// VP8HIP_S1_REF_LOOP=0: a workgroup per reference in batches too (same-box A/B runs)
+static bool search1_ref_loop() {
+    static const bool on = [] { const char *v = getenv("VP8HIP_S1_REF_LOOP"); return !(v && v[0] == '0'); }();
+    return on;
+}
 // VP8HIP_S1_PRE_LDS=0: the loop form as it was (every lane makes the current block's share itself); same-box A/B runs
 static bool search1_pre_lds() {
     static const bool on = [] { const char *v = getenv("VP8HIP_S1_PRE_LDS"); return !(v && v[0] == '0'); }();
@@ -711,6 +725,11 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
     if (nblk <= 0 || maxrefs == 0 || search1_skip()) return;
     if (search1_split((size_t)nblk * totrefs, false))
         VP8_LAUNCH(k_search1_b<true>, dim3((nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
+    else if (search1_pre_lds() && search1_ref_loop()) {
+        static const bool eight = [] { const char *v = getenv("VP8HIP_S1_REF_LOOP"); return v && v[0] == '8'; }();
+        if (eight) VP8_LAUNCH(k_search1_plr8_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, 1, n), dim3(256), 0, s, b);
+        else VP8_LAUNCH(k_search1_plr_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, 1, n), dim3(256), 0, s, b);
+    }
     else if (search1_pre_lds())
         VP8_LAUNCH(k_search1_pl_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
     else
