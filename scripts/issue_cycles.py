@@ -54,7 +54,7 @@ def cost_of(mn: str, operands: str):
     return C_SLOW, "slow", ""
 
 
-LOOP_TRIPS = {"k_search1<loop>": 4, "k_search1_pl": 4, "k_search1_pl_b": 4}    # kernel name -> trip count of its one backward branch (the four 4x4 sub-blocks)
+LOOP_TRIPS = {"k_search1<loop>": 4, "k_search1_pl": 4, "k_search1_pl_b": 4}      # (k_search1_plr_b has two nested loops -- references x sub-blocks --: priced through k_search1_pl)    # kernel name -> trip count of its one backward branch (the four 4x4 sub-blocks)
 
 
 def short_name(mangled: str) -> str:

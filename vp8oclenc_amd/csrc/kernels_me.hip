@@ -590,7 +590,6 @@ __global__ __launch_bounds__(256) void k_search1_b(BatchOf<Search1Args> b) { sea
 __global__ __launch_bounds__(256) void k_search1_pl(Search1Args a) { search1_body<false, true>(a); }
 __global__ __launch_bounds__(256) void k_search1_pl_b(BatchOf<Search1Args> b) { search1_body<false, true>(b.item[blockIdx.z]); }
 __global__ __launch_bounds__(256) void k_search1_plr_b(BatchOf<Search1Args> b) { search1_body<false, true, true>(b.item[blockIdx.z]); }
-__global__ __launch_bounds__(256, 8) void k_search1_plr8_b(BatchOf<Search1Args> b) { search1_body<false, true, true>(b.item[blockIdx.z]); }
 // VP8HIP_S1_REF_LOOP=0: a workgroup per reference in batches too (same-box A/B runs)
 static bool search1_ref_loop() {
     static const bool on = [] { const char *v = getenv("VP8HIP_S1_REF_LOOP"); return !(v && v[0] == '0'); }();
@@ -725,11 +724,8 @@ void launch_search1_batch(hipStream_t s, const Frame *const *cur, const RefSet *
     if (nblk <= 0 || maxrefs == 0 || search1_skip()) return;
     if (search1_split((size_t)nblk * totrefs, false))
         VP8_LAUNCH(k_search1_b<true>, dim3((nblk + S1Map<true>::BLOCKS_PER_WG - 1) / S1Map<true>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
-    else if (search1_pre_lds() && search1_ref_loop()) {
-        static const bool eight = [] { const char *v = getenv("VP8HIP_S1_REF_LOOP"); return v && v[0] == '8'; }();
-        if (eight) VP8_LAUNCH(k_search1_plr8_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, 1, n), dim3(256), 0, s, b);
-        else VP8_LAUNCH(k_search1_plr_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, 1, n), dim3(256), 0, s, b);
-    }
+    else if (search1_pre_lds() && search1_ref_loop())     // (70 registers, seven waves per SIMD; held to 64 it spills six and is no faster: 73.4-73.6 either way)
+        VP8_LAUNCH(k_search1_plr_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, 1, n), dim3(256), 0, s, b);
     else if (search1_pre_lds())
         VP8_LAUNCH(k_search1_pl_b, dim3((nblk + S1Map<false>::BLOCKS_PER_WG - 1) / S1Map<false>::BLOCKS_PER_WG, maxrefs, n), dim3(256), 0, s, b);
     else
