@@ -244,15 +244,17 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     if (SPREAD) {
         int *q3 = &s_pre[g][64];          // [candidate]: the cost of its fourth 4x4 block, made by another lane (the H array's bytes behind the pre table)
         const bool helper = lane >= 26;
-        const int hb = (lane - 26) * 3;
-        // one task: the metric of 4x4 block sb = (m * 2 + n) of candidate `cand` of block slot `slot`
-        auto task = [&](int slot, int cand, int poff /* dwords: 8 n + m */, int preoff /* ints: 16 sb */) {
-            const uint32_t *src = (cand < 25 ? &s_V[slot][cand * V_STRIDE] : &s_cz[slot][16]) + poff;
+        // (branch-free: a lane's own candidate or, for the idle lanes, candidate hb + j; the idle lanes' costs go to q3, everybody else's
+        // store lands in the table's unused word 31)
+        const uint32_t *own = k < 25 ? &s_V[g][k * V_STRIDE] : &s_cz[g][16];
+        const uint32_t *hsrc = &s_V[g][(lane - 26) * 3 * V_STRIDE + 9];     // idle lanes: candidate 3 (lane - 26) + j, 4x4 block 3 (n = m = 1)
+        int *hdst = &q3[(lane - 26) * 3];
+        auto metric = [&](const uint32_t *src, const int *pre16) {
             int pre[16];
             uint32_t pp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int4 v = *reinterpret_cast<const int4 *>(&s_pre[slot][preoff + 4 * j]);
+                const int4 v = *reinterpret_cast<const int4 *>(pre16 + 4 * j);
                 pre[4 * j] = v.x; pre[4 * j + 1] = v.y; pre[4 * j + 2] = v.z; pre[4 * j + 3] = v.w;
                 pp[j] = src[2 * j];
             }
@@ -260,18 +262,17 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
         };
 #pragma unroll
         for (int j = 0; j < 3; ++j) {       // rounds 0..2: a candidate's own lane its 4x4 blocks 0..2, the idle lanes block 3 of candidates 0..17
-            const int cand = helper ? hb + j : k;
-            const int c = task(g, cand, helper ? 8 * 1 + 1 : 8 * (j & 1) + (j >> 1), helper ? 48 : 16 * j);
-            if (helper) q3[cand] = c;
-            else diff += c;
+            const int c = metric(helper ? hsrc + j * V_STRIDE : own + (8 * (j & 1) + (j >> 1)), &s_pre[g][helper ? 48 : 16 * j]);
+            *(helper ? hdst + j : &q3[31]) = c;
+            diff += helper ? 0 : c;
         }
         __syncthreads();                    // every wave's V / pre / zero-MV arrays (and the idle lanes' costs) are in LDS
         if ((threadIdx.x >> 6) == 0) {      // wave 0: block 3 of candidates 18..25 of all eight block slots
             const int slot = wl >> 3, cand = 18 + (wl & 7);
-            s_pre[slot][64 + cand] = task(slot, cand, 8 * 1 + 1, 48);
+            s_pre[slot][64 + cand] = metric((cand < 25 ? &s_V[slot][cand * V_STRIDE] : &s_cz[slot][16]) + 9, &s_pre[slot][48]);
         }
         __syncthreads();
-        if (k < 26) diff += q3[k];
+        diff += q3[k < 26 ? k : 31];
     } else {
     uint32_t P[8][2];
     {
