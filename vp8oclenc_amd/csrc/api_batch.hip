@@ -230,23 +230,10 @@ static int batch_set_current(vp8hip_batch *b, const int *active, const void *con
     const Frame *f[MAX_BATCH];
     const void *py[MAX_BATCH], *pu[MAX_BATCH], *pv[MAX_BATCH];
     int n = 0;
-    // Frames that are already in device memory are not packed here: the pack rides in the pyramid launch that vp8hip_batch_inter_transform makes
-    // for the same frame (k_pyramid takes the new frame's samples from the tight source; flush_pack for whoever needs the surface earlier).
-    // With the part full a launch of the pack's own costs its place in the batch's queue, not its 11 us.  VP8HIP_BATCH_PACK_FUSED=0: as it was.
-    static const bool fuse_env = [] { const char *e = getenv("VP8HIP_BATCH_PACK_FUSED"); return !(e && e[0] == '0'); }();
-    bool fuse = fuse_env && !host && !b->prep;
-    for (int i = 0; i < b->n && fuse; ++i)
-        if (!(active && !active[i]) && !pyramid_can_pack(y[i], c0->src_w ? c0->src_w : c0->W)) fuse = false;
     for (int i = 0; i < b->n; ++i) {
         if (active && !active[i]) continue;
-        flush_pack(b->c[i]);      // (the frame that is being replaced, never consumed: its surface is the next frame's "previous frame")
         flush_scan(b->c[i]);      // (a parameter scan of the frame that is being replaced, asked for and never used: on that frame, now)
         next_current(b->c[i]);
-        if (fuse) {
-            b->c[i]->pack_req = PackSource{y[i], u[i], v[i], c0->src_w, c0->src_h};
-            b->c[i]->pack_deferred = true;
-            continue;
-        }
         f[n] = &b->c[i]->cur;
         py[n] = y[i]; pu[n] = u[i]; pv[n] = v[i];
         ++n;
@@ -351,9 +338,6 @@ int vp8hip_batch_auto_segments(vp8hip_batch *b, const int *active, const int *is
     // The scan rides in k_search2's launch of the same frame (vp8hip_batch_inter_transform, next; kernels_s2.hip says why): with the part
     // full a launch of its own holds the batch's stream for half a millisecond where its work is 15 us (VP8HIP_BATCH_SCAN_LAUNCH=1: as it was)
     static const bool own_launch = [] { const char *v = getenv("VP8HIP_BATCH_SCAN_LAUNCH"); return v && v[0] == '1'; }();
-    if (n && (b->prep || own_launch))       // the scan is launched right here, on the packed surface: a pack still waiting for the pyramid launch goes first
-        for (int i = 0; i < b->n; ++i)
-            if (!(active && !active[i])) flush_pack(b->c[i]);
     if (n && !b->prep && !own_launch) {
         int k = 0;
         for (int i = 0; i < b->n; ++i) {
@@ -380,8 +364,6 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     RefSet refs[MAX_BATCH];
     const Frame *cur[MAX_BATCH], *recon[MAX_BATCH], *pyr[2 * MAX_BATCH], *pyr_cur[MAX_BATCH];
     const ScanRequest *scans[MAX_BATCH] = {};   // the members' parameter scans still waiting for a launch to ride in (vp8hip_batch_auto_segments)
-    const PackSource *packs[2 * MAX_BATCH] = {};   // ... and their new frames' packs (vp8hip_batch_set_current_device), by surface of the pyramid launch
-    vp8hip_ctx *pack_owner[2 * MAX_BATCH] = {};
     int npyr_cur = 0;
     const NetSet *nets[MAX_BATCH];
     const MBOut *outs[MAX_BATCH];
@@ -398,31 +380,19 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
         if (active && !active[i]) continue;
         vp8hip_ctx *c = b->c[i];
         const int rc = inter_begin(c, prev_is_golden[i], prev_is_altref[i], use_golden[i], use_altref[i]);
-        if (rc) {   // (inter_check above has passed: not expected.)  The scans and packs collected so far have not been launched: they wait again
+        if (rc) {   // (inter_check above has passed: not expected.)  The scans collected so far have not been launched: they wait again
             for (int k = 0; k < n; ++k)
                 if (scans[k]) m[k]->scan_deferred = true;
-            for (int k = 0; k < npyr; ++k)
-                if (packs[k]) {
-                    pack_owner[k]->pack_deferred = true;
-                    pack_owner[k]->cur_pyramid_valid = false;
-                }
             return rc;
         }
         FrameSurf &last = c->frames[c->slot[0]];
-        if (c->pack_deferred && (c->cur_pyramid_valid || b->prep)) flush_pack(c);     // (not expected: a deferred pack belongs to a frame without a pyramid)
         if (!c->cur_pyramid_valid) {
             if (b->prep) pyr_cur[npyr_cur++] = &c->cur;   // the new frame's pyramid: head-of-frame work
-            else {
-                packs[npyr] = c->pack_deferred ? &c->pack_req : nullptr;      // the new frame's pack rides in this launch
-                pack_owner[npyr] = c;
-                c->pack_deferred = false;
-                pyr[npyr++] = &c->cur;
-            }
+            else pyr[npyr++] = &c->cur;
         }
         bool border_alone = false;
         if (!last.pyramid_valid) {
             if (!last.border_valid) pyr_border |= 1u << npyr;
-            packs[npyr] = nullptr;
             pyr[npyr++] = &last.f;
         } else if (!last.border_valid) {
             border_alone = true;
@@ -455,7 +425,7 @@ int vp8hip_batch_inter_transform(vp8hip_batch *b, const int *active, const int *
     batch_join_prep(b);   // the chain starts here: LAST's pyramid and replicated edges, the searches, the transform
     if (npyr) {
         Timed t(c0, VP8HIP_K_DOWNSAMPLE);
-        launch_pyramid_batch(s, pyr, npyr, pyr_border, packs);
+        launch_pyramid_batch(s, pyr, npyr, pyr_border);
     }
     const int net_width = c0->mbw * 2;
     // Fewer launches for the five levels of the hierarchical search?  Measured (profiles/README.md, round 6): NO.  k_search1_coarse_b (a workgroup

@@ -253,10 +253,7 @@ int join_lf(vp8hip_ctx *c, bool defer_ent) {
 // work enqueued on the batch's stream from here on sees what its head-of-frame stream has been given so far
 void batch_join_prep(vp8hip_batch *b) {
     if (!b) return;
-    for (int i = 0; i < b->n; ++i) {      // (a member's pack or parameter scan still waiting for a launch to ride in: ahead of whatever comes now)
-        flush_pack(b->c[i]);
-        flush_scan(b->c[i]);
-    }
+    for (int i = 0; i < b->n; ++i) flush_scan(b->c[i]);   // (a member's parameter scan still waiting for its search launch: ahead of whatever comes now)
     b->ent_fork_fresh = false;   // (every entry point that may enqueue passes here: the entropy stage's early fork point is stale)
     if (!b->prep || !b->prep_pending) return;
     b->prep_pending = false;
@@ -271,13 +268,6 @@ void side_stream_ordered(vp8hip_ctx *c) {
         __builtin_ia32_pause();
     }
     c->fork_by_verdict = false;
-}
-void flush_pack(vp8hip_ctx *c) {
-    if (!c->pack_deferred) return;
-    c->pack_deferred = false;
-    const PackSource &q = c->pack_req;
-    Timed t(c, VP8HIP_K_PACK);
-    launch_pack(c->stream, c->cur, q.y, q.u, q.v, q.sw, q.sh);
 }
 void flush_scan(vp8hip_ctx *c) {
     if (!c->scan_deferred) return;

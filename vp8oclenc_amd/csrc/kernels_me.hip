@@ -45,51 +45,6 @@ void launch_border(hipStream_t s, const Frame &f) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch.  A thread copies `per` units of 8 bytes,
-// 256 units apart (a workgroup = per x 2 KB): with one unit per thread a 1080p frame is 1530 workgroups of next to no work,
-// and under load it is the dispatch of workgroups, not the copying, that such a launch waits for (same box, headline with 1 / 8 /
-// 16 / 32 units per thread: 62.0 / 62.4 / 62.5 / 62.5 M MB/s).
-// ------------------------------------------------------------------------------------------------
-// The source may be smaller than the coded ("wrk") size -- 1920x1080 in, 1920x1088 coded: copy_with_padding, encIO.h:141-196,
-// happens here.  Rows below the source repeat its last row, samples to its right repeat the row's last sample (what the
-// reference does for Y and U and means for V: its V lines read and write U, :180-183, so V's right padding is never
-// written -- which bites only when the width is not a multiple of 16, none of BASELINE's configs; there this is the
-// intended result, not the reference's undefined one; tests/test_padding.py shows both).  sw, sh: luma size of the source; ssy, ssc: its row strides.
-struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; int sw, sh, ssy, ssc; };
-__device__ __forceinline__ void pack_body(const PackItem &a, int per, int blk) {
-    const Plane &py = a.py, &pu = a.pu, &pv = a.pv;
-    const uint8_t *sy = a.sy, *su = a.su, *sv = a.sv;
-    const int ny = (py.w >> 3) * py.h, nc = (pu.w >> 3) * pu.h;
-    for (int k = 0; k < per; ++k) {
-        int i = (blk * per + k) * 256 + (int)threadIdx.x;
-        const Plane *pl = &py;
-        const uint8_t *src = sy;
-        int sw = a.sw, sh = a.sh, ss = a.ssy;
-        if (i >= ny) {
-            i -= ny;
-            pl = &pu;
-            src = su;
-            sw >>= 1; sh >>= 1; ss = a.ssc;
-            if (i >= nc) { i -= nc; pl = &pv; src = sv; }
-            if (i >= nc) return;
-        }
-        const int upr = pl->w >> 3;     // 8-byte units per row
-        const int y = i / upr, x = (i % upr) * 8;
-        const uint8_t *row = src + (size_t)(y < sh ? y : sh - 1) * ss;
-        uint2 v;
-        if (x + 8 <= sw && ((ss | (int)(reinterpret_cast<uintptr_t>(src) & 7)) & 7) == 0) {
-            v = *reinterpret_cast<const uint2 *>(row + x);
-        } else {          // the unit hangs over the source's right edge, or the source rows are not 8-byte aligned
-            uint32_t w[2] = {0, 0};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j >> 2] |= (uint32_t)row[x + j < sw ? x + j : sw - 1] << (8 * (j & 3));
-            v = make_uint2(w[0], w[1]);
-        }
-        *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // downsample_x2, GPU_kernels.cl:429-451: dst = (a+b+c+d+2)/4 of each 2x2.
 // The whole pyramid in one launch (replaces 4 x downsample_x2 per surface, inter_part.h:11-33).
 // A workgroup takes a 64x64 tile of the full-resolution plane and produces the 32x32, 16x16, 8x8 and
@@ -99,13 +54,7 @@ __device__ __forceinline__ void pack_body(const PackItem &a, int per, int blk) {
 // A surface that has just come out of the loop filter also needs its replicated edges before it serves as a reference; the
 // pyramid reads the interior only, so the two do not depend on each other and share the launch (bit z of border_mask: the rows
 // of workgroups behind the tiles do surface z's edges, a wave per row of a plane) -- one link less in every frame's chain.
-// A NEW frame's pack (copy_with_padding, above) rides in the same launch: a surface with a source takes its full-resolution samples from the
-// tight source planes instead of from itself, writes them into the padded luma plane as it goes, and rows of workgroups behind the tiles
-// pack the chroma planes -- one read of the source, one launch less in every step of a batch (the part is full: a launch of the pack's own
-// waits for its place in the queue, not for its work).
-struct PyrSource { const uint8_t *y, *u, *v; int sw, sh; };     // y == nullptr: none
-struct PyrArgs { Frame f[2 * MAX_BATCH]; uint32_t border_mask; PyrSource src[2 * MAX_BATCH]; };   // blockIdx.z picks the surface: one or two of a context, or those of a batch
-constexpr int PYR_PACK_PER = 16;      // 8-byte units per thread of a chroma-pack workgroup
+struct PyrArgs { Frame f[2 * MAX_BATCH]; uint32_t border_mask; };   // blockIdx.z picks the surface: one or two of a context, or those of a batch
 static int border_jobs(const Frame &f) { return (f.Y[0].h + 2 * EXT) + 2 * (f.U.h + 2 * EXT); }
 
 __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
@@ -120,35 +69,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     // consecutive tiles (xcd_band, vp8hip_dev.h): the two halves of a line meet in ONE L2.
     const int tile = xcd_band((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, tiles_y * (int)gridDim.x);
     const int bx = tile % (int)gridDim.x, by = tile / (int)gridDim.x;
-    const PyrSource &ps = a.src[blockIdx.z];
     if ((int)blockIdx.y >= tiles_y) {
-        if (ps.y) {      // the new frame's chroma planes (pack_body's arithmetic; the planes picked by value, not through a pointer into a struct:
-                         // that would send the argument block to scratch memory)
-            const int blk = ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x;
-            const int csw = ps.sw >> 1, csh = ps.sh >> 1, upr = f.U.w >> 3, nc = upr * f.U.h;
-            for (int k = 0; k < PYR_PACK_PER; ++k) {
-                int i = (blk * PYR_PACK_PER + k) * 256 + t;
-                if (i >= 2 * nc) return;
-                const bool second = i >= nc;
-                i = second ? i - nc : i;
-                const uint8_t *src = second ? ps.v : ps.u;
-                uint8_t *dstp = second ? f.V.p : f.U.p;
-                const int dstride = second ? f.V.stride : f.U.stride;
-                const int y = i / upr, x = (i - y * upr) * 8;
-                const uint8_t *row = src + (size_t)(y < csh ? y : csh - 1) * csw;
-                uint2 v;
-                if (x + 8 <= csw && ((csw | (int)(reinterpret_cast<uintptr_t>(src) & 7)) & 7) == 0) {
-                    v = *reinterpret_cast<const uint2 *>(row + x);
-                } else {
-                    uint32_t w[2] = {0, 0};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) w[j >> 2] |= (uint32_t)row[x + j < csw ? x + j : csw - 1] << (8 * (j & 3));
-                    v = make_uint2(w[0], w[1]);
-                }
-                *reinterpret_cast<uint2 *>(dstp + (ptrdiff_t)y * dstride + x) = v;
-            }
-            return;
-        }
         if (!((a.border_mask >> blockIdx.z) & 1)) return;
         int job = (((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x) * 4 + (t >> 6);
         const int ny = P0.h + 2 * EXT, nc = f.U.h + 2 * EXT;
@@ -160,24 +81,9 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     // 4x4 source pixels -> 2x2 of level 1 -> 1 of level 2
     const int sx = imin(bx * 64 + 4 * tx, P0.w - 4), sy0 = by * 64 + 4 * ty;
     uint32_t r[4];
-    if (ps.y) {
-        // from the source (rows below it repeat its last row, samples to its right its row's last sample: encIO.h:141-196) into the padded plane
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint8_t *row = ps.y + (size_t)imin(sy0 + k, ps.sh - 1) * ps.sw;
-            if (sx + 4 <= ps.sw) r[k] = *reinterpret_cast<const uint32_t *>(row + sx);      // (the launcher fuses only sources whose rows are 4-byte aligned)
-            else {
-                r[k] = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[k] |= (uint32_t)row[imin(sx + j, ps.sw - 1)] << (8 * j);
-            }
-            if (sy0 + k < P0.h) *reinterpret_cast<uint32_t *>(P0.p + (ptrdiff_t)(sy0 + k) * P0.stride + sx) = r[k];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            r[k] = *reinterpret_cast<const uint32_t *>(P0.p + (ptrdiff_t)imin(sy0 + k, P0.h - 1) * P0.stride + sx);
-    }
+    for (int k = 0; k < 4; ++k)
+        r[k] = *reinterpret_cast<const uint32_t *>(P0.p + (ptrdiff_t)imin(sy0 + k, P0.h - 1) * P0.stride + sx);
     int l1[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -217,13 +123,9 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     }
 }
 
-static dim3 pyramid_grid(const Frame &f, int nframes, uint32_t border_mask, bool packing = false) {
+static dim3 pyramid_grid(const Frame &f, int nframes, uint32_t border_mask) {
     const int gx = (f.Y[0].w + 63) / 64, gy = (f.Y[0].h + 63) / 64;
-    int extra = border_mask ? ((border_jobs(f) + 3) / 4 + gx - 1) / gx : 0;
-    if (packing) {
-        const int units = 2 * ((f.U.w >> 3) * f.U.h), wgs = (units + 256 * PYR_PACK_PER - 1) / (256 * PYR_PACK_PER), rows = (wgs + gx - 1) / gx;
-        extra = rows > extra ? rows : extra;
-    }
+    const int extra = border_mask ? ((border_jobs(f) + 3) / 4 + gx - 1) / gx : 0;
     return dim3(gx, gy + extra, nframes);
 }
 void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t border_mask) {
@@ -231,27 +133,62 @@ void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t bord
     p.f[0] = *a;
     p.f[1] = b ? *b : *a;
     p.border_mask = border_mask;
-    p.src[0] = p.src[1] = PyrSource{nullptr, nullptr, nullptr, 0, 0};
     VP8_LAUNCH(k_pyramid, pyramid_grid(*a, b ? 2 : 1, border_mask), dim3(256), 0, s, p);
 }
-// may a new frame's pack ride in the pyramid launch?  (the luma path loads dwords from the tight source rows)
-bool pyramid_can_pack(const void *y, int sw) { return (sw & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0; }
-void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask, const PackSource *const *pack) {
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask) {
     if (nframes <= 0) return;
     PyrArgs p;
-    bool packing = false;
-    for (int i = 0; i < nframes; ++i) {
-        p.f[i] = *f[i];
-        const PackSource *q = pack ? pack[i] : nullptr;
-        p.src[i] = q ? PyrSource{(const uint8_t *)q->y, (const uint8_t *)q->u, (const uint8_t *)q->v, q->sw > 0 ? q->sw : f[i]->Y[0].w, q->sw > 0 ? q->sh : f[i]->Y[0].h}
-                     : PyrSource{nullptr, nullptr, nullptr, 0, 0};
-        packing |= q != nullptr;
-    }
+    for (int i = 0; i < nframes; ++i) p.f[i] = *f[i];
     p.border_mask = border_mask;
-    VP8_LAUNCH(k_pyramid, pyramid_grid(*f[0], nframes, border_mask, packing), dim3(256), 0, s, p);
+    VP8_LAUNCH(k_pyramid, pyramid_grid(*f[0], nframes, border_mask), dim3(256), 0, s, p);
 }
 
-__global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b, int per) { pack_body(b.item[blockIdx.z], per, (int)blockIdx.x); }
+// ------------------------------------------------------------------------------------------------
+// Tight HBM-resident Y,U,V planes -> the padded surfaces of a frame, one launch.  A thread copies `per` units of 8 bytes,
+// 256 units apart (a workgroup = per x 2 KB): with one unit per thread a 1080p frame is 1530 workgroups of next to no work,
+// and under load it is the dispatch of workgroups, not the copying, that such a launch waits for (same box, headline with 1 / 8 /
+// 16 / 32 units per thread: 62.0 / 62.4 / 62.5 / 62.5 M MB/s).
+// ------------------------------------------------------------------------------------------------
+// The source may be smaller than the coded ("wrk") size -- 1920x1080 in, 1920x1088 coded: copy_with_padding, encIO.h:141-196,
+// happens here.  Rows below the source repeat its last row, samples to its right repeat the row's last sample (what the
+// reference does for Y and U and means for V: its V lines read and write U, :180-183, so V's right padding is never
+// written -- which bites only when the width is not a multiple of 16, none of BASELINE's configs; there this is the
+// intended result, not the reference's undefined one; tests/test_padding.py shows both).  sw, sh: luma size of the source; ssy, ssc: its row strides.
+struct PackItem { Plane py, pu, pv; const uint8_t *sy, *su, *sv; int sw, sh, ssy, ssc; };
+__device__ __forceinline__ void pack_body(const PackItem &a, int per) {
+    const Plane &py = a.py, &pu = a.pu, &pv = a.pv;
+    const uint8_t *sy = a.sy, *su = a.su, *sv = a.sv;
+    const int ny = (py.w >> 3) * py.h, nc = (pu.w >> 3) * pu.h;
+    for (int k = 0; k < per; ++k) {
+        int i = ((int)blockIdx.x * per + k) * 256 + (int)threadIdx.x;
+        const Plane *pl = &py;
+        const uint8_t *src = sy;
+        int sw = a.sw, sh = a.sh, ss = a.ssy;
+        if (i >= ny) {
+            i -= ny;
+            pl = &pu;
+            src = su;
+            sw >>= 1; sh >>= 1; ss = a.ssc;
+            if (i >= nc) { i -= nc; pl = &pv; src = sv; }
+            if (i >= nc) return;
+        }
+        const int upr = pl->w >> 3;     // 8-byte units per row
+        const int y = i / upr, x = (i % upr) * 8;
+        const uint8_t *row = src + (size_t)(y < sh ? y : sh - 1) * ss;
+        uint2 v;
+        if (x + 8 <= sw && ((ss | (int)(reinterpret_cast<uintptr_t>(src) & 7)) & 7) == 0) {
+            v = *reinterpret_cast<const uint2 *>(row + x);
+        } else {          // the unit hangs over the source's right edge, or the source rows are not 8-byte aligned
+            uint32_t w[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j >> 2] |= (uint32_t)row[x + j < sw ? x + j : sw - 1] << (8 * (j & 3));
+            v = make_uint2(w[0], w[1]);
+        }
+        *reinterpret_cast<uint2 *>(pl->p + (ptrdiff_t)y * pl->stride + x) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_b(BatchOf<PackItem> b, int per) { pack_body(b.item[blockIdx.z], per); }
 static int pack_units_per_thread() {
     static const int per = [] { const char *e = getenv("VP8HIP_PACK_UNITS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     return per;

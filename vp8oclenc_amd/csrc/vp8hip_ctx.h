@@ -131,10 +131,6 @@ struct vp8hip_ctx {
     // (launch_search2_batch); whoever needs the segment data earlier launches it on its own first (flush_scan).
     bool scan_deferred = false;
     vp8::ScanRequest scan_req{};
-    // ... and so does the new frame's PACK (vp8hip_batch_set_current_device): it rides in the pyramid launch of vp8hip_batch_inter_transform
-    // (launch_pyramid_batch); whoever needs the packed surface earlier -- a key frame, a scan on its own, a download -- packs first (flush_pack)
-    bool pack_deferred = false;
-    vp8::PackSource pack_req{};
     bool lf_overlap = false, lf_pending = false;
     bool fork_by_verdict = false;      // the pending filter's launch has no fork event in front of it: see side_stream_ordered()
     bool fork_by_verdict_at_launch = false;   // ... as it was launched (fork_by_verdict is cleared once the ordering is established)
@@ -297,7 +293,6 @@ int join_lf_wait(vp8hip_ctx *c, hipStream_t side);
 bool side_sources_done(vp8hip_ctx *c);
 int join_lf(vp8hip_ctx *c, bool defer_ent = false);
 void flush_scan(vp8hip_ctx *c);
-void flush_pack(vp8hip_ctx *c);
 void batch_join_prep(vp8hip_batch *b);
 void side_stream_ordered(vp8hip_ctx *c);
 int check_device_timeout(vp8hip_ctx *c);
@@ -335,7 +330,7 @@ int prof_collect(vp8hip_ctx *c);
 // the proof: its sequence number arrives in host memory from INSIDE that launch, and a launch starts when everything before it on
 // its stream has completed.  So no event is recorded then, and the first entry point that would enqueue on the side stream makes
 // sure the number is there (the native frame loop has taken the verdict by then anyway: nothing waits).
-#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); side_stream_ordered(c); flush_pack(c); flush_scan(c); } } while (0)
+#define USE_DEVICE(c) do { if (c) { (void)hipSetDevice((c)->device); batch_join_prep((c)->batch); side_stream_ordered(c); flush_scan(c); } } while (0)
 #define USE_DEVICE_ONLY(c) do { if (c) (void)hipSetDevice((c)->device); } while (0)
 #define JOIN_LF(c) do { if (c) { const int jr_ = join_lf(c); if (jr_) return jr_; } } while (0)
 

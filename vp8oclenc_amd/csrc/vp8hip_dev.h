@@ -132,10 +132,7 @@ void launch_pyramid(hipStream_t s, const Frame *a, const Frame *b, uint32_t bord
 // sw, sh: luma size of the source planes (0 = the coded size); ssy, ssc: their row strides (0 = tight)
 void launch_pack(hipStream_t s, const Frame &f, const void *y, const void *u, const void *v, int sw = 0, int sh = 0, int ssy = 0, int ssc = 0);
 // batched forms: n <= MAX_BATCH contexts (pyramid: nframes <= 2 * MAX_BATCH surfaces)
-// a new frame's tight source planes (sw, sh: their luma size, 0 = the coded size) whose pack rides in the pyramid launch
-struct PackSource { const void *y, *u, *v; int sw, sh; };
-bool pyramid_can_pack(const void *y, int sw);
-void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask = 0, const PackSource *const *pack = nullptr);
+void launch_pyramid_batch(hipStream_t s, const Frame *const *f, int nframes, uint32_t border_mask = 0);
 // launch_auto_segments' work (same arguments) for a launch that lets it ride along (launch_search2_batch)
 struct ScanRequest { uint32_t *partial, *stats; SegData *sd; int32_t *strength_out; int is_key; int32_t refqi[4]; int qi_min; };
 void launch_pack_batch(hipStream_t s, const Frame *const *f, const void *const *y, const void *const *u, const void *const *v, int n,
