@@ -55,6 +55,8 @@ def main():
         table[key] = e
 
     per_level = collections.defaultdict(list)   # search1: level -> [(instr per ref, variant)]
+    plr = collections.defaultdict(list)         # search1, one workgroup for all references (batches): level -> [(instr per launch, launches)]
+    mix = collections.Counter()                 # launches of the run by number of references searched (from the level-4 launches)
     for (name, grid), vals in acc.items():
         v = sum(vals) / len(vals)
         if "k_search1" in name:
@@ -63,9 +65,15 @@ def main():
             for lvl in range(5):
                 nblk = ((W >> lvl) // 8) * ((H >> lvl) // 8)
                 wgs = (nblk + bpw - 1) // bpw
+                if "k_search1_plr" in name:      # one workgroup searches every enabled reference (grid y = 1): a launch's count covers the frame's references
+                    if wgs * 256 == grid:
+                        plr[lvl].append((v, len(vals)))
+                    continue
                 for refs in (1, 2, 3):
                     if wgs * 256 * refs == grid:
                         per_level[lvl].append((v / refs, variant, len(vals)))
+                        if lvl == 4:
+                            mix[refs] += len(vals)
         elif "k_search2" in name:
             nblk = W * H // 64
             for refs in (1, 2, 3):
@@ -78,6 +86,11 @@ def main():
                     if key in ("downsample", "border") and key in table and table[key]["fixed"] > v:
                         continue     # several grids (one or two frames' pyramids; borders of one plane set): keep the per-frame one
                     put(key, False, v, short)
+    avg_refs = sum(r * n for r, n in mix.items()) / max(sum(mix.values()), 1)
+    for lvl, items in plr.items():              # what batches launch: per reference = per launch / the run's references per frame
+        if avg_refs > 0:
+            per = sum(v * n for v, n in items) / sum(n for _, n in items) / avg_refs
+            per_level[lvl] = [(per, "k_search1_pl", 10 ** 9)]      # (priced with the one-reference kernel's cycles per instruction: the same instruction mix)
     for lvl, items in per_level.items():
         tot = sum(n for _, _, n in items)
         variant = max(items, key=lambda it: it[2])[1]
