@@ -267,7 +267,7 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
             diff += helper ? 0 : c;
         }
         __syncthreads();                    // every wave's V / pre / zero-MV arrays (and the idle lanes' costs) are in LDS
-        if ((threadIdx.x >> 6) == 0) {      // wave 0: block 3 of candidates 18..25 of all eight block slots
+        if ((int)(threadIdx.x >> 6) == (wg_x & 3)) {      // ONE wave (taking turns from workgroup to workgroup: the waves of a workgroup sit on different SIMDs): block 3 of candidates 18..25 of all eight block slots
             const int slot = wl >> 3, cand = 18 + (wl & 7);
             s_pre[slot][64 + cand] = metric((cand < 25 ? &s_V[slot][cand * V_STRIDE] : &s_cz[slot][16]) + 9, &s_pre[slot][48]);
         }
