@@ -252,3 +252,24 @@ def test_one_video_with_the_next_frame_prefetched_from_host_memory(W, H, src):
     for f in dev + host:
         for p in f:
             p.free()
+
+
+@pytest.mark.parametrize("env", [{"VP8HIP_BATCH_S1_COARSE": "1"}, {"VP8HIP_BATCH_S1_COARSE": "2"}, {"VP8HIP_BATCH_S1_COARSE": "3"},
+                                 {"VP8HIP_S1_PRE_LDS": "0"}, {"VP8HIP_S1_REF_LOOP": "0"}, {"VP8HIP_S2_SPREAD": "0"}],
+                         ids=lambda e: "-".join(f"{k[7:]}={v}" for k, v in e.items()))
+def test_the_switchable_forms_of_the_search_kernels_code_the_same_frames(env):
+    """The forms kept behind environment switches for same-box A/B runs (profiles/r06_*_ab.txt) -- the fused launches of a batch's hierarchical
+    search (measured slower, off by default) and the round-5 forms of the two search kernels (the current ones on by default) -- are read once
+    per process, so each runs in a process of its own: a small headline run whose every chunk must stand on the CPU oracle loop's table and
+    whose replayed chunk must equal the batched one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-side-legs", "--cpu-seconds", "0",
+                        "--gops-per-gpu", "12", "--batch", "6"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    oc = d["self_check"]["against_the_oracle"]
+    assert d["self_check"]["identical"] and oc["chunks_checked"] == 12 and oc["identical"] is True, d["self_check"]
