@@ -119,11 +119,14 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
     if rank == 0 and world == 1 and few:
         # BASELINE configs[2] as it is written: 300 frames, the reference's -g 150 -> two closed GOPs of 150 frames, both in flight,
         # each one video coded frame after frame from its key frame on; every frame counted (2 key frames among the 300)
-        el3, n3, k3, r3, _, mbs3 = literal_gops(api, args.width, args.height, 2, 150, local, nd)
+        # (the timed region is 0.06 s: three runs, the median quoted and all three shown -- one run on a box that was just given to us has read 9 % low)
+        runs3 = sorted((literal_gops(api, args.width, args.height, 2, 150, local, nd) for _ in range(3)), key=lambda r: r[0])
+        el3, n3, k3, r3, _, mbs3 = runs3[1]
         out["config3_literal"] = {"workload": f"{args.width}x{args.height}, 300 frames, -g 150: two closed GOPs of 150 frames in flight on one GPU, LAST+GOLDEN+ALTREF, "
                                               "check_SSIM in the loop, loop filter on the GPU, every frame counted",
                                   "value": round(mbs3 * n3 / el3, 1), "unit": "macroblocks/s", "fps": round(n3 / el3, 1), "ms_per_frame": round(el3 / n3 * 1e3, 4),
-                                  "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3}
+                                  "seconds": round(el3, 4), "frames": n3, "key_frames": k3, "frames_redone_as_key": r3,
+                                  "runs_fps": [round(r[1] / r[0], 1) for r in runs3], "quoted": "the median of three runs"}
         s1 = max(200, args.steps)
         ss = side_leg(api, args.width, args.height, 1, args.refs, args.ssim_target, s1, 20, local, nd=nd)
         ss["what"] = "ONE closed GOP coded frame after frame (what configs[2] literally is): bound by the latency of the frame's dependency chain"
