@@ -137,17 +137,23 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
         # (gop_shard.gather_frames); the time includes the gather.  All ranks take part (collective calls).
         from vp8oclenc_amd import gop_shard
         GOP5 = int(os.environ.get("VP8_BENCH_GOP5", "300"))
-        local_frames = {}
-        el5, n5, k5, r5, b5, mbs5 = literal_gops(api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
-                                                 frames_out=local_frames, frame_base=rank * GOP5, start=barrier)
-        # (literal_gops times its frame loop between synchronisations of its own; the clock goes on with the gather.  What is NOT in the
-        # time: making the synthetic frames and creating the encoder, which is init_all() in the reference)
-        t0 = time.perf_counter()
-        gathered = gop_shard.gather_frames(local_frames, GOP5 * world, dist)
-        barrier()
-        t5 = el5 + (time.perf_counter() - t0)
-        if dist is not None:
-            t5 = dist.max(t5)
+        # (a 0.11 s region: every rank runs it THREE times -- the same collective calls in the same order on all ranks -- and the median by the
+        # slowest rank's time is quoted, all three shown; the frames checked below are the last run's)
+        runs5 = []
+        for _ in range(3):
+            local_frames = {}
+            el5, n5, k5, r5, b5, mbs5 = literal_gops(api, args.width, args.height, 1, GOP5, local, nd, bitstream=True, seed=1 + rank,
+                                                     frames_out=local_frames, frame_base=rank * GOP5, start=barrier)
+            # (literal_gops times its frame loop between synchronisations of its own; the clock goes on with the gather.  What is NOT in the
+            # time: making the synthetic frames and creating the encoder, which is init_all() in the reference)
+            t0 = time.perf_counter()
+            gathered = gop_shard.gather_frames(local_frames, GOP5 * world, dist)
+            barrier()
+            t5 = el5 + (time.perf_counter() - t0)
+            if dist is not None:
+                t5 = dist.max(t5)
+            runs5.append((t5, el5))
+        t5, el5 = sorted(runs5)[1]
         # outside the time: THIS rank's 300 frames against the CPU oracle loop's (tests/golden/full_length/config5_rank<r>.json: CRC-32
         # and length of every frame, made by scripts/full_length_oracle.py --oracle from the same synthetic frames)
         import zlib
@@ -168,7 +174,8 @@ def few_stream_legs(args, api, dist, rank, world, local, nd, barrier, emit=None,
                             "finished VP8 frames gathered to rank 0 in frame order (vp8hip_group_gather_bytes: ncclSend / ncclRecv inside the library); the time includes the gather",
                 "value": round(mbs5 * GOP5 * world / t5, 1), "unit": "macroblocks/s", "fps": round(GOP5 * world / t5, 1), "seconds": round(t5, 4),
                 "frames": GOP5 * world, "key_frames": k5 * world, "bytes_gathered": int(sum(len(b) for b in gathered)),
-                "encode_seconds_rank0": round(el5, 4), "self_check_against_the_oracle": oracle5, "n_gpus": world, "rccl_ranks": None if dist is None else int(dist.count()),
+                "encode_seconds_rank0": round(el5, 4), "runs_fps": [round(GOP5 * world / r[0], 1) for r in runs5], "quoted": "the median of three runs",
+                "self_check_against_the_oracle": oracle5, "n_gpus": world, "rccl_ranks": None if dist is None else int(dist.count()),
                 "gpu_framework_in_process": "torch" if "torch" in sys.modules else "none"}
         del gathered, local_frames
         # one GOP split BY REFERENCE over up to three ranks: the searches of a frame on different GPUs, vector nets
