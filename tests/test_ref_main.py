@@ -64,6 +64,7 @@ def _y4m(path, W, H, frames, cut=None, seed=3):
     (1920, 1080, 4, None, ["-partitions", "8"]),
     (1920, 1080, 40, 23, ["-g", "16"]),                                                   # the metric's geometry: key frames at GOP boundaries, a cut, golden and altref periods
     (352, 288, 30, None, ["-g", "1"]),                                                    # every frame a key frame
+    (1920, 1080, 14, None, ["-g", "7", "-qmin", "40", "-qmax", "110", "-SSIM-target", "93", "-partitions", "2"]),   # the metric's geometry with the four-pass ladder and replaced macroblocks
 ])
 def test_the_references_main_writes_the_products_file(tmp_path, W, H, frames, cut, opts):
     if not (os.path.exists(BIN) and os.path.exists(BIN_HOST)):
