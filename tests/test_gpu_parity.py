@@ -399,7 +399,11 @@ def test_parameter_scans_on_device_match_host_mirror():
                 sd, red, sh = hip.get_segments()
                 assert (red, sh) == api.loopfilter_strength(y)
                 assert np.array_equal(sd, api.prepare_segments_data(is_key, ladder, qmin, red, sh).reshape(4, 11)), (W, H, k)
+            hip.chroma_change_async()                  # the two-halves form first (vp8hip_chroma_change_async / _result): the same two numbers
             ud, vd = hip.chroma_change()
+            assert hip.chroma_change_result() == (ud, vd), (W, H, k)
+            with pytest.raises(api.Vp8HipError):
+                hip.chroma_change_result()             # nothing pending any more: VP8HIP_ERR_STATE
             if prev is None:
                 assert (ud, vd) == (0, 0)
             else:

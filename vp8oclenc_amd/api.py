@@ -921,6 +921,15 @@ class Vp8Hip:
         self._chk(self.lib.vp8hip_chroma_change(self.h, C.byref(ud), C.byref(vd)), "chroma_change")
         return ud.value, vd.value
 
+    def chroma_change_async(self):
+        """the same scan enqueued behind the current frame's pack, nobody waiting (vp8hip_chroma_change_async); chroma_change_result() collects it"""
+        self._chk(self.lib.vp8hip_chroma_change_async(self.h), "chroma_change_async")
+
+    def chroma_change_result(self):
+        ud, vd = C.c_int32(), C.c_int32()
+        self._chk(self.lib.vp8hip_chroma_change_result(self.h, C.byref(ud), C.byref(vd)), "chroma_change_result")
+        return ud.value, vd.value
+
     def count_probs(self, num_partitions: int):
         """count_probs + num_div_denom (CPU_kernels.cl:536-778): (probs[1056], partition-0 denominators[1056])."""
         probs, denom = np.zeros(1056, np.uint32), np.zeros(1056, np.uint32)
