@@ -85,7 +85,7 @@ def main():
                 if short + "(" in name or name.endswith(short) or (short in name and "k_mbhdr" not in name):
                     if key in ("downsample", "border") and key in table and table[key]["fixed"] > v:
                         continue     # several grids (one or two frames' pyramids; borders of one plane set): keep the per-frame one
-                    put(key, False, v, short)
+                    put(key, False, v, "k_mb_p" if "k_mb_p" in name else short)     # (k_mb_p: three kinds of wave in a workgroup; priced with the static stream's average cycles per instruction)
     avg_refs = sum(r * n for r, n in mix.items()) / max(sum(mix.values()), 1)
     for lvl, items in plr.items():              # what batches launch: per reference = per launch / the run's references per frame
         if avg_refs > 0:

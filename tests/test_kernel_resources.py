@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vp8oclenc_amd", "csrc")
 HOT = {   # file -> {kernel name fragment: max VGPRs}
-    "kernels_mb.hip": {"k_mb_b": 128},
+    "kernels_mb.hip": {"k_mb_bE": 128, "k_mb_pE": 128, "k_mb_p_conformant": 128},     # both forms (VP8HIP_MB_PACKED): four waves per SIMD
     "kernels_s2.hip": {"k_search2ILb": 72, "k_search2_bILb": 72, "k_search2_bsILb": 72},      # seven waves per SIMD ... (both forms of the cost phase: SPREAD and lane = candidate)
     "kernels_me.hip": {"k_search1": 128, "k_search1_bILb0": 64, "k_search1_plE": 64, "k_search1_pl_b": 64, "k_search1_plr_b": 72, "k_search1_coarse": 64, "k_pyramid": 128, "k_pack_b": 64},   # the loop form: eight (a form with 7 % fewer instructions and 75 registers was no faster)
     "kernels_lf4.hip": {"k_loop_filter4": 128},

@@ -511,6 +511,303 @@ __device__ __forceinline__ void mb_body(const MBArgs &a, MBTile *s_t) {
     }
 }
 
+// ---- the same macroblock loop with every lane of the workgroup on a 4x4 block ---------------------------------------------------
+// The kernel is bound by what its waves ISSUE, and in the form above a wave issues the block phase (prediction, transforms,
+// quantisation, reconstruction: two thirds of its instructions) for 2 x 24 blocks on 64 lanes, and each of its three accumulation
+// chains (16 dependent steps of four additions) for 2 x 12 chains.  Here a workgroup of THREE waves takes eight macroblocks:
+//   waves 0, 1   the luma blocks of macroblocks 0-3 / 4-7 (16 lanes per macroblock = one DPP row: its sums are row reductions);
+//   wave 2       the chroma blocks of all eight (8 lanes per macroblock: U 0-3, V 0-3);
+// every lane owns a block, so eight macroblocks take three block phases where they took four.  A plane's SSIM terms are made by
+// the lanes of its blocks (the pixels they read are their own wave's), and the chains are dealt over the workgroup by LENGTH:
+// the 2 x 32 luma chains (64 terms: `variance' and `covariance' of 8 macroblocks x 4 components) are wave 0, the 2 x 64 chroma
+// chains (16 terms) waves 1 and 2 -- 24 chain steps of a wave per eight macroblocks where there were 128.  The three planes of a
+// macroblock now live in different waves: they meet in LDS (means, variances, the plane's metric, the chroma blocks' share of the
+// non-zero count) behind two workgroup barriers per pass, and the pass loop ends for the whole workgroup when a pass found no
+// macroblock below the target (a word in LDS the active macroblocks set before the first barrier).  A macroblock that has
+// left the loop is masked out of the block phase; its chains are summed again from the terms its last pass left (the same bits).
+// Same operations on the same values in the same order per macroblock: the outputs are the form above's, bit for bit.
+struct MBShare {
+    float M1[8][4], M2[8][4], D1[8][4], metric[8][4];   // [macroblock slot][plane]
+    int nzc[8];                                         // the chroma blocks' share of prepare_filter_mask's count
+    int any[2];                                         // [pass & 1]: a macroblock of the workgroup ran this pass
+};
+struct MBTileP { MBTile t; uint32_t skew[4]; };          // (a tile is 60 x 64 B: without the 16 bytes the chains of eight macroblocks read the same banks)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int quad_sum(int v) {         // over the four lanes of a quad, in every lane
+    v += dpp_i<0xb1>(v);                                 // quad_perm [1,0,3,2]
+    return v + dpp_i<0x4e>(v);                           // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ int half_row_sum(int v) { v = quad_sum(v); return v + dpp_i<0x141>(v); }   // eight lanes: + row_half_mirror
+__device__ __forceinline__ int row_sum(int v) { v = half_row_sum(v); return v + dpp_i<0x140>(v); }     // sixteen lanes: + row_mirror
+__device__ __forceinline__ float sum4_quad(float acc) {  // (((c0 + c1) + c2) + c3) of the quad's four components, in every lane
+    return __fadd_rn(__fadd_rn(__fadd_rn(dpp_f<0x00>(acc), dpp_f<0x55>(acc)), dpp_f<0xaa>(acc)), dpp_f<0xff>(acc));
+}
+template <int N4>
+__device__ __forceinline__ float chain_n(const float *p) {
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int q = 0; q < N4; q += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + q);
+        acc = q == 0 ? v.x : __fadd_rn(v.x, acc);
+        acc = __fadd_rn(v.y, acc);
+        acc = __fadd_rn(v.z, acc);
+        acc = __fadd_rn(v.w, acc);
+    }
+    return acc;
+}
+// wht_roundtrip_lane for a macroblock whose sixteen luma lanes are lanes base16 .. base16 + 15 of the wave
+__device__ __forceinline__ int wht_roundtrip_row(int x, int L, int base_bytes, int dc_q, int ac_q, const TDiv &ddc, const TDiv &dac, int &q) {
+    const int r = L >> 2, c = L & 3;
+    const int col = base_bytes + 4 * c, row = base_bytes + 4 * (L & 12);
+    auto gather_col = [&](int v, int i) { return had4(__builtin_amdgcn_ds_bpermute(col, v), __builtin_amdgcn_ds_bpermute(col + 16, v),
+                                                      __builtin_amdgcn_ds_bpermute(col + 32, v), __builtin_amdgcn_ds_bpermute(col + 48, v), i); };
+    auto gather_row = [&](int v, int i) { return had4(__builtin_amdgcn_ds_bpermute(row, v), __builtin_amdgcn_ds_bpermute(row + 4, v),
+                                                      __builtin_amdgcn_ds_bpermute(row + 8, v), __builtin_amdgcn_ds_bpermute(row + 12, v), i); };
+    int o = gather_row(gather_col(x, r), c);
+    o += (o > 0);
+    o >>= 1;
+    q = tdiv(o, L == 0 ? ddc : dac);
+    const int xq = __mul24(q, L == 0 ? dc_q : ac_q);
+    return (gather_col(gather_row(xq, c), r) + 3) >> 3;
+}
+
+template <bool CONFORMANT>
+__device__ __forceinline__ void mb_body_packed(const MBArgs &a, MBTileP *s_t, MBShare *s_x) {
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wl = threadIdx.x & 63;
+    const bool luma = w < 2;
+    const int g = luma ? w * 4 + (wl >> 4) : wl >> 3;          // the macroblock's slot in the workgroup
+    const int plane = luma ? 0 : 1 + ((wl >> 2) & 1);
+    const int bi = luma ? wl & 15 : wl & 3;                     // block index inside its plane
+    const int blkidx = luma ? bi : 12 + 4 * plane + bi;        // ... of macroblock_coeffs_t: 0-15 Y, 16-19 U, 20-23 V
+    const int mb_raw = xcd_band(blockIdx.x, gridDim.x) * 8 + g;
+    const bool live = mb_raw < a.mbs;
+    const int mb = live ? mb_raw : a.mbs - 1;
+    const int mbx = mb % a.mbw, mby = mb / a.mbw;
+    const int32_t *SD = a.sd->v;
+    const int bw = luma ? 4 : 2;
+    const int bx = bi % bw, by = bi / bw;
+    const int msz = luma ? 16 : 8;
+    const int posx = mbx * msz + bx * 4, posy = mby * msz + by * 4;
+    if (threadIdx.x == 0) s_x->any[0] = s_x->any[1] = 0;
+    // select_reference + pack_8x8_into_16x16, as in mb_body: every lane evaluates its macroblock's
+    const int b8w = a.mbw * 2;
+    const int cell0 = (mby * 2) * b8w + mbx * 2;
+    const int cidx[4] = {cell0, cell0 + 1, cell0 + b8w, cell0 + b8w + 1};
+    int diff1 = a.bdiff0[cidx[0]] + a.bdiff0[cidx[1]] + a.bdiff0[cidx[2]] + a.bdiff0[cidx[3]];
+    int diff2 = 0x7fffffff;
+    if (a.use_altref == 1)
+        diff2 = a.bdiff2[cidx[0]] + a.bdiff2[cidx[1]] + a.bdiff2[cidx[2]] + a.bdiff2[cidx[3]];
+    int ref = diff1 <= diff2 ? 0 : 2;
+    diff1 = diff1 <= diff2 ? diff1 : diff2;
+    diff2 = 0x7fffffff;
+    if (a.use_golden == 1)
+        diff2 = a.bdiff1[cidx[0]] + a.bdiff1[cidx[1]] + a.bdiff1[cidx[2]] + a.bdiff1[cidx[3]];
+    ref = diff1 <= diff2 ? ref : 1;
+    const uint32_t *vnet = reinterpret_cast<const uint32_t *>(ref == 0 ? a.vnet0 : (ref == 1 ? a.vnet1 : a.vnet2));
+    uint32_t mbv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mbv[k] = vnet[cidx[k]];
+    const int parts = (mbv[1] == mbv[0] && mbv[2] == mbv[0] && mbv[3] == mbv[0]) ? 0 : 1;
+    const bool head = luma && bi == 0;                          // the lane that stores its macroblock's outputs
+    if (head && live) {
+        a.o_ref[mb] = ref;
+        a.o_parts[mb] = parts;
+        *reinterpret_cast<uint4 *>(a.o_vec + 8 * mb) = make_uint4(mbv[0], mbv[1], mbv[2], mbv[3]);
+    }
+    uint8_t *const rpy = ref == 0 ? a.ref0.y : (ref == 1 ? a.ref1.y : a.ref2.y);
+    uint8_t *const rpu = ref == 0 ? a.ref0.u : (ref == 1 ? a.ref1.u : a.ref2.u);
+    uint8_t *const rpv = ref == 0 ? a.ref0.v : (ref == 1 ? a.ref1.v : a.ref2.v);
+    const int pstride = luma ? a.ystride : a.cstride, pw = luma ? a.yw : a.cw, ph = luma ? a.yh : a.ch;
+    const Plane cp{plane == 0 ? a.cur.y : (plane == 1 ? a.cur.u : a.cur.v), pstride, pw, ph};
+    const Plane rc{plane == 0 ? a.recon.y : (plane == 1 ? a.recon.u : a.recon.v), pstride, pw, ph};
+    const Plane rp{plane == 0 ? rpy : (plane == 1 ? rpu : rpv), pstride, pw, ph};
+    const int tile_off = plane == 0 ? 0 : (plane == 1 ? 256 : 320);
+    MBTile &T = s_t[g].t;
+
+    uint32_t predw[4];
+    {
+        const int quad = luma ? (by >> 1) * 2 + (bx >> 1) : by * 2 + bx;
+        const uint32_t vv = quad == 0 ? mbv[0] : (quad == 1 ? mbv[1] : (quad == 2 ? mbv[2] : mbv[3]));
+        const int vx = (int16_t)(vv & 0xffffu), vy = (int16_t)(vv >> 16);
+        const int gsh = luma ? 2 : 3, gm = luma ? 3 : 7;
+        const int fxp = posx * (gm + 1) + vx, fyp = posy * (gm + 1) + vy;
+        const int dx = (fxp & gm) * (luma ? 2 : 1), dy = (fyp & gm) * (luma ? 2 : 1);
+        const int ix = iclamp(fxp >> gsh, 2 - EXT, rp.w + EXT - 7), iy = iclamp(fyp >> gsh, 2 - EXT, rp.h + EXT - 7);
+        predict4x4<CONFORMANT>(rp, ix, iy, dx, dy, predw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t cw = *reinterpret_cast<const uint32_t *>(cp.p + (ptrdiff_t)(posy + r) * cp.stride + posx);
+            *reinterpret_cast<uint32_t *>(&T.cur[tile_off + (by * 4 + r) * msz + bx * 4]) = cw;
+        }
+    }
+    // ---- SSIM terms of the current frame, by the lanes of the plane: dwords bi + dstep * h of its 64 (16) ----
+    const uint32_t *cur32 = reinterpret_cast<const uint32_t *>(T.cur) + (tile_off >> 2);
+    const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(T.rec) + (tile_off >> 2);
+    const int dstep = luma ? 16 : 4, cs = luma ? 64 : 16;   // the plane's dwords per lane step; floats per float4 component of its chains
+    const float area = luma ? 256.0f : 64.0f;
+    float *fa = T.fa + tile_off + bi, *fb = T.fb + tile_off + bi;
+    auto plane_sum = [&](const uint32_t *t32) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) s = __builtin_amdgcn_sad_u8(t32[bi + dstep * h], 0u, s);
+        return luma ? row_sum((int)s) : quad_sum((int)s);
+    };
+    const float M1 = __fdiv_rn((float)plane_sum(cur32), area);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const uint32_t wd = cur32[bi + dstep * h];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __fsub_rn((float)byte_of(wd, k), M1);
+            fa[dstep * h + k * cs] = __fmul_rn(t, t);
+        }
+    }
+    if (bi == 0) s_x->M1[g][plane] = M1;
+    __syncthreads();
+    if (w == 0) {
+        if (wl < 32) {
+            const int m = wl >> 2, comp = wl & 3;
+            const float s = sum4_quad(chain_n<64>(s_t[m].t.fa + comp * 64));
+            if (comp == 0) s_x->D1[m][0] = __fdiv_rn(s, 256.0f);
+        }
+    } else if (w == 1) {
+        const int m = wl >> 3, p = 1 + ((wl >> 2) & 1), comp = wl & 3;
+        const float s = sum4_quad(chain_n<16>(s_t[m].t.fa + (p == 1 ? 256 : 320) + comp * 16));
+        if (comp == 0) s_x->D1[m][p] = __fdiv_rn(s, 64.0f);
+    }
+    __syncthreads();
+
+    float ssim = -2.0f;  // pack_8x8_into_16x16, :1352
+    int seg_final = a.o_seg[mb];
+    int nz_y = 0, nz_c = 0;    // prepare_filter_mask's count, luma and chroma blocks, from the last pass this macroblock ran
+    bool any_pass = false;
+    for (int seg = 3, round = 0; seg >= 0; --seg, ++round) {        // inter_part.h:329
+        const bool act = !(ssim > a.ssim_target);                   // dct4x4 gate, :1391
+        if (act) {
+            any_pass = true;
+            seg_final = seg;
+            const int i = SD[seg * SD_INTS + SD_Y_AC_I];
+            int dc_q, ac_q;
+            if (luma) {                              // :1394-1408
+                ac_q = k_ac_q[i];
+                dc_q = parts == 0 ? 1 : k_dc_q[qi(SD[SD_Y_DC_IDELTA] + i)];
+            } else {
+                dc_q = imin(k_dc_q[qi(SD[SD_UV_DC_IDELTA] + i)], 132);
+                ac_q = k_ac_q[qi(SD[SD_UV_AC_IDELTA] + i)];
+            }
+            int coef[16];
+            {
+                int res[16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t cw = *reinterpret_cast<const uint32_t *>(&T.cur[tile_off + (by * 4 + r) * msz + bx * 4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) res[4 * r + c] = byte_of(cw, c) - byte_of(predw[r], c);
+                }
+                fdct4x4(res, coef);
+                const TDiv ddc = tdiv_make(dc_q), dac = tdiv_make(ac_q);
+                coef[0] = tdiv(coef[0], ddc);        // truncating, :1478-1481
+#pragma unroll
+                for (int k = 1; k < 16; ++k) coef[k] = tdiv(coef[k], dac);
+            }
+            int nz_blk = 0;
+            if (luma && parts == 0) {                // wht4x4_iwht4x4, :1498-1543: the sixteen lanes of the macroblock's row
+                const int y2dc = k_dc_q[qi(SD[SD_Y2_DC_IDELTA] + i)] * 2;
+                const int y2ac = imax(31 * k_ac_q[qi(SD[SD_Y2_AC_IDELTA] + i)] / 20, 8);
+                int q24 = 0;
+                const int nd = wht_roundtrip_row((int16_t)coef[0], bi, (wl & 48) * 4, y2dc, y2ac, tdiv_make(y2dc), tdiv_make(y2ac), q24);
+                coef[0] = (int16_t)nd;               // stored as short, :1537
+                if (live) a.o_coeffs[((size_t)mb * 25 + 24) * 16 + inv_zigzag_rt(bi)] = (int16_t)q24;
+                nz_blk += iabs((int16_t)q24);
+            }
+            {                                        // idct4x4, :1545-1608
+                if (live) store_zigzag(a.o_coeffs + ((size_t)mb * 25 + blkidx) * 16, coef);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) nz_blk += iabs((int16_t)coef[k]);
+                if (!luma || parts != 0) nz_blk += iabs((int16_t)coef[0]);
+                int L[16];
+                L[0] = __mul24((int16_t)coef[0], dc_q);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) L[k] = __mul24((int16_t)coef[k], ac_q);
+                idct4x4(L);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uint32_t wd = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wd |= (uint32_t)sat8(L[4 * r + c] + byte_of(predw[r], c)) << (8 * c);
+                    *reinterpret_cast<uint32_t *>(&T.rec[tile_off + (by * 4 + r) * msz + bx * 4]) = wd;
+                    if (live) *reinterpret_cast<uint32_t *>(rc.p + (ptrdiff_t)(posy + r) * rc.stride + posx) = wd;
+                }
+            }
+            if (luma) nz_y = row_sum(nz_blk);
+            else {
+                const int n = half_row_sum(nz_blk);
+                if ((wl & 7) == 0) s_x->nzc[g] = n;
+            }
+            // count_SSIM_*: the plane's mean and its terms
+            const float M2 = __fdiv_rn((float)plane_sum(rec32), area);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const uint32_t wc = cur32[bi + dstep * h], wr = rec32[bi + dstep * h];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t1 = __fsub_rn((float)byte_of(wc, k), M1);
+                    const float t2 = __fsub_rn((float)byte_of(wr, k), M2);
+                    fa[dstep * h + k * cs] = __fmul_rn(t2, t2);
+                    fb[dstep * h + k * cs] = __fmul_rn(t1, t2);
+                }
+            }
+            if (bi == 0) {
+                s_x->M2[g][plane] = M2;
+                s_x->any[round & 1] = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_x->any[round & 1]) break;             // (the same word for every lane of the workgroup: they all leave, or none)
+        if (threadIdx.x == 0) s_x->any[(round + 1) & 1] = 0;
+        {   // the chains by length: wave 0 the luma chains of the eight macroblocks, waves 1 and 2 the chroma chains of four each;
+            // lanes 0-31 the squares (`variance'), 32-63 the products (`covariance')
+            const int comp = wl & 3;
+            const int m = w == 0 ? (wl >> 2) & 7 : (w - 1) * 4 + ((wl >> 3) & 3);
+            const int p = w == 0 ? 0 : 1 + ((wl >> 2) & 1);
+            const float *src = (wl < 32 ? s_t[m].t.fa : s_t[m].t.fb) + (p == 0 ? 0 : (p == 1 ? 256 : 320)) + comp * (w == 0 ? 64 : 16);
+            const float acc = w == 0 ? chain_n<64>(src) : chain_n<16>(src);
+            const float s = __fdiv_rn(sum4_quad(acc), w == 0 ? 256.0f : 64.0f);
+            const float C = __shfl_xor(s, 32, 64);
+            const float D = __fadd_rn(s_x->D1[m][p], s);
+            const float m1v = s_x->M1[m][p], m2v = s_x->M2[m][p];
+            const float k1 = 0.01f * 0.01f * 255 * 255, k2 = 0.03f * 0.03f * 255 * 255;
+            const float num = __fmul_rn(__fadd_rn(__fmul_rn(m1v, __fmul_rn(m2v, 2.0f)), k1), __fadd_rn(__fmul_rn(C, 2.0f), k2));
+            const float den = __fmul_rn(__fadd_rn(__fmul_rn(m1v, m1v), __fadd_rn(__fmul_rn(m2v, m2v), k1)), __fadd_rn(D, k2));
+            float metric = __fdiv_rn(num, den);
+            float dm = __fsub_rn(m1v, m2v);
+            dm = dm < 0 ? -dm : dm;
+            dm = dm > 4 ? __fmul_rn(0.02f, dm) : 0.0f;
+            metric = __fsub_rn(metric, dm);
+            if (wl < 32 && comp == 0) s_x->metric[m][p] = metric;
+        }
+        if (act && luma) nz_c = s_x->nzc[g];
+        __syncthreads();
+        const float4 mt = *reinterpret_cast<const float4 *>(s_x->metric[g]);
+        ssim = __fdiv_rn(__fadd_rn(__fadd_rn(mt.x, mt.y), mt.z), 3.0f);
+    }
+
+    // ---- results -------------------------------------------------------------------------------
+    if (head && live) {
+        if (any_pass) {
+            const int nz = nz_y + nz_c;
+            a.o_seg[mb] = seg_final;
+            a.o_nz[mb] = nz;
+            a.o_mask[mb] = (parts != 0 || nz > 0) ? -1 : 0;
+        }
+        a.o_ssim[mb] = ssim;
+        if (ssim < a.ssim_target) *a.o_flag = 1;
+    }
+}
+
 // One kernel for one context and for a batch (blockIdx.z = member; a single context is a batch of one).  The argument block
 // is read through the kernel-argument pointer: a by-value MBArgs whose members are picked by a per-lane index (the reference
 // of the macroblock) is copied to scratch memory by hipcc (296 B per lane, 21 -> 38 us per 1080p frame when it happened).
@@ -525,6 +822,22 @@ __global__ __launch_bounds__(256, 2) void k_mb_b(BatchOf<MBArgs> b) {
 __global__ __launch_bounds__(256, 2) void k_mb_b_conformant(BatchOf<MBArgs> b) {
     __shared__ __attribute__((aligned(16))) MBTile s_t[8];
     mb_body<true>(b.item[blockIdx.z], s_t);
+}
+
+// the packed form: 192 threads per eight macroblocks (VP8HIP_MB_PACKED=0: the form above, for same-box A/B runs)
+__global__ __launch_bounds__(192, 2) void k_mb_p(BatchOf<MBArgs> b) {
+    __shared__ __attribute__((aligned(16))) MBTileP s_t[8];
+    __shared__ __attribute__((aligned(16))) MBShare s_x;
+    mb_body_packed<false>(b.item[blockIdx.z], s_t, &s_x);
+}
+__global__ __launch_bounds__(192, 2) void k_mb_p_conformant(BatchOf<MBArgs> b) {
+    __shared__ __attribute__((aligned(16))) MBTileP s_t[8];
+    __shared__ __attribute__((aligned(16))) MBShare s_x;
+    mb_body_packed<true>(b.item[blockIdx.z], s_t, &s_x);
+}
+static bool mb_packed() {
+    static const bool on = [] { const char *v = getenv("VP8HIP_MB_PACKED"); return !(v && v[0] == '0'); }();
+    return on;
 }
 
 static MBArgs mb_args(const Frame &cur, const RefSet &refs, const NetSet &nets, const Frame &recon, const MBOut &o, const SegData *d_sd,
@@ -560,6 +873,11 @@ void launch_mb(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet
     BatchOf<MBArgs> b;
     b.n = 1;
     b.item[0] = a;
+    if (mb_packed()) {
+        if (conformant) VP8_LAUNCH(k_mb_p_conformant, dim3((a.mbs + 7) / 8, 1, 1), dim3(192), 0, s, b);
+        else VP8_LAUNCH(k_mb_p, dim3((a.mbs + 7) / 8, 1, 1), dim3(192), 0, s, b);
+        return;
+    }
     if (conformant) VP8_LAUNCH(k_mb_b_conformant, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
     else VP8_LAUNCH(k_mb_b, dim3((a.mbs + 7) / 8, 1, 1), dim3(256), 0, s, b);
 }
@@ -571,6 +889,11 @@ void launch_mb_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs,
     b.n = n;
     for (int i = 0; i < n; ++i) b.item[i] = mb_args(*cur[i], refs[i], *nets[i], *recon[i], *o[i], d_sd[i], ssim_target, mbw, mbh);
     if (mb_skip()) return;
+    if (mb_packed()) {
+        if (conformant) VP8_LAUNCH(k_mb_p_conformant, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(192), 0, s, b);
+        else VP8_LAUNCH(k_mb_p, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(192), 0, s, b);
+        return;
+    }
     if (conformant) VP8_LAUNCH(k_mb_b_conformant, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
     else VP8_LAUNCH(k_mb_b, dim3((b.item[0].mbs + 7) / 8, 1, n), dim3(256), 0, s, b);
 }
