@@ -9,7 +9,7 @@
 //   * The 16 x 32-byte window around the 1x winner is staged in LDS by ONE unaligned 16-byte global load per lane (the window
 //     starts at its own first byte).
 //   * Horizontal pass = one v_mfma_i32_32x32x32_i8: A = the two blocks' window rows, B = the taps of the four fractional x cases
-//     x 8 columns (a constant operand table, make_bh below), C = the rounding 64 as an inline constant.  A lane comes out with a
+//     x 8 columns (a constant operand table, make_bh below), the rounding 64 as one more product (k = 31: mfma_round).  A lane comes out with a
 //     column and four groups of four consecutive rows = four dwords of the TRANSPOSED H array, which go to LDS.
 //   * Vertical pass = three MFMAs over the wave's 2 x 5 x 8 columns: A = the taps of the four y cases (make_av), B = 32 columns of
 //     16 bytes, one ds_read_b128 each; a lane comes out with, per y case, one dword of the prediction [column][row half].  The
@@ -48,7 +48,7 @@ constexpr OperandTable make_bh() {   // B of the horizontal pass: lane l -> colu
         const int n = l & 31, xi = n >> 3, c = n & 7, xc = xi + (xi >> 1), s = xc >= 2 ? 1 : 0;
         for (int j = 0; j < 16; ++j) {
             const int k = 16 * (l >> 5) + j, tap = k - c - s;
-            const int v = (tap >= 0 && tap < 6) ? TAPS[xc][tap] : 0;
+            const int v = k == 31 ? 64 : (tap >= 0 && tap < 6) ? TAPS[xc][tap] : 0;      // k = 31: the rounding (see mfma_round)
             t.w[l][j >> 2] |= (uint32_t)(v & 255) << (8 * (j & 3));
         }
     }
@@ -60,7 +60,7 @@ constexpr OperandTable make_av() {   // A of the vertical pass: lane l -> row m 
         const int m = l & 31, f = m >> 3, i = m & 7, yc = f + (f >> 1), s = yc >= 2 ? 1 : 0;
         for (int j = 0; j < 16; ++j) {
             const int k = 16 * (l >> 5) + j, tap = k - i - s;
-            const int v = (tap >= 0 && tap < 6) ? TAPS[yc][tap] : 0;
+            const int v = k == 31 ? 64 : (tap >= 0 && tap < 6) ? TAPS[yc][tap] : 0;
             t.w[l][j >> 2] |= (uint32_t)(v & 255) << (8 * (j & 3));
         }
     }
@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t halfwave_min_upper(uint32_t key) {
 // sat_i8(a >> 7) in byte 0, sat_i8(b >> 7) in byte 1 (v_ashr_pk_i8_i32; as a 16-bit value the undefined bits 31:16 stay explicit).
 // Pixels travel as signed bytes p - 128 and every tap set sums to 128, so a pass computes sum((p-128) f) = sum(p f) - 128 * 128, and
 //     sat_i8((sum(p f) - 16384 + 64) >> 7) = sat_u8((sum(p f) + 64) >> 7) - 128:
-// the signed saturation of the biased sum IS the biased byte of the reference's clamped sample; the rounding 64 is the MFMA's C input.
+// the signed saturation of the biased sum IS the biased byte of the reference's clamped sample; the rounding 64 rides in the product (mfma_round).
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -121,8 +121,15 @@ __device__ __forceinline__ uint32_t pack4(unsigned short lo, unsigned short hi) 
 __device__ __forceinline__ uint32_t round_pack4(const v16i &acc, int q) {
     return pack4(ashr7_pk_i8(acc[4 * q], acc[4 * q + 1]), ashr7_pk_i8(acc[4 * q + 2], acc[4 * q + 3]));
 }
+// The rounding 64 of a pass rides in the product: k = 31 of the tap operand is 64 (make_bh, make_av; no tap reaches that far) and k = 31 of
+// the data operand is made 1 here -- byte 15 of the lanes of the upper k half, which otherwise meets a zero tap.  (As the C input the
+// constant cost sixteen registers: hipcc does not fold a splat into the instruction's inline-constant field.)  `upper`: 0 or -1.
+__device__ __forceinline__ v4i one_at_k31(v4i d, int upper) {
+    d.w = (int)(((uint32_t)d.w & (0xffffffffu >> (8 & upper))) | (0x01000000u & (uint32_t)upper));
+    return d;
+}
 __device__ __forceinline__ v16i mfma_round(v4i a, v4i b) {
-    const v16i c = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};   // an inline constant of the instruction
+    const v16i c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
 
@@ -131,8 +138,10 @@ __device__ __forceinline__ v16i mfma_round(v4i a, v4i b) {
 // same); here the idle lanes take the FOURTH 4x4 block of candidates 0..17 during the first three rounds, and the fourth 4x4 block of candidates
 // 18..25 of all eight blocks -- 64 tasks -- is one round of wave 0 alone: 3.25 rounds per wave on average instead of 4.  The costs meet in LDS
 // (in the H array's dead bytes), two workgroup barriers around wave 0's extra round.  Same integer sums in another order: the same result.
+// tn: the thread's number again, for what a workgroup that takes several groups (search2_groups) should NOT keep across its loop: every
+// register of lane arithmetic kept is one a wave of the SIMD cannot have, and the cheap ones (two or three instructions to make) are made again
 template <bool SPREAD>
-__device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_idx) {
+__device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_idx, int tn) {
     if (ref_idx >= a.nrefs) return;
     __shared__ __attribute__((aligned(16))) uint32_t s_HT[8][5 * HT_XC];
     __shared__ __attribute__((aligned(16))) uint32_t s_cz[8][32];   // [0..15] current block, [16..31] zero-MV block, both as [column][row half], biased bytes
@@ -156,21 +165,22 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     const int Lx = iclamp(cx + nx, 3 - EXT, a.w + EXT - 11), Ly = iclamp(cy + ny, 3 - EXT, a.h + EXT - 11);
     const Plane rf = a.ref[r];
     const int wl = threadIdx.x & 63, kh = wl >> 5, gp = g & ~1;   // lane of the wave, its k half in an MFMA operand, the wave's first slot
+    const int g_n = tn >> 5, lane_n = tn & 31, wl_n = tn & 63, kh_n = wl_n >> 5, gp_n = g_n & ~1;
     // The window from its own first byte (Lx - 3: any alignment; the part's global loads need none): lane = (row, half) takes 16
     // bytes, 16 rows of 32 bytes -- the six-tap passes need 14 x 19, the rest stays inside the planes' allocated margin (PAD) and
     // meets zero taps.  One load and one ds_write_b128 per lane, no loop.
     {
-        const int row = lane >> 1, half = lane & 1;
+        const int row = lane_n >> 1, half = lane_n & 1;
         v4i v;
         __builtin_memcpy(&v, rf.p + (ptrdiff_t)(Ly - 3 + row) * rf.stride + (Lx - 3) + 16 * half, 16);
-        *reinterpret_cast<v4i *>(&s_win[g][row * WIN_ROW + 4 * half]) = v ^ (int)0x80808080u;
+        *reinterpret_cast<v4i *>(&s_win[g_n][row * WIN_ROW + 4 * half]) = v ^ (int)0x80808080u;
     }
     {   // current block (lanes 0-15) and zero-MV block (16-31): one dword each, scattered as column bytes
-        const int sel = lane >> 4, row = (lane >> 1) & 7, half = lane & 1;
+        const int sel = lane_n >> 4, row = (lane_n >> 1) & 7, half = lane_n & 1;
         const uint8_t *base = sel ? rf.p : a.cur.p;
         const int stride = sel ? rf.stride : a.cur.stride;
         const uint32_t v = *reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)(cy + row) * stride + cx + 4 * half) ^ 0x80808080u;
-        uint8_t *cz = reinterpret_cast<uint8_t *>(s_cz[g]) + sel * 64 + half * 32 + row;
+        uint8_t *cz = reinterpret_cast<uint8_t *>(s_cz[g_n]) + sel * 64 + half * 32 + row;
 #pragma unroll
         for (int j = 0; j < 4; ++j) cz[j * 8] = (uint8_t)(v >> (8 * j));
     }
@@ -181,22 +191,22 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     // meet zero taps or land in bytes nobody reads), B = the taps of the four fractional x cases (K_BH).  A lane comes out with
     // column n = (x case, c) and four groups of four consecutive rows: each group one dword of the TRANSPOSED H array.
     {
-        const int m = wl & 31;
-        const v4i aw = *reinterpret_cast<const v4i *>(&s_win[gp + (m >> 4)][(m & 15) * WIN_ROW + 4 * kh]);
-        const v4i bh = *reinterpret_cast<const v4i *>(K_BH.w[wl]);
-        const v16i acc = mfma_round(aw, bh);
+        const int m = wl & 31, m_n = wl_n & 31;
+        const v4i aw = *reinterpret_cast<const v4i *>(&s_win[gp_n + (m_n >> 4)][(m_n & 15) * WIN_ROW + 4 * kh_n]);
+        const v4i bh = *reinterpret_cast<const v4i *>(K_BH.w[wl_n]);
+        const v16i acc = mfma_round(one_at_k31(aw, -kh_n), bh);
         const int xi = m >> 3, c = m & 7, xc = xi + (xi >> 1);
         uint32_t *ht = &s_HT[gp][xc * HT_XC + c * 4 + kh];   // rows 4 * kh .. of column c; + 2: rows 8 + 4 * kh ..; next slot: the other block
 #pragma unroll
         for (int q = 0; q < 4; ++q) ht[(q >> 1) * (5 * HT_XC) + 2 * (q & 1)] = round_pack4(acc, q);
     }
-    {   // whole-pel x case: column c of the window, rows 4*rg..4*rg+3 (rows 14,15 only ever meet zero taps)
-        const int c = lane & 7, rg = lane >> 3;
-        const uint8_t *wb = reinterpret_cast<const uint8_t *>(s_win[g]) + 3 + c;
+    {   // whole-pel x case: column c of the window, rows 4*rg..4*rg+3 (rows 14, 15 -- staged like the others -- only ever meet zero taps)
+        const int c = lane_n & 7, rg = lane_n >> 3;
+        const uint8_t *wb = reinterpret_cast<const uint8_t *>(s_win[g_n]) + 3 + c + rg * (16 * WIN_ROW);
         uint32_t v = 0;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[imin(4 * rg + rr, 13) * (4 * WIN_ROW)] << (8 * rr);
-        s_HT[g][2 * HT_XC + c * 4 + rg] = v;
+        for (int rr = 0; rr < 4; ++rr) v |= (uint32_t)wb[rr * (4 * WIN_ROW)] << (8 * rr);
+        s_HT[g_n][2 * HT_XC + c * 4 + rg] = v;
     }
     lds_fence();
 
@@ -205,14 +215,14 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     // each (the lanes of the upper k half read the same column: their A entries are zero).  A lane comes out with its column and, per
     // y case, the four rows 4 * kh .. 4 * kh + 3: one dword of the prediction [column][row half].  The whole-pel y case is a copy.
     {
-        const v4i av = *reinterpret_cast<const v4i *>(K_AV.w[wl]);
+        const v4i av = *reinterpret_cast<const v4i *>(K_AV.w[wl_n]);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int ng = 32 * t + (wl & 31);
             const bool on = t < 2 || (wl & 31) < 16;
             const int blk = ng >= 40 ? 1 : 0, rem = on ? ng - 40 * blk : 0, xc = rem >> 3, c = rem & 7;
             const v4i hv = *reinterpret_cast<const v4i *>(&s_HT[gp + blk][xc * HT_XC + c * 4]);
-            const v16i acc = mfma_round(av, hv);
+            const v16i acc = mfma_round(av, one_at_k31(hv, -kh_n));
             if (on) {
                 uint32_t *sv = &s_V[gp + blk][xc * V_STRIDE + c * 2 + kh];
 #pragma unroll
@@ -226,11 +236,11 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     lds_fence();
     {   // the current block's share of the metric (vp8hip_dev.h, weight_pre_column): 16 columns x 4 quantities, two per lane.
         // Order = the order the cost loop below walks the 4x4 blocks: q = (m*2 + n)*4 + j  <->  column 4n+j, row half m
-        const int q = lane & 15, m = q >> 3, n = (q >> 2) & 1, j = q & 3;
-        const uint32_t ccol = s_cz[g][(4 * n + j) * 2 + m];
-        int *pre = &s_pre[g][q * 4 + (lane >> 4) * 2];
-        pre[0] = dot4s(ccol, lane < 16 ? K_W_R0 : K_W_X, 0);
-        pre[1] = dot4s(ccol, lane < 16 ? K_W_R2 : K_W_Y, 0);
+        const int q = lane_n & 15, m = q >> 3, n = (q >> 2) & 1, j = q & 3;
+        const uint32_t ccol = s_cz[g_n][(4 * n + j) * 2 + m];
+        int *pre = &s_pre[g_n][q * 4 + (lane_n >> 4) * 2];
+        pre[0] = dot4s(ccol, lane_n < 16 ? K_W_R0 : K_W_X, 0);
+        pre[1] = dot4s(ccol, lane_n < 16 ? K_W_R2 : K_W_Y, 0);
     }
     lds_fence();
 
@@ -318,17 +328,30 @@ __device__ __forceinline__ void search2_body(const S2Args &a, int wg_x, int ref_
     }
 }
 
-template <bool SPREAD>
+// ITER: a workgroup takes ITER consecutive groups of eight blocks, one after the other.  A third of what a wave issues for a group does not
+// depend on the group -- the lane's place in the operand tables of the two passes and the tables themselves, its LDS addresses in every stage, its
+// candidate's offset and penalty -- and the compiler keeps all of it in registers across the loop (the price: registers, i.e. waves per SIMD).
+template <bool SPREAD, int ITER>
+__device__ __forceinline__ void search2_groups(const S2Args &a, int grp, int ref_idx) {
+    if (ITER == 1) { search2_body<SPREAD>(a, grp, ref_idx, (int)threadIdx.x); return; }
+#pragma unroll 1
+    for (int it = 0; it < ITER; ++it) {
+        int tn = (int)threadIdx.x;
+        asm volatile("" : "+v"(tn));     // (the same number, as far as the compiler can tell a new one per group)
+        search2_body<SPREAD>(a, grp * ITER + it, ref_idx, tn);
+    }
+}
+template <bool SPREAD, int ITER>
 __global__ __launch_bounds__(256, 4) void k_search2(S2Args a) {   // (a register budget of 128 also makes the MFMAs write VGPRs: no v_accvgpr_read per result)
     launch_clock_begin(a.clk);
-    search2_body<SPREAD>(a, xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
+    search2_groups<SPREAD, ITER>(a, xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(a.clk);
 }
 static_assert(sizeof(BatchOf<S2Args>) <= 4096, "a batch's argument blocks travel in the 4 KiB kernel-argument segment");
-template <bool SPREAD>
+template <bool SPREAD, int ITER>
 __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
     launch_clock_begin(b.item[0].clk);
-    search2_body<SPREAD>(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
+    search2_groups<SPREAD, ITER>(b.item[blockIdx.z], xcd_band(blockIdx.x, gridDim.x), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
 // The same launch carrying the loop-filter strength scans of its members' NEW frames (kernels_rc_dev.h): the workgroups behind the
@@ -339,7 +362,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
 // spread through the launch's 12 000 per member.
 struct S2Scans { rc::ScanCore item[MAX_BATCH]; uint32_t mask; int nbx, wgs; };
 static_assert(sizeof(BatchOf<S2Args>) + sizeof(S2Scans) <= 4096, "the kernel-argument segment");
-template <bool SPREAD>
+template <bool SPREAD, int ITER>
 __global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scans sc) {
     if ((int)blockIdx.x >= sc.nbx) {
         const int wg = (int)blockIdx.x - sc.nbx;
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scan
         return;
     }
     launch_clock_begin(b.item[0].clk);
-    search2_body<SPREAD>(b.item[blockIdx.z], xcd_band(blockIdx.x, sc.nbx), blockIdx.y);
+    search2_groups<SPREAD, ITER>(b.item[blockIdx.z], xcd_band(blockIdx.x, sc.nbx), blockIdx.y);
     launch_clock_end(b.item[0].clk);
 }
 // Persistent form: a grid no larger than what the part holds at once, every workgroup walking the (context, reference,
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void k_search2_p(BatchOf<S2Args> b, int nbx
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int item = w / (nbx * maxrefs), rem = w - item * (nbx * maxrefs);
         const int ref_idx = rem / nbx, wg_x = rem - ref_idx * nbx;
-        search2_body<false>(b.item[item], wg_x, ref_idx);
+        search2_body<false>(b.item[item], wg_x, ref_idx, (int)threadIdx.x);
         lds_fence();   // the next round reuses this workgroup's LDS: every read of this round has returned
     }
 }
@@ -392,6 +415,11 @@ static bool search2_spread() {
     static const bool on = [] { const char *v = getenv("VP8HIP_S2_SPREAD"); return !(v && v[0] == '0'); }();
     return on;
 }
+// VP8HIP_S2_ITER=1/2/4: groups of eight blocks a workgroup takes one after the other (same-box A/B runs)
+static int search2_iter() {
+    static const int n = [] { const char *v = getenv("VP8HIP_S2_ITER"); const int k = v && v[0] ? atoi(v) : 4; return k == 1 || k == 2 ? k : 4; }();
+    return n;
+}
 static bool search2_skip() {
     static const bool skip = experiment_skip("s2");
     return skip;   // timing experiment only
@@ -400,8 +428,11 @@ static bool search2_skip() {
 void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const NetSet &nets, unsigned long long *clk) {
     const S2Args a = search2_args(cur, refs, nets, clk);
     if (a.nrefs == 0 || search2_skip()) return;
-    if (search2_spread()) VP8_LAUNCH(k_search2<true>, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
-    else VP8_LAUNCH(k_search2<false>, dim3((a.nblk + 7) / 8, a.nrefs), dim3(256), 0, s, a);
+    const int nbx = (a.nblk + 7) / 8;
+    if (!search2_spread()) VP8_LAUNCH((k_search2<false, 1>), dim3(nbx, a.nrefs), dim3(256), 0, s, a);
+    else if (search2_iter() == 4) VP8_LAUNCH((k_search2<true, 4>), dim3((nbx + 3) / 4, a.nrefs), dim3(256), 0, s, a);
+    else if (search2_iter() == 2) VP8_LAUNCH((k_search2<true, 2>), dim3((nbx + 1) / 2, a.nrefs), dim3(256), 0, s, a);
+    else VP8_LAUNCH((k_search2<true, 1>), dim3(nbx, a.nrefs), dim3(256), 0, s, a);
 }
 
 bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *refs, const NetSet *const *nets, int n, unsigned long long *clk,
@@ -430,15 +461,20 @@ bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         sc.item[i] = rc::ScanCore{q.partial, q.partial + 2 * rc::MAX_PARTIALS, q.stats, q.sd, q.strength_out,
                                   rc::SegArgs{y.w * y.h, (y.h - 1) * (y.w - 1), q.is_key, q.refqi[0], q.refqi[1], q.refqi[2], q.refqi[3], q.qi_min}};
     }
+    const int iter = search2_spread() ? search2_iter() : 1, ngrp = (nbx + iter - 1) / iter;     // workgroups that search: each takes `iter` groups of eight blocks
     if (!sc.mask) {
-        if (search2_spread()) VP8_LAUNCH(k_search2_b<true>, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
-        else VP8_LAUNCH(k_search2_b<false>, dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+        if (!search2_spread()) VP8_LAUNCH((k_search2_b<false, 1>), dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
+        else if (iter == 4) VP8_LAUNCH((k_search2_b<true, 4>), dim3(ngrp, maxrefs, n), dim3(256), 0, s, b);
+        else if (iter == 2) VP8_LAUNCH((k_search2_b<true, 2>), dim3(ngrp, maxrefs, n), dim3(256), 0, s, b);
+        else VP8_LAUNCH((k_search2_b<true, 1>), dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
         return false;
     }
-    sc.nbx = nbx;
+    sc.nbx = ngrp;
     sc.wgs = (b.item[0].h + rc::ROWS_PER_BLOCK - 1) / rc::ROWS_PER_BLOCK;
-    if (search2_spread()) VP8_LAUNCH(k_search2_bs<true>, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
-    else VP8_LAUNCH(k_search2_bs<false>, dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    if (!search2_spread()) VP8_LAUNCH((k_search2_bs<false, 1>), dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    else if (iter == 4) VP8_LAUNCH((k_search2_bs<true, 4>), dim3(ngrp + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    else if (iter == 2) VP8_LAUNCH((k_search2_bs<true, 2>), dim3(ngrp + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
+    else VP8_LAUNCH((k_search2_bs<true, 1>), dim3(nbx + sc.wgs, maxrefs, n), dim3(256), 0, s, b, sc);
     return true;
 }
 
