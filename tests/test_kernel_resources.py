@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vp8oclenc_amd", "csrc")
 HOT = {   # file -> {kernel name fragment: max VGPRs}
     "kernels_mb.hip": {"k_mb_bE": 128, "k_mb_pE": 128, "k_mb_p_conformant": 128},     # both forms (VP8HIP_MB_PACKED): four waves per SIMD
-    "kernels_s2.hip": {"k_search2ILb": 72, "k_search2_bILb": 72, "k_search2_bsILb1ELi1": 72, "k_search2_bsILb0": 72, "k_search2_bsILb1ELi4": 80},      # seven waves per SIMD ... (both forms of the cost phase: SPREAD and lane = candidate); the form that carries the scans AND takes four groups per workgroup: six (measured so: profiles/r06_s2_iter_ab.txt)
+    "kernels_s2.hip": {"k_search2ILb": 72, "k_search2_bILb": 72, "k_search2_bsILb": 72},      # seven waves per SIMD ... (both forms of the cost phase: SPREAD and lane = candidate; one group of eight blocks per workgroup or four in a loop)
     "kernels_me.hip": {"k_search1": 128, "k_search1_bILb0": 64, "k_search1_plE": 64, "k_search1_pl_b": 64, "k_search1_plr_b": 72, "k_search1_coarse": 64, "k_pyramid": 128, "k_pack_b": 64},   # the loop form: eight (a form with 7 % fewer instructions and 75 registers was no faster)
     "kernels_lf4.hip": {"k_loop_filter4": 128},
 }
-LDS = {"k_search2ILb": 23296, "k_search2_bILb": 23296, "k_search2_bsILb1ELi1": 23296, "k_search2_bsILb0": 23296, "k_search2_bsILb1ELi4": 23296}   # ... and seven workgroups per CU (163 840 / 7); an MFMA result must land in VGPRs (no AGPRs)
+LDS = {"k_search2ILb": 23296, "k_search2_bILb": 23296, "k_search2_bsILb": 23296}   # ... and seven workgroups per CU (163 840 / 7); an MFMA result must land in VGPRs (no AGPRs)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")

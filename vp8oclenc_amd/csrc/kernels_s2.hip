@@ -362,8 +362,9 @@ __global__ __launch_bounds__(256, 4) void k_search2_b(BatchOf<S2Args> b) {
 // spread through the launch's 12 000 per member.
 struct S2Scans { rc::ScanCore item[MAX_BATCH]; uint32_t mask; int nbx, wgs; };
 static_assert(sizeof(BatchOf<S2Args>) + sizeof(S2Scans) <= 4096, "the kernel-argument segment");
+// (waves_per_eu: with the scans' body in the same function the register allocator otherwise settles at 76 -- six waves per SIMD; told to, it fits the same code into 70)
 template <bool SPREAD, int ITER>
-__global__ __launch_bounds__(256, 4) void k_search2_bs(BatchOf<S2Args> b, S2Scans sc) {
+__global__ __attribute__((amdgpu_waves_per_eu(7, 8))) __launch_bounds__(256) void k_search2_bs(BatchOf<S2Args> b, S2Scans sc) {
     if ((int)blockIdx.x >= sc.nbx) {
         const int wg = (int)blockIdx.x - sc.nbx;
         if (blockIdx.y == 0 && ((sc.mask >> blockIdx.z) & 1) && wg < sc.wgs) rc::strength_segments_body(b.item[blockIdx.z].cur, sc.item[blockIdx.z], wg, sc.wgs);
