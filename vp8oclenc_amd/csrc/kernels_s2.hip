@@ -416,10 +416,11 @@ static bool search2_spread() {
     static const bool on = [] { const char *v = getenv("VP8HIP_S2_SPREAD"); return !(v && v[0] == '0'); }();
     return on;
 }
-// VP8HIP_S2_ITER=1/2/4: groups of eight blocks a workgroup takes one after the other (same-box A/B runs)
-static int search2_iter() {
-    static const int n = [] { const char *v = getenv("VP8HIP_S2_ITER"); const int k = v && v[0] ? atoi(v) : 4; return k == 1 || k == 2 ? k : 4; }();
-    return n;
+// VP8HIP_S2_ITER=1/2/4: groups of eight blocks a workgroup takes one after the other (same-box A/B runs).  Batches: four.  One video: one --
+// its launch is a few rounds of workgroups long, and workgroups four times as long make its end ragged (53.0 against 54.3 us)
+static int search2_iter(bool batch) {
+    static const int forced = [] { const char *v = getenv("VP8HIP_S2_ITER"); const int k = v && v[0] ? atoi(v) : 0; return k == 1 || k == 2 || k == 4 ? k : 0; }();
+    return forced ? forced : (batch ? 4 : 1);
 }
 static bool search2_skip() {
     static const bool skip = experiment_skip("s2");
@@ -431,8 +432,8 @@ void launch_search2(hipStream_t s, const Frame &cur, const RefSet &refs, const N
     if (a.nrefs == 0 || search2_skip()) return;
     const int nbx = (a.nblk + 7) / 8;
     if (!search2_spread()) VP8_LAUNCH((k_search2<false, 1>), dim3(nbx, a.nrefs), dim3(256), 0, s, a);
-    else if (search2_iter() == 4) VP8_LAUNCH((k_search2<true, 4>), dim3((nbx + 3) / 4, a.nrefs), dim3(256), 0, s, a);
-    else if (search2_iter() == 2) VP8_LAUNCH((k_search2<true, 2>), dim3((nbx + 1) / 2, a.nrefs), dim3(256), 0, s, a);
+    else if (search2_iter(false) == 4) VP8_LAUNCH((k_search2<true, 4>), dim3((nbx + 3) / 4, a.nrefs), dim3(256), 0, s, a);
+    else if (search2_iter(false) == 2) VP8_LAUNCH((k_search2<true, 2>), dim3((nbx + 1) / 2, a.nrefs), dim3(256), 0, s, a);
     else VP8_LAUNCH((k_search2<true, 1>), dim3(nbx, a.nrefs), dim3(256), 0, s, a);
 }
 
@@ -462,7 +463,7 @@ bool launch_search2_batch(hipStream_t s, const Frame *const *cur, const RefSet *
         sc.item[i] = rc::ScanCore{q.partial, q.partial + 2 * rc::MAX_PARTIALS, q.stats, q.sd, q.strength_out,
                                   rc::SegArgs{y.w * y.h, (y.h - 1) * (y.w - 1), q.is_key, q.refqi[0], q.refqi[1], q.refqi[2], q.refqi[3], q.qi_min}};
     }
-    const int iter = search2_spread() ? search2_iter() : 1, ngrp = (nbx + iter - 1) / iter;     // workgroups that search: each takes `iter` groups of eight blocks
+    const int iter = search2_spread() ? search2_iter(true) : 1, ngrp = (nbx + iter - 1) / iter;     // workgroups that search: each takes `iter` groups of eight blocks
     if (!sc.mask) {
         if (!search2_spread()) VP8_LAUNCH((k_search2_b<false, 1>), dim3(nbx, maxrefs, n), dim3(256), 0, s, b);
         else if (iter == 4) VP8_LAUNCH((k_search2_b<true, 4>), dim3(ngrp, maxrefs, n), dim3(256), 0, s, b);
