@@ -56,6 +56,7 @@ def main():
 
     per_level = collections.defaultdict(list)   # search1: level -> [(instr per ref, variant)]
     plr = collections.defaultdict(list)         # search1, one workgroup for all references (batches): level -> [(instr per launch, launches)]
+    s2_batch = []                               # search2 as batches launch it: [(instr per launch, references, launches)]
     mix = collections.Counter()                 # launches of the run by number of references searched (from the level-4 launches)
     for (name, grid), vals in acc.items():
         v = sum(vals) / len(vals)
@@ -76,9 +77,14 @@ def main():
                             mix[refs] += len(vals)
         elif "k_search2" in name:
             nblk = W * H // 64
+            nbx = (nblk + 7) // 8
             for refs in (1, 2, 3):
-                if (nblk + 7) // 8 * 256 * refs == grid:
+                if nbx * 256 * refs == grid:
                     per_level["s2"].append((v / refs, "k_search2", len(vals)))
+                # what batches launch: a workgroup takes four groups of eight blocks (kernels_s2.hip, search2_groups), and the launch carries the
+                # strength scan of the member's new frame (ceil(H / 8) workgroups per reference slice; its instructions are taken out below)
+                if "k_search2_bs" in name and ((nbx + 3) // 4 + (H + 7) // 8) * 256 * refs == grid:
+                    s2_batch.append((v, refs, len(vals)))
         else:
             for short, key in (("k_mb", "mb"), ("k_loop_filter3", "loop_filter"), ("k_loop_filter4", "loop_filter4"), ("k_pyramid", "downsample"), ("k_pack", "pack"), ("k_border", "border"),
                                ("k_strength_segments", "lf_strength")):
@@ -86,6 +92,9 @@ def main():
                     if key in ("downsample", "border") and key in table and table[key]["fixed"] > v:
                         continue     # several grids (one or two frames' pyramids; borders of one plane set): keep the per-frame one
                     put(key, False, v, "k_mb_p" if "k_mb_p" in name else short)     # (k_mb_p: three kinds of wave in a workgroup; priced with the static stream's average cycles per instruction)
+    if s2_batch and "lf_strength" in table:      # the headline's form of the kernel, per reference, without the scan that rides in it
+        per = sum((v - table["lf_strength"]["fixed"]) / refs * n for v, refs, n in s2_batch) / sum(n for _, _, n in s2_batch)
+        per_level["s2"] = [(per, "k_search2", 10 ** 9)]
     avg_refs = sum(r * n for r, n in mix.items()) / max(sum(mix.values()), 1)
     for lvl, items in plr.items():              # what batches launch: per reference = per launch / the run's references per frame
         if avg_refs > 0:

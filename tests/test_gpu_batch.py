@@ -255,7 +255,8 @@ def test_one_video_with_the_next_frame_prefetched_from_host_memory(W, H, src):
 
 
 @pytest.mark.parametrize("env", [{"VP8HIP_BATCH_S1_COARSE": "1"}, {"VP8HIP_BATCH_S1_COARSE": "2"}, {"VP8HIP_BATCH_S1_COARSE": "3"},
-                                 {"VP8HIP_S1_PRE_LDS": "0"}, {"VP8HIP_S1_REF_LOOP": "0"}, {"VP8HIP_S2_SPREAD": "0"}],
+                                 {"VP8HIP_S1_PRE_LDS": "0"}, {"VP8HIP_S1_REF_LOOP": "0"}, {"VP8HIP_S2_SPREAD": "0"},
+                                 {"VP8HIP_S2_ITER": "1"}, {"VP8HIP_S2_ITER": "2"}, {"VP8HIP_MB_PACKED": "0"}],
                          ids=lambda e: "-".join(f"{k[7:]}={v}" for k, v in e.items()))
 def test_bench_with_the_switchable_forms_of_the_search_kernels_codes_the_same_frames(env):
     """The forms kept behind environment switches for same-box A/B runs (profiles/r06_*_ab.txt) -- the fused launches of a batch's hierarchical
