@@ -231,6 +231,20 @@ def test_integration_section_2_is_what_the_drop_in_script_does():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_integration_section_7_names_every_environment_variable_the_library_reads():
+    """INTEGRATION.md section 7 against the sources: every VP8HIP_* the library asks getenv for is in the table, and the table names none that is not read"""
+    import glob
+    import re
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "vp8oclenc_amd", "csrc", "*")):
+        read |= set(re.findall(r'(?:getenv|experiment_env)\("(VP8HIP_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("## 7. Environment the library reads"):]
+    named = set(re.findall(r"`(VP8HIP_[A-Z0-9_]+)(?:=\d)?`", section))
+    assert read - named == set(), f"read by the library, missing from INTEGRATION.md section 7: {sorted(read - named)}"
+    assert named - read - {"VP8HIP_EXPERIMENTS"} == set(), f"named in INTEGRATION.md section 7, read nowhere: {sorted(named - read)}"
+
+
 def test_the_library_sets_the_hardware_queue_count_when_it_is_loaded(tmp_path):
     """The HIP runtime reads GPU_MAX_HW_QUEUES once, at the process's first HIP call; the reference creates the queues it needs itself
     (init.h:1162-1165), and a drop-in must not depend on its host's environment for that: a constructor in libvp8hip.so sets 16
