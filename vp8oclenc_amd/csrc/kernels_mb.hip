@@ -532,8 +532,9 @@ struct MBShare {
     int any[2];                                         // [pass & 1]: a macroblock of the workgroup ran this pass
 };
 struct MBTileP { MBTile t; uint32_t skew[4]; };          // (a tile is 60 x 64 B: without the 16 bytes the chains of eight macroblocks read the same banks)
+// (every pattern used here gives every lane a source; with "old" a constant hipcc folds the move into the addition that follows: v_add_u32_dpp)
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ int quad_sum(int v) {         // over the four lanes of a quad, in every lane

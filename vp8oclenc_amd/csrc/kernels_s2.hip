@@ -97,12 +97,18 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint32_t dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep their own value
 }
+// (a lane without a source takes the minimum's identity: written so, hipcc folds the move into the minimum -- one v_min_u32_dpp per step where
+// "keeps its own value" cost a copy, the move and the minimum)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_max(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ uint32_t halfwave_min_upper(uint32_t key) {
-    key = umin(key, dpp<0xb1>(key));         // quad_perm [1,0,3,2]
-    key = umin(key, dpp<0x4e>(key));         // quad_perm [2,3,0,1]
-    key = umin(key, dpp<0x141>(key));        // row_half_mirror
-    key = umin(key, dpp<0x140>(key));        // row_mirror
-    return umin(key, dpp<0x142, 0xa>(key));  // row_bcast:15 into rows 1 and 3
+    key = umin(key, dpp_or_max<0xb1>(key));         // quad_perm [1,0,3,2]
+    key = umin(key, dpp_or_max<0x4e>(key));         // quad_perm [2,3,0,1]
+    key = umin(key, dpp_or_max<0x141>(key));        // row_half_mirror
+    key = umin(key, dpp_or_max<0x140>(key));        // row_mirror
+    return umin(key, dpp_or_max<0x142, 0xa>(key));  // row_bcast:15 into rows 1 and 3
 }
 
 // sat_i8(a >> 7) in byte 0, sat_i8(b >> 7) in byte 1 (v_ashr_pk_i8_i32; as a 16-bit value the undefined bits 31:16 stay explicit).
