@@ -369,7 +369,7 @@ __device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, i
             }
         }
     }
-    const int pen_scale = a.pixel_rate < 4 ? 32 : 0;
+    const int pen_mask = a.pixel_rate < 4 ? -1 : 0;     // x 32 on the two finest levels, x 0 above (a shift and a mask: `* pen_scale' with a scale the compiler cannot see compiles to a 64-bit multiply-add per candidate)
     const int pen_y = iabs(iabs(py - cy) - v0y);
     uint32_t best = 0xffffffffu;
 #pragma unroll
@@ -377,7 +377,7 @@ __device__ __forceinline__ uint32_t search1_block(const Search1Args &a, int r, i
         const int px = (int16_t)(xb + i);
         const bool valid = loadable && px >= 0 && px <= a.w - 8;
         // :542-543 (sic): |displacement| minus the signed parent vector, only on the two finest levels
-        const int diff = (acc[i] + (iabs(iabs(px - cx) - v0x) + pen_y) * pen_scale) & 0xffff;   // ushort accumulator
+        const int diff = (acc[i] + (((iabs(iabs(px - cx) - v0x) + pen_y) << 5) & pen_mask)) & 0xffff;   // ushort accumulator
         const uint32_t key = (valid && diff < 0x7fff) ? ((uint32_t)diff << 8) | (uint32_t)(j * 5 + i) : 0xffffffffu;
         best = key < best ? key : best;
     }
